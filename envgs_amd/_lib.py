@@ -1,0 +1,66 @@
+"""ctypes loader for libenvgs_hip.so (the C-ABI of include/*.h).  Fails loudly: there is no CPU or
+PyTorch fallback for the product path -- if the HIP library is missing or does not load, importing an
+operator raises."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libenvgs_hip.so")
+_lib = None
+
+c_void_p, c_int, c_uint32, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_size_t
+
+
+class RasterCfg(ctypes.Structure):
+    """struct envgs_raster_cfg (include/envgs_raster.h)."""
+    _fields_ = [("P", ctypes.c_int32), ("sh_degree", ctypes.c_int32), ("sh_coeffs", ctypes.c_int32),
+                ("channels", ctypes.c_int32), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("bg_len", ctypes.c_int32), ("debug", ctypes.c_int32), ("scale_modifier", ctypes.c_float),
+                ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float)]
+
+
+class TraceCfg(ctypes.Structure):
+    """struct envgs_trace_cfg (include/envgs_trace.h)."""
+    _fields_ = [("P", ctypes.c_int32), ("num_rays", ctypes.c_int32), ("sh_degree", ctypes.c_int32),
+                ("sh_coeffs", ctypes.c_int32), ("max_trace_depth", ctypes.c_int32), ("start_from_first", ctypes.c_int32),
+                ("has_others", ctypes.c_int32), ("bg_len", ctypes.c_int32), ("debug", ctypes.c_int32),
+                ("scale_modifier", ctypes.c_float), ("specular_threshold", ctypes.c_float)]
+
+
+# every symbol include/*.h declares: name -> (restype, argtypes)
+_P = c_void_p
+SYMBOLS = {
+    "envgs_raster_scan_temp_bytes": (c_size_t, [ctypes.c_int32]),
+    "envgs_raster_sort_temp_bytes": (c_size_t, [c_uint32, ctypes.c_int32, ctypes.c_int32]),
+    "envgs_raster_project": (c_int, [ctypes.POINTER(RasterCfg)] + [_P] * 15 + [_P, c_size_t, ctypes.POINTER(c_uint32), _P]),
+    "envgs_raster_bin_and_render": (c_int, [ctypes.POINTER(RasterCfg), c_uint32] + [_P] * 9 + [_P, c_size_t] + [_P] * 6 + [_P]),
+    "envgs_raster_backward": (c_int, [ctypes.POINTER(RasterCfg), c_uint32] + [_P] * 28 + [_P]),
+}
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "envgs_amd: %s is missing. Build it with `python -m envgs_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the render-and-trace path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("envgs_amd: %s failed with code %d (%s)" % (
+            what, rc, {-1: "bad argument", -2: "temp buffer too small"}.get(rc, "hipError_t")))

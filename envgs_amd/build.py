@@ -1,0 +1,62 @@
+"""Builds libenvgs_hip.so (all HIP kernels + the C-ABI of include/*.h) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the authoring container; the built .so travels to
+the GPU box with the snapshot (it is git-ignored, not gpurun-ignored).  No torch headers are involved:
+the library is plain HIP behind an extern "C" boundary and is loaded with ctypes (envgs_amd/_lib.py).
+"""
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "libenvgs_hip.so")
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fvisibility=hidden",
+          "-Wall", "-Wno-unused-function"]
+# per-file extra flags; raster_project.hip feeds bit-exact integer keys -> no FMA contraction there
+EXTRA = {"raster_project.hip": ["-ffp-contract=off"]}
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers_mtime():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    hs += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src, force, hdr_m):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    path = os.path.join(CSRC, src)
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_m):
+        return obj, False
+    cmd = ["hipcc"] + COMMON + EXTRA.get(src, []) + ["-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr[-4000:]))
+    return obj, True
+
+
+def build_library(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_m = _headers_mtime()
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        res = list(ex.map(lambda s: _compile(s, force, hdr_m), _sources()))
+    objs = [o for o, _ in res]
+    if force or any(ch for _, ch in res) or not os.path.exists(LIB):
+        cmd = ["hipcc", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+        if verbose:
+            print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in os.sys.argv, verbose=True)

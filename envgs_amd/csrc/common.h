@@ -1,0 +1,83 @@
+// common.h -- shared device helpers for the gfx950 surfel kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/envgs_raster.h"
+
+namespace envgs {
+
+constexpr int TILE = ENVGS_TILE;              // 16x16 pixel tiles (binning granularity of the reference)
+constexpr int GEOM = ENVGS_GEOM_STRIDE;       // floats per surfel record
+constexpr int GREC = ENVGS_GRAD_STRIDE;       // floats per gradient record
+constexpr float NEAR_N = 0.2f;
+constexpr float FAR_N = 100.0f;
+constexpr float FILTER_SIZE = 0.707106f;
+constexpr float FILTER_INV_SQ = 2.0f;
+constexpr float ALPHA_CAP = 0.99f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float T_EPS = 0.0001f;
+
+#define ENVGS_CHECK_LAUNCH(cfg, stream)                                             \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) return (int)e__;                                     \
+        if ((cfg)->debug) {                                                         \
+            e__ = hipStreamSynchronize((hipStream_t)(stream));                      \
+            if (e__ != hipSuccess) return (int)e__;                                 \
+        }                                                                           \
+    } while (0)
+
+// ---- wave64 cross-lane helpers (DPP; no LDS traffic) -------------------------------------------
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = true>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, BOUND));
+}
+
+// Sum over the 64 lanes; the result is returned wave-uniform (in an SGPR via readlane 63).
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_mov<0xB1>(v);                 // quad_perm [1,0,3,2]  (xor 1)
+    v += dpp_mov<0x4E>(v);                 // quad_perm [2,3,0,1]  (xor 2)
+    v += dpp_mov<0x141>(v);                // row_half_mirror      (xor 4 once quads are uniform)
+    v += dpp_mov<0x140>(v);                // row_mirror           (xor 8 once octets are uniform)
+    v += dpp_mov<0x142, 0xa, 0xf, false>(v);   // row_bcast15 into rows 1,3
+    v += dpp_mov<0x143, 0xc, 0xf, false>(v);   // row_bcast31 into rows 2,3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+
+__device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
+
+// ---- launchers implemented in the kernel translation units ---------------------------------------
+int launch_project(const envgs_raster_cfg *cfg, const float *means3D, const float *scales, const float *rotations,
+                   const float *opacities, const float *shs, const float *transmat_precomp, const float *viewmatrix,
+                   const float *projmatrix, const float *campos, float *geom, float *rgb, uint8_t *clamped,
+                   int32_t *radii, uint32_t *tiles_touched, hipStream_t stream);
+int launch_scan(const uint32_t *in, uint32_t *out, int n, void *temp, size_t temp_bytes, hipStream_t stream);
+size_t scan_temp_bytes(int n);
+size_t sort_temp_bytes(uint32_t n, int end_bit);
+int launch_bin(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const int32_t *radii, const uint32_t *offsets,
+               uint64_t *keys_unsorted, uint32_t *vals_unsorted, uint64_t *keys_sorted, uint32_t *point_list,
+               void *sort_temp, size_t sort_temp_bytes, uint32_t *ranges, hipStream_t stream);
+int launch_render_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
+                      const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
+                      int32_t *n_contrib, float *weight, hipStream_t stream);
+int launch_render_bwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
+                      const float *colors, const float *bg, const float *final_T, const int32_t *n_contrib,
+                      const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream);
+int launch_project_bwd(const envgs_raster_cfg *cfg, const float *geom, const float *means3D, const float *scales,
+                       const float *rotations, const float *shs, const uint8_t *clamped, const float *transmat_precomp,
+                       const int32_t *radii, const float *viewmatrix, const float *projmatrix, const float *campos,
+                       const float *grad_rec, float *dmeans3D, float *dmeans2D, float *dscales, float *drots, float *dshs,
+                       float *dcolors, float *dopacities, float *dtransmat_precomp, hipStream_t stream);
+
+__host__ __device__ inline int tile_bits(int width, int height) {
+    int tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+    int b = 0;
+    while ((1 << b) < tiles) b++;
+    return b < 1 ? 1 : b;
+}
+
+}  // namespace envgs

@@ -1,0 +1,349 @@
+// raster_render.hip -- R6 (front-to-back compositing) and R7 (its back-to-front gradient).
+//
+// CDNA4 mapping: one 256-lane workgroup per 16x16 tile (the reference's binning granularity, so tile /
+// sort indices stay bit-comparable); each of its 4 wavefronts owns one 8x8 pixel quadrant, so a
+// wavefront's 64 lanes stay spatially compact: they agree on "this splat misses us" far more often than
+// a 16x4 strip would.  Per-tile splat lists are staged through LDS in batches of 256 records with
+// coalesced 16 B loads of the 64 B geom record; the inner loop reads each record as an LDS broadcast.
+// Cross-pixel sums (per-surfel weight in R6, the 15+C gradient words in R7) are reduced across the
+// wavefront with DPP row operations (no LDS, no per-lane atomics) and leave the wavefront as ONE
+// global_atomic_add_f32 instruction whose active lanes hit one 128 B gradient record.
+//
+// Stands behind GaussianRasterizer forward/backward (easyvolcap/utils/gaussian2d_utils.py:1089-1099);
+// output channel order: :1119-1144.  Arithmetic: 2DGS ray-splat intersection (Huang et al. 2024), restated
+// in oracle/surfel_raster_oracle.c ("parity unpinned" there).
+#include "common.h"
+
+namespace envgs {
+
+struct Hit {
+    float sx, sy, pz, kx, ky, kz, lx, ly, lz, rho3d, rho2d, dx, dy, depth, G, alpha;
+    bool ok;
+};
+
+// Ray / splat evaluation for pixel (px,py).  rec = the 16-float geom record (wave-uniform).
+__device__ __forceinline__ Hit eval_splat(const float4 r0, const float4 r1, const float4 r2, const float4 r3, float px, float py)
+{
+    Hit h;
+    const float Tux = r0.x, Tuy = r0.y, Tuz = r0.z, Tvx = r0.w, Tvy = r1.x, Tvz = r1.y, Twx = r1.z, Twy = r1.w, Twz = r2.x;
+    const float cx = r2.y, cy = r2.z, opa = r3.z;
+    h.kx = px * Twx - Tux; h.ky = px * Twy - Tuy; h.kz = px * Twz - Tuz;
+    h.lx = py * Twx - Tvx; h.ly = py * Twy - Tvy; h.lz = py * Twz - Tvz;
+    const float ppx = h.ky * h.lz - h.kz * h.ly;
+    const float ppy = h.kz * h.lx - h.kx * h.lz;
+    const float ppz = h.kx * h.ly - h.ky * h.lx;
+    h.pz = ppz;
+    const float inv = __builtin_amdgcn_rcpf(ppz);
+    h.sx = ppx * inv; h.sy = ppy * inv;
+    h.rho3d = h.sx * h.sx + h.sy * h.sy;
+    h.dx = cx - px; h.dy = cy - py;
+    h.rho2d = FILTER_INV_SQ * (h.dx * h.dx + h.dy * h.dy);
+    const bool use3d = h.rho3d <= h.rho2d;
+    const float rho = use3d ? h.rho3d : h.rho2d;
+    h.depth = use3d ? (h.sx * Twx + h.sy * Twy) + Twz : Twz;
+    const float power = -0.5f * rho;
+    h.G = __expf(power);
+    const float a = opa * h.G;
+    h.alpha = a < ALPHA_CAP ? a : ALPHA_CAP;
+    h.ok = (ppz != 0.0f) && (h.depth >= NEAR_N) && (power <= 0.0f) && (h.alpha >= ALPHA_MIN);
+    return h;
+}
+
+template <int C>
+struct TileLds {
+    float4 rec[4][256];
+    float col[C][256];
+    uint32_t id[256];
+};
+
+// ------------------------------------------------------------------------------------------ R6 ---
+template <int C>
+__global__ void __launch_bounds__(256)
+composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+              const float *__restrict__ geom, const float *__restrict__ colors, const float *__restrict__ bg,
+              float *__restrict__ out_color, float *__restrict__ allmap, float *__restrict__ final_T,
+              int32_t *__restrict__ n_contrib, float *__restrict__ weight)
+{
+    __shared__ TileLds<C> lds;
+    const int gx = (W + TILE - 1) / TILE;
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int pxi = tx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int pyi = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float px = (float)pxi, py = (float)pyi;
+    const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+
+    bool done = !inside;
+    float T = 1.0f, Cacc[C], N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f;
+    int32_t last = 0, medc = -1;
+#pragma unroll
+    for (int c = 0; c < C; c++) Cacc[c] = 0.f;
+
+    for (uint32_t base = r0; base < r1; base += 256) {
+        if (__syncthreads_and(done)) break;
+        if (base + tid < r1) {
+            const uint32_t g = point_list[base + tid];
+            const float4 *gp = reinterpret_cast<const float4 *>(geom + (size_t)g * GEOM);
+            lds.id[tid] = g;
+            lds.rec[0][tid] = gp[0]; lds.rec[1][tid] = gp[1]; lds.rec[2][tid] = gp[2]; lds.rec[3][tid] = gp[3];
+#pragma unroll
+            for (int c = 0; c < C; c++) lds.col[c][tid] = colors[(size_t)g * C + c];
+        }
+        __syncthreads();
+        const int count = (int)min(256u, r1 - base);
+        for (int j = 0; j < count; j++) {
+            if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+            const Hit h = eval_splat(lds.rec[0][j], lds.rec[1][j], lds.rec[2][j], lds.rec[3][j], px, py);
+            bool contrib = !done && h.ok;
+            const float test_T = T * (1.0f - h.alpha);
+            const bool stop = contrib && test_T < T_EPS;
+            done = done || stop;
+            contrib = contrib && !stop;
+            float w = 0.f;
+            if (contrib) {
+                const float4 r2 = lds.rec[2][j], r3 = lds.rec[3][j];
+                w = h.alpha * T;
+                const float A = 1.0f - T;
+                const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / h.depth);
+                dist += (m * m * A + M2 - 2.0f * m * M1) * w;
+                D += h.depth * w;
+                M1 += m * w;
+                M2 += m * m * w;
+                const int32_t contributor = (int32_t)(base - r0) + j + 1;
+                if (T > 0.5f) { med = h.depth; medc = contributor; }
+                N0 += r2.w * w; N1 += r3.x * w; N2 += r3.y * w;
+#pragma unroll
+                for (int c = 0; c < C; c++) Cacc[c] += lds.col[c][j] * w;
+                T = test_T;
+                last = contributor;
+            }
+            if (__builtin_amdgcn_ballot_w64(contrib) != 0) {
+                const float ws = wave_sum(w);
+                if (lane == 0) atomic_add_f32(weight + lds.id[j], ws);
+            }
+        }
+    }
+
+    if (inside) {
+        const size_t HW = (size_t)H * W, pid = (size_t)pyi * W + pxi;
+        final_T[pid] = T; final_T[HW + pid] = M1; final_T[2 * HW + pid] = M2;
+        n_contrib[pid] = last; n_contrib[HW + pid] = medc;
+#pragma unroll
+        for (int c = 0; c < C; c++) out_color[c * HW + pid] = Cacc[c] + T * (c < bg_len ? bg[c] : 0.0f);
+        allmap[0 * HW + pid] = D;
+        allmap[1 * HW + pid] = 1.0f - T;
+        allmap[2 * HW + pid] = N0; allmap[3 * HW + pid] = N1; allmap[4 * HW + pid] = N2;
+        allmap[5 * HW + pid] = med;
+        allmap[6 * HW + pid] = dist;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ R7 ---
+template <int C>
+__global__ void __launch_bounds__(256)
+composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+              const float *__restrict__ geom, const float *__restrict__ colors, const float *__restrict__ bg,
+              const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
+              const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap, float *__restrict__ grad_rec)
+{
+    constexpr int V = 15 + C;          // gradient words per surfel
+    __shared__ TileLds<C> lds;
+    __shared__ int s_max_last;
+    const int gx = (W + TILE - 1) / TILE;
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int pxi = tx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int pyi = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const float px = (float)pxi, py = (float)pyi;
+    const uint32_t r0 = ranges[2 * tile];
+    const size_t HW = (size_t)H * W, pid = (size_t)(inside ? pyi : 0) * W + (inside ? pxi : 0);
+
+    const float T_final = inside ? final_T[pid] : 0.f;
+    float T = T_final;
+    const int32_t last = inside ? n_contrib[pid] : 0;
+    const int32_t medc = inside ? n_contrib[HW + pid] : 0;
+    float dpix[C], accum_rec[C], last_color[C];
+    float bg_dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        dpix[c] = inside ? dL_dcolor[c * HW + pid] : 0.f;
+        accum_rec[c] = 0.f; last_color[c] = 0.f;
+        bg_dot += (c < bg_len ? bg[c] : 0.0f) * dpix[c];
+    }
+    const float dL_ddepth = inside ? dL_dallmap[0 * HW + pid] : 0.f;
+    const float dL_daccum = inside ? dL_dallmap[1 * HW + pid] : 0.f;
+    const float dL_dn0 = inside ? dL_dallmap[2 * HW + pid] : 0.f;
+    const float dL_dn1 = inside ? dL_dallmap[3 * HW + pid] : 0.f;
+    const float dL_dn2 = inside ? dL_dallmap[4 * HW + pid] : 0.f;
+    const float dL_dmed = inside ? dL_dallmap[5 * HW + pid] : 0.f;
+    const float dL_dreg = inside ? dL_dallmap[6 * HW + pid] : 0.f;
+    const float final_D = inside ? final_T[HW + pid] : 0.f;
+    const float final_D2 = inside ? final_T[2 * HW + pid] : 0.f;
+    const float final_A = 1.0f - T_final;
+    float last_alpha = 0.f, last_depth = 0.f, ln0 = 0.f, ln1 = 0.f, ln2 = 0.f, accum_depth_rec = 0.f, accum_alpha_rec = 0.f,
+          an0 = 0.f, an1 = 0.f, an2 = 0.f, last_dL_dT = 0.f;
+
+    // Entries behind the deepest last-contributor of this tile were never blended by any pixel: skip them.
+    if (tid == 0) s_max_last = 0;
+    __syncthreads();
+    {
+        int m = last;
+        m = max(m, __shfl_xor(m, 1)); m = max(m, __shfl_xor(m, 2)); m = max(m, __shfl_xor(m, 4));
+        m = max(m, __shfl_xor(m, 8)); m = max(m, __shfl_xor(m, 16)); m = max(m, __shfl_xor(m, 32));
+        if (lane == 0) atomicMax(&s_max_last, m);
+    }
+    __syncthreads();
+    const int max_last = s_max_last;
+
+    for (int top = max_last; top > 0; top -= 256) {
+        // stage entries [top-256, top) in reverse: LDS slot t holds list index top-1-t
+        __syncthreads();
+        if (top - 1 - tid >= 0) {
+            const uint32_t g = point_list[r0 + (uint32_t)(top - 1 - tid)];
+            const float4 *gp = reinterpret_cast<const float4 *>(geom + (size_t)g * GEOM);
+            lds.id[tid] = g;
+            lds.rec[0][tid] = gp[0]; lds.rec[1][tid] = gp[1]; lds.rec[2][tid] = gp[2]; lds.rec[3][tid] = gp[3];
+#pragma unroll
+            for (int c = 0; c < C; c++) lds.col[c][tid] = colors[(size_t)g * C + c];
+        }
+        __syncthreads();
+        const int count = min(256, top);
+        for (int j = 0; j < count; j++) {
+            const int ci = top - 1 - j;                       // 0-based position in the tile list
+            const bool cand = ci < last;
+            if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
+            const float4 q0 = lds.rec[0][j], q1 = lds.rec[1][j], q2 = lds.rec[2][j], q3 = lds.rec[3][j];
+            const Hit h = eval_splat(q0, q1, q2, q3, px, py);
+            const bool act = cand && h.ok;
+            if (__builtin_amdgcn_ballot_w64(act) == 0) continue;
+
+            float gv[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) gv[v] = 0.f;
+            if (act) {
+                const float Twx = q1.z, Twy = q1.w, opa = q3.z;
+                const float nrm0 = q2.w, nrm1 = q3.x, nrm2 = q3.y;
+                const float alpha = h.alpha, G = h.G;
+                T = T / (1.0f - alpha);
+                const float w = alpha * T;
+                float dL_dalpha = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float col = lds.col[c][j];
+                    accum_rec[c] = last_alpha * last_color[c] + (1.f - last_alpha) * accum_rec[c];
+                    last_color[c] = col;
+                    dL_dalpha += (col - accum_rec[c]) * dpix[c];
+                    gv[15 + c] = w * dpix[c];
+                }
+                float dL_dz = 0.f;
+                const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / h.depth);
+                const float dmd_dd = (FAR_N * NEAR_N) / ((FAR_N - NEAR_N) * h.depth * h.depth);
+                if (ci == medc - 1) dL_dz += dL_dmed;
+                const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.0f * m_d * final_D) * dL_dreg;
+                dL_dalpha += dL_dweight - last_dL_dT;
+                last_dL_dT = dL_dweight * alpha + (1.0f - alpha) * last_dL_dT;
+                const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
+                dL_dz += dL_dmd * dmd_dd;
+                accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                last_depth = h.depth;
+                dL_dalpha += (h.depth - accum_depth_rec) * dL_ddepth;
+                accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
+                dL_dalpha += (1.0f - accum_alpha_rec) * dL_daccum;
+                an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = nrm0; dL_dalpha += (nrm0 - an0) * dL_dn0;
+                an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = nrm1; dL_dalpha += (nrm1 - an1) * dL_dn1;
+                an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = nrm2; dL_dalpha += (nrm2 - an2) * dL_dn2;
+                gv[9] = w * dL_dn0; gv[10] = w * dL_dn1; gv[11] = w * dL_dn2;
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                const float dL_dG = opa * dL_dalpha;
+                dL_dz += w * dL_ddepth;
+                if (h.rho3d <= h.rho2d) {
+                    const float dsx = dL_dG * -G * h.sx + dL_dz * Twx;
+                    const float dsy = dL_dG * -G * h.sy + dL_dz * Twy;
+                    const float ipz = __builtin_amdgcn_rcpf(h.pz);
+                    const float dpx = dsx * ipz, dpy = dsy * ipz, dpz = -(dpx * h.sx + dpy * h.sy);
+                    const float dkx = h.ly * dpz - h.lz * dpy, dky = h.lz * dpx - h.lx * dpz, dkz = h.lx * dpy - h.ly * dpx;
+                    const float dlx = dpy * h.kz - dpz * h.ky, dly = dpz * h.kx - dpx * h.kz, dlz = dpx * h.ky - dpy * h.kx;
+                    gv[0] = -dkx; gv[1] = -dky; gv[2] = -dkz;
+                    gv[3] = -dlx; gv[4] = -dly; gv[5] = -dlz;
+                    gv[6] = px * dkx + py * dlx + dL_dz * h.sx;
+                    gv[7] = px * dky + py * dly + dL_dz * h.sy;
+                    gv[8] = px * dkz + py * dlz + dL_dz;
+                } else {
+                    gv[13] = dL_dG * (-G * FILTER_INV_SQ * h.dx);
+                    gv[14] = dL_dG * (-G * FILTER_INV_SQ * h.dy);
+                    gv[8] = dL_dz;
+                }
+                gv[12] = G * dL_dalpha;
+            }
+            // wavefront reduction: lane v ends up owning the sum of word v, then one coalesced atomic
+            float mine = 0.f;
+#pragma unroll
+            for (int v = 0; v < V; v++) { const float sv = wave_sum(gv[v]); mine = (lane == v) ? sv : mine; }
+            if (lane < V) atomic_add_f32(grad_rec + (size_t)lds.id[j] * GREC + lane, mine);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ launchers ---
+template <int C>
+static int run_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
+                   const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
+                   int32_t *n_contrib, float *weight, hipStream_t stream)
+{
+    const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
+    hipLaunchKernelGGL(composite_fwd<C>, dim3(gx * gy), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
+                       point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight);
+    ENVGS_CHECK_LAUNCH(cfg, stream);
+    return 0;
+}
+
+int launch_render_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
+                      const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
+                      int32_t *n_contrib, float *weight, hipStream_t stream)
+{
+    if (cfg->P > 0) {
+        hipError_t e = hipMemsetAsync(weight, 0, sizeof(float) * (size_t)cfg->P, stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    switch (cfg->channels) {
+    case 3: return run_fwd<3>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream);
+    case 5: return run_fwd<5>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream);
+    case 7: return run_fwd<7>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream);
+    default: return ENVGS_ERR_BAD_ARG;
+    }
+}
+
+template <int C>
+static int run_bwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
+                   const float *colors, const float *bg, const float *final_T, const int32_t *n_contrib,
+                   const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream)
+{
+    const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
+    hipLaunchKernelGGL(composite_bwd<C>, dim3(gx * gy), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
+                       point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec);
+    ENVGS_CHECK_LAUNCH(cfg, stream);
+    return 0;
+}
+
+int launch_render_bwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
+                      const float *colors, const float *bg, const float *final_T, const int32_t *n_contrib,
+                      const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream)
+{
+    if (cfg->P <= 0) return 0;
+    hipError_t e = hipMemsetAsync(grad_rec, 0, sizeof(float) * GREC * (size_t)cfg->P, stream);
+    if (e != hipSuccess) return (int)e;
+    switch (cfg->channels) {
+    case 3: return run_bwd<3>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream);
+    case 5: return run_bwd<5>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream);
+    case 7: return run_bwd<7>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream);
+    default: return ENVGS_ERR_BAD_ARG;
+    }
+}
+
+}  // namespace envgs

@@ -1,0 +1,210 @@
+"""Host-side mirror of the reference's surfel rasterizer interface, over the C-ABI of include/envgs_raster.h.
+
+Same names, argument meaning and error behaviour as the packages the reference imports at
+easyvolcap/utils/gaussian2d_utils.py:1013-1015 and calls at :1025-1038 / :1089-1099:
+
+    GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier,
+                                  viewmatrix, projmatrix, sh_degree, campos, prefiltered, debug)
+    GaussianRasterizer(raster_settings)(means3D, means2D, opacities, shs=None, colors_precomp=None,
+                                        scales=None, rotations=None, cov3D_precomp=None)
+        -> rendered_image (C,H,W), radii (P,) int32, allmap (7,H,W), weight (P,1)
+
+The channel count C (3 / 5 / 7) is the only thing that differs between the three packages; it is bound
+by `make_package(C)`.  PyTorch is plumbing here (device memory, streams, autograd graph); every stage
+runs in hand-written HIP.  No fallback: a missing library raises at first use.
+"""
+from typing import NamedTuple
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _stream(dev):
+    return _lib.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _cfg(settings, P, C, sh_coeffs, bg_len):
+    deg = settings.sh_degree
+    deg = int(deg.item()) if torch.is_tensor(deg) else int(deg)
+    return _lib.RasterCfg(P, deg, sh_coeffs, C, int(settings.image_width), int(settings.image_height), bg_len,
+                          1 if settings.debug else 0, float(settings.scale_modifier), float(settings.tanfovx),
+                          float(settings.tanfovy))
+
+
+def rasterize_forward(C, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings,
+                      keep_binning=False):
+    """R1..R6 through the C-ABI.  Returns (outputs, saved-state dict).  All tensors live on means3D.device."""
+    lib = _lib.load()
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("envgs_amd rasterizer needs tensors on the GPU (got %s); there is no CPU path" % dev)
+    P = means3D.shape[0]
+    H, W = int(settings.image_height), int(settings.image_width)
+    means3D = _f32c(means3D); opacities = _f32c(opacities)
+    shs = _f32c(shs); colors_precomp = _f32c(colors_precomp)
+    scales = _f32c(scales); rotations = _f32c(rotations); cov3D_precomp = _f32c(cov3D_precomp)
+    if shs is not None and C != 3:
+        raise RuntimeError("in-kernel SH evaluation produces 3 channels; the %d-channel rasterizer needs colors_precomp" % C)
+    if colors_precomp is not None and colors_precomp.shape[-1] != C:
+        raise RuntimeError("colors_precomp has %d channels, this rasterizer composites %d" % (colors_precomp.shape[-1], C))
+    bg = _f32c(settings.bg).reshape(-1).to(dev)
+    view = _f32c(settings.viewmatrix).to(dev); proj = _f32c(settings.projmatrix).to(dev)
+    campos = _f32c(settings.campos).reshape(-1).to(dev)
+    sh_coeffs = 0 if shs is None else int(shs.shape[1])
+    cfg = _cfg(settings, P, C, sh_coeffs, min(int(bg.numel()), C))
+    stream = _stream(dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+
+    geom = torch.empty(P, 16, **f32)
+    radii = torch.empty(P, **i32)
+    tiles = torch.empty(P, **i32)
+    offsets = torch.empty(P, **i32)
+    rgb = torch.empty(P, 3, **f32) if shs is not None else None
+    clamped = torch.empty(P, 3, dtype=torch.uint8, device=dev) if shs is not None else None
+    scan_bytes = lib.envgs_raster_scan_temp_bytes(P)
+    scan_temp = torch.empty(max(scan_bytes, 1), dtype=torch.uint8, device=dev)
+    n_host = _lib.c_uint32(0)
+    p = _lib.ptr
+    _lib.check(lib.envgs_raster_project(cfg, p(means3D), p(scales), p(rotations), p(opacities), p(shs), p(cov3D_precomp),
+                                        p(view), p(proj), p(campos), p(geom), p(rgb), p(clamped), p(radii), p(tiles),
+                                        p(offsets), p(scan_temp), scan_bytes, n_host, stream), "envgs_raster_project")
+    N = int(n_host.value)
+
+    colors = rgb if shs is not None else colors_precomp
+    tiles_n = ((W + 15) // 16) * ((H + 15) // 16)
+    keys_u = torch.empty(max(N, 1), dtype=torch.int64, device=dev)
+    keys_s = torch.empty(max(N, 1), dtype=torch.int64, device=dev)
+    vals_u = torch.empty(max(N, 1), **i32)
+    point_list = torch.empty(max(N, 1), **i32)
+    sort_bytes = lib.envgs_raster_sort_temp_bytes(max(N, 1), W, H)
+    sort_temp = torch.empty(max(sort_bytes, 1), dtype=torch.uint8, device=dev)
+    ranges = torch.empty(tiles_n, 2, **i32)
+    out_color = torch.empty(C, H, W, **f32)
+    allmap = torch.empty(7, H, W, **f32)
+    final_T = torch.empty(3, H, W, **f32)
+    n_contrib = torch.empty(2, H, W, **i32)
+    weight = torch.empty(P, 1, **f32)
+    _lib.check(lib.envgs_raster_bin_and_render(cfg, N, p(geom), p(radii), p(offsets), p(colors), p(bg), p(keys_u), p(vals_u),
+                                               p(keys_s), p(point_list), p(sort_temp), sort_bytes, p(ranges), p(out_color),
+                                               p(allmap), p(final_T), p(n_contrib), p(weight), stream),
+               "envgs_raster_bin_and_render")
+    saved = dict(cfg=cfg, N=N, geom=geom, colors=colors, bg=bg, point_list=point_list, ranges=ranges, final_T=final_T,
+                 n_contrib=n_contrib, means3D=means3D, scales=scales, rotations=rotations, shs=shs, clamped=clamped,
+                 cov3D_precomp=cov3D_precomp, radii=radii, view=view, proj=proj, campos=campos)
+    if keep_binning:
+        saved.update(tiles_touched=tiles, offsets=offsets, keys_unsorted=keys_u, vals_unsorted=vals_u, keys_sorted=keys_s)
+    return (out_color, radii, allmap, weight), saved
+
+
+def rasterize_backward(saved, dL_dcolor, dL_dallmap):
+    """R7+R8 through the C-ABI.  Returns dict of parameter gradients (None where not applicable)."""
+    lib = _lib.load()
+    cfg = saved["cfg"]
+    P, C = cfg.P, cfg.channels
+    dev = saved["geom"].device
+    f32 = dict(dtype=torch.float32, device=dev)
+    dL_dcolor = _f32c(dL_dcolor); dL_dallmap = _f32c(dL_dallmap)
+    shs, cov = saved["shs"], saved["cov3D_precomp"]
+    grad_rec = torch.empty(P, 32, **f32)
+    dmeans3D = torch.empty(P, 3, **f32)
+    dmeans2D = torch.empty(P, 3, **f32)
+    dopac = torch.empty(P, 1, **f32)
+    dscales = torch.empty(P, 2, **f32) if cov is None else None
+    drots = torch.empty(P, 4, **f32) if cov is None else None
+    dcov = torch.empty(P, 9, **f32) if cov is not None else None
+    dshs = torch.empty_like(shs) if shs is not None else None
+    dcolors = torch.empty(P, C, **f32) if shs is None else None
+    p = _lib.ptr
+    _lib.check(lib.envgs_raster_backward(cfg, saved["N"], p(saved["geom"]), p(saved["colors"]), p(saved["bg"]),
+                                         p(saved["point_list"]), p(saved["ranges"]), p(saved["final_T"]), p(saved["n_contrib"]),
+                                         p(dL_dcolor), p(dL_dallmap), p(saved["means3D"]), p(saved["scales"]), p(saved["rotations"]),
+                                         p(shs), p(saved["clamped"]), p(cov), p(saved["radii"]), p(saved["view"]), p(saved["proj"]),
+                                         p(saved["campos"]), p(grad_rec), p(dmeans3D), p(dmeans2D), p(dscales), p(drots), p(dshs),
+                                         p(dcolors), p(dopac), p(dcov), _stream(dev)), "envgs_raster_backward")
+    return dict(means3D=dmeans3D, means2D=dmeans2D, shs=dshs, colors_precomp=dcolors, opacities=dopac, scales=dscales,
+                rotations=drots, cov3D_precomp=dcov, grad_rec=grad_rec)
+
+
+def make_package(C):
+    """Bind the channel count: returns (GaussianRasterizationSettings, GaussianRasterizer) for one drop-in package."""
+
+    class _RasterizeGaussians(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+            none = lambda t: None if (t is None or t.numel() == 0) else t
+            outs, saved = rasterize_forward(C, means3D, none(sh), none(colors_precomp), opacities, none(scales),
+                                            none(rotations), none(cov3Ds_precomp), raster_settings)
+            ctx.saved = saved
+            ctx.in_dtypes = tuple(None if t is None else t.dtype for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
+            color, radii, allmap, weight = outs
+            ctx.mark_non_differentiable(radii, weight)
+            return color, radii, allmap, weight
+
+        @staticmethod
+        def backward(ctx, grad_color, grad_radii, grad_allmap, grad_weight):
+            saved = ctx.saved
+            cfg = saved["cfg"]
+            dev = saved["geom"].device
+            if grad_color is None: grad_color = torch.zeros(cfg.channels, cfg.height, cfg.width, device=dev)
+            if grad_allmap is None: grad_allmap = torch.zeros(7, cfg.height, cfg.width, device=dev)
+            g = rasterize_backward(saved, grad_color, grad_allmap)
+            outs = (g["means3D"] if saved["cov3D_precomp"] is None or saved["shs"] is not None else None, g["means2D"],
+                    g["shs"], g["colors_precomp"], g["opacities"], g["scales"], g["rotations"], g["cov3D_precomp"])
+            outs = tuple(None if (o is None or dt is None) else o.to(dt) for o, dt in zip(outs, ctx.in_dtypes))
+            return outs + (None,)
+
+    class GaussianRasterizer(nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def markVisible(self, positions):
+            """Frustum test used by some 3DGS-lineage callers: view depth > 0.2."""
+            with torch.no_grad():
+                V = self.raster_settings.viewmatrix.to(positions.device).float()
+                z = positions.float() @ V[:3, 2] + V[3, 2]
+                return z > 0.2
+
+        def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                    cov3D_precomp=None):
+            rs = self.raster_settings
+            if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+                raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+            if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+               ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+                raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+            e = torch.Tensor([])
+            return _RasterizeGaussians.apply(means3D, means2D, e if shs is None else shs,
+                                             e if colors_precomp is None else colors_precomp, opacities,
+                                             e if scales is None else scales, e if rotations is None else rotations,
+                                             e if cov3D_precomp is None else cov3D_precomp, rs)
+
+    GaussianRasterizer.channels = C
+    GaussianRasterizer._function = _RasterizeGaussians
+    return GaussianRasterizationSettings, GaussianRasterizer

@@ -1,0 +1,130 @@
+/*
+ * envgs_raster.h -- C-ABI of the MI355X-native surfel rasterizer (libenvgs_hip.so).
+ *
+ * This is the drop-in boundary for the reference's three pybind/torch extensions
+ *   diff_surfel_rasterization_wet, _wet_ch05, _wet_ch07
+ * whose Python call site is easyvolcap/utils/gaussian2d_utils.py:1025-1038 (settings) and
+ * :1089-1099 (call).  The reference has no C layer of its own to mirror (SURVEY.md section 8b:
+ * "the FFI is pybind inside each package"), so each entry point below names the reference
+ * interface it stands behind.  Plain pointers and sizes only; every pointer is a DEVICE pointer
+ * (HBM) unless its name ends in _host.  `stream` is a hipStream_t passed as void*.
+ * All functions return 0 on success, or a negative envgs_status / positive hipError_t.
+ *
+ * Memory is owned by the caller (torch allocates it; the library never calls hipMalloc), so the
+ * same buffers can be reused across calls and P / image size may change from call to call
+ * (densification re-allocates every parameter: SURVEY.md section 3.6).
+ *
+ * HBM layouts (fp32 unless noted):
+ *   geom      (P,16)  per-surfel record, 64 B aligned:
+ *                     [0..2] Tu  [3..5] Tv  [6..8] Tw   (transMat rows: coefficients of u, v, 1)
+ *                     [9..10] screen centre x,y  [11..13] view-space normal (camera facing)
+ *                     [14] opacity  [15] view depth (sort key)
+ *   colors    (P,C)   the caller's colors_precomp, or `rgb` (P,3) produced from SH by _project
+ *   grad_rec  (P,32)  per-surfel gradient record, 128 B aligned, accumulated by _backward:
+ *                     [0..8] dL/dtransMat  [9..11] dL/dnormal  [12] dL/dopacity  [13..14] dL/dmean2D
+ *                     [15..15+C) dL/dcolour
+ *   final_T   (3,H,W) T, M1, M2      n_contrib (2,H,W) int32: last contributor, median contributor
+ *   allmap    (7,H,W) 0 depth, 1 alpha, 2-4 normal, 5 median depth, 6 distortion
+ *                     (order read by gaussian2d_utils.py:1119-1144)
+ */
+#ifndef ENVGS_RASTER_H
+#define ENVGS_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define ENVGS_API __attribute__((visibility("default")))
+#else
+#define ENVGS_API
+#endif
+
+#define ENVGS_TILE 16
+#define ENVGS_GEOM_STRIDE 16
+#define ENVGS_GRAD_STRIDE 32
+
+typedef enum envgs_status {
+    ENVGS_OK = 0,
+    ENVGS_ERR_BAD_ARG = -1,      /* unsupported channel count / SH degree / null pointer */
+    ENVGS_ERR_TEMP_TOO_SMALL = -2
+} envgs_status;
+
+/* Mirrors GaussianRasterizationSettings (gaussian2d_utils.py:1025-1038) minus the tensors. */
+typedef struct envgs_raster_cfg {
+    int32_t P;              /* number of surfels */
+    int32_t sh_degree;      /* active degree 0..3 (settings.sh_degree) */
+    int32_t sh_coeffs;      /* coefficients stored per surfel, shs is (P, sh_coeffs, 3); 0 if colours are precomputed */
+    int32_t channels;       /* 3 (-wet) / 5 (-wet-ch05) / 7 (-wet-ch07) */
+    int32_t width, height;  /* settings.image_width / image_height */
+    int32_t bg_len;         /* entries in bg; channels >= bg_len composite against 0 */
+    int32_t debug;          /* settings.debug: synchronise + check after every kernel */
+    float scale_modifier;   /* settings.scale_modifier */
+    float tanfovx, tanfovy; /* carried for API completeness; the projection uses projmatrix */
+} envgs_raster_cfg;
+
+/* Bytes of scratch the prefix sum over P counters and the pair sort over N tile instances need. */
+ENVGS_API size_t envgs_raster_scan_temp_bytes(int32_t P);
+ENVGS_API size_t envgs_raster_sort_temp_bytes(uint32_t N, int32_t width, int32_t height);
+
+/*
+ * Stage R1+R2 (GaussianRasterizer.forward, first half): per-surfel projection + Jacobian (transMat),
+ * view normal, 3-sigma AABB -> radius / tile rect, SH -> RGB; then the inclusive scan of tiles_touched.
+ * Exactly one of (scales, rotations) / transmat_precomp and one of shs / colours is used:
+ *   shs == NULL  -> colours are the caller's colors_precomp (not touched here)
+ *   shs != NULL  -> rgb (P,3) and clamped (P,3) uint8 are written
+ * Writes the number of tile instances N to *num_rendered_host after synchronising `stream`
+ * (the caller sizes the binning buffers with it).
+ */
+ENVGS_API int envgs_raster_project(const envgs_raster_cfg *cfg,
+                         const float *means3D, const float *scales, const float *rotations,
+                         const float *opacities, const float *shs, const float *transmat_precomp,
+                         const float *viewmatrix, const float *projmatrix, const float *campos,
+                         float *geom, float *rgb, uint8_t *clamped, int32_t *radii,
+                         uint32_t *tiles_touched, uint32_t *offsets,
+                         void *scan_temp, size_t scan_temp_bytes,
+                         uint32_t *num_rendered_host, void *stream);
+
+/*
+ * Stages R3-R6 (GaussianRasterizer.forward, second half): key emit (tile id << 32 | depth bits),
+ * stable radix sort, per-tile ranges, front-to-back compositing of `channels` colours + the 7 allmap
+ * channels + the per-surfel accumulated weight (the "-wet" output, gaussian2d_utils.py:1090,1114).
+ * keys_sorted / point_list / ranges are outputs the backward pass (and the parity tests) read.
+ */
+ENVGS_API int envgs_raster_bin_and_render(const envgs_raster_cfg *cfg, uint32_t N,
+                                const float *geom, const int32_t *radii, const uint32_t *offsets,
+                                const float *colors, const float *bg,
+                                uint64_t *keys_unsorted, uint32_t *vals_unsorted,
+                                uint64_t *keys_sorted, uint32_t *point_list,
+                                void *sort_temp, size_t sort_temp_bytes, uint32_t *ranges,
+                                float *out_color, float *allmap, float *final_T, int32_t *n_contrib,
+                                float *weight, void *stream);
+
+/*
+ * Stages R7+R8 (GaussianRasterizer backward): back-to-front gradient of the compositing, reduced per
+ * wavefront into grad_rec, then chained to the parameters.  Output pointers that do not apply may be NULL:
+ *   dshs (P,sh_coeffs,3) when shs != NULL, else dcolors (P,C);
+ *   dscales/drots/dmeans3D when transmat_precomp == NULL, else dtransmat_precomp (P,9).
+ * dmeans2D (P,3) receives the densification proxy read by gaussian2d_utils.py:901-909.
+ */
+ENVGS_API int envgs_raster_backward(const envgs_raster_cfg *cfg, uint32_t N,
+                          const float *geom, const float *colors, const float *bg,
+                          const uint32_t *point_list, const uint32_t *ranges,
+                          const float *final_T, const int32_t *n_contrib,
+                          const float *dL_dcolor, const float *dL_dallmap,
+                          const float *means3D, const float *scales, const float *rotations,
+                          const float *shs, const uint8_t *clamped, const float *transmat_precomp,
+                          const int32_t *radii,
+                          const float *viewmatrix, const float *projmatrix, const float *campos,
+                          float *grad_rec,
+                          float *dmeans3D, float *dmeans2D, float *dscales, float *drots,
+                          float *dshs, float *dcolors, float *dopacities, float *dtransmat_precomp,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENVGS_RASTER_H */
