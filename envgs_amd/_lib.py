@@ -35,6 +35,9 @@ SYMBOLS = {
     "envgs_raster_project": (c_int, [ctypes.POINTER(RasterCfg)] + [_P] * 15 + [_P, c_size_t, ctypes.POINTER(c_uint32), _P]),
     "envgs_raster_bin_and_render": (c_int, [ctypes.POINTER(RasterCfg), c_uint32] + [_P] * 9 + [_P, c_size_t] + [_P] * 6 + [_P]),
     "envgs_raster_backward": (c_int, [ctypes.POINTER(RasterCfg), c_uint32] + [_P] * 28 + [_P]),
+    "envgs_prof_enable": (None, [c_int]),
+    "envgs_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
+    "envgs_prof_kernel_name": (ctypes.c_char_p, [c_int]),
 }
 
 

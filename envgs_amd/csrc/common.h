@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/envgs_raster.h"
+#include "prof.h"
 
 namespace envgs {
 

@@ -1,0 +1,18 @@
+// prof.h -- optional per-kernel HIP-event timing on the launch stream (used by bench.py's roofline leg).
+// Disabled by default: zero events are created unless envgs_prof_enable(1) was called.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace envgs {
+enum KernelId {
+    K_PROJECT = 0, K_SCAN, K_EMIT_KEYS, K_SORT, K_RANGES, K_COMPOSITE_FWD, K_COMPOSITE_BWD, K_PROJECT_BWD,
+    K_BVH_BUILD, K_TRACE_FWD, K_TRACE_BWD, K_COUNT
+};
+void prof_begin(int id, hipStream_t stream);
+void prof_end(int id, hipStream_t stream);
+struct ProfScope {
+    int id; hipStream_t s;
+    ProfScope(int id_, hipStream_t s_) : id(id_), s(s_) { prof_begin(id, s); }
+    ~ProfScope() { prof_end(id, s); }
+};
+}  // namespace envgs

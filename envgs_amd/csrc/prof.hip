@@ -1,0 +1,85 @@
+// prof.hip -- HIP-event kernel timers behind envgs_prof_* (include/envgs_raster.h).
+#include "prof.h"
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/envgs_raster.h"
+
+namespace envgs {
+namespace {
+struct Pair { hipEvent_t a, b; };
+bool g_on = false;
+std::mutex g_mu;
+std::vector<Pair> g_open[K_COUNT];       // recorded, not yet read
+std::vector<Pair> g_pool;                // recycled events
+hipEvent_t g_cur[K_COUNT];
+bool g_has_cur[K_COUNT];
+
+Pair get_pair()
+{
+    if (!g_pool.empty()) { Pair p = g_pool.back(); g_pool.pop_back(); return p; }
+    Pair p;
+    (void)hipEventCreate(&p.a);
+    (void)hipEventCreate(&p.b);
+    return p;
+}
+}  // namespace
+
+void prof_begin(int id, hipStream_t stream)
+{
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Pair p = get_pair();
+    (void)hipEventRecord(p.a, stream);
+    g_open[id].push_back(p);
+    g_has_cur[id] = true;
+}
+
+void prof_end(int id, hipStream_t stream)
+{
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_has_cur[id] || g_open[id].empty()) return;
+    (void)hipEventRecord(g_open[id].back().b, stream);
+    g_has_cur[id] = false;
+}
+}  // namespace envgs
+
+using namespace envgs;
+
+extern "C" {
+
+void envgs_prof_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+}
+
+int envgs_prof_read(int kernel_id, double *total_ms, int *launches)
+{
+    if (kernel_id < 0 || kernel_id >= K_COUNT || !total_ms || !launches) return ENVGS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    double tot = 0.0;
+    int n = 0;
+    for (Pair &p : g_open[kernel_id]) {
+        if (hipEventSynchronize(p.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { tot += ms; n++; }
+        g_pool.push_back(p);
+    }
+    g_open[kernel_id].clear();
+    *total_ms = tot;
+    *launches = n;
+    return 0;
+}
+
+const char *envgs_prof_kernel_name(int kernel_id)
+{
+    static const char *names[K_COUNT] = {"project_surfels", "scan_tiles_touched", "emit_tile_keys", "radix_sort_pairs",
+                                         "find_tile_ranges", "composite_fwd", "composite_bwd", "project_surfels_bwd",
+                                         "bvh_build", "trace_fwd", "trace_bwd"};
+    return (kernel_id >= 0 && kernel_id < K_COUNT) ? names[kernel_id] : "";
+}
+
+}  // extern "C"

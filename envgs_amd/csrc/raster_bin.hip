@@ -22,6 +22,7 @@ size_t scan_temp_bytes(int n)
 int launch_scan(const uint32_t *in, uint32_t *out, int n, void *temp, size_t temp_bytes, hipStream_t stream)
 {
     if (n <= 0) return 0;
+    ProfScope prof_(K_SCAN, stream);
     hipError_t e = rocprim::inclusive_scan(temp, temp_bytes, in, out, (size_t)n, rocprim::plus<uint32_t>(), stream);
     return (int)e;
 }
@@ -80,14 +81,19 @@ int launch_bin(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const
     hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)gx * gy, stream);
     if (e != hipSuccess) return (int)e;
     if (N == 0 || cfg->P <= 0) return 0;
+    prof_begin(K_EMIT_KEYS, stream);
     hipLaunchKernelGGL(emit_tile_keys, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, cfg->width, cfg->height,
                        geom, radii, offsets, keys_unsorted, vals_unsorted);
     ENVGS_CHECK_LAUNCH(cfg, stream);
+    prof_end(K_EMIT_KEYS, stream);
     const int end_bit = 32 + tile_bits(cfg->width, cfg->height);
+    prof_begin(K_SORT, stream);
     size_t need = sort_temp_bytes;
     e = rocprim::radix_sort_pairs(sort_temp, need, keys_unsorted, keys_sorted, vals_unsorted, point_list, (size_t)N, 0u,
                                   (unsigned)end_bit, stream);
+    prof_end(K_SORT, stream);
     if (e != hipSuccess) return (int)e;
+    ProfScope prof_(K_RANGES, stream);
     hipLaunchKernelGGL(find_tile_ranges, dim3((N + 255) / 256), dim3(256), 0, stream, N, keys_sorted, ranges);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;

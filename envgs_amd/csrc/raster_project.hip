@@ -156,6 +156,7 @@ int launch_project(const envgs_raster_cfg *cfg, const float *means3D, const floa
     const int P = cfg->P;
     if (P <= 0) return 0;
     const int blocks = (P + 255) / 256;
+    ProfScope prof_(K_PROJECT, stream);
     hipLaunchKernelGGL(project_surfels, dim3(blocks), dim3(256), 0, stream, P, cfg->sh_degree, cfg->sh_coeffs,
                        cfg->channels, cfg->width, cfg->height, cfg->scale_modifier, means3D, scales, rotations,
                        opacities, shs, transmat_precomp, viewmatrix, projmatrix, campos, geom, rgb, clamped, radii,

@@ -202,6 +202,7 @@ int launch_project_bwd(const envgs_raster_cfg *cfg, const float *geom, const flo
 {
     const int P = cfg->P;
     if (P <= 0) return 0;
+    ProfScope prof_(K_PROJECT_BWD, stream);
     hipLaunchKernelGGL(project_surfels_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, cfg->sh_degree, cfg->sh_coeffs,
                        cfg->channels, cfg->width, cfg->height, cfg->scale_modifier, geom, means3D, scales, rotations, shs,
                        clamped, transmat_precomp, radii, viewmatrix, projmatrix, campos, grad_rec, dmeans3D, dmeans2D,

@@ -297,6 +297,7 @@ static int run_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const ui
                    int32_t *n_contrib, float *weight, hipStream_t stream)
 {
     const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
+    ProfScope prof_(K_COMPOSITE_FWD, stream);
     hipLaunchKernelGGL(composite_fwd<C>, dim3(gx * gy), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
                        point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight);
     ENVGS_CHECK_LAUNCH(cfg, stream);
@@ -325,6 +326,7 @@ static int run_bwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const ui
                    const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream)
 {
     const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
+    ProfScope prof_(K_COMPOSITE_BWD, stream);
     hipLaunchKernelGGL(composite_bwd<C>, dim3(gx * gy), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
                        point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec);
     ENVGS_CHECK_LAUNCH(cfg, stream);

@@ -21,6 +21,9 @@ from torch import nn
 from . import _lib
 
 
+LAST_STATS = {}     # N (tile instances) etc. of the most recent forward; read by bench.py for the roofline figures
+
+
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
     image_width: int
@@ -95,6 +98,7 @@ def rasterize_forward(C, means3D, shs, colors_precomp, opacities, scales, rotati
                                         p(view), p(proj), p(campos), p(geom), p(rgb), p(clamped), p(radii), p(tiles),
                                         p(offsets), p(scan_temp), scan_bytes, n_host, stream), "envgs_raster_project")
     N = int(n_host.value)
+    LAST_STATS.update(N=N, P=P, H=H, W=W, C=C)
 
     colors = rgb if shs is not None else colors_precomp
     tiles_n = ((W + 15) // 16) * ((H + 15) // 16)

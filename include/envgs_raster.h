@@ -124,6 +124,18 @@ ENVGS_API int envgs_raster_backward(const envgs_raster_cfg *cfg, uint32_t N,
                           float *dshs, float *dcolors, float *dopacities, float *dtransmat_precomp,
                           void *stream);
 
+/*
+ * Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg; the
+ * reference's counterpart is its `timer.record` sections, easyvolcap/utils/console_utils.py:615-693).
+ * kernel_id: 0 project_surfels, 1 scan, 2 emit_tile_keys, 3 radix_sort_pairs, 4 find_tile_ranges,
+ *            5 composite_fwd, 6 composite_bwd, 7 project_surfels_bwd, 8 bvh_build, 9 trace_fwd, 10 trace_bwd.
+ * envgs_prof_read synchronises on the recorded events, returns the summed milliseconds and launch count
+ * since the last read, and resets the counter.
+ */
+ENVGS_API void envgs_prof_enable(int on);
+ENVGS_API int envgs_prof_read(int kernel_id, double *total_ms, int *launches);
+ENVGS_API const char *envgs_prof_kernel_name(int kernel_id);
+
 #ifdef __cplusplus
 }
 #endif

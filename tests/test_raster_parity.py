@@ -194,3 +194,55 @@ def test_edge_cases():
     with torch.inference_mode():
         color2, *_ = R(means3D=g["means3D"].to(dev), **args)
     assert torch.isfinite(color2).all()
+
+
+def test_full_size_baseline_config_vs_oracle():
+    """BASELINE configs[1] at full size: 300 k surfels, 800x800, SH degree 3 -- forward indices bit-exact,
+    pixels and gradients within tolerance, plus size-independent properties (sortedness, range partition)."""
+    from envgs_amd import raster, synth
+    from oracle import raster as orc
+    import diff_surfel_rasterization_wet as mod
+    dev = torch.device("cuda:0")
+    P, H, W = 300000, 800, 800
+    g = synth.base_gaussians(P, seed=0)
+    cam = synth.orbit_camera(3, H=H, W=W)
+    bg = torch.ones(3)
+    st = _settings(mod, cam, bg, 3, dev)
+    gd = {k: v.to(dev) for k, v in g.items()}
+    outs, saved = raster.rasterize_forward(3, gd["means3D"], gd["shs"], None, gd["opacities"], gd["scales"], gd["rotations"],
+                                           None, st, keep_binning=True)
+    gen = torch.Generator().manual_seed(1)
+    dcol = torch.randn(3, H, W, generator=gen) / (H * W)
+    dall = torch.randn(7, H, W, generator=gen) / (H * W)
+    grads = raster.rasterize_backward(saved, dcol.to(dev), dall.to(dev))
+    torch.cuda.synchronize()
+    N = saved["N"]
+    # properties that need no oracle: keys sorted, ranges partition [0,N), every list entry is a visible surfel
+    ks = saved["keys_sorted"].cpu().numpy().view(np.uint64)[:N]
+    assert np.all(ks[1:] >= ks[:-1])
+    r = saved["ranges"].cpu().numpy().view(np.uint32).astype(np.int64)
+    assert int((r[:, 1] - r[:, 0]).sum()) == N
+    pl = saved["point_list"].cpu().numpy().view(np.uint32)[:N]
+    rad = saved["radii"].cpu().numpy()
+    assert np.all(rad[pl] > 0)
+    assert int(saved["tiles_touched"].cpu().numpy().view(np.uint32).astype(np.int64).sum()) == N
+
+    ca = cam_args(cam)
+    ref = orc.raster_forward(g["means3D"].numpy(), g["opacities"].numpy(), ca["viewmatrix"].numpy(), ca["projmatrix"].numpy(),
+                             ca["campos"].numpy(), W, H, scales=g["scales"].numpy(), rotations=g["rotations"].numpy(),
+                             shs=g["shs"].numpy(), sh_degree=3, bg=bg.numpy())
+    assert ref["N"] == N
+    np.testing.assert_array_equal(rad, ref["radii"])
+    np.testing.assert_array_equal(pl, ref["point_list"])
+    np.testing.assert_array_equal(r.astype(np.uint32), ref["ranges"])
+    color, _, allmap, weight = [o.cpu().numpy() for o in outs]
+    assert rel_err(color, ref["out_color"]) < PIX_TOL
+    for ch in (0, 1, 2, 3, 4):
+        assert rel_err(allmap[ch], ref["allmap"][ch]) < PIX_TOL, ch
+    assert (saved["n_contrib"].cpu().numpy()[0] != ref["n_contrib"][0]).mean() < 2e-3
+    assert rel_err(weight[:, 0], ref["weight"]) < PIX_TOL
+    rb = orc.raster_backward(ref, dcol.numpy(), dall.numpy())
+    for k_hip, k_ref in (("means3D", "dmeans3D"), ("scales", "dscales"), ("rotations", "drots"), ("opacities", "dopacities"),
+                         ("shs", "dshs"), ("means2D", "dmeans2D")):
+        a = grads[k_hip].cpu().numpy().reshape(rb[k_ref].shape)
+        assert rel_err(a, rb[k_ref]) < 1e-3, k_hip
