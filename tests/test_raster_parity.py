@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import small_scene, cam_args, rel_err
+from tests.util import small_scene, cam_args, rel_err, assert_close_frac
 
 pytestmark = pytest.mark.gpu
 
@@ -236,13 +236,13 @@ def test_full_size_baseline_config_vs_oracle():
     np.testing.assert_array_equal(pl, ref["point_list"])
     np.testing.assert_array_equal(r.astype(np.uint32), ref["ranges"])
     color, _, allmap, weight = [o.cpu().numpy() for o in outs]
-    assert rel_err(color, ref["out_color"]) < PIX_TOL
+    assert_close_frac(color, ref["out_color"], PIX_TOL, flip_bound=0.02, what="color")
     for ch in (0, 1, 2, 3, 4):
-        assert rel_err(allmap[ch], ref["allmap"][ch]) < PIX_TOL, ch
-    assert (saved["n_contrib"].cpu().numpy()[0] != ref["n_contrib"][0]).mean() < 2e-3
-    assert rel_err(weight[:, 0], ref["weight"]) < PIX_TOL
+        assert_close_frac(allmap[ch], ref["allmap"][ch], PIX_TOL, flip_bound=0.02, what="allmap%d" % ch)
+    assert (saved["n_contrib"].cpu().numpy()[0] != ref["n_contrib"][0]).mean() < 1e-4
+    assert_close_frac(weight[:, 0], ref["weight"], PIX_TOL, flip_bound=0.02, what="weight")
     rb = orc.raster_backward(ref, dcol.numpy(), dall.numpy())
     for k_hip, k_ref in (("means3D", "dmeans3D"), ("scales", "dscales"), ("rotations", "drots"), ("opacities", "dopacities"),
                          ("shs", "dshs"), ("means2D", "dmeans2D")):
         a = grads[k_hip].cpu().numpy().reshape(rb[k_ref].shape)
-        assert rel_err(a, rb[k_ref]) < 1e-3, k_hip
+        assert_close_frac(a, rb[k_ref], 2e-4, max_bad_frac=1e-4, flip_bound=0.05, what=k_hip)

@@ -29,3 +29,19 @@ def npy(d):
 def rel_err(a, b, eps=1e-8):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + eps))
+
+
+def assert_close_frac(a, b, tol, max_bad_frac=1e-4, flip_bound=None, what=""):
+    """|a-b| <= tol * max|b| everywhere except a vanishing fraction of elements.
+
+    The compositing has hard thresholds (alpha >= 1/255, T*(1-alpha) < 1e-4, T > 0.5, rho3d <= rho2d).  At the
+    BASELINE size ~3e8 (pixel, splat) evaluations are made, and a handful land inside the fp noise between the
+    GPU's v_exp_f32 / v_rcp_f32 and glibc's expf / IEEE division, flipping one splat in one pixel (an O(1/255)
+    change).  Those are not kernel errors; they are bounded in count (max_bad_frac) and size (flip_bound)."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    scale = np.abs(b).max() + 1e-12
+    err = np.abs(a - b) / scale
+    bad = err > tol
+    assert bad.mean() <= max_bad_frac, "%s: %.3g of elements beyond %.1e (max %.3g)" % (what, bad.mean(), tol, err.max())
+    if flip_bound is not None:
+        assert err.max() <= flip_bound, "%s: max rel err %.3g > flip bound %.3g" % (what, err.max(), flip_bound)
