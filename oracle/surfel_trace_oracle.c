@@ -1,0 +1,430 @@
+/*
+ * surfel_trace_oracle.c -- CPU restatement (brute force, no acceleration structure) of the
+ * differentiable surfel ray tracer EnvGS calls through `diff_surfel_tracing`.
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+ *
+ * PARITY STATUS: "parity unpinned".  The CUDA/OptiX sources of diff-surfel-tracing are NOT in
+ * /root/reference (empty submodule).  What IS in tree, and is followed here:
+ *   - call boundary, argument and output layout : easyvolcap/utils/optix_utils.py:104-119,188-201
+ *   - proxy geometry = 3-sigma quad in the tangent plane (uv in [-3,3]^2) : optix_utils.py:39-69 (get_disks)
+ *   - per-bounce `mid` layout (16 ch: rayo 0:3, rayd 3:6, dpt 6, acc 7, norm 8:11, aux 11:13, rgb 13:16) : optix_utils.py:30-37
+ *   - near plane 0.2 for camera rays : optix_utils.py:212
+ *   - SH basis : easyvolcap/utils/sh_utils.py:642-727 ; colour = clamp_min(SH + 0.5, 0) : optix_utils.py:168-169
+ *   - un-normalised ray directions ("must be in z_depth") : optix_utils.py:124-127 -> t is in units of |d|
+ * The body (ray/plane intersection in the surfel's uv frame, alpha rule, thresholds, front-to-back
+ * compositing) follows the 3DGRT / 2DGS published algorithms with the SAME constants as the rasterizer
+ * oracle (alpha = min(0.99, o*exp(-(u^2+v^2)/2)), skip alpha < 1/255, stop when T*(1-alpha) < 1e-4).
+ * Definitions this project had to choose (DESIGN.md section "tracer semantics"):
+ *   - hits are ordered by (t, surfel id); only hits inside the 3-sigma quad count (that is what the triangle
+ *     proxy of the reference can report);
+ *   - SH is evaluated along the normalised ray direction;
+ *   - normals are flipped to face the ray (n.d < 0), world space;
+ *   - dpt = sum w*t (not divided by acc), rgb = sum w*c + T*bg, aux = sum w*others;
+ *   - start_from_first: t_min = 0.2 (camera rays) else t > 0;
+ *   - grads3D.grad (densification signal) = dL/dmeans3D;
+ *   - bounces (max_trace_depth > 0): stage k+1 starts at o + d*dpt_k/acc_k along d - 2(d.n)n with n = normalised
+ *     accumulated normal, is traced when aux[0] (specular) > specular_threshold and acc_k > 0.5; stage radiance is
+ *     blended rgb_k <- (1-s_k)*rgb_k + s_k*rgb_{k+1}; secondary rays are DETACHED (gradients only through stage 0).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NEAR_N 0.2f
+#define FAR_N 100.0f
+#define ALPHA_CAP 0.99f
+#define ALPHA_MIN (1.0f / 255.0f)
+#define T_EPS 0.0001f
+#define UV_MAX 3.0f
+#define MID_CH 16
+
+static const float SH_C0 = 0.28209479177387814f;
+static const float SH_C1 = 0.4886025119029199f;
+static const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                               -1.0925484305920792f, 0.5462742152960396f};
+static const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                               0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                               -0.5900435899266435f};
+
+typedef struct {
+    int P, R;             /* surfels, rays */
+    int D, M;             /* active SH degree, stored coefficients (0 => colors_precomp) */
+    int max_trace_depth;
+    int start_from_first;
+    int has_others;
+    int bg_len;
+    float scale_modifier;
+    float specular_threshold;
+} trc_cfg;
+
+typedef struct { float a[3], b[3], n[3], mu[3], su, sv, opa; } surfel_t;
+
+static void make_surfel(const trc_cfg *cfg, int i, const float *means, const float *scales, const float *rots,
+                        const float *opac, surfel_t *s)
+{
+    const float *q = rots + 4 * i;
+    float nn = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    float inv = 1.0f / nn;
+    float r = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+    s->a[0] = 1.f - 2.f * (y * y + z * z); s->a[1] = 2.f * (x * y + r * z); s->a[2] = 2.f * (x * z - r * y);
+    s->b[0] = 2.f * (x * y - r * z); s->b[1] = 1.f - 2.f * (x * x + z * z); s->b[2] = 2.f * (y * z + r * x);
+    s->n[0] = 2.f * (x * z + r * y); s->n[1] = 2.f * (y * z - r * x); s->n[2] = 1.f - 2.f * (x * x + y * y);
+    s->mu[0] = means[3 * i]; s->mu[1] = means[3 * i + 1]; s->mu[2] = means[3 * i + 2];
+    s->su = scales[2 * i] * cfg->scale_modifier; s->sv = scales[2 * i + 1] * cfg->scale_modifier;
+    s->opa = opac[i];
+}
+
+typedef struct { float t, u, v, G, alpha, denom; } rhit_t;
+
+/* ray / surfel: returns 1 when the hit counts (inside the 3-sigma quad, alpha >= 1/255, t > tmin) */
+static int hit_surfel(const surfel_t *s, const float *o, const float *d, float tmin, rhit_t *h)
+{
+    float denom = s->n[0] * d[0] + s->n[1] * d[1] + s->n[2] * d[2];
+    if (denom == 0.0f) return 0;
+    float num = s->n[0] * (s->mu[0] - o[0]) + s->n[1] * (s->mu[1] - o[1]) + s->n[2] * (s->mu[2] - o[2]);
+    float t = num / denom;
+    if (!(t > tmin)) return 0;
+    float qx = o[0] + t * d[0] - s->mu[0], qy = o[1] + t * d[1] - s->mu[1], qz = o[2] + t * d[2] - s->mu[2];
+    float u = (s->a[0] * qx + s->a[1] * qy + s->a[2] * qz) / s->su;
+    float v = (s->b[0] * qx + s->b[1] * qy + s->b[2] * qz) / s->sv;
+    if (!(fabsf(u) <= UV_MAX && fabsf(v) <= UV_MAX)) return 0;
+    float G = expf(-0.5f * (u * u + v * v));
+    float a = s->opa * G;
+    float alpha = a < ALPHA_CAP ? a : ALPHA_CAP;
+    if (alpha < ALPHA_MIN) return 0;
+    h->t = t; h->u = u; h->v = v; h->G = G; h->alpha = alpha; h->denom = denom;
+    return 1;
+}
+
+static void sh_basis(int D, const float *dir, float basis[16])
+{
+    float x = dir[0], y = dir[1], z = dir[2];
+    basis[0] = SH_C0;
+    if (D > 0) {
+        basis[1] = -SH_C1 * y; basis[2] = SH_C1 * z; basis[3] = -SH_C1 * x;
+        if (D > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            basis[4] = SH_C2[0] * xy; basis[5] = SH_C2[1] * yz; basis[6] = SH_C2[2] * (2.0f * zz - xx - yy);
+            basis[7] = SH_C2[3] * xz; basis[8] = SH_C2[4] * (xx - yy);
+            if (D > 2) {
+                basis[9] = SH_C3[0] * y * (3.0f * xx - yy); basis[10] = SH_C3[1] * xy * z;
+                basis[11] = SH_C3[2] * y * (4.0f * zz - xx - yy); basis[12] = SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                basis[13] = SH_C3[4] * x * (4.0f * zz - xx - yy); basis[14] = SH_C3[5] * z * (xx - yy);
+                basis[15] = SH_C3[6] * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+}
+
+/* d basis / d dir (for the SH view-direction gradient) */
+static void sh_basis_grad(int D, const float *dir, float gx[16], float gy[16], float gz[16])
+{
+    float x = dir[0], y = dir[1], z = dir[2];
+    for (int k = 0; k < 16; k++) { gx[k] = gy[k] = gz[k] = 0.f; }
+    if (D > 0) {
+        gy[1] = -SH_C1; gz[2] = SH_C1; gx[3] = -SH_C1;
+        if (D > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            gx[4] = SH_C2[0] * y; gy[4] = SH_C2[0] * x;
+            gy[5] = SH_C2[1] * z; gz[5] = SH_C2[1] * y;
+            gx[6] = SH_C2[2] * -2.f * x; gy[6] = SH_C2[2] * -2.f * y; gz[6] = SH_C2[2] * 4.f * z;
+            gx[7] = SH_C2[3] * z; gz[7] = SH_C2[3] * x;
+            gx[8] = SH_C2[4] * 2.f * x; gy[8] = SH_C2[4] * -2.f * y;
+            if (D > 2) {
+                gx[9] = SH_C3[0] * 6.f * xy; gy[9] = SH_C3[0] * 3.f * (xx - yy);
+                gx[10] = SH_C3[1] * yz; gy[10] = SH_C3[1] * xz; gz[10] = SH_C3[1] * xy;
+                gx[11] = SH_C3[2] * -2.f * xy; gy[11] = SH_C3[2] * (4.f * zz - xx - 3.f * yy); gz[11] = SH_C3[2] * 8.f * yz;
+                gx[12] = SH_C3[3] * -6.f * xz; gy[12] = SH_C3[3] * -6.f * yz; gz[12] = SH_C3[3] * 3.f * (2.f * zz - xx - yy);
+                gx[13] = SH_C3[4] * (4.f * zz - 3.f * xx - yy); gy[13] = SH_C3[4] * -2.f * xy; gz[13] = SH_C3[4] * 8.f * xz;
+                gx[14] = SH_C3[5] * 2.f * xz; gy[14] = SH_C3[5] * -2.f * yz; gz[14] = SH_C3[5] * (xx - yy);
+                gx[15] = SH_C3[6] * 3.f * (xx - yy); gy[15] = SH_C3[6] * -6.f * xy;
+            }
+        }
+    }
+}
+
+static void surfel_color(const trc_cfg *cfg, int g, const float *shs, const float *colors_precomp, const float basis[16],
+                         float col[3], int clampd[3])
+{
+    if (cfg->M > 0) {
+        const float *sh = shs + (size_t)g * cfg->M * 3;
+        int nb = (cfg->D + 1) * (cfg->D + 1);
+        for (int c = 0; c < 3; c++) {
+            float r = 0.f;
+            for (int k = 0; k < nb; k++) r += basis[k] * sh[k * 3 + c];
+            r += 0.5f;
+            clampd[c] = r < 0.f;
+            col[c] = r < 0.f ? 0.f : r;
+        }
+    } else {
+        for (int c = 0; c < 3; c++) { col[c] = colors_precomp[3 * g + c]; clampd[c] = 0; }
+    }
+}
+
+typedef struct { float t; int id; rhit_t h; } ent_t;
+static int ent_cmp(const void *a, const void *b)
+{
+    const ent_t *x = (const ent_t *)a, *y = (const ent_t *)b;
+    if (x->t != y->t) return x->t < y->t ? -1 : 1;
+    return x->id < y->id ? -1 : (x->id > y->id);
+}
+
+typedef struct { float rgb[3], dpt, acc, nrm[3], dist, aux[2], T; int nhit; } stage_t;
+
+/* one stage: trace ray (o,d), composite front to back.  ents is scratch of size P. */
+static void trace_stage(const trc_cfg *cfg, const surfel_t *S, const float *shs, const float *colors_precomp,
+                        const float *others, const float *bg, const float *o, const float *d, float tmin, ent_t *ents,
+                        stage_t *out, double *wet)
+{
+    int n = 0;
+    for (int i = 0; i < cfg->P; i++) {
+        rhit_t h;
+        if (hit_surfel(&S[i], o, d, tmin, &h)) { ents[n].t = h.t; ents[n].id = i; ents[n].h = h; n++; }
+    }
+    qsort(ents, n, sizeof(ent_t), ent_cmp);
+    float dl = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    float dir[3] = {d[0] / dl, d[1] / dl, d[2] / dl};
+    float basis[16];
+    sh_basis(cfg->D, dir, basis);
+    memset(out, 0, sizeof(*out));
+    float T = 1.0f, M1 = 0.f, M2 = 0.f;
+    for (int k = 0; k < n; k++) {
+        const rhit_t *h = &ents[k].h;
+        const int g = ents[k].id;
+        float test_T = T * (1.0f - h->alpha);
+        if (test_T < T_EPS) break;
+        float w = h->alpha * T;
+        float col[3]; int cl[3];
+        surfel_color(cfg, g, shs, colors_precomp, basis, col, cl);
+        float tt = h->t > NEAR_N ? h->t : NEAR_N;
+        float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / tt);
+        out->dist += (m * m * (1.0f - T) + M2 - 2.0f * m * M1) * w;
+        M1 += m * w; M2 += m * m * w;
+        for (int c = 0; c < 3; c++) out->rgb[c] += w * col[c];
+        out->dpt += w * h->t;
+        out->acc += w;
+        float sgn = h->denom < 0.0f ? 1.0f : -1.0f;
+        for (int c = 0; c < 3; c++) out->nrm[c] += w * sgn * S[g].n[c];
+        if (others) { out->aux[0] += w * others[2 * g]; out->aux[1] += w * others[2 * g + 1]; }
+        if (wet) {
+#pragma omp atomic
+            wet[g] += (double)w;
+        }
+        T = test_T;
+        out->nhit++;
+    }
+    out->T = T;
+    for (int c = 0; c < 3; c++) out->rgb[c] += T * (c < cfg->bg_len ? bg[c] : 0.0f);
+}
+
+/*
+ * Forward.  Outputs: rgb (R,3) dpt (R) acc (R) norm (R,3) dist (R) aux (R,2) mid (R,16*(depth+1)) wet (P) double,
+ * final_T (R) (stage-0 transmittance; saved for the backward), nhits (R) int32.
+ */
+void trc_forward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, const float *means, const float *scales,
+                 const float *rots, const float *opac, const float *shs, const float *colors_precomp, const float *others,
+                 const float *bg, float *rgb, float *dpt, float *acc, float *norm, float *dist, float *aux, float *mid,
+                 double *wet, float *final_T, int32_t *nhits)
+{
+    const int P = cfg->P, R = cfg->R, ND = cfg->max_trace_depth + 1;
+    surfel_t *S = (surfel_t *)malloc(sizeof(surfel_t) * (P ? P : 1));
+    for (int i = 0; i < P; i++) make_surfel(cfg, i, means, scales, rots, opac, &S[i]);
+    memset(wet, 0, sizeof(double) * P);
+    memset(mid, 0, sizeof(float) * (size_t)R * MID_CH * ND);
+#pragma omp parallel
+    {
+        ent_t *ents = (ent_t *)malloc(sizeof(ent_t) * (P ? P : 1));
+#pragma omp for schedule(dynamic, 16)
+        for (int r = 0; r < R; r++) {
+            float o[3] = {ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]};
+            float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+            stage_t st[8];
+            int ns = 0;
+            float tmin = cfg->start_from_first ? NEAR_N : 0.0f;
+            for (int k = 0; k < ND && k < 8; k++) {
+                trace_stage(cfg, S, shs, colors_precomp, others, bg, o, d, tmin, ents, &st[k], k == 0 ? wet : NULL);
+                float *m = mid + ((size_t)r * ND + k) * MID_CH;
+                m[0] = o[0]; m[1] = o[1]; m[2] = o[2]; m[3] = d[0]; m[4] = d[1]; m[5] = d[2];
+                m[6] = st[k].dpt; m[7] = st[k].acc; m[8] = st[k].nrm[0]; m[9] = st[k].nrm[1]; m[10] = st[k].nrm[2];
+                m[11] = st[k].aux[0]; m[12] = st[k].aux[1]; m[13] = st[k].rgb[0]; m[14] = st[k].rgb[1]; m[15] = st[k].rgb[2];
+                ns = k + 1;
+                if (k + 1 >= ND) break;
+                if (!(st[k].aux[0] > cfg->specular_threshold && st[k].acc > 0.5f)) break;
+                float nl = sqrtf(st[k].nrm[0] * st[k].nrm[0] + st[k].nrm[1] * st[k].nrm[1] + st[k].nrm[2] * st[k].nrm[2]);
+                if (!(nl > 0.0f)) break;
+                float nh[3] = {st[k].nrm[0] / nl, st[k].nrm[1] / nl, st[k].nrm[2] / nl};
+                float tdep = st[k].dpt / st[k].acc;
+                float dn = d[0] * nh[0] + d[1] * nh[1] + d[2] * nh[2];
+                for (int c = 0; c < 3; c++) { o[c] = o[c] + d[c] * tdep; }
+                for (int c = 0; c < 3; c++) { d[c] = d[c] - 2.0f * dn * nh[c]; }
+                tmin = 1e-3f;
+            }
+            /* blend the stages back to front */
+            float col[3] = {st[ns - 1].rgb[0], st[ns - 1].rgb[1], st[ns - 1].rgb[2]};
+            for (int k = ns - 2; k >= 0; k--) {
+                float s = st[k].aux[0];
+                for (int c = 0; c < 3; c++) col[c] = (1.0f - s) * st[k].rgb[c] + s * col[c];
+            }
+            for (int c = 0; c < 3; c++) rgb[3 * r + c] = col[c];
+            dpt[r] = st[0].dpt; acc[r] = st[0].acc; dist[r] = st[0].dist;
+            for (int c = 0; c < 3; c++) norm[3 * r + c] = st[0].nrm[c];
+            aux[2 * r] = st[0].aux[0]; aux[2 * r + 1] = st[0].aux[1];
+            final_T[r] = st[0].T; nhits[r] = st[0].nhit;
+        }
+        free(ents);
+    }
+    free(S);
+}
+
+/*
+ * Backward of stage 0 (max_trace_depth == 0 semantics; secondary rays are detached).
+ * Upstream: dL_drgb (R,3) dL_ddpt (R) dL_dacc (R) dL_dnorm (R,3) dL_daux (R,2).   (dist carries no gradient here.)
+ * Outputs (double, zeroed here): dmeans (P,3) dscales (P,2) drots (P,4) dopac (P) dshs (P,M,3) | dcolors (P,3),
+ * dothers (P,2), dray_o (R,3), dray_d (R,3).
+ * The 0.99 alpha cap is treated as identity in the gradient, like the rasterizer.
+ */
+void trc_backward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, const float *means, const float *scales,
+                  const float *rots, const float *opac, const float *shs, const float *colors_precomp, const float *others,
+                  const float *bg, const float *dL_drgb, const float *dL_ddpt, const float *dL_dacc, const float *dL_dnorm,
+                  const float *dL_daux, double *dmeans, double *dscales, double *drots, double *dopac, double *dshs,
+                  double *dcolors, double *dothers, double *dray_o, double *dray_d)
+{
+    const int P = cfg->P, R = cfg->R, M = cfg->M;
+    surfel_t *S = (surfel_t *)malloc(sizeof(surfel_t) * (P ? P : 1));
+    for (int i = 0; i < P; i++) make_surfel(cfg, i, means, scales, rots, opac, &S[i]);
+    double *dA = (double *)calloc((size_t)3 * P + 1, sizeof(double)), *dB = (double *)calloc((size_t)3 * P + 1, sizeof(double)),
+           *dN = (double *)calloc((size_t)3 * P + 1, sizeof(double));
+    memset(dmeans, 0, sizeof(double) * 3 * P); memset(dscales, 0, sizeof(double) * 2 * P);
+    memset(drots, 0, sizeof(double) * 4 * P); memset(dopac, 0, sizeof(double) * P);
+    if (M > 0) memset(dshs, 0, sizeof(double) * (size_t)P * M * 3); else memset(dcolors, 0, sizeof(double) * 3 * P);
+    if (others) memset(dothers, 0, sizeof(double) * 2 * P);
+    memset(dray_o, 0, sizeof(double) * 3 * R); memset(dray_d, 0, sizeof(double) * 3 * R);
+#define ACC(arr, idx, v) do { double v__ = (double)(v); _Pragma("omp atomic") arr[idx] += v__; } while (0)
+#pragma omp parallel
+    {
+        ent_t *ents = (ent_t *)malloc(sizeof(ent_t) * (P ? P : 1));
+#pragma omp for schedule(dynamic, 16)
+        for (int r = 0; r < R; r++) {
+            const float o[3] = {ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]};
+            const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
+            const float tmin = cfg->start_from_first ? NEAR_N : 0.0f;
+            stage_t fin;
+            trace_stage(cfg, S, shs, colors_precomp, others, bg, o, d, tmin, ents, &fin, NULL);   /* final sums; ents sorted */
+            int n = 0;
+            for (int i = 0; i < P; i++) { rhit_t h; if (hit_surfel(&S[i], o, d, tmin, &h)) { ents[n].t = h.t; ents[n].id = i; ents[n].h = h; n++; } }
+            qsort(ents, n, sizeof(ent_t), ent_cmp);
+            const float dl2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], dl = sqrtf(dl2);
+            const float dir[3] = {d[0] / dl, d[1] / dl, d[2] / dl};
+            float basis[16], bgx[16], bgy[16], bgz[16];
+            sh_basis(cfg->D, dir, basis);
+            sh_basis_grad(cfg->D, dir, bgx, bgy, bgz);
+            const float gR[3] = {dL_drgb[3 * r], dL_drgb[3 * r + 1], dL_drgb[3 * r + 2]};
+            const float gD = dL_ddpt[r], gA = dL_dacc[r];
+            const float gN[3] = {dL_dnorm[3 * r], dL_dnorm[3 * r + 1], dL_dnorm[3 * r + 2]};
+            const float gX[2] = {dL_daux[2 * r], dL_daux[2 * r + 1]};
+            /* running prefix sums (through hit k) of the composited quantities */
+            float T = 1.0f, crgb[3] = {0, 0, 0}, cD = 0.f, cA = 0.f, cN[3] = {0, 0, 0}, cX[2] = {0, 0};
+            float bgdot = 0.f;
+            for (int c = 0; c < 3; c++) bgdot += (c < cfg->bg_len ? bg[c] : 0.0f) * gR[c];
+            /* final sums WITHOUT the background term */
+            float frgb[3];
+            for (int c = 0; c < 3; c++) frgb[c] = fin.rgb[c] - fin.T * (c < cfg->bg_len ? bg[c] : 0.0f);
+            double ddir[3] = {0, 0, 0}, dO[3] = {0, 0, 0}, dD[3] = {0, 0, 0};
+            for (int k = 0; k < n; k++) {
+                const rhit_t *h = &ents[k].h;
+                const int g = ents[k].id;
+                const surfel_t *s = &S[g];
+                const float alpha = h->alpha;
+                const float test_T = T * (1.0f - alpha);
+                if (test_T < T_EPS) break;
+                const float w = alpha * T;
+                float col[3]; int cl[3];
+                surfel_color(cfg, g, shs, colors_precomp, basis, col, cl);
+                const float sgn = h->denom < 0.0f ? 1.0f : -1.0f;
+                const float nf[3] = {sgn * s->n[0], sgn * s->n[1], sgn * s->n[2]};
+                const float ox0 = others ? others[2 * g] : 0.f, ox1 = others ? others[2 * g + 1] : 0.f;
+                /* prefix through k */
+                for (int c = 0; c < 3; c++) crgb[c] += w * col[c];
+                cD += w * h->t; cA += w;
+                for (int c = 0; c < 3; c++) cN[c] += w * nf[c];
+                cX[0] += w * ox0; cX[1] += w * ox1;
+                /* dL/dalpha_k = T_k * value_k - (suffix after k) / (1 - alpha_k) */
+                const float inv1m = 1.0f / (1.0f - alpha);
+                float dLa = 0.f;
+                for (int c = 0; c < 3; c++) dLa += gR[c] * (T * col[c] - (frgb[c] - crgb[c]) * inv1m);
+                dLa += gD * (T * h->t - (fin.dpt - cD) * inv1m);
+                dLa += gA * (T - (fin.acc - cA) * inv1m);
+                for (int c = 0; c < 3; c++) dLa += gN[c] * (T * nf[c] - (fin.nrm[c] - cN[c]) * inv1m);
+                dLa += gX[0] * (T * ox0 - (fin.aux[0] - cX[0]) * inv1m) + gX[1] * (T * ox1 - (fin.aux[1] - cX[1]) * inv1m);
+                dLa += -(fin.T * inv1m) * bgdot;
+                /* direct terms */
+                float dcol[3];
+                for (int c = 0; c < 3; c++) dcol[c] = cl[c] ? 0.f : w * gR[c];
+                if (M > 0) {
+                    int nb = (cfg->D + 1) * (cfg->D + 1);
+                    const float *sh = shs + (size_t)g * M * 3;
+                    for (int kk = 0; kk < nb; kk++)
+                        for (int c = 0; c < 3; c++) {
+                            ACC(dshs, ((size_t)g * M + kk) * 3 + c, basis[kk] * dcol[c]);
+                            ddir[0] += (double)(bgx[kk] * sh[kk * 3 + c] * dcol[c]);
+                            ddir[1] += (double)(bgy[kk] * sh[kk * 3 + c] * dcol[c]);
+                            ddir[2] += (double)(bgz[kk] * sh[kk * 3 + c] * dcol[c]);
+                        }
+                } else {
+                    for (int c = 0; c < 3; c++) ACC(dcolors, 3 * (size_t)g + c, dcol[c]);
+                }
+                if (others) { ACC(dothers, 2 * (size_t)g, w * gX[0]); ACC(dothers, 2 * (size_t)g + 1, w * gX[1]); }
+                for (int c = 0; c < 3; c++) ACC(dN, 3 * (size_t)g + c, w * sgn * gN[c]);
+                float dLt = w * gD;
+                /* alpha = opa * G ; G = exp(-(u^2+v^2)/2) */
+                ACC(dopac, g, h->G * dLa);
+                const float dLG = s->opa * dLa;
+                const float dLu = dLG * (-h->G * h->u), dLv = dLG * (-h->G * h->v);
+                const float qx = o[0] + h->t * d[0] - s->mu[0], qy = o[1] + h->t * d[1] - s->mu[1], qz = o[2] + h->t * d[2] - s->mu[2];
+                const float q[3] = {qx, qy, qz};
+                const float cu = dLu / s->su, cv = dLv / s->sv;
+                float dq[3];
+                for (int c = 0; c < 3; c++) dq[c] = cu * s->a[c] + cv * s->b[c];
+                for (int c = 0; c < 3; c++) { ACC(dA, 3 * (size_t)g + c, cu * q[c]); ACC(dB, 3 * (size_t)g + c, cv * q[c]); }
+                ACC(dscales, 2 * (size_t)g, -dLu * h->u / s->su * cfg->scale_modifier);
+                ACC(dscales, 2 * (size_t)g + 1, -dLv * h->v / s->sv * cfg->scale_modifier);
+                /* q = o + t d - mu */
+                const float dLt_tot = dLt + dq[0] * d[0] + dq[1] * d[1] + dq[2] * d[2];
+                const float k_t = dLt_tot / h->denom;
+                for (int c = 0; c < 3; c++) {
+                    ACC(dmeans, 3 * (size_t)g + c, -dq[c] + k_t * s->n[c]);
+                    dO[c] += (double)(dq[c] - k_t * s->n[c]);
+                    dD[c] += (double)(h->t * dq[c] - k_t * h->t * s->n[c]);
+                    ACC(dN, 3 * (size_t)g + c, -k_t * q[c]);
+                }
+                T = test_T;
+            }
+            /* SH direction gradient back through d/|d| */
+            {
+                double dd0 = ddir[0], dd1 = ddir[1], dd2 = ddir[2];
+                double inv3 = 1.0 / ((double)dl2 * (double)dl);
+                dD[0] += ((dl2 - d[0] * d[0]) * dd0 - d[1] * d[0] * dd1 - d[2] * d[0] * dd2) * inv3;
+                dD[1] += (-d[0] * d[1] * dd0 + (dl2 - d[1] * d[1]) * dd1 - d[2] * d[1] * dd2) * inv3;
+                dD[2] += (-d[0] * d[2] * dd0 - d[1] * d[2] * dd1 + (dl2 - d[2] * d[2]) * dd2) * inv3;
+            }
+            for (int c = 0; c < 3; c++) { dray_o[3 * r + c] = dO[c]; dray_d[3 * r + c] = dD[c]; }
+        }
+        free(ents);
+    }
+#undef ACC
+    /* columns a,b,n of R -> unit quaternion gradient (no projection through the normalisation) */
+    for (int i = 0; i < P; i++) {
+        const float *q = rots + 4 * i;
+        float nn = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        double r = q[0] / nn, x = q[1] / nn, y = q[2] / nn, z = q[3] / nn;
+        double V[3][3];
+        for (int rr = 0; rr < 3; rr++) { V[rr][0] = dA[3 * i + rr]; V[rr][1] = dB[3 * i + rr]; V[rr][2] = dN[3 * i + rr]; }
+        drots[4 * i + 0] = 2. * (x * (V[2][1] - V[1][2]) + y * (V[0][2] - V[2][0]) + z * (V[1][0] - V[0][1]));
+        drots[4 * i + 1] = 2. * (-2. * x * (V[1][1] + V[2][2]) + y * (V[1][0] + V[0][1]) + z * (V[2][0] + V[0][2]) + r * (V[2][1] - V[1][2]));
+        drots[4 * i + 2] = 2. * (x * (V[1][0] + V[0][1]) - 2. * y * (V[0][0] + V[2][2]) + z * (V[2][1] + V[1][2]) + r * (V[0][2] - V[2][0]));
+        drots[4 * i + 3] = 2. * (x * (V[2][0] + V[0][2]) + y * (V[2][1] + V[1][2]) - 2. * z * (V[0][0] + V[1][1]) + r * (V[1][0] - V[0][1]));
+    }
+    free(dA); free(dB); free(dN); free(S);
+}
