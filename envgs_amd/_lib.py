@@ -24,6 +24,7 @@ class TraceCfg(ctypes.Structure):
     _fields_ = [("P", ctypes.c_int32), ("num_rays", ctypes.c_int32), ("sh_degree", ctypes.c_int32),
                 ("sh_coeffs", ctypes.c_int32), ("max_trace_depth", ctypes.c_int32), ("start_from_first", ctypes.c_int32),
                 ("has_others", ctypes.c_int32), ("bg_len", ctypes.c_int32), ("debug", ctypes.c_int32),
+                ("ray_h", ctypes.c_int32), ("ray_w", ctypes.c_int32),
                 ("scale_modifier", ctypes.c_float), ("specular_threshold", ctypes.c_float)]
 
 
@@ -35,6 +36,10 @@ SYMBOLS = {
     "envgs_raster_project": (c_int, [ctypes.POINTER(RasterCfg)] + [_P] * 15 + [_P, c_size_t, ctypes.POINTER(c_uint32), _P]),
     "envgs_raster_bin_and_render": (c_int, [ctypes.POINTER(RasterCfg), c_uint32] + [_P] * 9 + [_P, c_size_t] + [_P] * 6 + [_P]),
     "envgs_raster_backward": (c_int, [ctypes.POINTER(RasterCfg), c_uint32] + [_P] * 28 + [_P]),
+    "envgs_bvh_temp_bytes": (c_size_t, [ctypes.c_int32]),
+    "envgs_bvh_build": (c_int, [ctypes.c_int32, _P, _P, _P, c_size_t, ctypes.c_int32, _P]),
+    "envgs_trace_forward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 22 + [_P]),
+    "envgs_trace_backward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 35 + [_P]),
     "envgs_prof_enable": (None, [c_int]),
     "envgs_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     "envgs_prof_kernel_name": (ctypes.c_char_p, [c_int]),

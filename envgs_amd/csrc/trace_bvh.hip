@@ -1,0 +1,286 @@
+// trace_bvh.hip -- T1: LBVH over the surfel proxies (replaces the OptiX GAS build of the reference).
+//
+//   quad AABBs + scene bounds -> 30-bit Morton code of the centroid || surfel id (unique 62-bit keys)
+//   -> radix sort (rocPRIM) -> Karras-2012 hierarchy (one lane per internal node, clz on key pairs)
+//   -> bottom-up AABB fit: every leaf walks up; the second arriver at a node (atomic counter) unions the two
+//      child boxes stored IN the node and writes the result into ITS parent's child-box slot.
+// Cross-workgroup hand-off in the fit follows the agent-scope rule of the CDNA4 guide (G16): child-box words are
+// written and read with agent-scope relaxed atomics (sc1, L1-bypassing) around a fenced counter increment.
+// Node = 64 B with both child boxes inline, so one 64 B fetch during traversal decides both children.
+//
+// Stands behind SurfelTracer.build_acceleration_structure (easyvolcap/utils/optix_utils.py:71-85): called every
+// training iteration with rebuild=True, so the whole build is a handful of HBM-bound passes over P records.
+#include "common.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "../../include/envgs_trace.h"
+
+namespace envgs {
+
+constexpr int NODE = ENVGS_NODE_STRIDE;
+
+struct BvhTemp {
+    uint64_t *keys_in, *keys_out;
+    float *leaf_box;        // (P,6)
+    float *partial;         // (nblocks,6)
+    float *bounds;          // 6
+    int *leaf_parent;       // (P)  (parent << 1) | is_right
+    int *node_parent;       // (P-1)
+    unsigned *flags;        // (P-1)
+    void *sort_temp;
+    size_t sort_bytes;
+    size_t total;
+};
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static BvhTemp carve(int P, void *base)
+{
+    BvhTemp t;
+    const int n = P > 0 ? P : 1;
+    const int nblocks = (n + 255) / 256;
+    size_t sort_bytes = 0;
+    (void)rocprim::radix_sort_keys(nullptr, sort_bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)n, 0u, 62u);
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align_up(bytes); return (void *)r; };
+    t.keys_in = (uint64_t *)take(sizeof(uint64_t) * n);
+    t.keys_out = (uint64_t *)take(sizeof(uint64_t) * n);
+    t.leaf_box = (float *)take(sizeof(float) * 6 * n);
+    t.partial = (float *)take(sizeof(float) * 6 * nblocks);
+    t.bounds = (float *)take(sizeof(float) * 8);
+    t.leaf_parent = (int *)take(sizeof(int) * n);
+    t.node_parent = (int *)take(sizeof(int) * n);
+    t.flags = (unsigned *)take(sizeof(unsigned) * n);
+    t.sort_temp = take(sort_bytes);
+    t.sort_bytes = sort_bytes;
+    t.total = off;
+    return t;
+}
+
+// ---- 1. quad AABBs + per-block bounds -----------------------------------------------------------
+__global__ void __launch_bounds__(256)
+quad_boxes(int P, const float *__restrict__ verts, float *__restrict__ leaf_box, float *__restrict__ partial)
+{
+    __shared__ float s_red[6][4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    if (i < P) {
+        const float *v = verts + (size_t)i * 12;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) { const float x = v[k * 3 + c]; mn[c] = fminf(mn[c], x); mx[c] = fmaxf(mx[c], x); }
+        // conservative pad: the hit test is analytic (|u|,|v| <= 3), the box comes from rounded vertices
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float pad = 1e-5f * (fabsf(mn[c]) + fabsf(mx[c]) + (mx[c] - mn[c])) + 1e-7f;
+            mn[c] -= pad; mx[c] += pad;
+            leaf_box[(size_t)i * 6 + c] = mn[c];
+            leaf_box[(size_t)i * 6 + 3 + c] = mx[c];
+        }
+    }
+    // block reduction of the bounds (wave shuffles, then 4 partials through LDS)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float a = mn[c], b = mx[c];
+        for (int o = 32; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); }
+        if (lane == 0) { s_red[c][wave] = a; s_red[3 + c][wave] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int c = threadIdx.x;
+        float r = s_red[c][0];
+        for (int w = 1; w < 4; w++) r = c < 3 ? fminf(r, s_red[c][w]) : fmaxf(r, s_red[c][w]);
+        partial[(size_t)blockIdx.x * 6 + c] = r;
+    }
+}
+
+__global__ void __launch_bounds__(256) bounds_final(int nblocks, const float *__restrict__ partial, float *__restrict__ bounds)
+{
+    __shared__ float s_red[6][4];
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { mn[c] = fminf(mn[c], partial[(size_t)b * 6 + c]); mx[c] = fmaxf(mx[c], partial[(size_t)b * 6 + 3 + c]); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float a = mn[c], b = mx[c];
+        for (int o = 32; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); }
+        if (lane == 0) { s_red[c][wave] = a; s_red[3 + c][wave] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int c = threadIdx.x;
+        float r = s_red[c][0];
+        for (int w = 1; w < 4; w++) r = c < 3 ? fminf(r, s_red[c][w]) : fmaxf(r, s_red[c][w]);
+        bounds[c] = r;
+    }
+}
+
+// ---- 2. Morton keys -----------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t expand10(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+morton_keys(int P, const float *__restrict__ leaf_box, const float *__restrict__ bounds, uint64_t *__restrict__ keys)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    uint32_t code = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float lo = bounds[c], hi = bounds[3 + c];
+        const float ctr = 0.5f * (leaf_box[(size_t)i * 6 + c] + leaf_box[(size_t)i * 6 + 3 + c]);
+        const float ext = hi - lo;
+        float u = ext > 0.f ? (ctr - lo) / ext : 0.f;
+        u = fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
+        code |= expand10((uint32_t)u) << (2 - c);
+    }
+    keys[i] = ((uint64_t)code << 32) | (uint32_t)i;
+}
+
+// ---- 3. Karras hierarchy ------------------------------------------------------------------------
+__device__ __forceinline__ int delta(const uint64_t *__restrict__ keys, int P, int i, int j)
+{
+    if (j < 0 || j >= P) return -1;
+    return __clzll((long long)(keys[i] ^ keys[j]));
+}
+
+__global__ void __launch_bounds__(256)
+build_hierarchy(int P, const uint64_t *__restrict__ keys, float *__restrict__ nodes, int *__restrict__ leaf_parent,
+                int *__restrict__ node_parent)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P - 1) return;
+    const int d = (delta(keys, P, i, i + 1) - delta(keys, P, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, P, i, i - d);
+    int lmax = 2;
+    while (delta(keys, P, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, P, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, P, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, P, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    int left, right;
+    if (lo == gamma) { left = ~(int)(uint32_t)(keys[gamma] & 0xFFFFFFFFu); leaf_parent[gamma] = (i << 1); }
+    else { left = gamma; node_parent[gamma] = (i << 1); }
+    if (hi == gamma + 1) { right = ~(int)(uint32_t)(keys[gamma + 1] & 0xFFFFFFFFu); leaf_parent[gamma + 1] = (i << 1) | 1; }
+    else { right = gamma + 1; node_parent[gamma + 1] = (i << 1) | 1; }
+    float *nd = nodes + (size_t)i * NODE;
+    nd[12] = __int_as_float(left);
+    nd[13] = __int_as_float(right);
+    if (i == 0) { node_parent[0] = -1; nd[14] = __int_as_float(-1); }
+}
+
+// ---- 4. bottom-up fit -----------------------------------------------------------------------------
+__device__ __forceinline__ void store_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float load_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ void __launch_bounds__(256)
+fit_boxes(int P, const uint64_t *__restrict__ keys, const float *__restrict__ leaf_box, const int *__restrict__ leaf_parent,
+          const int *__restrict__ node_parent, unsigned *__restrict__ flags, float *__restrict__ nodes)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= P) return;
+    const uint32_t sid = (uint32_t)(keys[j] & 0xFFFFFFFFu);
+    float box[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) box[c] = leaf_box[(size_t)sid * 6 + c];
+    int link = leaf_parent[j];
+    for (int guard = 0; guard < 128; guard++) {
+        const int p = link >> 1, right = link & 1;
+        float *slot = nodes + (size_t)p * NODE + right * 6;
+#pragma unroll
+        for (int c = 0; c < 6; c++) store_agent(slot + c, box[c]);
+        __threadfence();
+        const unsigned old = atomicAdd(flags + p, 1u);
+        if (old == 0u) return;                       // first arriver: the sibling will carry on
+        __threadfence();
+        const float *other = nodes + (size_t)p * NODE + (1 - right) * 6;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            box[c] = fminf(box[c], load_agent(other + c));
+            box[3 + c] = fmaxf(box[3 + c], load_agent(other + 3 + c));
+        }
+        link = node_parent[p];
+        if (link < 0) return;                        // p was the root
+        if (p != 0) nodes[(size_t)p * NODE + 14] = __int_as_float(link >> 1);
+    }
+}
+
+// P == 1: a single node whose left child is the only surfel and whose right child can never be hit.
+__global__ void single_leaf_node(const float *__restrict__ leaf_box, float *__restrict__ nodes)
+{
+    if (threadIdx.x == 0) {
+        for (int c = 0; c < 6; c++) nodes[c] = leaf_box[c];
+        // a degenerate far-away box: an INVERTED box would pass the min/max slab test, a far point never does
+        for (int c = 0; c < 3; c++) { nodes[6 + c] = 1.0e30f; nodes[9 + c] = 1.0e30f; }
+        nodes[12] = __int_as_float(~0);
+        nodes[13] = __int_as_float(~0);
+        nodes[14] = __int_as_float(-1);
+        nodes[15] = 0.f;
+    }
+}
+
+}  // namespace envgs
+
+using namespace envgs;
+
+extern "C" {
+
+size_t envgs_bvh_temp_bytes(int32_t P) { return carve(P, nullptr).total; }
+
+int envgs_bvh_build(int32_t P, const float *vertices, float *nodes, void *temp, size_t temp_bytes, int32_t debug, void *stream_)
+{
+    if (P < 0) return ENVGS_ERR_BAD_ARG;
+    if (P == 0) return 0;
+    if (!vertices || !nodes || !temp) return ENVGS_ERR_BAD_ARG;
+    BvhTemp t = carve(P, temp);
+    if (temp_bytes < t.total) return ENVGS_ERR_TEMP_TOO_SMALL;
+    hipStream_t stream = (hipStream_t)stream_;
+    envgs_raster_cfg dbg; dbg.debug = debug;
+    const envgs_raster_cfg *cfg = &dbg;
+    ProfScope prof_(K_BVH_BUILD, stream);
+    const int nblocks = (P + 255) / 256;
+    hipLaunchKernelGGL(quad_boxes, dim3(nblocks), dim3(256), 0, stream, P, vertices, t.leaf_box, t.partial);
+    ENVGS_CHECK_LAUNCH(cfg, stream);
+    if (P == 1) {
+        hipLaunchKernelGGL(single_leaf_node, dim3(1), dim3(64), 0, stream, t.leaf_box, nodes);
+        ENVGS_CHECK_LAUNCH(cfg, stream);
+        return 0;
+    }
+    hipLaunchKernelGGL(bounds_final, dim3(1), dim3(256), 0, stream, nblocks, t.partial, t.bounds);
+    ENVGS_CHECK_LAUNCH(cfg, stream);
+    hipLaunchKernelGGL(morton_keys, dim3(nblocks), dim3(256), 0, stream, P, t.leaf_box, t.bounds, t.keys_in);
+    ENVGS_CHECK_LAUNCH(cfg, stream);
+    size_t sb = t.sort_bytes;
+    hipError_t e = rocprim::radix_sort_keys(t.sort_temp, sb, t.keys_in, t.keys_out, (size_t)P, 0u, 62u, stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(t.flags, 0, sizeof(unsigned) * (size_t)P, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(build_hierarchy, dim3((P - 1 + 255) / 256), dim3(256), 0, stream, P, t.keys_out, nodes, t.leaf_parent, t.node_parent);
+    ENVGS_CHECK_LAUNCH(cfg, stream);
+    hipLaunchKernelGGL(fit_boxes, dim3(nblocks), dim3(256), 0, stream, P, t.keys_out, t.leaf_box, t.leaf_parent, t.node_parent, t.flags, nodes);
+    ENVGS_CHECK_LAUNCH(cfg, stream);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,613 @@
+// trace_render.hip -- T2 (trace forward) and T3 (trace backward): differentiable front-to-back compositing of
+// 2D Gaussians along arbitrary rays, over the LBVH of trace_bvh.hip.
+//
+// CDNA4 mapping: persistent wavefronts (one 64-lane workgroup each, grid = a few per CU) pull batches of 64 rays
+// from a global counter; one lane = one ray.  Traversal keeps the per-lane node stack in LDS ([level][lane], so a
+// push/pop is one conflict-free ds_write/ds_read_b32 per wavefront) and the K nearest accepted hits sorted in
+// registers; a ray is composited in rounds of K hits, restarting the traversal from (t, id) of the last hit, until
+// its transmittance drops below 1e-4 or the scene is exhausted.  A BVH node is one 64 B record holding both child
+// boxes; a surfel is one 64 B record (centre, opacity, a/s_u, b/s_v, normal).  The backward re-traces in the
+// identical order and uses the stored stage-0 sums for the suffix terms, so no hit list is ever written to HBM.
+//
+// Stands behind SurfelTracer.forward/backward (easyvolcap/utils/optix_utils.py:188-201); semantics are restated in
+// oracle/surfel_trace_oracle.c ("parity unpinned": the OptiX sources are not in the reference tree).
+#include "common.h"
+
+#include "../../include/envgs_trace.h"
+
+namespace envgs {
+
+constexpr int KBUF = 16;            // hits buffered per round
+constexpr int STACK = 64;           // LBVH depth bound: 62-bit keys
+constexpr int MAX_ROUNDS = 256;     // safety bound: 4096 hits per ray
+constexpr float UV_MAX = 3.0f;
+constexpr int MID = ENVGS_MID_CHANNELS;
+constexpr int SREC = ENVGS_SREC_STRIDE;
+constexpr int NODE = ENVGS_NODE_STRIDE;
+
+constexpr float kC0 = 0.28209479177387814f;
+constexpr float kC1 = 0.4886025119029199f;
+__device__ __constant__ float tC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                        -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ float tC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                        0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                        -0.5900435899266435f};
+
+// ---- per-surfel record ----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+make_surfel_records(int P, float mod, const float *__restrict__ means, const float *__restrict__ scales,
+                    const float *__restrict__ rots, const float *__restrict__ opac, float *__restrict__ srec)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float q0 = rots[4 * i], q1 = rots[4 * i + 1], q2 = rots[4 * i + 2], q3 = rots[4 * i + 3];
+    const float inv = 1.0f / sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    const float r = q0 * inv, x = q1 * inv, y = q2 * inv, z = q3 * inv;
+    const float su = scales[2 * i] * mod, sv = scales[2 * i + 1] * mod;
+    float4 *o = reinterpret_cast<float4 *>(srec + (size_t)i * SREC);
+    o[0] = make_float4(means[3 * i], means[3 * i + 1], means[3 * i + 2], opac[i]);
+    o[1] = make_float4((1.f - 2.f * (y * y + z * z)) / su, (2.f * (x * y + r * z)) / su, (2.f * (x * z - r * y)) / su, su);
+    o[2] = make_float4((2.f * (x * y - r * z)) / sv, (1.f - 2.f * (x * x + z * z)) / sv, (2.f * (y * z + r * x)) / sv, sv);
+    o[3] = make_float4(2.f * (x * z + r * y), 2.f * (y * z - r * x), 1.f - 2.f * (x * x + y * y), 0.f);
+}
+
+struct SurfHit { float t, u, v, G, alpha, denom; bool ok; };
+
+__device__ __forceinline__ SurfHit hit_surfel(const float4 s0, const float4 s1, const float4 s2, const float4 s3,
+                                              const float ox, const float oy, const float oz, const float dx,
+                                              const float dy, const float dz)
+{
+    SurfHit h;
+    h.denom = s3.x * dx + s3.y * dy + s3.z * dz;
+    const float num = s3.x * (s0.x - ox) + s3.y * (s0.y - oy) + s3.z * (s0.z - oz);
+    h.t = num / h.denom;
+    const float qx = ox + h.t * dx - s0.x, qy = oy + h.t * dy - s0.y, qz = oz + h.t * dz - s0.z;
+    h.u = s1.x * qx + s1.y * qy + s1.z * qz;
+    h.v = s2.x * qx + s2.y * qy + s2.z * qz;
+    h.G = __expf(-0.5f * (h.u * h.u + h.v * h.v));
+    const float a = s0.w * h.G;
+    h.alpha = a < ALPHA_CAP ? a : ALPHA_CAP;
+    h.ok = (h.denom != 0.0f) && (fabsf(h.u) <= UV_MAX) && (fabsf(h.v) <= UV_MAX) && (h.alpha >= ALPHA_MIN);
+    return h;
+}
+
+__device__ __forceinline__ void sh_basis(int D, float x, float y, float z, float *b)
+{
+    b[0] = kC0;
+    if (D > 0) {
+        b[1] = -kC1 * y; b[2] = kC1 * z; b[3] = -kC1 * x;
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = tC2[0] * xy; b[5] = tC2[1] * yz; b[6] = tC2[2] * (2.0f * zz - xx - yy); b[7] = tC2[3] * xz; b[8] = tC2[4] * (xx - yy);
+            if (D > 2) {
+                b[9] = tC3[0] * y * (3.0f * xx - yy); b[10] = tC3[1] * xy * z; b[11] = tC3[2] * y * (4.0f * zz - xx - yy);
+                b[12] = tC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy); b[13] = tC3[4] * x * (4.0f * zz - xx - yy);
+                b[14] = tC3[5] * z * (xx - yy); b[15] = tC3[6] * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void sh_basis_grad(int D, float x, float y, float z, float *gx, float *gy, float *gz)
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) { gx[k] = 0.f; gy[k] = 0.f; gz[k] = 0.f; }
+    if (D > 0) {
+        gy[1] = -kC1; gz[2] = kC1; gx[3] = -kC1;
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            gx[4] = tC2[0] * y; gy[4] = tC2[0] * x;
+            gy[5] = tC2[1] * z; gz[5] = tC2[1] * y;
+            gx[6] = tC2[2] * -2.f * x; gy[6] = tC2[2] * -2.f * y; gz[6] = tC2[2] * 4.f * z;
+            gx[7] = tC2[3] * z; gz[7] = tC2[3] * x;
+            gx[8] = tC2[4] * 2.f * x; gy[8] = tC2[4] * -2.f * y;
+            if (D > 2) {
+                gx[9] = tC3[0] * 6.f * xy; gy[9] = tC3[0] * 3.f * (xx - yy);
+                gx[10] = tC3[1] * yz; gy[10] = tC3[1] * xz; gz[10] = tC3[1] * xy;
+                gx[11] = tC3[2] * -2.f * xy; gy[11] = tC3[2] * (4.f * zz - xx - 3.f * yy); gz[11] = tC3[2] * 8.f * yz;
+                gx[12] = tC3[3] * -6.f * xz; gy[12] = tC3[3] * -6.f * yz; gz[12] = tC3[3] * 3.f * (2.f * zz - xx - yy);
+                gx[13] = tC3[4] * (4.f * zz - 3.f * xx - yy); gy[13] = tC3[4] * -2.f * xy; gz[13] = tC3[4] * 8.f * xz;
+                gx[14] = tC3[5] * 2.f * xz; gy[14] = tC3[5] * -2.f * yz; gz[14] = tC3[5] * (xx - yy);
+                gx[15] = tC3[6] * 3.f * (xx - yy); gy[15] = tC3[6] * -6.f * xy;
+            }
+        }
+    }
+}
+
+struct TraceArgs {
+    int P, R, D, M, ND, start_from_first, has_others, bg_len;
+    float spec_thr;
+    const float4 *nodes;
+    const float4 *srec;
+    const float *shs, *colors, *others, *bg;
+    const float *ray_o, *ray_d;
+    unsigned *counter;
+    // forward outputs
+    float *rgb, *dpt, *acc, *norm, *dist, *aux, *mid, *wet, *final_T;
+    // backward inputs / outputs
+    const float *f_rgb, *f_dpt, *f_acc, *f_norm, *f_aux, *f_T;
+    const float *g_rgb, *g_dpt, *g_acc, *g_norm, *g_aux;
+    float *rot_rec, *dmeans, *dscales, *dopac, *dshs, *dcolors, *dothers, *dray_o, *dray_d;
+    float mod;
+};
+
+// K-nearest buffer ordered by (t, id); insertion is a fully unrolled compare-exchange chain (registers only).
+struct KBuf {
+    float t[KBUF];
+    int id[KBUF];
+    int n;
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int i = 0; i < KBUF; i++) { t[i] = 3.0e38f; id[i] = 0x7fffffff; }
+        n = 0;
+    }
+    __device__ __forceinline__ void insert(float ct, int cid) {
+#pragma unroll
+        for (int i = 0; i < KBUF; i++) {
+            const bool before = (ct < t[i]) || (ct == t[i] && cid < id[i]);
+            const float tt = before ? t[i] : ct; const int ii = before ? id[i] : cid;
+            t[i] = before ? ct : t[i]; id[i] = before ? cid : id[i];
+            ct = tt; cid = ii;
+        }
+        n = n < KBUF ? n + 1 : KBUF;
+    }
+};
+
+// One traversal round: collect the K nearest accepted hits with (t,id) > (tlo,idlo).
+__device__ __forceinline__ void traverse(const TraceArgs &A, int (*stk)[64], const int lane, const bool active,
+                                         const float ox, const float oy, const float oz, const float dx, const float dy,
+                                         const float dz, const float tlo, const int idlo, KBuf &kb)
+{
+    kb.reset();
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    int sp = 0;
+    int cur = active ? 0 : -1;                  // node 0 is the root; -1 = nothing to do
+    float tmax = 3.0e38f;
+    while (true) {
+        if (cur < 0) {
+            if (sp == 0) break;
+            cur = stk[--sp][lane];
+        }
+        const float4 *nd = A.nodes + (size_t)cur * 4;
+        const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+        const int lc = __float_as_int(n3.x), rc = __float_as_int(n3.y);
+        // slabs: left box min (n0.x,n0.y,n0.z) max (n0.w,n1.x,n1.y); right box min (n1.z,n1.w,n2.x) max (n2.y,n2.z,n2.w)
+        float a0 = (n0.x - ox) * ix, a1 = (n0.w - ox) * ix, b0 = (n0.y - oy) * iy, b1 = (n1.x - oy) * iy, c0 = (n0.z - oz) * iz, c1 = (n1.y - oz) * iz;
+        float tnL = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
+        float tfL = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+        a0 = (n1.z - ox) * ix; a1 = (n2.y - ox) * ix; b0 = (n1.w - oy) * iy; b1 = (n2.z - oy) * iy; c0 = (n2.x - oz) * iz; c1 = (n2.w - oz) * iz;
+        float tnR = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
+        float tfR = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+        bool hitL = (tnL <= tfL) && (tfL >= tlo) && (tnL <= tmax);
+        bool hitR = (tnR <= tfR) && (tfR >= tlo) && (tnR <= tmax);
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const bool hit = side == 0 ? hitL : hitR;
+            const int ch = side == 0 ? lc : rc;
+            if (hit && ch < 0) {
+                const int sid = ~ch;
+                const float4 *sr = A.srec + (size_t)sid * 4;
+                const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], sr[3], ox, oy, oz, dx, dy, dz);
+                const bool after = (h.t > tlo) || (h.t == tlo && sid > idlo);
+                const bool fits = (kb.n < KBUF) || (h.t < kb.t[KBUF - 1]) || (h.t == kb.t[KBUF - 1] && sid < kb.id[KBUF - 1]);
+                if (h.ok && after && fits) {
+                    kb.insert(h.t, sid);
+                    if (kb.n == KBUF) tmax = kb.t[KBUF - 1];
+                }
+            }
+        }
+        hitL = hitL && lc >= 0;
+        hitR = hitR && rc >= 0;
+        if (hitL && hitR) {
+            const bool leftFirst = tnL <= tnR;
+            stk[sp++][lane] = leftFirst ? rc : lc;
+            cur = leftFirst ? lc : rc;
+        } else if (hitL) cur = lc;
+        else if (hitR) cur = rc;
+        else cur = -1;
+    }
+}
+
+struct StageSums { float rgb[3], dpt, acc, nrm[3], dist, aux[2], T, M1, M2; };
+
+__device__ __forceinline__ void surfel_color(const TraceArgs &A, int sid, const float *basis, float *col, bool *cl)
+{
+    if (A.M > 0) {
+        const float *sh = A.shs + (size_t)sid * A.M * 3;
+        const int nb = (A.D + 1) * (A.D + 1);
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        for (int k = 0; k < nb; k++) { const float b = basis[k]; r0 += b * sh[k * 3]; r1 += b * sh[k * 3 + 1]; r2 += b * sh[k * 3 + 2]; }
+        r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+        cl[0] = r0 < 0.f; cl[1] = r1 < 0.f; cl[2] = r2 < 0.f;
+        col[0] = cl[0] ? 0.f : r0; col[1] = cl[1] ? 0.f : r1; col[2] = cl[2] ? 0.f : r2;
+    } else {
+        col[0] = A.colors[3 * sid]; col[1] = A.colors[3 * sid + 1]; col[2] = A.colors[3 * sid + 2];
+        cl[0] = cl[1] = cl[2] = false;
+    }
+}
+
+__device__ __forceinline__ int ray_index(int slot, int R, int rh, int rw)
+{
+    // 64 consecutive slots = one 8x8 pixel block when the ray tensor is an (H,W) image with H,W % 8 == 0
+    if (rh > 0 && (rh & 7) == 0 && (rw & 7) == 0) {
+        const int blk = slot >> 6, in = slot & 63;
+        const int bw = rw >> 3;
+        const int by = blk / bw, bx = blk - by * bw;
+        return (by * 8 + (in >> 3)) * rw + bx * 8 + (in & 7);
+    }
+    return slot;
+}
+
+// ------------------------------------------------------------------------------------------ T2 ---
+__global__ void __launch_bounds__(64)
+trace_fwd(const TraceArgs A, const int ray_h, const int ray_w)
+{
+    __shared__ int stk[STACK][64];
+    const int lane = threadIdx.x;
+    while (true) {
+        int base = 0;
+        if (lane == 0) base = (int)atomicAdd(A.counter, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= A.R) break;
+        const int slot = base + lane;
+        const bool valid = slot < A.R;
+        const int r = valid ? ray_index(slot, A.R, ray_h, ray_w) : 0;
+        float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
+        float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
+        float tmin = A.start_from_first ? NEAR_N : 0.0f;
+        float out_rgb[3] = {0.f, 0.f, 0.f};
+        float thr = 1.0f;                               // product of specular weights of the previous stages
+        bool chain = valid;
+        StageSums s0;
+        for (int stage = 0; stage < A.ND; stage++) {
+            StageSums S;
+            S.rgb[0] = S.rgb[1] = S.rgb[2] = 0.f; S.dpt = 0.f; S.acc = 0.f; S.nrm[0] = S.nrm[1] = S.nrm[2] = 0.f;
+            S.dist = 0.f; S.aux[0] = S.aux[1] = 0.f; S.T = 1.0f; S.M1 = 0.f; S.M2 = 0.f;
+            float basis[16];
+            {
+                const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+                sh_basis(A.D, dx * il, dy * il, dz * il, basis);
+            }
+            bool done = !chain || A.P == 0;
+            float tlo = tmin; int idlo = 0x7fffffff;
+            for (int round = 0; round < MAX_ROUNDS; round++) {
+                if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+                KBuf kb;
+                traverse(A, stk, lane, !done, ox, oy, oz, dx, dy, dz, tlo, idlo, kb);
+#pragma unroll 1
+                for (int i = 0; i < KBUF; i++) {
+                    int sid = 0;
+#pragma unroll
+                    for (int k = 0; k < KBUF; k++) sid = (k == i) ? kb.id[k] : sid;     // dynamic pick from the register buffer
+                    if (!done && i < kb.n) {
+                        const float4 *sr = A.srec + (size_t)sid * 4;
+                        const float4 s3 = sr[3];
+                        const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], s3, ox, oy, oz, dx, dy, dz);
+                        const float test_T = S.T * (1.0f - h.alpha);
+                        if (test_T < T_EPS) { done = true; }
+                        else {
+                            const float w = h.alpha * S.T;
+                            float col[3]; bool cl[3];
+                            surfel_color(A, sid, basis, col, cl);
+                            const float tt = h.t > NEAR_N ? h.t : NEAR_N;
+                            const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / tt);
+                            S.dist += (m * m * (1.0f - S.T) + S.M2 - 2.0f * m * S.M1) * w;
+                            S.M1 += m * w; S.M2 += m * m * w;
+                            S.rgb[0] += w * col[0]; S.rgb[1] += w * col[1]; S.rgb[2] += w * col[2];
+                            S.dpt += w * h.t; S.acc += w;
+                            const float sg = h.denom < 0.0f ? w : -w;
+                            S.nrm[0] += sg * s3.x; S.nrm[1] += sg * s3.y; S.nrm[2] += sg * s3.z;
+                            if (A.has_others) { S.aux[0] += w * A.others[2 * sid]; S.aux[1] += w * A.others[2 * sid + 1]; }
+                            if (stage == 0) atomic_add_f32(A.wet + sid, w);
+                            S.T = test_T;
+                        }
+                    }
+                }
+                if (!done) {
+                    if (kb.n < KBUF) done = true;
+                    else { tlo = kb.t[KBUF - 1]; idlo = kb.id[KBUF - 1]; }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) S.rgb[c] += S.T * (c < A.bg_len ? A.bg[c] : 0.0f);
+            if (valid && chain) {
+                float *m = A.mid + ((size_t)r * A.ND + stage) * MID;
+                m[0] = ox; m[1] = oy; m[2] = oz; m[3] = dx; m[4] = dy; m[5] = dz; m[6] = S.dpt; m[7] = S.acc;
+                m[8] = S.nrm[0]; m[9] = S.nrm[1]; m[10] = S.nrm[2]; m[11] = S.aux[0]; m[12] = S.aux[1];
+                m[13] = S.rgb[0]; m[14] = S.rgb[1]; m[15] = S.rgb[2];
+            }
+            if (stage == 0) s0 = S;
+            if (chain) {
+                // rgb = (1-s0) c0 + s0 ((1-s1) c1 + s1 c2 ...): this stage enters with weight thr * (1 - s_stage) unless it is the last
+                const float nl = sqrtf(S.nrm[0] * S.nrm[0] + S.nrm[1] * S.nrm[1] + S.nrm[2] * S.nrm[2]);
+                const bool bounce = (stage + 1 < A.ND) && (S.aux[0] > A.spec_thr) && (S.acc > 0.5f) && (nl > 0.0f);
+                const float wgt = bounce ? thr * (1.0f - S.aux[0]) : thr;
+                out_rgb[0] += wgt * S.rgb[0]; out_rgb[1] += wgt * S.rgb[1]; out_rgb[2] += wgt * S.rgb[2];
+                if (bounce) {
+                    thr *= S.aux[0];
+                    const float inl = 1.0f / nl;
+                    const float nx = S.nrm[0] * inl, ny = S.nrm[1] * inl, nz = S.nrm[2] * inl;
+                    const float td = S.dpt / S.acc;
+                    const float dn = dx * nx + dy * ny + dz * nz;
+                    ox = ox + dx * td; oy = oy + dy * td; oz = oz + dz * td;
+                    dx = dx - 2.0f * dn * nx; dy = dy - 2.0f * dn * ny; dz = dz - 2.0f * dn * nz;
+                    tmin = 1e-3f;
+                } else chain = false;
+            }
+        }
+        if (valid) {
+            A.rgb[3 * r] = out_rgb[0]; A.rgb[3 * r + 1] = out_rgb[1]; A.rgb[3 * r + 2] = out_rgb[2];
+            A.dpt[r] = s0.dpt; A.acc[r] = s0.acc; A.dist[r] = s0.dist;
+            A.norm[3 * r] = s0.nrm[0]; A.norm[3 * r + 1] = s0.nrm[1]; A.norm[3 * r + 2] = s0.nrm[2];
+            A.aux[2 * r] = s0.aux[0]; A.aux[2 * r + 1] = s0.aux[1];
+            A.final_T[r] = s0.T;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ T3 ---
+__global__ void __launch_bounds__(64)
+trace_bwd(const TraceArgs A, const int ray_h, const int ray_w)
+{
+    __shared__ int stk[STACK][64];
+    const int lane = threadIdx.x;
+    while (true) {
+        int base = 0;
+        if (lane == 0) base = (int)atomicAdd(A.counter, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= A.R) break;
+        const int slot = base + lane;
+        const bool valid = slot < A.R;
+        const int r = valid ? ray_index(slot, A.R, ray_h, ray_w) : 0;
+        const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
+        const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
+        const float tmin = A.start_from_first ? NEAR_N : 0.0f;
+        const float gR0 = A.g_rgb[3 * r], gR1 = A.g_rgb[3 * r + 1], gR2 = A.g_rgb[3 * r + 2];
+        const float gD = A.g_dpt[r], gA = A.g_acc[r];
+        const float gN0 = A.g_norm[3 * r], gN1 = A.g_norm[3 * r + 1], gN2 = A.g_norm[3 * r + 2];
+        const float gX0 = A.g_aux[2 * r], gX1 = A.g_aux[2 * r + 1];
+        const float fT = A.f_T[r];
+        float bg0 = 0 < A.bg_len ? A.bg[0] : 0.f, bg1 = 1 < A.bg_len ? A.bg[1] : 0.f, bg2 = 2 < A.bg_len ? A.bg[2] : 0.f;
+        const float bgdot = bg0 * gR0 + bg1 * gR1 + bg2 * gR2;
+        // final sums without the background term (suffix = final - prefix)
+        const float fr0 = A.f_rgb[3 * r] - fT * bg0, fr1 = A.f_rgb[3 * r + 1] - fT * bg1, fr2 = A.f_rgb[3 * r + 2] - fT * bg2;
+        const float fD = A.f_dpt[r], fA = A.f_acc[r];
+        const float fN0 = A.f_norm[3 * r], fN1 = A.f_norm[3 * r + 1], fN2 = A.f_norm[3 * r + 2];
+        const float fX0 = A.f_aux[2 * r], fX1 = A.f_aux[2 * r + 1];
+        const float dl2 = dx * dx + dy * dy + dz * dz, il = 1.0f / sqrtf(dl2);
+        float basis[16];
+        sh_basis(A.D, dx * il, dy * il, dz * il, basis);
+        float T = 1.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f, cD = 0.f, cA = 0.f, cN0 = 0.f, cN1 = 0.f, cN2 = 0.f, cX0 = 0.f, cX1 = 0.f;
+        float dO0 = 0.f, dO1 = 0.f, dO2 = 0.f, dD0 = 0.f, dD1 = 0.f, dD2 = 0.f, dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
+        bool done = !valid || A.P == 0;
+        float tlo = tmin; int idlo = 0x7fffffff;
+        for (int round = 0; round < MAX_ROUNDS; round++) {
+            if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+            KBuf kb;
+            traverse(A, stk, lane, !done, ox, oy, oz, dx, dy, dz, tlo, idlo, kb);
+#pragma unroll 1
+            for (int i = 0; i < KBUF; i++) {
+                // dynamic index into the register buffer: pick element i with a select chain
+                float ht = 0.f; int sid = 0;
+#pragma unroll
+                for (int k = 0; k < KBUF; k++) { ht = (k == i) ? kb.t[k] : ht; sid = (k == i) ? kb.id[k] : sid; }
+                if (done || i >= kb.n) continue;
+                const float4 *sr = A.srec + (size_t)sid * 4;
+                const float4 s0 = sr[0], s1 = sr[1], s2 = sr[2], s3 = sr[3];
+                const SurfHit h = hit_surfel(s0, s1, s2, s3, ox, oy, oz, dx, dy, dz);
+                const float alpha = h.alpha;
+                const float test_T = T * (1.0f - alpha);
+                if (test_T < T_EPS) { done = true; continue; }
+                const float w = alpha * T;
+                float col[3]; bool cl[3];
+                surfel_color(A, sid, basis, col, cl);
+                const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
+                const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
+                const float x0 = A.has_others ? A.others[2 * sid] : 0.f, x1 = A.has_others ? A.others[2 * sid + 1] : 0.f;
+                c0 += w * col[0]; c1 += w * col[1]; c2 += w * col[2];
+                cD += w * h.t; cA += w;
+                cN0 += w * nf0; cN1 += w * nf1; cN2 += w * nf2;
+                cX0 += w * x0; cX1 += w * x1;
+                const float inv1m = 1.0f / (1.0f - alpha);
+                float dLa = gR0 * (T * col[0] - (fr0 - c0) * inv1m) + gR1 * (T * col[1] - (fr1 - c1) * inv1m) + gR2 * (T * col[2] - (fr2 - c2) * inv1m);
+                dLa += gD * (T * h.t - (fD - cD) * inv1m);
+                dLa += gA * (T - (fA - cA) * inv1m);
+                dLa += gN0 * (T * nf0 - (fN0 - cN0) * inv1m) + gN1 * (T * nf1 - (fN1 - cN1) * inv1m) + gN2 * (T * nf2 - (fN2 - cN2) * inv1m);
+                dLa += gX0 * (T * x0 - (fX0 - cX0) * inv1m) + gX1 * (T * x1 - (fX1 - cX1) * inv1m);
+                dLa += -(fT * inv1m) * bgdot;
+                const float dc0 = cl[0] ? 0.f : w * gR0, dc1 = cl[1] ? 0.f : w * gR1, dc2 = cl[2] ? 0.f : w * gR2;
+                if (A.M > 0) {
+                    float bgx[16], bgy[16], bgz[16];
+                    sh_basis_grad(A.D, dx * il, dy * il, dz * il, bgx, bgy, bgz);
+                    const float *sh = A.shs + (size_t)sid * A.M * 3;
+                    float *dsh = A.dshs + (size_t)sid * A.M * 3;
+                    const int nb = (A.D + 1) * (A.D + 1);
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        if (k < nb) {
+                            const float b = basis[k];
+                            atomic_add_f32(dsh + k * 3, b * dc0); atomic_add_f32(dsh + k * 3 + 1, b * dc1); atomic_add_f32(dsh + k * 3 + 2, b * dc2);
+                            const float sd = sh[k * 3] * dc0 + sh[k * 3 + 1] * dc1 + sh[k * 3 + 2] * dc2;
+                            dd0 += bgx[k] * sd; dd1 += bgy[k] * sd; dd2 += bgz[k] * sd;
+                        }
+                    }
+                } else {
+                    atomic_add_f32(A.dcolors + 3 * sid, dc0); atomic_add_f32(A.dcolors + 3 * sid + 1, dc1); atomic_add_f32(A.dcolors + 3 * sid + 2, dc2);
+                }
+                if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * gX1); }
+                atomic_add_f32(A.dopac + sid, h.G * dLa);
+                const float dLG = s0.w * dLa;
+                const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
+                const float su = s1.w, sv = s2.w;
+                const float qx = ox + h.t * dx - s0.x, qy = oy + h.t * dy - s0.y, qz = oz + h.t * dz - s0.z;
+                // u = (a/su).q : dL/dq = dLu*(a/su) + dLv*(b/sv) ; dL/da = (dLu/su) q ; dL/dsu = -dLu*u/su
+                const float dq0 = dLu * s1.x + dLv * s2.x, dq1 = dLu * s1.y + dLv * s2.y, dq2 = dLu * s1.z + dLv * s2.z;
+                const float cu = dLu / su, cv = dLv / sv;
+                float *rr = A.rot_rec + (size_t)sid * ENVGS_ROTREC_STRIDE;
+                const float dLt_tot = w * gD + dq0 * dx + dq1 * dy + dq2 * dz;
+                const float kt = dLt_tot / h.denom;
+                atomic_add_f32(rr + 0, cu * qx); atomic_add_f32(rr + 1, cu * qy); atomic_add_f32(rr + 2, cu * qz);
+                atomic_add_f32(rr + 3, cv * qx); atomic_add_f32(rr + 4, cv * qy); atomic_add_f32(rr + 5, cv * qz);
+                atomic_add_f32(rr + 6, w * sgn * gN0 - kt * qx); atomic_add_f32(rr + 7, w * sgn * gN1 - kt * qy); atomic_add_f32(rr + 8, w * sgn * gN2 - kt * qz);
+                atomic_add_f32(A.dscales + 2 * sid, -dLu * h.u / su * A.mod);
+                atomic_add_f32(A.dscales + 2 * sid + 1, -dLv * h.v / sv * A.mod);
+                atomic_add_f32(A.dmeans + 3 * sid, -dq0 + kt * s3.x);
+                atomic_add_f32(A.dmeans + 3 * sid + 1, -dq1 + kt * s3.y);
+                atomic_add_f32(A.dmeans + 3 * sid + 2, -dq2 + kt * s3.z);
+                dO0 += dq0 - kt * s3.x; dO1 += dq1 - kt * s3.y; dO2 += dq2 - kt * s3.z;
+                dD0 += h.t * (dq0 - kt * s3.x); dD1 += h.t * (dq1 - kt * s3.y); dD2 += h.t * (dq2 - kt * s3.z);
+                T = test_T;
+            }
+            if (!done) {
+                if (kb.n < KBUF) done = true;
+                else { tlo = kb.t[KBUF - 1]; idlo = kb.id[KBUF - 1]; }
+            }
+        }
+        if (valid) {
+            const float inv3 = il * il * il;
+            dD0 += ((dl2 - dx * dx) * dd0 - dy * dx * dd1 - dz * dx * dd2) * inv3;
+            dD1 += (-dx * dy * dd0 + (dl2 - dy * dy) * dd1 - dz * dy * dd2) * inv3;
+            dD2 += (-dx * dz * dd0 - dy * dz * dd1 + (dl2 - dz * dz) * dd2) * inv3;
+            A.dray_o[3 * r] = dO0; A.dray_o[3 * r + 1] = dO1; A.dray_o[3 * r + 2] = dO2;
+            A.dray_d[3 * r] = dD0; A.dray_d[3 * r + 1] = dD1; A.dray_d[3 * r + 2] = dD2;
+        }
+    }
+}
+
+// rotation columns (a,b,n) gradient -> unit-quaternion gradient; also copies dmeans into the densification sink
+__global__ void __launch_bounds__(256)
+finish_rotations(int P, const float *__restrict__ rots, const float *__restrict__ rot_rec, const float *__restrict__ dmeans,
+                 float *__restrict__ drots, float *__restrict__ dgrads3D)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float q0 = rots[4 * i], q1 = rots[4 * i + 1], q2 = rots[4 * i + 2], q3 = rots[4 * i + 3];
+    const float inv = 1.0f / sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    const float r = q0 * inv, x = q1 * inv, y = q2 * inv, z = q3 * inv;
+    const float *rr = rot_rec + (size_t)i * ENVGS_ROTREC_STRIDE;
+    // V[row][col]: col 0 = dL/da, col 1 = dL/db, col 2 = dL/dn
+#define VR(a, b) rr[(b) * 3 + (a)]
+    drots[4 * i + 0] = 2.f * (x * (VR(2, 1) - VR(1, 2)) + y * (VR(0, 2) - VR(2, 0)) + z * (VR(1, 0) - VR(0, 1)));
+    drots[4 * i + 1] = 2.f * (-2.f * x * (VR(1, 1) + VR(2, 2)) + y * (VR(1, 0) + VR(0, 1)) + z * (VR(2, 0) + VR(0, 2)) + r * (VR(2, 1) - VR(1, 2)));
+    drots[4 * i + 2] = 2.f * (x * (VR(1, 0) + VR(0, 1)) - 2.f * y * (VR(0, 0) + VR(2, 2)) + z * (VR(2, 1) + VR(1, 2)) + r * (VR(0, 2) - VR(2, 0)));
+    drots[4 * i + 3] = 2.f * (x * (VR(2, 0) + VR(0, 2)) + y * (VR(2, 1) + VR(1, 2)) - 2.f * z * (VR(0, 0) + VR(1, 1)) + r * (VR(1, 0) - VR(0, 1)));
+#undef VR
+    if (dgrads3D) { dgrads3D[3 * i] = dmeans[3 * i]; dgrads3D[3 * i + 1] = dmeans[3 * i + 1]; dgrads3D[3 * i + 2] = dmeans[3 * i + 2]; }
+}
+
+static int persistent_grid(int R)
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int want = (R + 63) / 64;
+    const int cap = cus * 8;
+    return want < cap ? (want > 0 ? want : 1) : cap;
+}
+
+}  // namespace envgs
+
+using namespace envgs;
+
+static void ray_layout(const envgs_trace_cfg *cfg, int *rh, int *rw)
+{
+    const bool ok = cfg->ray_h > 0 && cfg->ray_w > 0 && (long long)cfg->ray_h * cfg->ray_w == cfg->num_rays;
+    *rh = ok ? cfg->ray_h : 0;
+    *rw = ok ? cfg->ray_w : 0;
+}
+
+extern "C" {
+
+int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const float *ray_o, const float *ray_d,
+                        const float *means3D, const float *scales, const float *rotations, const float *opacities,
+                        const float *shs, const float *colors_precomp, const float *others_precomp, const float *bg,
+                        float *srec, uint32_t *counters, float *rgb, float *dpt, float *acc, float *norm, float *dist,
+                        float *aux, float *mid, float *wet, float *final_T, void *stream_)
+{
+    if (!cfg || cfg->P < 0 || cfg->num_rays < 0 || cfg->sh_degree < 0 || cfg->sh_degree > 3 || cfg->max_trace_depth < 0 || cfg->max_trace_depth > 7)
+        return ENVGS_ERR_BAD_ARG;
+    if (cfg->num_rays == 0) return 0;
+    if (!ray_o || !ray_d || !bg || !counters || !rgb || !dpt || !acc || !norm || !dist || !aux || !mid || !final_T) return ENVGS_ERR_BAD_ARG;
+    if (cfg->P > 0 && (!nodes || !means3D || !scales || !rotations || !opacities || !srec || !wet)) return ENVGS_ERR_BAD_ARG;
+    if (cfg->P > 0 && (cfg->sh_coeffs > 0 ? (!shs || cfg->sh_coeffs < (cfg->sh_degree + 1) * (cfg->sh_degree + 1)) : !colors_precomp)) return ENVGS_ERR_BAD_ARG;
+    if (cfg->has_others && cfg->P > 0 && !others_precomp) return ENVGS_ERR_BAD_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    envgs_raster_cfg dbg; dbg.debug = cfg->debug;
+    const envgs_raster_cfg *dcfg = &dbg;
+    hipError_t e = hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return (int)e;
+    if (cfg->P > 0) {
+        e = hipMemsetAsync(wet, 0, sizeof(float) * (size_t)cfg->P, stream);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(make_surfel_records, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, cfg->scale_modifier,
+                           means3D, scales, rotations, opacities, srec);
+        ENVGS_CHECK_LAUNCH(dcfg, stream);
+    }
+    e = hipMemsetAsync(mid, 0, sizeof(float) * (size_t)cfg->num_rays * MID * (cfg->max_trace_depth + 1), stream);
+    if (e != hipSuccess) return (int)e;
+    TraceArgs A;
+    A = TraceArgs{};
+    A.P = cfg->P; A.R = cfg->num_rays; A.D = cfg->sh_degree; A.M = cfg->sh_coeffs; A.ND = cfg->max_trace_depth + 1;
+    A.start_from_first = cfg->start_from_first; A.has_others = cfg->has_others; A.bg_len = cfg->bg_len; A.spec_thr = cfg->specular_threshold;
+    A.nodes = (const float4 *)nodes; A.srec = (const float4 *)srec; A.shs = shs; A.colors = colors_precomp; A.others = others_precomp;
+    A.bg = bg; A.ray_o = ray_o; A.ray_d = ray_d; A.counter = counters;
+    A.rgb = rgb; A.dpt = dpt; A.acc = acc; A.norm = norm; A.dist = dist; A.aux = aux; A.mid = mid; A.wet = wet; A.final_T = final_T;
+    A.mod = cfg->scale_modifier;
+    int rh, rw; ray_layout(cfg, &rh, &rw);
+    ProfScope prof_(K_TRACE_FWD, stream);
+    hipLaunchKernelGGL(trace_fwd, dim3(persistent_grid(cfg->num_rays)), dim3(64), 0, stream, A, rh, rw);
+    ENVGS_CHECK_LAUNCH(dcfg, stream);
+    return 0;
+}
+
+int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const float *ray_o, const float *ray_d,
+                         const float *means3D, const float *scales, const float *rotations, const float *opacities,
+                         const float *shs, const float *colors_precomp, const float *others_precomp, const float *bg,
+                         const float *srec, uint32_t *counters, const float *rgb, const float *dpt, const float *acc,
+                         const float *norm, const float *aux, const float *final_T, const float *dL_drgb, const float *dL_ddpt,
+                         const float *dL_dacc, const float *dL_dnorm, const float *dL_daux, float *rot_rec, float *dmeans3D,
+                         float *dgrads3D, float *dscales, float *drots, float *dopacities, float *dshs, float *dcolors,
+                         float *dothers, float *dray_o, float *dray_d, void *stream_)
+{
+    if (!cfg || cfg->P < 0 || cfg->num_rays < 0) return ENVGS_ERR_BAD_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    envgs_raster_cfg dbg; dbg.debug = cfg->debug;
+    const envgs_raster_cfg *dcfg = &dbg;
+    const size_t P = (size_t)cfg->P, R = (size_t)cfg->num_rays;
+    hipError_t e;
+#define ZERO(ptr, n) do { if ((ptr) && (n) > 0) { e = hipMemsetAsync((ptr), 0, sizeof(float) * (n), stream); if (e != hipSuccess) return (int)e; } } while (0)
+    ZERO(rot_rec, P * ENVGS_ROTREC_STRIDE); ZERO(dmeans3D, P * 3); ZERO(dgrads3D, P * 3); ZERO(dscales, P * 2); ZERO(drots, P * 4);
+    ZERO(dopacities, P); ZERO(dothers, P * 2); ZERO(dray_o, R * 3); ZERO(dray_d, R * 3);
+    if (cfg->sh_coeffs > 0) ZERO(dshs, P * cfg->sh_coeffs * 3); else ZERO(dcolors, P * 3);
+#undef ZERO
+    if (cfg->num_rays == 0 || cfg->P == 0) return 0;
+    if (!nodes || !ray_o || !ray_d || !srec || !counters || !rgb || !dpt || !acc || !norm || !aux || !final_T || !dL_drgb || !dL_ddpt ||
+        !dL_dacc || !dL_dnorm || !dL_daux || !rot_rec || !dmeans3D || !dscales || !drots || !dopacities || !dray_o || !dray_d || !rotations || !bg)
+        return ENVGS_ERR_BAD_ARG;
+    if (cfg->sh_coeffs > 0 ? (!shs || !dshs) : (!colors_precomp || !dcolors)) return ENVGS_ERR_BAD_ARG;
+    e = hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return (int)e;
+    TraceArgs A;
+    A = TraceArgs{};
+    A.P = cfg->P; A.R = cfg->num_rays; A.D = cfg->sh_degree; A.M = cfg->sh_coeffs; A.ND = 1;
+    A.start_from_first = cfg->start_from_first; A.has_others = cfg->has_others; A.bg_len = cfg->bg_len; A.spec_thr = cfg->specular_threshold;
+    A.nodes = (const float4 *)nodes; A.srec = (const float4 *)srec; A.shs = shs; A.colors = colors_precomp; A.others = others_precomp;
+    A.bg = bg; A.ray_o = ray_o; A.ray_d = ray_d; A.counter = counters;
+    A.f_rgb = rgb; A.f_dpt = dpt; A.f_acc = acc; A.f_norm = norm; A.f_aux = aux; A.f_T = final_T;
+    A.g_rgb = dL_drgb; A.g_dpt = dL_ddpt; A.g_acc = dL_dacc; A.g_norm = dL_dnorm; A.g_aux = dL_daux;
+    A.rot_rec = rot_rec; A.dmeans = dmeans3D; A.dscales = dscales; A.dopac = dopacities; A.dshs = dshs; A.dcolors = dcolors;
+    A.dothers = dothers; A.dray_o = dray_o; A.dray_d = dray_d; A.mod = cfg->scale_modifier;
+    int rh, rw; ray_layout(cfg, &rh, &rw);
+    {
+        ProfScope prof_(K_TRACE_BWD, stream);
+        hipLaunchKernelGGL(trace_bwd, dim3(persistent_grid(cfg->num_rays)), dim3(64), 0, stream, A, rh, rw);
+    }
+    ENVGS_CHECK_LAUNCH(dcfg, stream);
+    hipLaunchKernelGGL(finish_rotations, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, rotations, rot_rec, dmeans3D, drots, dgrads3D);
+    ENVGS_CHECK_LAUNCH(dcfg, stream);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,9 +1,29 @@
-"""Host-side mirror of the reference's `diff_surfel_tracing` interface (easyvolcap/utils/optix_utils.py:7,24,78,104-119,188-201).
-Filled in with the HIP LBVH tracer; this first revision only carries the interface records."""
+"""Host-side mirror of the reference's `diff_surfel_tracing` interface, over the C-ABI of include/envgs_trace.h.
+
+Same names, argument meaning and error behaviour as the extension the reference imports at
+easyvolcap/utils/optix_utils.py:7 and drives at :24, :78, :104-119 and :188-201:
+
+    SurfelTracingSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projmatrix,
+                          sh_degree, campos, prefiltered, debug, max_trace_depth, specular_threshold)
+    tracer = SurfelTracer()
+    tracer.build_acceleration_structure(vertices, faces, rebuild=True)
+    rgb, dpt, acc, norm, dist, aux, mid, wet = tracer(ray_o, ray_d, v, means3D=..., grads3D=..., shs=..., colors_precomp=...,
+                                                      others_precomp=..., opacities=..., scales=..., rotations=...,
+                                                      cov3D_precomp=..., tracer_settings=..., start_from_first=...)
+
+Outputs are channels-last with the ray tensor's leading shape: rgb (...,3), dpt (...,1), acc (...,1), norm (...,3),
+dist (...,1), aux (...,2), mid (...,16*(max_trace_depth+1)), wet (P,1).  Differentiable inputs: ray_o, ray_d, means3D,
+grads3D (gradient sink for the densification signal), shs | colors_precomp, others_precomp, opacities, scales, rotations.
+
+OptiX is replaced by a hand-written HIP LBVH (Morton build every call with rebuild=True, like the reference rebuilds
+its GAS every training iteration) and a persistent-wavefront traversal.  No fallback path exists.
+"""
 from typing import NamedTuple
 
 import torch
 from torch import nn
+
+from . import _lib
 
 
 class SurfelTracingSettings(NamedTuple):
@@ -23,12 +43,165 @@ class SurfelTracingSettings(NamedTuple):
     specular_threshold: float
 
 
+LAST_STATS = {}
+
+
+def _f32c(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _stream(dev):
+    return _lib.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def build_bvh(vertices, debug=False):
+    """LBVH over the (4P,3) quad vertices.  Returns the (max(P-1,1),16) node tensor."""
+    lib = _lib.load()
+    v = _f32c(vertices.detach())
+    if v.device.type != "cuda":
+        raise RuntimeError("envgs_amd tracer needs tensors on the GPU (got %s); there is no CPU path" % v.device)
+    if v.dim() != 2 or v.shape[1] != 3 or v.shape[0] % 4 != 0:
+        raise RuntimeError("vertices must be (4P,3) in the get_disks layout, got %s" % (tuple(v.shape),))
+    P = v.shape[0] // 4
+    dev = v.device
+    nodes = torch.empty(max(P - 1, 1), 16, dtype=torch.float32, device=dev)
+    tb = lib.envgs_bvh_temp_bytes(P)
+    temp = torch.empty(max(tb, 1), dtype=torch.uint8, device=dev)
+    _lib.check(lib.envgs_bvh_build(P, _lib.ptr(v), _lib.ptr(nodes), _lib.ptr(temp), tb, 1 if debug else 0, _stream(dev)),
+               "envgs_bvh_build")
+    return nodes, P
+
+
+def _cfg(settings, P, R, shs, others, start_from_first, ray_shape):
+    deg = settings.sh_degree
+    deg = int(deg.item()) if torch.is_tensor(deg) else int(deg)
+    rh, rw = (int(ray_shape[0]), int(ray_shape[1])) if len(ray_shape) == 2 else (0, 0)
+    bg_len = min(int(settings.bg.numel()), 3)
+    return _lib.TraceCfg(P, R, deg, 0 if shs is None else int(shs.shape[1]), int(settings.max_trace_depth),
+                         1 if start_from_first else 0, 0 if others is None else 1, bg_len, 1 if settings.debug else 0,
+                         rh, rw, float(settings.scale_modifier), float(settings.specular_threshold))
+
+
+def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_precomp, opacities, scales, rotations, settings,
+                  start_from_first):
+    lib = _lib.load()
+    dev = means3D.device
+    lead = tuple(ray_o.shape[:-1])
+    ro = _f32c(ray_o).reshape(-1, 3); rd = _f32c(ray_d).reshape(-1, 3)
+    R, P = ro.shape[0], means3D.shape[0]
+    means3D = _f32c(means3D); opacities = _f32c(opacities); scales = _f32c(scales); rotations = _f32c(rotations)
+    shs = _f32c(shs); colors_precomp = _f32c(colors_precomp); others_precomp = _f32c(others_precomp)
+    bg = _f32c(settings.bg).reshape(-1).to(dev)
+    cfg = _cfg(settings, P, R, shs, others_precomp, start_from_first, lead)
+    ND = cfg.max_trace_depth + 1
+    f32 = dict(dtype=torch.float32, device=dev)
+    srec = torch.empty(max(P, 1), 16, **f32)
+    counters = torch.empty(4, dtype=torch.int32, device=dev)
+    rgb = torch.empty(R, 3, **f32); dpt = torch.empty(R, 1, **f32); acc = torch.empty(R, 1, **f32)
+    norm = torch.empty(R, 3, **f32); dist = torch.empty(R, 1, **f32); aux = torch.empty(R, 2, **f32)
+    mid = torch.empty(R, 16 * ND, **f32); wet = torch.empty(P, 1, **f32); final_T = torch.empty(R, **f32)
+    p = _lib.ptr
+    _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
+                                       p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),
+                                       p(norm), p(dist), p(aux), p(mid), p(wet), p(final_T), _stream(dev)), "envgs_trace_forward")
+    LAST_STATS.update(P=P, R=R)
+    saved = dict(cfg=cfg, nodes=nodes, ro=ro, rd=rd, means3D=means3D, scales=scales, rotations=rotations, opacities=opacities,
+                 shs=shs, colors_precomp=colors_precomp, others=others_precomp, bg=bg, srec=srec, counters=counters,
+                 rgb=rgb, dpt=dpt, acc=acc, norm=norm, aux=aux, final_T=final_T, lead=lead)
+    outs = (rgb.reshape(lead + (3,)), dpt.reshape(lead + (1,)), acc.reshape(lead + (1,)), norm.reshape(lead + (3,)),
+            dist.reshape(lead + (1,)), aux.reshape(lead + (2,)), mid.reshape(lead + (16 * ND,)), wet)
+    return outs, saved
+
+
+def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
+    lib = _lib.load()
+    cfg = saved["cfg"]
+    P, R = cfg.P, cfg.num_rays
+    dev = saved["ro"].device
+    f32 = dict(dtype=torch.float32, device=dev)
+    z = lambda g, c: torch.zeros(R, c, **f32) if g is None else _f32c(g).reshape(R, c)
+    g_rgb, g_dpt, g_acc, g_norm, g_aux = z(g_rgb, 3), z(g_dpt, 1), z(g_acc, 1), z(g_norm, 3), z(g_aux, 2)
+    shs, others = saved["shs"], saved["others"]
+    rot_rec = torch.empty(max(P, 1), 12, **f32)
+    dmeans = torch.empty(P, 3, **f32); dgrads3D = torch.empty(P, 3, **f32); dscales = torch.empty(P, 2, **f32)
+    drots = torch.empty(P, 4, **f32); dopac = torch.empty(P, 1, **f32)
+    dshs = torch.empty_like(shs) if shs is not None else None
+    dcolors = torch.empty(P, 3, **f32) if shs is None else None
+    dothers = torch.empty(P, 2, **f32) if others is not None else None
+    dro = torch.empty(R, 3, **f32); drd = torch.empty(R, 3, **f32)
+    p = _lib.ptr
+    s = saved
+    _lib.check(lib.envgs_trace_backward(cfg, p(s["nodes"]), p(s["ro"]), p(s["rd"]), p(s["means3D"]), p(s["scales"]), p(s["rotations"]),
+                                        p(s["opacities"]), p(shs), p(s["colors_precomp"]), p(others), p(s["bg"]), p(s["srec"]),
+                                        p(s["counters"]), p(s["rgb"]), p(s["dpt"]), p(s["acc"]), p(s["norm"]), p(s["aux"]), p(s["final_T"]),
+                                        p(g_rgb), p(g_dpt), p(g_acc), p(g_norm), p(g_aux), p(rot_rec), p(dmeans), p(dgrads3D), p(dscales),
+                                        p(drots), p(dopac), p(dshs), p(dcolors), p(dothers), p(dro), p(drd), _stream(dev)),
+               "envgs_trace_backward")
+    lead = s["lead"]
+    return dict(ray_o=dro.reshape(lead + (3,)), ray_d=drd.reshape(lead + (3,)), means3D=dmeans, grads3D=dgrads3D, shs=dshs,
+                colors_precomp=dcolors, others_precomp=dothers, opacities=dopac, scales=dscales, rotations=drots)
+
+
+class _TraceSurfels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ray_o, ray_d, v, means3D, grads3D, shs, colors_precomp, others_precomp, opacities, scales, rotations,
+                cov3D_precomp, tracer_settings, start_from_first, nodes):
+        none = lambda t: None if (t is None or t.numel() == 0) else t
+        outs, saved = trace_forward(nodes, ray_o, ray_d, means3D, none(shs), none(colors_precomp), none(others_precomp), opacities,
+                                    scales, rotations, tracer_settings, start_from_first)
+        ctx.saved = saved
+        ctx.in_dtypes = tuple(None if t is None else t.dtype for t in (ray_o, ray_d, means3D, grads3D, shs, colors_precomp,
+                                                                        others_precomp, opacities, scales, rotations))
+        rgb, dpt, acc, norm, dist, aux, mid, wet = outs
+        ctx.mark_non_differentiable(dist, mid, wet)
+        return rgb, dpt, acc, norm, dist, aux, mid, wet
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_dpt, g_acc, g_norm, g_dist, g_aux, g_mid, g_wet):
+        g = trace_backward(ctx.saved, g_rgb, g_dpt, g_acc, g_norm, g_aux)
+        order = ("ray_o", "ray_d", "means3D", "grads3D", "shs", "colors_precomp", "others_precomp", "opacities", "scales", "rotations")
+        vals = [None if (g[k] is None or dt is None) else g[k].to(dt) for k, dt in zip(order, ctx.in_dtypes)]
+        ro, rd, m3, g3, sh, col, oth, op, sc, rot = vals
+        return ro, rd, None, m3, g3, sh, col, oth, op, sc, rot, None, None, None, None
+
+
 class SurfelTracer(nn.Module):
     def __init__(self):
         super().__init__()
+        _lib.load()                       # fail at construction (optix_utils.py:24 creates the OptiX context here)
+        self.nodes = None
+        self.num_surfels = 0
 
-    def build_acceleration_structure(self, vertices, faces, rebuild=True):
-        raise RuntimeError("envgs_amd: the HIP LBVH tracer is not built into this revision")
+    def build_acceleration_structure(self, vertices, faces=None, rebuild=True):
+        """optix_utils.py:78.  `faces` must be the get_disks layout (2 triangles per 4 consecutive vertices)."""
+        if faces is not None and faces.shape[0] * 2 != vertices.shape[0]:
+            raise RuntimeError("faces (%d,3) do not match vertices (%d,3): expected 2 triangles per 4 vertices" % (faces.shape[0], vertices.shape[0]))
+        if rebuild or self.nodes is None:
+            self.nodes, self.num_surfels = build_bvh(vertices)
 
-    def forward(self, *a, **k):
-        raise RuntimeError("envgs_amd: the HIP LBVH tracer is not built into this revision")
+    def forward(self, ray_o, ray_d, v=None, *, means3D, grads3D=None, shs=None, colors_precomp=None, others_precomp=None,
+                opacities=None, scales=None, rotations=None, cov3D_precomp=None, tracer_settings=None, start_from_first=True):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if cov3D_precomp is not None:
+            raise Exception('The HIP surfel tracer intersects surfels analytically in world space and needs scales / rotations; '
+                            'a precomputed screen-space transMat (cov3D_precomp) cannot be traced.')
+        if scales is None or rotations is None:
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        if self.nodes is None:
+            if v is None:
+                raise RuntimeError("SurfelTracer: no acceleration structure; call build_acceleration_structure first")
+            self.build_acceleration_structure(v)
+        if means3D.shape[0] != self.num_surfels:
+            raise RuntimeError("SurfelTracer: acceleration structure holds %d surfels, call has %d (rebuild after densification)"
+                               % (self.num_surfels, means3D.shape[0]))
+        if grads3D is None:
+            grads3D = torch.zeros_like(means3D)
+        e = torch.Tensor([])
+        return _TraceSurfels.apply(ray_o, ray_d, v, means3D, grads3D, e if shs is None else shs,
+                                   e if colors_precomp is None else colors_precomp, e if others_precomp is None else others_precomp,
+                                   opacities, scales, rotations, None, tracer_settings, bool(start_from_first), self.nodes)

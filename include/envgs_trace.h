@@ -1,0 +1,108 @@
+/*
+ * envgs_trace.h -- C-ABI of the MI355X-native surfel ray tracer (libenvgs_hip.so).
+ *
+ * Drop-in boundary for the reference's `diff_surfel_tracing` extension (CUDA + OptiX 7), whose Python call
+ * sites are easyvolcap/utils/optix_utils.py:24 (SurfelTracer()), :78 (build_acceleration_structure),
+ * :104-119 (SurfelTracingSettings) and :188-201 (the traced call).  OptiX's GAS + any-hit pipeline is replaced
+ * by a hand-written LBVH: Morton codes of the surfel proxies -> radix sort -> Karras hierarchy -> bottom-up AABB
+ * fit, and a persistent-wavefront traversal with the per-lane node stack in LDS and a K-nearest hit buffer in
+ * registers (front-to-back compositing in rounds of K hits).
+ *
+ * Plain pointers and sizes; every pointer is a DEVICE pointer unless it ends in _host; `stream` is a hipStream_t
+ * passed as void*.  Returns 0, a negative envgs_status, or a positive hipError_t.  The caller owns all memory.
+ *
+ * HBM layouts (fp32 unless noted):
+ *   vertices  (4P,3)   the quad vertices of optix_utils.py:39-69 (get_disks); 4 consecutive vertices = one surfel
+ *   nodes     (max(P-1,1),16)  LBVH internal nodes, 64 B each:
+ *                      [0..5] left child AABB (min xyz, max xyz)  [6..11] right child AABB
+ *                      [12] left child  [13] right child  (int32 bits; >= 0 internal node, < 0 leaf = ~surfel id)
+ *                      [14] parent (int32 bits)  [15] unused
+ *   srec      (P,16)   per-surfel trace record, rebuilt every forward from the current parameters:
+ *                      [0..2] centre  [3] opacity  [4..6] tangent a / s_u  [7] s_u  [8..10] tangent b / s_v  [11] s_v
+ *                      [12..14] normal  [15] unused
+ *   rot_rec   (P,12)   backward accumulator for dL/d(a,b,n) (the rotation columns), chained to the quaternion
+ *   outputs   rgb (R,3) dpt (R) acc (R) norm (R,3) dist (R) aux (R,2) mid (R,16*(max_trace_depth+1)) wet (P)
+ *             mid layout per bounce: rayo 0:3, rayd 3:6, dpt 6, acc 7, norm 8:11, aux 11:13, rgb 13:16
+ *             (optix_utils.py:30-37)
+ */
+#ifndef ENVGS_TRACE_H
+#define ENVGS_TRACE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "envgs_raster.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ENVGS_NODE_STRIDE 16
+#define ENVGS_SREC_STRIDE 16
+#define ENVGS_ROTREC_STRIDE 12
+#define ENVGS_MID_CHANNELS 16
+
+/* Mirrors SurfelTracingSettings (optix_utils.py:104-119) minus the tensors, plus the call's start_from_first. */
+typedef struct envgs_trace_cfg {
+    int32_t P;                 /* surfels */
+    int32_t num_rays;          /* R */
+    int32_t sh_degree;         /* active degree 0..3 */
+    int32_t sh_coeffs;         /* coefficients stored per surfel (shs is (P, sh_coeffs, 3)); 0 => colors_precomp (P,3) */
+    int32_t max_trace_depth;   /* specular bounces after the primary stage */
+    int32_t start_from_first;  /* 1: rays are camera rays (t_min = 0.2); 0: rays are already-reflected rays (t > 0) */
+    int32_t has_others;        /* others_precomp (P,2) present */
+    int32_t bg_len;
+    int32_t debug;
+    int32_t ray_h, ray_w;      /* if the rays are an (H,W) image (ray_h*ray_w == num_rays) wavefronts take 8x8 pixel blocks; else 0 */
+    float scale_modifier;
+    float specular_threshold;
+} envgs_trace_cfg;
+
+/* Scratch bytes for the Morton sort + build of P surfels. */
+ENVGS_API size_t envgs_bvh_temp_bytes(int32_t P);
+
+/*
+ * SurfelTracer.build_acceleration_structure(vertices, faces, rebuild) (optix_utils.py:78).
+ * Builds the LBVH over the P quads (faces are implied by the get_disks layout: 2 triangles per 4 vertices).
+ * nodes: (max(P-1,1),16) floats out.  temp: envgs_bvh_temp_bytes(P).
+ */
+ENVGS_API int envgs_bvh_build(int32_t P, const float *vertices, float *nodes, void *temp, size_t temp_bytes, int32_t debug,
+                              void *stream);
+
+/*
+ * SurfelTracer.forward (optix_utils.py:188-201): trace R rays through the surfel set, composite front to back.
+ * srec (P,16) is scratch written here (and read again by the backward).  counters: >= 4 uint32 of scratch.
+ * final_T (R): stage-0 transmittance, kept for the backward.
+ */
+ENVGS_API int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes,
+                                  const float *ray_o, const float *ray_d,
+                                  const float *means3D, const float *scales, const float *rotations, const float *opacities,
+                                  const float *shs, const float *colors_precomp, const float *others_precomp, const float *bg,
+                                  float *srec, uint32_t *counters,
+                                  float *rgb, float *dpt, float *acc, float *norm, float *dist, float *aux, float *mid,
+                                  float *wet, float *final_T, void *stream);
+
+/*
+ * SurfelTracer backward: gradients of stage 0 w.r.t. the surfel parameters AND the rays (reflected rays are
+ * differentiable: easyvolcap/models/samplers/envgs_sampler.py:454-455).  Bounce stages are detached.
+ * Outputs are zeroed here.  dshs (P,sh_coeffs,3) or dcolors (P,3); dothers may be NULL; dgrads3D (P,3) receives the
+ * densification signal (= dL/dmeans3D; consumer: envgs_sampler.py:357-361).
+ */
+ENVGS_API int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes,
+                                   const float *ray_o, const float *ray_d,
+                                   const float *means3D, const float *scales, const float *rotations, const float *opacities,
+                                   const float *shs, const float *colors_precomp, const float *others_precomp, const float *bg,
+                                   const float *srec, uint32_t *counters,
+                                   const float *rgb, const float *dpt, const float *acc, const float *norm, const float *aux,
+                                   const float *final_T,
+                                   const float *dL_drgb, const float *dL_ddpt, const float *dL_dacc, const float *dL_dnorm,
+                                   const float *dL_daux,
+                                   float *rot_rec,
+                                   float *dmeans3D, float *dgrads3D, float *dscales, float *drots, float *dopacities,
+                                   float *dshs, float *dcolors, float *dothers, float *dray_o, float *dray_d,
+                                   void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENVGS_TRACE_H */

@@ -1,0 +1,125 @@
+"""GPU parity: the HIP LBVH tracer (through the C-ABI and the drop-in SurfelTracer) against the brute-force
+CPU oracle.  Hit sets are validated implicitly: identical composited sums and per-surfel weights for every ray."""
+import numpy as np
+import pytest
+import torch
+
+from envgs_amd import synth
+from tests.test_oracle_trace import trace_scene
+from tests.util import rel_err, assert_close_frac
+
+pytestmark = pytest.mark.gpu
+
+
+def _settings(mod, bg, deg, dev, depth=0, thr=0.0, H=1, W=1):
+    I = torch.eye(4, device=dev)
+    return mod.SurfelTracingSettings(image_height=H, image_width=W, tanfovx=1.0, tanfovy=1.0, bg=bg.to(dev), scale_modifier=1.0,
+                                     viewmatrix=I, projmatrix=I, sh_degree=torch.tensor([deg], device=dev), campos=torch.zeros(3, device=dev),
+                                     prefiltered=False, debug=False, max_trace_depth=depth, specular_threshold=thr)
+
+
+def _run_hip(g, ro, rd, bg, deg, use_sh, sff, grads=None, depth=0, thr=0.0, shape=None):
+    import diff_surfel_tracing as mod
+    dev = torch.device("cuda:0")
+    L = {k: g[k].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "others")}
+    if use_sh: L["shs"] = g["shs"].to(dev).requires_grad_(True)
+    else: L["colors_precomp"] = g["colors_precomp"].to(dev).requires_grad_(True)
+    o = ro.to(dev).requires_grad_(True); d = rd.to(dev).requires_grad_(True)
+    oo, dd = (o, d) if shape is None else (o.reshape(shape + (3,)), d.reshape(shape + (3,)))
+    v, f = synth.get_disks(L["means3D"].detach(), L["scales"].detach(), L["rotations"].detach())
+    tracer = mod.SurfelTracer()
+    tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
+    g3 = torch.zeros_like(L["means3D"], requires_grad=True) + 0
+    g3.retain_grad()
+    outs = tracer(oo, dd, v, means3D=L["means3D"], grads3D=g3, shs=L.get("shs"), colors_precomp=L.get("colors_precomp"),
+                  others_precomp=L["others"], opacities=L["opacities"], scales=L["scales"], rotations=L["rotations"],
+                  cov3D_precomp=None, tracer_settings=_settings(mod, bg, deg, dev, depth, thr), start_from_first=sff)
+    if grads is not None:
+        rgb, dpt, acc, norm, dist, aux, mid, wet = outs
+        R = ro.shape[0]
+        loss = sum((x.reshape(R, -1) * y.to(dev).reshape(R, -1)).sum() for x, y in zip((rgb, dpt, acc, norm, aux), grads))
+        loss.backward()
+    torch.cuda.synchronize()
+    return outs, L, o, d, g3
+
+
+@pytest.mark.parametrize("use_sh,camera,deg,P,R", [(True, True, 3, 150, 400), (False, False, 0, 150, 400), (True, False, 2, 2000, 1024),
+                                                   (True, False, 1, 1, 64), (False, True, 0, 40, 130)])
+def test_trace_forward_backward_vs_oracle(use_sh, camera, deg, P, R):
+    from oracle import trace as otr
+    g, ro, rd = trace_scene(P=P, R=R, seed=7, camera=camera)
+    if P > 500:
+        g["scales"] = g["scales"] * 0.35                       # many small surfels: deep tree, > K hits per ray for some
+    R = ro.shape[0]
+    bg = torch.tensor([0.3, 0.1, 0.7])
+    gen = torch.Generator().manual_seed(9)
+    gr = [torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen),
+          torch.randn(R, 3, generator=gen), torch.randn(R, 2, generator=gen)]
+    outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, deg, use_sh, camera, grads=gr)
+    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
+    ckw = dict(shs=g["shs"].numpy(), sh_degree=deg) if use_sh else dict(colors_precomp=g["colors_precomp"].numpy())
+    ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(),
+                            g["opacities"].numpy(), others=g["others"].numpy(), bg=bg.numpy(), start_from_first=camera, **ckw)
+    if P > 1: assert ref["nhits"].mean() > 1
+    for a, b, nm in ((rgb, ref["rgb"], "rgb"), (dpt[:, 0], ref["dpt"], "dpt"), (acc[:, 0], ref["acc"], "acc"), (norm, ref["norm"], "norm"),
+                     (aux, ref["aux"], "aux"), (wet[:, 0], ref["wet"], "wet")):
+        assert_close_frac(a, b, 1e-4, max_bad_frac=2e-3, flip_bound=0.05, what=nm)
+    assert_close_frac(dist[:, 0], ref["dist"], 5e-3, max_bad_frac=2e-3, what="dist")
+    np.testing.assert_allclose(mid[:, 0:3], ro.numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(mid[:, 13:16], rgb, rtol=1e-6, atol=1e-7)
+
+    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
+    tol = 1e-3
+    chk = lambda a, b, nm: assert_close_frac(a, b, tol, max_bad_frac=5e-3, flip_bound=0.2, what=nm)
+    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
+    chk(g3.grad.cpu().numpy(), rb["dmeans3D"], "grads3D")
+    chk(L["scales"].grad.cpu().numpy(), rb["dscales"], "dscales")
+    chk(L["rotations"].grad.cpu().numpy(), rb["drots"], "drots")
+    chk(L["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"], "dopac")
+    chk(L["others"].grad.cpu().numpy(), rb["dothers"], "dothers")
+    if use_sh: chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
+    else: chk(L["colors_precomp"].grad.cpu().numpy(), rb["dcolors"], "dcolors")
+    chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
+    chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
+
+
+def test_trace_bounces_and_image_shaped_rays():
+    from oracle import trace as otr
+    g, ro, rd = trace_scene(P=150, R=400, seed=4, camera=True)       # 20x20 camera rays
+    bg = torch.tensor([0.0, 0.0, 0.0])
+    outs, *_ = _run_hip(g, ro, rd, bg, 1, True, True, depth=2, thr=0.1, shape=(20, 20))
+    rgb, dpt, acc, norm, dist, aux, mid, wet = outs
+    assert rgb.shape == (20, 20, 3) and dpt.shape == (20, 20, 1) and mid.shape == (20, 20, 48) and wet.shape == (150, 1)
+    ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(),
+                            g["opacities"].numpy(), shs=g["shs"].numpy(), sh_degree=1, others=g["others"].numpy(), bg=bg.numpy(),
+                            max_trace_depth=2, specular_threshold=0.1, start_from_first=True)
+    assert_close_frac(rgb.detach().reshape(-1, 3).cpu().numpy(), ref["rgb"], 2e-4, max_bad_frac=5e-3, flip_bound=0.1, what="rgb")
+    assert_close_frac(mid.detach().reshape(-1, 48).cpu().numpy(), ref["mid"], 2e-4, max_bad_frac=5e-3, flip_bound=0.2, what="mid")
+
+
+def test_trace_edge_cases():
+    import diff_surfel_tracing as mod
+    dev = torch.device("cuda:0")
+    g, ro, rd = trace_scene(P=50, R=64, seed=2, camera=False)
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    # rays that miss everything: background, zero weight, zero gradients
+    far = ro + torch.tensor([1000.0, 0, 0]); away = torch.tensor([1.0, 0, 0]).expand_as(rd).contiguous()
+    outs, L, o, d, g3 = _run_hip(g, far, away, bg, 2, True, False, grads=[torch.ones(64, 3), torch.ones(64), torch.ones(64), torch.ones(64, 3), torch.ones(64, 2)])
+    rgb, dpt, acc, norm, dist, aux, mid, wet = outs
+    assert torch.allclose(rgb, bg.to(dev).expand_as(rgb)) and float(acc.abs().max()) == 0 and float(wet.abs().max()) == 0
+    assert float(L["means3D"].grad.abs().max()) == 0 and float(o.grad.abs().max()) == 0
+    # validation mirrors the reference wrapper; stale BVH after "densification" is an error, not silent garbage
+    tracer = mod.SurfelTracer()
+    v, f = synth.get_disks(g["means3D"], g["scales"], g["rotations"])
+    tracer.build_acceleration_structure(v.to(dev), f.to(dev), rebuild=True)
+    kw = dict(means3D=g["means3D"].to(dev), grads3D=None, shs=g["shs"].to(dev), colors_precomp=None, others_precomp=None,
+              opacities=g["opacities"].to(dev), scales=g["scales"].to(dev), rotations=g["rotations"].to(dev), cov3D_precomp=None,
+              tracer_settings=_settings(mod, bg, 0, dev), start_from_first=False)
+    with pytest.raises(Exception):
+        tracer(ro.to(dev), rd.to(dev), None, **{**kw, "colors_precomp": torch.rand(50, 3, device=dev)})
+    with pytest.raises(Exception):
+        tracer(ro.to(dev), rd.to(dev), None, **{**kw, "means3D": torch.rand(60, 3, device=dev)})
+    # cached BVH (v=None at test time, optix_utils.py:83) under inference_mode, (1,S,3) rays
+    with torch.inference_mode():
+        rgb2, *_ = tracer(ro.to(dev)[None], rd.to(dev)[None], None, **kw)
+    assert rgb2.shape == (1, 64, 3) and torch.isfinite(rgb2).all()
