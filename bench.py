@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="raster", choices=["raster", "envgs"])
     ap.add_argument("--gaussians", type=int, default=300000)
+    ap.add_argument("--env-gaussians", type=int, default=163840)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
@@ -84,12 +85,21 @@ def main():
 
     names = ["means3D", "shs", "opacities", "scales", "rotations"]
     params = {k: g[k].clone().requires_grad_(True) for k in names}
+    env_params = {}
     if envgs:
         params["specular"] = g["specular"].clone().requires_grad_(True)
         params["roughness"] = g["roughness"].clone().requires_grad_(True)
+        ge = synth.env_gaussians(args.env_gaussians, seed=1, device=dev)
+        env_params = {k: ge[k].clone().requires_grad_(True) for k in names}
 
     if envgs:
         import diff_surfel_rasterization_wet_ch05 as pkg
+        import diff_surfel_tracing as tpkg
+        from envgs_amd import envgs_step, tracing
+        tracer = tpkg.SurfelTracer()
+        rays = [synth.get_rays(c) for c in cams]
+        env_bg = torch.zeros(3, device=dev)
+        dcol_hw3 = dcol[:3].permute(1, 2, 0).contiguous()
     else:
         import diff_surfel_rasterization_wet as pkg
     sh_degree = torch.tensor([3], device=dev)
@@ -101,20 +111,25 @@ def main():
             campos=cam.camera_center, prefiltered=False, debug=False)
 
     n_acc = {"N": 0, "steps": 0}
+    all_params = list(params.values()) + list(env_params.values())
 
     def step(it):
-        cam = cams[(it * world + rank) % 8]
-        means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+        vi = (it * world + rank) % 8
+        cam = cams[vi]
         if envgs:
-            raise SystemExit("envgs workload: tracer not wired into bench yet")
-        color, radii, allmap, weight = pkg.GaussianRasterizer(raster_settings=settings(cam))(
-            means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
-            opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"], cov3D_precomp=None)
+            out = envgs_step.envgs_forward(pkg, tpkg, tracer, cam, rays[vi], params, env_params, bg, env_bg, sh_degree)
+            allmap = out["base"]["allmap"]
+            loss = (out["rgb"] * dcol_hw3).sum() + (allmap * dall).sum()
+        else:
+            means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+            color, radii, allmap, weight = pkg.GaussianRasterizer(raster_settings=settings(cam))(
+                means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
+                opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"], cov3D_precomp=None)
+            loss = (color * dcol).sum() + (allmap * dall).sum()
         n_acc["N"] += raster.LAST_STATS["N"]; n_acc["steps"] += 1
-        loss = (color * dcol).sum() + (allmap * dall).sum()
         loss.backward()
-        nbytes = edist.allreduce_grads(list(params.values()), average=True) if world > 1 else 0
-        for p_ in params.values():
+        nbytes = edist.allreduce_grads(all_params, average=True) if world > 1 else 0
+        for p_ in all_params:
             p_.grad = None
         return nbytes
 
@@ -153,7 +168,7 @@ def main():
         if c_.value > 0:
             name = lib.envgs_prof_kernel_name(k).decode()
             ms = t_.value / c_.value
-            ab = algorithmic_bytes(name, P, N_avg, HW, C, True)
+            ab = algorithmic_bytes(name, P, N_avg, HW, C, not envgs)
             kernels[name] = {"ms": round(ms, 4), "launches": c_.value, "alg_MB": round(ab / 1e6, 2),
                              "GBps": round(ab / 1e9 / (ms / 1e3), 1) if ab and ms > 0 else None}
 
@@ -166,12 +181,12 @@ def main():
             A = kernels[dom]["GBps"]
             roof = {"kernel": dom, "bound": "hbm", "achieved": A, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(A / HBM_PEAK_GBS, 5), "traffic": None,
-                    "alg_bytes_per_launch": int(algorithmic_bytes(dom, P, N_avg, HW, C, True)),
+                    "alg_bytes_per_launch": int(algorithmic_bytes(dom, P, N_avg, HW, C, not envgs)),
                     "ms_per_launch": kernels[dom]["ms"], "tile_instances_N": int(N_avg),
                     "note": "R7 performs ~150 flop per (pixel,splat) evaluation; it is VALU/cross-lane bound, not HBM bound "
                             "(SURVEY.md section 8d) -- the HBM fraction is reported as mandated"}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not envgs:
             cpu = cpu_baseline(g, cams[0], bg, dcol, dall, H, W, args.cpu_reps)
         line = {
             "metric": "train iters/s (fwd+bwd of the render hot path, one 800x800 view per GPU per iter) + render Mpix/s",
@@ -180,11 +195,12 @@ def main():
             "dtype": "f32", "data": "synthetic (seeded, BASELINE.md section 3; random-init Gaussians)",
             "config": {"workload": ("Ref-Real sedan-like full EnvGS (ch05 raster + env LBVH trace)" if envgs else
                                     "Ref-NeRF toaster-like base 2DGS raster only (BASELINE configs[1]), SH deg 3 in-kernel"),
-                       "gaussians": P, "resolution": [H, W], "channels": C, "views": 8,
+                       "gaussians": P, "env_gaussians": (args.env_gaussians if envgs else 0), "resolution": [H, W], "channels": C, "views": 8,
                        "parallelism": "dp%d (camera batch sharded, flat grad all-reduce)" % world,
                        "allreduce_bytes_per_step": int(ar_bytes)},
             "train_mpix_per_s": round(value * HW / 1e6, 2),
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+            "trace_counts": (tracing.last_trace_counts() if envgs else None),
         }
         print(json.dumps(line))
     if world > 1:

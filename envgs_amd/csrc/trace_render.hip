@@ -122,12 +122,13 @@ struct TraceArgs {
     const float *shs, *colors, *others, *bg;
     const float *ray_o, *ray_d;
     unsigned *counter;
+    unsigned long long *stats;      // [hits, node visits, rounds] totals of the forward (diagnostics)
     // forward outputs
     float *rgb, *dpt, *acc, *norm, *dist, *aux, *mid, *wet, *final_T;
     // backward inputs / outputs
     const float *f_rgb, *f_dpt, *f_acc, *f_norm, *f_aux, *f_T;
     const float *g_rgb, *g_dpt, *g_acc, *g_norm, *g_aux;
-    float *rot_rec, *dmeans, *dscales, *dopac, *dshs, *dcolors, *dothers, *dray_o, *dray_d;
+    float *geo_rec, *dshs, *dcolors, *dothers, *dray_o, *dray_d;
     float mod;
 };
 
@@ -156,7 +157,7 @@ struct KBuf {
 // One traversal round: collect the K nearest accepted hits with (t,id) > (tlo,idlo).
 __device__ __forceinline__ void traverse(const TraceArgs &A, int (*stk)[64], const int lane, const bool active,
                                          const float ox, const float oy, const float oz, const float dx, const float dy,
-                                         const float dz, const float tlo, const int idlo, KBuf &kb)
+                                         const float dz, const float tlo, const int idlo, KBuf &kb, unsigned &visits)
 {
     kb.reset();
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
@@ -169,6 +170,7 @@ __device__ __forceinline__ void traverse(const TraceArgs &A, int (*stk)[64], con
             cur = stk[--sp][lane];
         }
         const float4 *nd = A.nodes + (size_t)cur * 4;
+        visits++;
         const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
         const int lc = __float_as_int(n3.x), rc = __float_as_int(n3.y);
         // slabs: left box min (n0.x,n0.y,n0.z) max (n0.w,n1.x,n1.y); right box min (n1.z,n1.w,n2.x) max (n2.y,n2.z,n2.w)
@@ -256,6 +258,7 @@ trace_fwd(const TraceArgs A, const int ray_h, const int ray_w)
         float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
         float tmin = A.start_from_first ? NEAR_N : 0.0f;
         float out_rgb[3] = {0.f, 0.f, 0.f};
+        unsigned st_hits = 0, st_visits = 0, st_rounds = 0;
         float thr = 1.0f;                               // product of specular weights of the previous stages
         bool chain = valid;
         StageSums s0;
@@ -273,7 +276,8 @@ trace_fwd(const TraceArgs A, const int ray_h, const int ray_w)
             for (int round = 0; round < MAX_ROUNDS; round++) {
                 if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
                 KBuf kb;
-                traverse(A, stk, lane, !done, ox, oy, oz, dx, dy, dz, tlo, idlo, kb);
+                st_rounds += done ? 0u : 1u;
+                traverse(A, stk, lane, !done, ox, oy, oz, dx, dy, dz, tlo, idlo, kb, st_visits);
 #pragma unroll 1
                 for (int i = 0; i < KBUF; i++) {
                     int sid = 0;
@@ -300,6 +304,7 @@ trace_fwd(const TraceArgs A, const int ray_h, const int ray_w)
                             if (A.has_others) { S.aux[0] += w * A.others[2 * sid]; S.aux[1] += w * A.others[2 * sid + 1]; }
                             if (stage == 0) atomic_add_f32(A.wet + sid, w);
                             S.T = test_T;
+                            st_hits++;
                         }
                     }
                 }
@@ -342,15 +347,58 @@ trace_fwd(const TraceArgs A, const int ray_h, const int ray_w)
             A.aux[2 * r] = s0.aux[0]; A.aux[2 * r + 1] = s0.aux[1];
             A.final_T[r] = s0.T;
         }
+        if (A.stats) {
+            // per-wavefront totals -> 3 atomics per 64 rays
+            const float fh = wave_sum((float)st_hits), fv = wave_sum((float)st_visits), fr = wave_sum((float)st_rounds);
+            if (lane == 0) {
+                atomicAdd(A.stats + 0, (unsigned long long)fh);
+                atomicAdd(A.stats + 1, (unsigned long long)fv);
+                atomicAdd(A.stats + 2, (unsigned long long)fr);
+            }
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------ T3 ---
+// SH basis k as (l0 + l1 x + l2 y + l3 z) * (q0 + q1 xx + q2 yy + q3 zz + q4 xy + q5 yz + q6 xz): lets lane j evaluate
+// "its" basis function (k = j / 3) of ANOTHER lane's ray direction during the cooperative gradient flush.
+__device__ __constant__ float kShForm[16][11] = {
+    {1, 0, 0, 0, 0.28209479177387814f, 0, 0, 0, 0, 0, 0},
+    {0, 0, 1, 0, -0.4886025119029199f, 0, 0, 0, 0, 0, 0},
+    {0, 0, 0, 1, 0.4886025119029199f, 0, 0, 0, 0, 0, 0},
+    {0, 1, 0, 0, -0.4886025119029199f, 0, 0, 0, 0, 0, 0},
+    {1, 0, 0, 0, 0, 0, 0, 0, 1.0925484305920792f, 0, 0},
+    {1, 0, 0, 0, 0, 0, 0, 0, 0, -1.0925484305920792f, 0},
+    {1, 0, 0, 0, 0, -0.31539156525252005f, -0.31539156525252005f, 2.f * 0.31539156525252005f, 0, 0, 0},
+    {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, -1.0925484305920792f},
+    {1, 0, 0, 0, 0, 0.5462742152960396f, -0.5462742152960396f, 0, 0, 0, 0},
+    {0, 0, 1, 0, 0, 3.f * -0.5900435899266435f, 0.5900435899266435f, 0, 0, 0, 0},
+    {0, 0, 0, 1, 0, 0, 0, 0, 2.890611442640554f, 0, 0},
+    {0, 0, 1, 0, 0, 0.4570457994644658f, 0.4570457994644658f, 4.f * -0.4570457994644658f, 0, 0, 0},
+    {0, 0, 0, 1, 0, -3.f * 0.3731763325901154f, -3.f * 0.3731763325901154f, 2.f * 0.3731763325901154f, 0, 0, 0},
+    {0, 1, 0, 0, 0, 0.4570457994644658f, 0.4570457994644658f, 4.f * -0.4570457994644658f, 0, 0, 0},
+    {0, 0, 0, 1, 0, 1.445305721320277f, -1.445305721320277f, 0, 0, 0, 0},
+    {0, 1, 0, 0, 0, -0.5900435899266435f, 3.f * 0.5900435899266435f, 0, 0, 0, 0},
+};
+
+constexpr int NFLD = 22;   // LDS hand-off fields per lane: sid, dc[3], geo[15], dir[3]
+constexpr int GEO = ENVGS_GEOREC_STRIDE;
+
 __global__ void __launch_bounds__(64)
 trace_bwd(const TraceArgs A, const int ray_h, const int ray_w)
 {
     __shared__ int stk[STACK][64];
+    __shared__ float fld[NFLD][65];                 // row stride 65: lanes 48..62 read 15 different rows of one column conflict-free
     const int lane = threadIdx.x;
+    // this lane's role in the cooperative flush
+    const int fk = lane / 3, fc = lane - 3 * fk;     // SH coefficient index and colour channel for lanes 0..47
+    float form[11];
+#pragma unroll
+    for (int i = 0; i < 11; i++) form[i] = kShForm[fk < 16 ? fk : 0][i];
+    const int nb = (A.D + 1) * (A.D + 1);
+    const bool sh_lane = A.M > 0 ? (lane < 48 && fk < nb) : (lane < 3);
+    const bool geo_lane = lane >= 48 && lane < 48 + 15;
+
     while (true) {
         int base = 0;
         if (lane == 0) base = (int)atomicAdd(A.counter, 64u);
@@ -375,88 +423,117 @@ trace_bwd(const TraceArgs A, const int ray_h, const int ray_w)
         const float fN0 = A.f_norm[3 * r], fN1 = A.f_norm[3 * r + 1], fN2 = A.f_norm[3 * r + 2];
         const float fX0 = A.f_aux[2 * r], fX1 = A.f_aux[2 * r + 1];
         const float dl2 = dx * dx + dy * dy + dz * dz, il = 1.0f / sqrtf(dl2);
-        float basis[16];
-        sh_basis(A.D, dx * il, dy * il, dz * il, basis);
+        const float ux = dx * il, uy = dy * il, uz = dz * il;
+        float basis[16], Sk[16];
+        sh_basis(A.D, ux, uy, uz, basis);
+#pragma unroll
+        for (int k = 0; k < 16; k++) Sk[k] = 0.f;
+        __syncthreads();                                  // previous batch's flush reads are done
+        fld[19][lane] = ux; fld[20][lane] = uy; fld[21][lane] = uz;
         float T = 1.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f, cD = 0.f, cA = 0.f, cN0 = 0.f, cN1 = 0.f, cN2 = 0.f, cX0 = 0.f, cX1 = 0.f;
-        float dO0 = 0.f, dO1 = 0.f, dO2 = 0.f, dD0 = 0.f, dD1 = 0.f, dD2 = 0.f, dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
+        float dO0 = 0.f, dO1 = 0.f, dO2 = 0.f, dD0 = 0.f, dD1 = 0.f, dD2 = 0.f;
         bool done = !valid || A.P == 0;
         float tlo = tmin; int idlo = 0x7fffffff;
         for (int round = 0; round < MAX_ROUNDS; round++) {
             if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
             KBuf kb;
-            traverse(A, stk, lane, !done, ox, oy, oz, dx, dy, dz, tlo, idlo, kb);
+            unsigned visits_unused = 0;
+            traverse(A, stk, lane, !done, ox, oy, oz, dx, dy, dz, tlo, idlo, kb, visits_unused);
 #pragma unroll 1
             for (int i = 0; i < KBUF; i++) {
-                // dynamic index into the register buffer: pick element i with a select chain
-                float ht = 0.f; int sid = 0;
+                if (__builtin_amdgcn_ballot_w64(!done && i < kb.n) == 0) break;
+                int sid = 0;
 #pragma unroll
-                for (int k = 0; k < KBUF; k++) { ht = (k == i) ? kb.t[k] : ht; sid = (k == i) ? kb.id[k] : sid; }
-                if (done || i >= kb.n) continue;
-                const float4 *sr = A.srec + (size_t)sid * 4;
-                const float4 s0 = sr[0], s1 = sr[1], s2 = sr[2], s3 = sr[3];
-                const SurfHit h = hit_surfel(s0, s1, s2, s3, ox, oy, oz, dx, dy, dz);
-                const float alpha = h.alpha;
-                const float test_T = T * (1.0f - alpha);
-                if (test_T < T_EPS) { done = true; continue; }
-                const float w = alpha * T;
-                float col[3]; bool cl[3];
-                surfel_color(A, sid, basis, col, cl);
-                const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
-                const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
-                const float x0 = A.has_others ? A.others[2 * sid] : 0.f, x1 = A.has_others ? A.others[2 * sid + 1] : 0.f;
-                c0 += w * col[0]; c1 += w * col[1]; c2 += w * col[2];
-                cD += w * h.t; cA += w;
-                cN0 += w * nf0; cN1 += w * nf1; cN2 += w * nf2;
-                cX0 += w * x0; cX1 += w * x1;
-                const float inv1m = 1.0f / (1.0f - alpha);
-                float dLa = gR0 * (T * col[0] - (fr0 - c0) * inv1m) + gR1 * (T * col[1] - (fr1 - c1) * inv1m) + gR2 * (T * col[2] - (fr2 - c2) * inv1m);
-                dLa += gD * (T * h.t - (fD - cD) * inv1m);
-                dLa += gA * (T - (fA - cA) * inv1m);
-                dLa += gN0 * (T * nf0 - (fN0 - cN0) * inv1m) + gN1 * (T * nf1 - (fN1 - cN1) * inv1m) + gN2 * (T * nf2 - (fN2 - cN2) * inv1m);
-                dLa += gX0 * (T * x0 - (fX0 - cX0) * inv1m) + gX1 * (T * x1 - (fX1 - cX1) * inv1m);
-                dLa += -(fT * inv1m) * bgdot;
-                const float dc0 = cl[0] ? 0.f : w * gR0, dc1 = cl[1] ? 0.f : w * gR1, dc2 = cl[2] ? 0.f : w * gR2;
-                if (A.M > 0) {
-                    float bgx[16], bgy[16], bgz[16];
-                    sh_basis_grad(A.D, dx * il, dy * il, dz * il, bgx, bgy, bgz);
-                    const float *sh = A.shs + (size_t)sid * A.M * 3;
-                    float *dsh = A.dshs + (size_t)sid * A.M * 3;
-                    const int nb = (A.D + 1) * (A.D + 1);
+                for (int k = 0; k < KBUF; k++) sid = (k == i) ? kb.id[k] : sid;     // dynamic pick from the register buffer
+                bool has = false;
+                float dc0 = 0.f, dc1 = 0.f, dc2 = 0.f, gv[15];
 #pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        if (k < nb) {
-                            const float b = basis[k];
-                            atomic_add_f32(dsh + k * 3, b * dc0); atomic_add_f32(dsh + k * 3 + 1, b * dc1); atomic_add_f32(dsh + k * 3 + 2, b * dc2);
-                            const float sd = sh[k * 3] * dc0 + sh[k * 3 + 1] * dc1 + sh[k * 3 + 2] * dc2;
-                            dd0 += bgx[k] * sd; dd1 += bgy[k] * sd; dd2 += bgz[k] * sd;
+                for (int k = 0; k < 15; k++) gv[k] = 0.f;
+                if (!done && i < kb.n) {
+                    const float4 *sr = A.srec + (size_t)sid * 4;
+                    const float4 s0 = sr[0], s1 = sr[1], s2 = sr[2], s3 = sr[3];
+                    const SurfHit h = hit_surfel(s0, s1, s2, s3, ox, oy, oz, dx, dy, dz);
+                    const float alpha = h.alpha;
+                    const float test_T = T * (1.0f - alpha);
+                    if (test_T < T_EPS) { done = true; }
+                    else {
+                        has = true;
+                        const float w = alpha * T;
+                        float col[3]; bool cl[3];
+                        surfel_color(A, sid, basis, col, cl);
+                        const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
+                        const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
+                        const float x0 = A.has_others ? A.others[2 * sid] : 0.f, x1 = A.has_others ? A.others[2 * sid + 1] : 0.f;
+                        c0 += w * col[0]; c1 += w * col[1]; c2 += w * col[2];
+                        cD += w * h.t; cA += w;
+                        cN0 += w * nf0; cN1 += w * nf1; cN2 += w * nf2;
+                        cX0 += w * x0; cX1 += w * x1;
+                        const float inv1m = 1.0f / (1.0f - alpha);
+                        float dLa = gR0 * (T * col[0] - (fr0 - c0) * inv1m) + gR1 * (T * col[1] - (fr1 - c1) * inv1m) + gR2 * (T * col[2] - (fr2 - c2) * inv1m);
+                        dLa += gD * (T * h.t - (fD - cD) * inv1m);
+                        dLa += gA * (T - (fA - cA) * inv1m);
+                        dLa += gN0 * (T * nf0 - (fN0 - cN0) * inv1m) + gN1 * (T * nf1 - (fN1 - cN1) * inv1m) + gN2 * (T * nf2 - (fN2 - cN2) * inv1m);
+                        dLa += gX0 * (T * x0 - (fX0 - cX0) * inv1m) + gX1 * (T * x1 - (fX1 - cX1) * inv1m);
+                        dLa += -(fT * inv1m) * bgdot;
+                        dc0 = cl[0] ? 0.f : w * gR0; dc1 = cl[1] ? 0.f : w * gR1; dc2 = cl[2] ? 0.f : w * gR2;
+                        if (A.M > 0) {
+                            // dL/d(dir) = sum_k grad(basis_k) * (sh_k . dc): accumulate the 16 scalars, apply grad(basis) once per ray
+                            const float *sh = A.shs + (size_t)sid * A.M * 3;
+#pragma unroll
+                            for (int k = 0; k < 16; k++)
+                                if (k < nb) Sk[k] += sh[k * 3] * dc0 + sh[k * 3 + 1] * dc1 + sh[k * 3 + 2] * dc2;
                         }
+                        if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * gX1); }
+                        const float dLG = s0.w * dLa;
+                        const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
+                        const float su = s1.w, sv = s2.w;
+                        const float qx = ox + h.t * dx - s0.x, qy = oy + h.t * dy - s0.y, qz = oz + h.t * dz - s0.z;
+                        // u = (a/su).q : dL/dq = dLu*(a/su) + dLv*(b/sv) ; dL/da = (dLu/su) q ; dL/dsu = -dLu*u/su
+                        const float dq0 = dLu * s1.x + dLv * s2.x, dq1 = dLu * s1.y + dLv * s2.y, dq2 = dLu * s1.z + dLv * s2.z;
+                        const float cu = dLu / su, cv = dLv / sv;
+                        const float dLt_tot = w * gD + dq0 * dx + dq1 * dy + dq2 * dz;
+                        const float kt = dLt_tot / h.denom;
+                        gv[0] = -dq0 + kt * s3.x; gv[1] = -dq1 + kt * s3.y; gv[2] = -dq2 + kt * s3.z;
+                        gv[3] = cu * qx; gv[4] = cu * qy; gv[5] = cu * qz;
+                        gv[6] = cv * qx; gv[7] = cv * qy; gv[8] = cv * qz;
+                        gv[9] = w * sgn * gN0 - kt * qx; gv[10] = w * sgn * gN1 - kt * qy; gv[11] = w * sgn * gN2 - kt * qz;
+                        gv[12] = -dLu * h.u / su * A.mod; gv[13] = -dLv * h.v / sv * A.mod;
+                        gv[14] = h.G * dLa;
+                        dO0 += dq0 - kt * s3.x; dO1 += dq1 - kt * s3.y; dO2 += dq2 - kt * s3.z;
+                        dD0 += h.t * (dq0 - kt * s3.x); dD1 += h.t * (dq1 - kt * s3.y); dD2 += h.t * (dq2 - kt * s3.z);
+                        T = test_T;
                     }
-                } else {
-                    atomic_add_f32(A.dcolors + 3 * sid, dc0); atomic_add_f32(A.dcolors + 3 * sid + 1, dc1); atomic_add_f32(A.dcolors + 3 * sid + 2, dc2);
                 }
-                if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * gX1); }
-                atomic_add_f32(A.dopac + sid, h.G * dLa);
-                const float dLG = s0.w * dLa;
-                const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
-                const float su = s1.w, sv = s2.w;
-                const float qx = ox + h.t * dx - s0.x, qy = oy + h.t * dy - s0.y, qz = oz + h.t * dz - s0.z;
-                // u = (a/su).q : dL/dq = dLu*(a/su) + dLv*(b/sv) ; dL/da = (dLu/su) q ; dL/dsu = -dLu*u/su
-                const float dq0 = dLu * s1.x + dLv * s2.x, dq1 = dLu * s1.y + dLv * s2.y, dq2 = dLu * s1.z + dLv * s2.z;
-                const float cu = dLu / su, cv = dLv / sv;
-                float *rr = A.rot_rec + (size_t)sid * ENVGS_ROTREC_STRIDE;
-                const float dLt_tot = w * gD + dq0 * dx + dq1 * dy + dq2 * dz;
-                const float kt = dLt_tot / h.denom;
-                atomic_add_f32(rr + 0, cu * qx); atomic_add_f32(rr + 1, cu * qy); atomic_add_f32(rr + 2, cu * qz);
-                atomic_add_f32(rr + 3, cv * qx); atomic_add_f32(rr + 4, cv * qy); atomic_add_f32(rr + 5, cv * qz);
-                atomic_add_f32(rr + 6, w * sgn * gN0 - kt * qx); atomic_add_f32(rr + 7, w * sgn * gN1 - kt * qy); atomic_add_f32(rr + 8, w * sgn * gN2 - kt * qz);
-                atomic_add_f32(A.dscales + 2 * sid, -dLu * h.u / su * A.mod);
-                atomic_add_f32(A.dscales + 2 * sid + 1, -dLv * h.v / sv * A.mod);
-                atomic_add_f32(A.dmeans + 3 * sid, -dq0 + kt * s3.x);
-                atomic_add_f32(A.dmeans + 3 * sid + 1, -dq1 + kt * s3.y);
-                atomic_add_f32(A.dmeans + 3 * sid + 2, -dq2 + kt * s3.z);
-                dO0 += dq0 - kt * s3.x; dO1 += dq1 - kt * s3.y; dO2 += dq2 - kt * s3.z;
-                dD0 += h.t * (dq0 - kt * s3.x); dD1 += h.t * (dq1 - kt * s3.y); dD2 += h.t * (dq2 - kt * s3.z);
-                T = test_T;
+                // ---- cooperative flush: one hit at a time, the WHOLE wavefront writes that surfel's contiguous gradient words:
+                // lanes 0..47 the (16,3) SH block, lanes 48..62 the 15-word geometry record -> 1 instruction, ~3 cache lines per hit
+                // (instead of 63 per-lane atomics that each touch 64 different lines).
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(has);
+                if (hm == 0) continue;
+                fld[0][lane] = __int_as_float(sid); fld[1][lane] = dc0; fld[2][lane] = dc1; fld[3][lane] = dc2;
+#pragma unroll
+                for (int k = 0; k < 15; k++) fld[4 + k][lane] = gv[k];
+                __syncthreads();
+                unsigned long long m = hm;
+                while (m) {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int hs = __float_as_int(fld[0][l]);
+                    float val = 0.f; float *dst = nullptr;
+                    if (A.M > 0) {
+                        const float x = fld[19][l], y = fld[20][l], z = fld[21][l];
+                        const float lin = form[0] + form[1] * x + form[2] * y + form[3] * z;
+                        const float quad = form[4] + form[5] * (x * x) + form[6] * (y * y) + form[7] * (z * z) + form[8] * (x * y) + form[9] * (y * z) + form[10] * (x * z);
+                        const float dcc = fc == 0 ? fld[1][l] : (fc == 1 ? fld[2][l] : fld[3][l]);
+                        val = lin * quad * dcc;
+                        dst = A.dshs + (size_t)hs * A.M * 3 + lane;
+                    } else {
+                        val = fld[1 + (lane < 3 ? lane : 0)][l];
+                        dst = A.dcolors + (size_t)hs * 3 + lane;
+                    }
+                    if (geo_lane) { val = fld[4 + (lane - 48)][l]; dst = A.geo_rec + (size_t)hs * GEO + (lane - 48); }
+                    if (sh_lane || geo_lane) atomic_add_f32(dst, val);
+                }
+                __syncthreads();
             }
             if (!done) {
                 if (kb.n < KBUF) done = true;
@@ -464,6 +541,13 @@ trace_bwd(const TraceArgs A, const int ray_h, const int ray_w)
             }
         }
         if (valid) {
+            float dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
+            if (A.M > 0) {
+                float bgx[16], bgy[16], bgz[16];
+                sh_basis_grad(A.D, ux, uy, uz, bgx, bgy, bgz);
+#pragma unroll
+                for (int k = 0; k < 16; k++) { dd0 += bgx[k] * Sk[k]; dd1 += bgy[k] * Sk[k]; dd2 += bgz[k] * Sk[k]; }
+            }
             const float inv3 = il * il * il;
             dD0 += ((dl2 - dx * dx) * dd0 - dy * dx * dd1 - dz * dx * dd2) * inv3;
             dD1 += (-dx * dy * dd0 + (dl2 - dy * dy) * dd1 - dz * dy * dd2) * inv3;
@@ -474,17 +558,19 @@ trace_bwd(const TraceArgs A, const int ray_h, const int ray_w)
     }
 }
 
-// rotation columns (a,b,n) gradient -> unit-quaternion gradient; also copies dmeans into the densification sink
+// per-surfel geometry record [dmu 3, da 3, db 3, dn 3, dsu, dsv, dopacity] -> parameter gradients; the rotation columns
+// (a,b,n) chain to the unit quaternion; dmeans is also copied into the densification sink.
 __global__ void __launch_bounds__(256)
-finish_rotations(int P, const float *__restrict__ rots, const float *__restrict__ rot_rec, const float *__restrict__ dmeans,
-                 float *__restrict__ drots, float *__restrict__ dgrads3D)
+finish_surfel_grads(int P, const float *__restrict__ rots, const float *__restrict__ geo_rec, float *__restrict__ dmeans,
+                    float *__restrict__ dscales, float *__restrict__ dopac, float *__restrict__ drots, float *__restrict__ dgrads3D)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const float q0 = rots[4 * i], q1 = rots[4 * i + 1], q2 = rots[4 * i + 2], q3 = rots[4 * i + 3];
     const float inv = 1.0f / sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
     const float r = q0 * inv, x = q1 * inv, y = q2 * inv, z = q3 * inv;
-    const float *rr = rot_rec + (size_t)i * ENVGS_ROTREC_STRIDE;
+    const float *g = geo_rec + (size_t)i * GEO;
+    const float *rr = g + 3;
     // V[row][col]: col 0 = dL/da, col 1 = dL/db, col 2 = dL/dn
 #define VR(a, b) rr[(b) * 3 + (a)]
     drots[4 * i + 0] = 2.f * (x * (VR(2, 1) - VR(1, 2)) + y * (VR(0, 2) - VR(2, 0)) + z * (VR(1, 0) - VR(0, 1)));
@@ -492,7 +578,10 @@ finish_rotations(int P, const float *__restrict__ rots, const float *__restrict_
     drots[4 * i + 2] = 2.f * (x * (VR(1, 0) + VR(0, 1)) - 2.f * y * (VR(0, 0) + VR(2, 2)) + z * (VR(2, 1) + VR(1, 2)) + r * (VR(0, 2) - VR(2, 0)));
     drots[4 * i + 3] = 2.f * (x * (VR(2, 0) + VR(0, 2)) + y * (VR(2, 1) + VR(1, 2)) - 2.f * z * (VR(0, 0) + VR(1, 1)) + r * (VR(1, 0) - VR(0, 1)));
 #undef VR
-    if (dgrads3D) { dgrads3D[3 * i] = dmeans[3 * i]; dgrads3D[3 * i + 1] = dmeans[3 * i + 1]; dgrads3D[3 * i + 2] = dmeans[3 * i + 2]; }
+    dmeans[3 * i] = g[0]; dmeans[3 * i + 1] = g[1]; dmeans[3 * i + 2] = g[2];
+    dscales[2 * i] = g[12]; dscales[2 * i + 1] = g[13];
+    dopac[i] = g[14];
+    if (dgrads3D) { dgrads3D[3 * i] = g[0]; dgrads3D[3 * i + 1] = g[1]; dgrads3D[3 * i + 2] = g[2]; }
 }
 
 static int persistent_grid(int R)
@@ -536,7 +625,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     hipStream_t stream = (hipStream_t)stream_;
     envgs_raster_cfg dbg; dbg.debug = cfg->debug;
     const envgs_raster_cfg *dcfg = &dbg;
-    hipError_t e = hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(counters, 0, 16 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
     if (cfg->P > 0) {
         e = hipMemsetAsync(wet, 0, sizeof(float) * (size_t)cfg->P, stream);
@@ -552,7 +641,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     A.P = cfg->P; A.R = cfg->num_rays; A.D = cfg->sh_degree; A.M = cfg->sh_coeffs; A.ND = cfg->max_trace_depth + 1;
     A.start_from_first = cfg->start_from_first; A.has_others = cfg->has_others; A.bg_len = cfg->bg_len; A.spec_thr = cfg->specular_threshold;
     A.nodes = (const float4 *)nodes; A.srec = (const float4 *)srec; A.shs = shs; A.colors = colors_precomp; A.others = others_precomp;
-    A.bg = bg; A.ray_o = ray_o; A.ray_d = ray_d; A.counter = counters;
+    A.bg = bg; A.ray_o = ray_o; A.ray_d = ray_d; A.counter = counters; A.stats = (unsigned long long *)(counters + 2);
     A.rgb = rgb; A.dpt = dpt; A.acc = acc; A.norm = norm; A.dist = dist; A.aux = aux; A.mid = mid; A.wet = wet; A.final_T = final_T;
     A.mod = cfg->scale_modifier;
     int rh, rw; ray_layout(cfg, &rh, &rw);
@@ -567,7 +656,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
                          const float *shs, const float *colors_precomp, const float *others_precomp, const float *bg,
                          const float *srec, uint32_t *counters, const float *rgb, const float *dpt, const float *acc,
                          const float *norm, const float *aux, const float *final_T, const float *dL_drgb, const float *dL_ddpt,
-                         const float *dL_dacc, const float *dL_dnorm, const float *dL_daux, float *rot_rec, float *dmeans3D,
+                         const float *dL_dacc, const float *dL_dnorm, const float *dL_daux, float *geo_rec, float *dmeans3D,
                          float *dgrads3D, float *dscales, float *drots, float *dopacities, float *dshs, float *dcolors,
                          float *dothers, float *dray_o, float *dray_d, void *stream_)
 {
@@ -578,16 +667,16 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     const size_t P = (size_t)cfg->P, R = (size_t)cfg->num_rays;
     hipError_t e;
 #define ZERO(ptr, n) do { if ((ptr) && (n) > 0) { e = hipMemsetAsync((ptr), 0, sizeof(float) * (n), stream); if (e != hipSuccess) return (int)e; } } while (0)
-    ZERO(rot_rec, P * ENVGS_ROTREC_STRIDE); ZERO(dmeans3D, P * 3); ZERO(dgrads3D, P * 3); ZERO(dscales, P * 2); ZERO(drots, P * 4);
+    ZERO(geo_rec, P * ENVGS_GEOREC_STRIDE); ZERO(dmeans3D, P * 3); ZERO(dgrads3D, P * 3); ZERO(dscales, P * 2); ZERO(drots, P * 4);
     ZERO(dopacities, P); ZERO(dothers, P * 2); ZERO(dray_o, R * 3); ZERO(dray_d, R * 3);
     if (cfg->sh_coeffs > 0) ZERO(dshs, P * cfg->sh_coeffs * 3); else ZERO(dcolors, P * 3);
 #undef ZERO
     if (cfg->num_rays == 0 || cfg->P == 0) return 0;
     if (!nodes || !ray_o || !ray_d || !srec || !counters || !rgb || !dpt || !acc || !norm || !aux || !final_T || !dL_drgb || !dL_ddpt ||
-        !dL_dacc || !dL_dnorm || !dL_daux || !rot_rec || !dmeans3D || !dscales || !drots || !dopacities || !dray_o || !dray_d || !rotations || !bg)
+        !dL_dacc || !dL_dnorm || !dL_daux || !geo_rec || !dmeans3D || !dscales || !drots || !dopacities || !dray_o || !dray_d || !rotations || !bg)
         return ENVGS_ERR_BAD_ARG;
     if (cfg->sh_coeffs > 0 ? (!shs || !dshs) : (!colors_precomp || !dcolors)) return ENVGS_ERR_BAD_ARG;
-    e = hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), stream);
+    e = hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
     TraceArgs A;
     A = TraceArgs{};
@@ -597,7 +686,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     A.bg = bg; A.ray_o = ray_o; A.ray_d = ray_d; A.counter = counters;
     A.f_rgb = rgb; A.f_dpt = dpt; A.f_acc = acc; A.f_norm = norm; A.f_aux = aux; A.f_T = final_T;
     A.g_rgb = dL_drgb; A.g_dpt = dL_ddpt; A.g_acc = dL_dacc; A.g_norm = dL_dnorm; A.g_aux = dL_daux;
-    A.rot_rec = rot_rec; A.dmeans = dmeans3D; A.dscales = dscales; A.dopac = dopacities; A.dshs = dshs; A.dcolors = dcolors;
+    A.geo_rec = geo_rec; A.dshs = dshs; A.dcolors = dcolors;
     A.dothers = dothers; A.dray_o = dray_o; A.dray_d = dray_d; A.mod = cfg->scale_modifier;
     int rh, rw; ray_layout(cfg, &rh, &rw);
     {
@@ -605,7 +694,8 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
         hipLaunchKernelGGL(trace_bwd, dim3(persistent_grid(cfg->num_rays)), dim3(64), 0, stream, A, rh, rw);
     }
     ENVGS_CHECK_LAUNCH(dcfg, stream);
-    hipLaunchKernelGGL(finish_rotations, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, rotations, rot_rec, dmeans3D, drots, dgrads3D);
+    hipLaunchKernelGGL(finish_surfel_grads, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, rotations, geo_rec, dmeans3D, dscales,
+                       dopacities, drots, dgrads3D);
     ENVGS_CHECK_LAUNCH(dcfg, stream);
     return 0;
 }

@@ -1,0 +1,92 @@
+"""The caller-side glue of one full EnvGS step, re-derived for bench.py / tests: it drives the two drop-in extensions in
+exactly the order and with exactly the arguments the reference's sampler does, using plain torch for the elementwise
+parts the reference also does in torch.  Nothing here is needed when the real EasyVolcap loop is the caller.
+
+Followed call sequence (all paths relative to /root/reference):
+  easyvolcap/models/samplers/envgs_sampler.py:482-565      EnvGSSampler.forward
+  easyvolcap/utils/gaussian2d_utils.py:1003-1155            render(): base pass through diff_surfel_rasterization_wet_ch05
+  easyvolcap/models/samplers/envgs_sampler.py:420-455       get_reflect_rays: ref_d = d - 2(d.n)n, ref_o = o + d*depth
+  easyvolcap/utils/optix_utils.py:71-85,87-267              build_bvh (get_disks + rebuild) and render_gaussians (env pass)
+  easyvolcap/models/samplers/envgs_sampler.py:474           rgb = (1 - spec) * rgb_base + spec * rgb_env
+"""
+import torch
+
+from . import synth
+
+C0 = 0.28209479177387814
+C1 = 0.4886025119029199
+C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
+C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+      1.445305721320277, -0.5900435899266435]
+
+
+def eval_sh(deg, sh, dirs):
+    """sh (P,3,K), dirs (P,3) unit.  Same polynomial as easyvolcap/utils/sh_utils.py:642-727 (pinned in tests/test_golden.py)."""
+    r = C0 * sh[..., 0]
+    if deg > 0:
+        x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
+        r = r - C1 * y * sh[..., 1] + C1 * z * sh[..., 2] - C1 * x * sh[..., 3]
+        if deg > 1:
+            xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+            r = (r + C2[0] * xy * sh[..., 4] + C2[1] * yz * sh[..., 5] + C2[2] * (2.0 * zz - xx - yy) * sh[..., 6]
+                 + C2[3] * xz * sh[..., 7] + C2[4] * (xx - yy) * sh[..., 8])
+            if deg > 2:
+                r = (r + C3[0] * y * (3 * xx - yy) * sh[..., 9] + C3[1] * xy * z * sh[..., 10]
+                     + C3[2] * y * (4 * zz - xx - yy) * sh[..., 11] + C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12]
+                     + C3[4] * x * (4 * zz - xx - yy) * sh[..., 13] + C3[5] * z * (xx - yy) * sh[..., 14]
+                     + C3[6] * x * (xx - 3 * yy) * sh[..., 15])
+    return r
+
+
+def base_pass(pkg, cam, base, bg, sh_degree, scale_modifier=1.0):
+    """render() of gaussian2d_utils.py with pipe.convert_SHs_python=True and render_reflection (ch05)."""
+    dev = base["means3D"].device
+    st = pkg.GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg,
+        scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+        sh_degree=sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
+    means2D = torch.zeros_like(base["means3D"], requires_grad=True, device=dev) + 0
+    shs_view = base["shs"].transpose(1, 2)
+    dir_pp = base["means3D"] - cam.camera_center[None]
+    dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+    colors = torch.clamp_min(eval_sh(int(sh_degree), shs_view, dir_pp) + 0.5, 0.0)
+    colors = torch.cat([colors, base["specular"], base["roughness"]], dim=-1)
+    img, radii, allmap, weight = pkg.GaussianRasterizer(raster_settings=st)(
+        means3D=base["means3D"], means2D=means2D, shs=None, colors_precomp=colors, opacities=base["opacities"],
+        scales=base["scales"], rotations=base["rotations"], cov3D_precomp=None)
+    alpha = allmap[1:2]
+    normal = (allmap[2:5].permute(1, 2, 0) @ cam.world_view_transform[:3, :3].T).permute(2, 0, 1)
+    depth = torch.nan_to_num(allmap[0:1] / alpha, 0, 0)
+    return dict(rgb=img[:3], spec=img[3:4], rough=img[4:5], alpha=alpha, normal=normal, depth=depth, radii=radii,
+                weight=weight, means2D=means2D, allmap=allmap)
+
+
+def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree):
+    """HardwareRendering.render_gaussians of optix_utils.py with start_from_first=False, max_trace_depth=0."""
+    ts = tpkg.SurfelTracingSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=env_bg,
+        scale_modifier=1.0, viewmatrix=cam.world_view_transform.contiguous(), projmatrix=cam.full_proj_transform.contiguous(),
+        sh_degree=sh_degree, campos=cam.camera_center.contiguous(), prefiltered=False, debug=False, max_trace_depth=0,
+        specular_threshold=0.0)
+    v, f = synth.get_disks(env["means3D"], env["scales"], env["rotations"])
+    tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
+    grads3D = torch.zeros_like(env["means3D"], requires_grad=True) + 0
+    return tracer(ref_o.contiguous(), ref_d.contiguous(), v, means3D=env["means3D"].contiguous(), grads3D=grads3D,
+                  shs=env["shs"].contiguous(), colors_precomp=None, others_precomp=None, opacities=env["opacities"].contiguous(),
+                  scales=env["scales"].contiguous(), rotations=env["rotations"].contiguous(), cov3D_precomp=None,
+                  tracer_settings=ts, start_from_first=False)
+
+
+def envgs_forward(pkg, tpkg, tracer, cam, rays, base, env, bg, env_bg, sh_degree):
+    """One EnvGS forward: base raster -> reflect -> env trace -> blend.  Returns dict of (H,W,*) maps."""
+    H, W = cam.image_height, cam.image_width
+    b = base_pass(pkg, cam, base, bg, sh_degree)
+    ray_o, ray_d = rays
+    nrm = b["normal"].permute(1, 2, 0)
+    nrm = nrm / nrm.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    ref_d = ray_d - 2 * (ray_d * nrm).sum(-1, keepdim=True) * nrm
+    ref_o = ray_o + ray_d * b["depth"].permute(1, 2, 0)
+    rgb_env, dpt, acc, norm, dist, aux, mid, wet = env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree)
+    spec = b["spec"].permute(1, 2, 0)
+    rgb = (1 - spec) * b["rgb"].permute(1, 2, 0) + spec * rgb_env
+    return dict(rgb=rgb, base=b, rgb_env=rgb_env, env_wet=wet, ref_o=ref_o, ref_d=ref_d)

@@ -100,7 +100,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     ND = cfg.max_trace_depth + 1
     f32 = dict(dtype=torch.float32, device=dev)
     srec = torch.empty(max(P, 1), 16, **f32)
-    counters = torch.empty(4, dtype=torch.int32, device=dev)
+    counters = torch.empty(16, dtype=torch.int32, device=dev)
     rgb = torch.empty(R, 3, **f32); dpt = torch.empty(R, 1, **f32); acc = torch.empty(R, 1, **f32)
     norm = torch.empty(R, 3, **f32); dist = torch.empty(R, 1, **f32); aux = torch.empty(R, 2, **f32)
     mid = torch.empty(R, 16 * ND, **f32); wet = torch.empty(P, 1, **f32); final_T = torch.empty(R, **f32)
@@ -108,7 +108,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
                                        p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),
                                        p(norm), p(dist), p(aux), p(mid), p(wet), p(final_T), _stream(dev)), "envgs_trace_forward")
-    LAST_STATS.update(P=P, R=R)
+    LAST_STATS.update(P=P, R=R, counters=counters)
     saved = dict(cfg=cfg, nodes=nodes, ro=ro, rd=rd, means3D=means3D, scales=scales, rotations=rotations, opacities=opacities,
                  shs=shs, colors_precomp=colors_precomp, others=others_precomp, bg=bg, srec=srec, counters=counters,
                  rgb=rgb, dpt=dpt, acc=acc, norm=norm, aux=aux, final_T=final_T, lead=lead)
@@ -126,7 +126,7 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
     z = lambda g, c: torch.zeros(R, c, **f32) if g is None else _f32c(g).reshape(R, c)
     g_rgb, g_dpt, g_acc, g_norm, g_aux = z(g_rgb, 3), z(g_dpt, 1), z(g_acc, 1), z(g_norm, 3), z(g_aux, 2)
     shs, others = saved["shs"], saved["others"]
-    rot_rec = torch.empty(max(P, 1), 12, **f32)
+    geo_rec = torch.empty(max(P, 1), 16, **f32)
     dmeans = torch.empty(P, 3, **f32); dgrads3D = torch.empty(P, 3, **f32); dscales = torch.empty(P, 2, **f32)
     drots = torch.empty(P, 4, **f32); dopac = torch.empty(P, 1, **f32)
     dshs = torch.empty_like(shs) if shs is not None else None
@@ -138,7 +138,7 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
     _lib.check(lib.envgs_trace_backward(cfg, p(s["nodes"]), p(s["ro"]), p(s["rd"]), p(s["means3D"]), p(s["scales"]), p(s["rotations"]),
                                         p(s["opacities"]), p(shs), p(s["colors_precomp"]), p(others), p(s["bg"]), p(s["srec"]),
                                         p(s["counters"]), p(s["rgb"]), p(s["dpt"]), p(s["acc"]), p(s["norm"]), p(s["aux"]), p(s["final_T"]),
-                                        p(g_rgb), p(g_dpt), p(g_acc), p(g_norm), p(g_aux), p(rot_rec), p(dmeans), p(dgrads3D), p(dscales),
+                                        p(g_rgb), p(g_dpt), p(g_acc), p(g_norm), p(g_aux), p(geo_rec), p(dmeans), p(dgrads3D), p(dscales),
                                         p(drots), p(dopac), p(dshs), p(dcolors), p(dothers), p(dro), p(drd), _stream(dev)),
                "envgs_trace_backward")
     lead = s["lead"]
@@ -205,3 +205,12 @@ class SurfelTracer(nn.Module):
         return _TraceSurfels.apply(ray_o, ray_d, v, means3D, grads3D, e if shs is None else shs,
                                    e if colors_precomp is None else colors_precomp, e if others_precomp is None else others_precomp,
                                    opacities, scales, rotations, None, tracer_settings, bool(start_from_first), self.nodes)
+
+
+def last_trace_counts():
+    """(composited hits, BVH node visits, traversal rounds) of the most recent forward (synchronises)."""
+    c = LAST_STATS.get("counters")
+    if c is None:
+        return None
+    v = c[2:8].cpu().view(torch.int64)
+    return dict(hits=int(v[0]), node_visits=int(v[1]), rounds=int(v[2]), rays=LAST_STATS["R"])

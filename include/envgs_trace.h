@@ -20,7 +20,8 @@
  *   srec      (P,16)   per-surfel trace record, rebuilt every forward from the current parameters:
  *                      [0..2] centre  [3] opacity  [4..6] tangent a / s_u  [7] s_u  [8..10] tangent b / s_v  [11] s_v
  *                      [12..14] normal  [15] unused
- *   rot_rec   (P,12)   backward accumulator for dL/d(a,b,n) (the rotation columns), chained to the quaternion
+ *   geo_rec   (P,16)   backward accumulator, one 64 B record per surfel: [0..2] dL/dcentre  [3..5] dL/da  [6..8] dL/db
+ *                      [9..11] dL/dn (rotation columns, chained to the quaternion)  [12..13] dL/dscale  [14] dL/dopacity
  *   outputs   rgb (R,3) dpt (R) acc (R) norm (R,3) dist (R) aux (R,2) mid (R,16*(max_trace_depth+1)) wet (P)
  *             mid layout per bounce: rayo 0:3, rayd 3:6, dpt 6, acc 7, norm 8:11, aux 11:13, rgb 13:16
  *             (optix_utils.py:30-37)
@@ -39,7 +40,7 @@ extern "C" {
 
 #define ENVGS_NODE_STRIDE 16
 #define ENVGS_SREC_STRIDE 16
-#define ENVGS_ROTREC_STRIDE 12
+#define ENVGS_GEOREC_STRIDE 16
 #define ENVGS_MID_CHANNELS 16
 
 /* Mirrors SurfelTracingSettings (optix_utils.py:104-119) minus the tensors, plus the call's start_from_first. */
@@ -71,7 +72,9 @@ ENVGS_API int envgs_bvh_build(int32_t P, const float *vertices, float *nodes, vo
 
 /*
  * SurfelTracer.forward (optix_utils.py:188-201): trace R rays through the surfel set, composite front to back.
- * srec (P,16) is scratch written here (and read again by the backward).  counters: >= 4 uint32 of scratch.
+ * srec (P,16) is scratch written here (and read again by the backward).  counters: 16 uint32 of scratch; after the
+ * forward, words [2..7] hold three uint64 totals: composited hits, BVH node visits, traversal rounds (diagnostics that
+ * the roofline accounting of bench.py needs: BASELINE.md section 4 "hits / node_visits are data dependent").
  * final_T (R): stage-0 transmittance, kept for the backward.
  */
 ENVGS_API int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes,
@@ -97,7 +100,7 @@ ENVGS_API int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *node
                                    const float *final_T,
                                    const float *dL_drgb, const float *dL_ddpt, const float *dL_dacc, const float *dL_dnorm,
                                    const float *dL_daux,
-                                   float *rot_rec,
+                                   float *geo_rec,
                                    float *dmeans3D, float *dgrads3D, float *dscales, float *drots, float *dopacities,
                                    float *dshs, float *dcolors, float *dothers, float *dray_o, float *dray_d,
                                    void *stream);
