@@ -143,7 +143,9 @@ def main():
         step(it)
     n_acc.update(N=0, steps=0)
     lib.envgs_prof_enable(1)
-    for k in range(11):                           # drain anything recorded during warm-up
+    NK = 0
+    while lib.envgs_prof_kernel_name(NK): NK += 1
+    for k in range(NK):                           # drain anything recorded during warm-up
         t_, c_ = ctypes.c_double(0), ctypes.c_int(0)
         lib.envgs_prof_read(k, ctypes.byref(t_), ctypes.byref(c_))
     sync_all()
@@ -162,7 +164,7 @@ def main():
     # per-kernel HIP-event times (this rank)
     N_avg = n_acc["N"] / max(n_acc["steps"], 1)
     kernels = {}
-    for k in range(11):
+    for k in range(NK):
         t_, c_ = ctypes.c_double(0), ctypes.c_int(0)
         lib.envgs_prof_read(k, ctypes.byref(t_), ctypes.byref(c_))
         if c_.value > 0:

@@ -38,8 +38,9 @@ SYMBOLS = {
     "envgs_raster_backward": (c_int, [ctypes.POINTER(RasterCfg), c_uint32] + [_P] * 28 + [_P]),
     "envgs_bvh_temp_bytes": (c_size_t, [ctypes.c_int32]),
     "envgs_bvh_build": (c_int, [ctypes.c_int32, _P, _P, _P, c_size_t, ctypes.c_int32, _P]),
-    "envgs_trace_forward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 22 + [_P]),
-    "envgs_trace_backward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 35 + [_P]),
+    "envgs_trace_stack_spill_ints": (c_size_t, [ctypes.c_int32]),
+    "envgs_trace_forward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 22 + [_P, _P, _P, ctypes.c_int32, _P, _P]),
+    "envgs_trace_backward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 35 + [_P, _P, _P, ctypes.c_int32, _P]),
     "envgs_prof_enable": (None, [c_int]),
     "envgs_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     "envgs_prof_kernel_name": (ctypes.c_char_p, [c_int]),

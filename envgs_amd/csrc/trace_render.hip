@@ -19,6 +19,7 @@ namespace envgs {
 
 constexpr int KBUF = 16;            // hits buffered per round
 constexpr int STACK = 64;           // LBVH depth bound: 62-bit keys
+constexpr int LDS_STACK = 24;       // collect_hits keeps this many levels in LDS, the rest in an HBM slab
 constexpr int MAX_ROUNDS = 256;     // safety bound: 4096 hits per ray
 constexpr float UV_MAX = 3.0f;
 constexpr int MID = ENVGS_MID_CHANNELS;
@@ -130,6 +131,13 @@ struct TraceArgs {
     const float *g_rgb, *g_dpt, *g_acc, *g_norm, *g_aux;
     float *geo_rec, *dshs, *dcolors, *dothers, *dray_o, *dray_d;
     float mod;
+    // per-ray hit lists (list path): entry = (t, surfel id), [R][cap]
+    uint2 *hits;
+    int *hit_cnt;       // hits found per ray (may exceed cap: the ray then takes the K-buffer path)
+    int *n_used;        // hits composited before termination
+    int cap;
+    int *stack_spill;   // collect_hits: (grid, STACK, 64) ints of stack overflow space
+    int only_overflow;  // K-buffer kernels: process only rays whose hit_cnt exceeds cap
 };
 
 // K-nearest buffer ordered by (t, id); insertion is a fully unrolled compare-exchange chain (registers only).
@@ -252,8 +260,12 @@ trace_fwd(const TraceArgs A, const int ray_h, const int ray_w)
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= A.R) break;
         const int slot = base + lane;
-        const bool valid = slot < A.R;
+        bool valid = slot < A.R;
         const int r = valid ? ray_index(slot, A.R, ray_h, ray_w) : 0;
+        if (A.only_overflow) {
+            valid = valid && A.hit_cnt[r] > A.cap;
+            if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
+        }
         float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
         float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
         float tmin = A.start_from_first ? NEAR_N : 0.0f;
@@ -384,61 +396,211 @@ __device__ __constant__ float kShForm[16][11] = {
 constexpr int NFLD = 22;   // LDS hand-off fields per lane: sid, dc[3], geo[15], dir[3]
 constexpr int GEO = ENVGS_GEOREC_STRIDE;
 
+// Per-ray constants of the backward pass (upstream gradients and the stored stage-0 sums).
+struct BwdRay {
+    float ox, oy, oz, dx, dy, dz;
+    float gR0, gR1, gR2, gD, gA, gN0, gN1, gN2, gX0, gX1;
+    float fT, bgdot, fr0, fr1, fr2, fD, fA, fN0, fN1, fN2, fX0, fX1;
+    float dl2, il, ux, uy, uz;
+};
+// Running prefix sums and the ray-gradient accumulators.
+struct BwdAcc {
+    float T, c0, c1, c2, cD, cA, cN0, cN1, cN2, cX0, cX1;
+    float dO0, dO1, dO2, dD0, dD1, dD2;
+    float Sk[16];
+};
+
+__device__ __forceinline__ void bwd_load_ray(const TraceArgs &A, int r, BwdRay &B)
+{
+    B.ox = A.ray_o[3 * r]; B.oy = A.ray_o[3 * r + 1]; B.oz = A.ray_o[3 * r + 2];
+    B.dx = A.ray_d[3 * r]; B.dy = A.ray_d[3 * r + 1]; B.dz = A.ray_d[3 * r + 2];
+    B.gR0 = A.g_rgb[3 * r]; B.gR1 = A.g_rgb[3 * r + 1]; B.gR2 = A.g_rgb[3 * r + 2];
+    B.gD = A.g_dpt[r]; B.gA = A.g_acc[r];
+    B.gN0 = A.g_norm[3 * r]; B.gN1 = A.g_norm[3 * r + 1]; B.gN2 = A.g_norm[3 * r + 2];
+    B.gX0 = A.g_aux[2 * r]; B.gX1 = A.g_aux[2 * r + 1];
+    B.fT = A.f_T[r];
+    const float bg0 = 0 < A.bg_len ? A.bg[0] : 0.f, bg1 = 1 < A.bg_len ? A.bg[1] : 0.f, bg2 = 2 < A.bg_len ? A.bg[2] : 0.f;
+    B.bgdot = bg0 * B.gR0 + bg1 * B.gR1 + bg2 * B.gR2;
+    // final sums without the background term (suffix = final - prefix)
+    B.fr0 = A.f_rgb[3 * r] - B.fT * bg0; B.fr1 = A.f_rgb[3 * r + 1] - B.fT * bg1; B.fr2 = A.f_rgb[3 * r + 2] - B.fT * bg2;
+    B.fD = A.f_dpt[r]; B.fA = A.f_acc[r];
+    B.fN0 = A.f_norm[3 * r]; B.fN1 = A.f_norm[3 * r + 1]; B.fN2 = A.f_norm[3 * r + 2];
+    B.fX0 = A.f_aux[2 * r]; B.fX1 = A.f_aux[2 * r + 1];
+    B.dl2 = B.dx * B.dx + B.dy * B.dy + B.dz * B.dz; B.il = 1.0f / sqrtf(B.dl2);
+    B.ux = B.dx * B.il; B.uy = B.dy * B.il; B.uz = B.dz * B.il;
+}
+
+__device__ __forceinline__ void bwd_init_acc(BwdAcc &a)
+{
+    a.T = 1.0f; a.c0 = a.c1 = a.c2 = a.cD = a.cA = a.cN0 = a.cN1 = a.cN2 = a.cX0 = a.cX1 = 0.f;
+    a.dO0 = a.dO1 = a.dO2 = a.dD0 = a.dD1 = a.dD2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) a.Sk[k] = 0.f;
+}
+
+// Gradient of one composited hit.  Returns false when the ray terminates at this hit (it is then NOT blended).
+// Out: dc[3] (dL/dcolour of the surfel from this hit) and gv[15] (the geometry-record words).
+__device__ __forceinline__ bool bwd_hit(const TraceArgs &A, const BwdRay &B, BwdAcc &a, const float *basis, const int nb,
+                                        const int sid, float &dc0, float &dc1, float &dc2, float *gv)
+{
+    const float4 *sr = A.srec + (size_t)sid * 4;
+    const float4 s0 = sr[0], s1 = sr[1], s2 = sr[2], s3 = sr[3];
+    const SurfHit h = hit_surfel(s0, s1, s2, s3, B.ox, B.oy, B.oz, B.dx, B.dy, B.dz);
+    const float alpha = h.alpha;
+    const float test_T = a.T * (1.0f - alpha);
+    if (test_T < T_EPS) return false;
+    const float T = a.T;
+    const float w = alpha * T;
+    float col[3]; bool cl[3];
+    surfel_color(A, sid, basis, col, cl);
+    const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
+    const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
+    const float x0 = A.has_others ? A.others[2 * sid] : 0.f, x1 = A.has_others ? A.others[2 * sid + 1] : 0.f;
+    a.c0 += w * col[0]; a.c1 += w * col[1]; a.c2 += w * col[2];
+    a.cD += w * h.t; a.cA += w;
+    a.cN0 += w * nf0; a.cN1 += w * nf1; a.cN2 += w * nf2;
+    a.cX0 += w * x0; a.cX1 += w * x1;
+    const float inv1m = 1.0f / (1.0f - alpha);
+    float dLa = B.gR0 * (T * col[0] - (B.fr0 - a.c0) * inv1m) + B.gR1 * (T * col[1] - (B.fr1 - a.c1) * inv1m) + B.gR2 * (T * col[2] - (B.fr2 - a.c2) * inv1m);
+    dLa += B.gD * (T * h.t - (B.fD - a.cD) * inv1m);
+    dLa += B.gA * (T - (B.fA - a.cA) * inv1m);
+    dLa += B.gN0 * (T * nf0 - (B.fN0 - a.cN0) * inv1m) + B.gN1 * (T * nf1 - (B.fN1 - a.cN1) * inv1m) + B.gN2 * (T * nf2 - (B.fN2 - a.cN2) * inv1m);
+    dLa += B.gX0 * (T * x0 - (B.fX0 - a.cX0) * inv1m) + B.gX1 * (T * x1 - (B.fX1 - a.cX1) * inv1m);
+    dLa += -(B.fT * inv1m) * B.bgdot;
+    dc0 = cl[0] ? 0.f : w * B.gR0; dc1 = cl[1] ? 0.f : w * B.gR1; dc2 = cl[2] ? 0.f : w * B.gR2;
+    if (A.M > 0) {
+        // dL/d(dir) = sum_k grad(basis_k) * (sh_k . dc): accumulate the 16 scalars, apply grad(basis) once per ray
+        const float *sh = A.shs + (size_t)sid * A.M * 3;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k < nb) a.Sk[k] += sh[k * 3] * dc0 + sh[k * 3 + 1] * dc1 + sh[k * 3 + 2] * dc2;
+    }
+    if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * B.gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * B.gX1); }
+    const float dLG = s0.w * dLa;
+    const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
+    const float su = s1.w, sv = s2.w;
+    const float qx = B.ox + h.t * B.dx - s0.x, qy = B.oy + h.t * B.dy - s0.y, qz = B.oz + h.t * B.dz - s0.z;
+    // u = (a/su).q : dL/dq = dLu*(a/su) + dLv*(b/sv) ; dL/da = (dLu/su) q ; dL/dsu = -dLu*u/su
+    const float dq0 = dLu * s1.x + dLv * s2.x, dq1 = dLu * s1.y + dLv * s2.y, dq2 = dLu * s1.z + dLv * s2.z;
+    const float cu = dLu / su, cv = dLv / sv;
+    const float dLt_tot = w * B.gD + dq0 * B.dx + dq1 * B.dy + dq2 * B.dz;
+    const float kt = dLt_tot / h.denom;
+    gv[0] = -dq0 + kt * s3.x; gv[1] = -dq1 + kt * s3.y; gv[2] = -dq2 + kt * s3.z;
+    gv[3] = cu * qx; gv[4] = cu * qy; gv[5] = cu * qz;
+    gv[6] = cv * qx; gv[7] = cv * qy; gv[8] = cv * qz;
+    gv[9] = w * sgn * B.gN0 - kt * qx; gv[10] = w * sgn * B.gN1 - kt * qy; gv[11] = w * sgn * B.gN2 - kt * qz;
+    gv[12] = -dLu * h.u / su * A.mod; gv[13] = -dLv * h.v / sv * A.mod;
+    gv[14] = h.G * dLa;
+    a.dO0 += dq0 - kt * s3.x; a.dO1 += dq1 - kt * s3.y; a.dO2 += dq2 - kt * s3.z;
+    a.dD0 += h.t * (dq0 - kt * s3.x); a.dD1 += h.t * (dq1 - kt * s3.y); a.dD2 += h.t * (dq2 - kt * s3.z);
+    a.T = test_T;
+    return true;
+}
+
+// Cooperative flush: one hit at a time, the WHOLE wavefront writes that surfel's contiguous gradient words:
+// lanes 0..47 the (16,3) SH block, lanes 48..62 the 15-word geometry record -> 1 instruction, ~3 cache lines per hit
+// (instead of 63 per-lane atomics that each touch 64 different lines).  Must be called wave-uniformly.
+struct FlushRole { float form[11]; int fc; bool sh_lane, geo_lane; };
+
+__device__ __forceinline__ FlushRole flush_role(const TraceArgs &A, int lane)
+{
+    FlushRole R;
+    const int fk = lane / 3;
+    R.fc = lane - 3 * fk;
+#pragma unroll
+    for (int i = 0; i < 11; i++) R.form[i] = kShForm[fk < 16 ? fk : 0][i];
+    const int nb = (A.D + 1) * (A.D + 1);
+    R.sh_lane = A.M > 0 ? (lane < 48 && fk < nb) : (lane < 3);
+    R.geo_lane = lane >= 48 && lane < 48 + 15;
+    return R;
+}
+
+__device__ __forceinline__ void flush_hits(const TraceArgs &A, float (*fld)[65], const int lane, const FlushRole &R,
+                                           const bool has, const int sid, const float dc0, const float dc1, const float dc2, const float *gv)
+{
+    const unsigned long long hm = __builtin_amdgcn_ballot_w64(has);
+    if (hm == 0) return;
+    fld[0][lane] = __int_as_float(sid); fld[1][lane] = dc0; fld[2][lane] = dc1; fld[3][lane] = dc2;
+#pragma unroll
+    for (int k = 0; k < 15; k++) fld[4 + k][lane] = gv[k];
+    __syncthreads();
+    unsigned long long m = hm;
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        const int hs = __float_as_int(fld[0][l]);
+        float val = 0.f; float *dst = nullptr;
+        if (A.M > 0) {
+            const float x = fld[19][l], y = fld[20][l], z = fld[21][l];
+            const float lin = R.form[0] + R.form[1] * x + R.form[2] * y + R.form[3] * z;
+            const float quad = R.form[4] + R.form[5] * (x * x) + R.form[6] * (y * y) + R.form[7] * (z * z) + R.form[8] * (x * y) + R.form[9] * (y * z) + R.form[10] * (x * z);
+            const float dcc = R.fc == 0 ? fld[1][l] : (R.fc == 1 ? fld[2][l] : fld[3][l]);
+            val = lin * quad * dcc;
+            dst = A.dshs + (size_t)hs * A.M * 3 + lane;
+        } else {
+            val = fld[1 + (lane < 3 ? lane : 0)][l];
+            dst = A.dcolors + (size_t)hs * 3 + lane;
+        }
+        if (R.geo_lane) { val = fld[4 + (lane - 48)][l]; dst = A.geo_rec + (size_t)hs * GEO + (lane - 48); }
+        if (R.sh_lane || R.geo_lane) atomic_add_f32(dst, val);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void bwd_store_ray(const TraceArgs &A, int r, const BwdRay &B, const BwdAcc &a)
+{
+    float dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
+    if (A.M > 0) {
+        float bgx[16], bgy[16], bgz[16];
+        sh_basis_grad(A.D, B.ux, B.uy, B.uz, bgx, bgy, bgz);
+#pragma unroll
+        for (int k = 0; k < 16; k++) { dd0 += bgx[k] * a.Sk[k]; dd1 += bgy[k] * a.Sk[k]; dd2 += bgz[k] * a.Sk[k]; }
+    }
+    const float inv3 = B.il * B.il * B.il;
+    const float e0 = a.dD0 + ((B.dl2 - B.dx * B.dx) * dd0 - B.dy * B.dx * dd1 - B.dz * B.dx * dd2) * inv3;
+    const float e1 = a.dD1 + (-B.dx * B.dy * dd0 + (B.dl2 - B.dy * B.dy) * dd1 - B.dz * B.dy * dd2) * inv3;
+    const float e2 = a.dD2 + (-B.dx * B.dz * dd0 - B.dy * B.dz * dd1 + (B.dl2 - B.dz * B.dz) * dd2) * inv3;
+    A.dray_o[3 * r] = a.dO0; A.dray_o[3 * r + 1] = a.dO1; A.dray_o[3 * r + 2] = a.dO2;
+    A.dray_d[3 * r] = e0; A.dray_d[3 * r + 1] = e1; A.dray_d[3 * r + 2] = e2;
+}
+
+// K-buffer backward (re-traces).  Used for bounce-free rays whose hit list overflowed, and when no list was kept.
 __global__ void __launch_bounds__(64)
 trace_bwd(const TraceArgs A, const int ray_h, const int ray_w)
 {
     __shared__ int stk[STACK][64];
     __shared__ float fld[NFLD][65];                 // row stride 65: lanes 48..62 read 15 different rows of one column conflict-free
     const int lane = threadIdx.x;
-    // this lane's role in the cooperative flush
-    const int fk = lane / 3, fc = lane - 3 * fk;     // SH coefficient index and colour channel for lanes 0..47
-    float form[11];
-#pragma unroll
-    for (int i = 0; i < 11; i++) form[i] = kShForm[fk < 16 ? fk : 0][i];
+    const FlushRole role = flush_role(A, lane);
     const int nb = (A.D + 1) * (A.D + 1);
-    const bool sh_lane = A.M > 0 ? (lane < 48 && fk < nb) : (lane < 3);
-    const bool geo_lane = lane >= 48 && lane < 48 + 15;
-
     while (true) {
         int base = 0;
         if (lane == 0) base = (int)atomicAdd(A.counter, 64u);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= A.R) break;
         const int slot = base + lane;
-        const bool valid = slot < A.R;
+        bool valid = slot < A.R;
         const int r = valid ? ray_index(slot, A.R, ray_h, ray_w) : 0;
-        const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
-        const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
+        if (A.only_overflow) {
+            valid = valid && A.hit_cnt[r] > A.cap;
+            if (__builtin_amdgcn_ballot_w64(valid) == 0) continue;
+        }
+        BwdRay B;
+        bwd_load_ray(A, r, B);
+        BwdAcc acc;
+        bwd_init_acc(acc);
         const float tmin = A.start_from_first ? NEAR_N : 0.0f;
-        const float gR0 = A.g_rgb[3 * r], gR1 = A.g_rgb[3 * r + 1], gR2 = A.g_rgb[3 * r + 2];
-        const float gD = A.g_dpt[r], gA = A.g_acc[r];
-        const float gN0 = A.g_norm[3 * r], gN1 = A.g_norm[3 * r + 1], gN2 = A.g_norm[3 * r + 2];
-        const float gX0 = A.g_aux[2 * r], gX1 = A.g_aux[2 * r + 1];
-        const float fT = A.f_T[r];
-        float bg0 = 0 < A.bg_len ? A.bg[0] : 0.f, bg1 = 1 < A.bg_len ? A.bg[1] : 0.f, bg2 = 2 < A.bg_len ? A.bg[2] : 0.f;
-        const float bgdot = bg0 * gR0 + bg1 * gR1 + bg2 * gR2;
-        // final sums without the background term (suffix = final - prefix)
-        const float fr0 = A.f_rgb[3 * r] - fT * bg0, fr1 = A.f_rgb[3 * r + 1] - fT * bg1, fr2 = A.f_rgb[3 * r + 2] - fT * bg2;
-        const float fD = A.f_dpt[r], fA = A.f_acc[r];
-        const float fN0 = A.f_norm[3 * r], fN1 = A.f_norm[3 * r + 1], fN2 = A.f_norm[3 * r + 2];
-        const float fX0 = A.f_aux[2 * r], fX1 = A.f_aux[2 * r + 1];
-        const float dl2 = dx * dx + dy * dy + dz * dz, il = 1.0f / sqrtf(dl2);
-        const float ux = dx * il, uy = dy * il, uz = dz * il;
-        float basis[16], Sk[16];
-        sh_basis(A.D, ux, uy, uz, basis);
-#pragma unroll
-        for (int k = 0; k < 16; k++) Sk[k] = 0.f;
+        float basis[16];
+        sh_basis(A.D, B.ux, B.uy, B.uz, basis);
         __syncthreads();                                  // previous batch's flush reads are done
-        fld[19][lane] = ux; fld[20][lane] = uy; fld[21][lane] = uz;
-        float T = 1.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f, cD = 0.f, cA = 0.f, cN0 = 0.f, cN1 = 0.f, cN2 = 0.f, cX0 = 0.f, cX1 = 0.f;
-        float dO0 = 0.f, dO1 = 0.f, dO2 = 0.f, dD0 = 0.f, dD1 = 0.f, dD2 = 0.f;
+        fld[19][lane] = B.ux; fld[20][lane] = B.uy; fld[21][lane] = B.uz;
         bool done = !valid || A.P == 0;
         float tlo = tmin; int idlo = 0x7fffffff;
         for (int round = 0; round < MAX_ROUNDS; round++) {
             if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
             KBuf kb;
             unsigned visits_unused = 0;
-            traverse(A, stk, lane, !done, ox, oy, oz, dx, dy, dz, tlo, idlo, kb, visits_unused);
+            traverse(A, stk, lane, !done, B.ox, B.oy, B.oz, B.dx, B.dy, B.dz, tlo, idlo, kb, visits_unused);
 #pragma unroll 1
             for (int i = 0; i < KBUF; i++) {
                 if (__builtin_amdgcn_ballot_w64(!done && i < kb.n) == 0) break;
@@ -450,111 +612,242 @@ trace_bwd(const TraceArgs A, const int ray_h, const int ray_w)
 #pragma unroll
                 for (int k = 0; k < 15; k++) gv[k] = 0.f;
                 if (!done && i < kb.n) {
-                    const float4 *sr = A.srec + (size_t)sid * 4;
-                    const float4 s0 = sr[0], s1 = sr[1], s2 = sr[2], s3 = sr[3];
-                    const SurfHit h = hit_surfel(s0, s1, s2, s3, ox, oy, oz, dx, dy, dz);
-                    const float alpha = h.alpha;
-                    const float test_T = T * (1.0f - alpha);
-                    if (test_T < T_EPS) { done = true; }
-                    else {
-                        has = true;
-                        const float w = alpha * T;
-                        float col[3]; bool cl[3];
-                        surfel_color(A, sid, basis, col, cl);
-                        const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
-                        const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
-                        const float x0 = A.has_others ? A.others[2 * sid] : 0.f, x1 = A.has_others ? A.others[2 * sid + 1] : 0.f;
-                        c0 += w * col[0]; c1 += w * col[1]; c2 += w * col[2];
-                        cD += w * h.t; cA += w;
-                        cN0 += w * nf0; cN1 += w * nf1; cN2 += w * nf2;
-                        cX0 += w * x0; cX1 += w * x1;
-                        const float inv1m = 1.0f / (1.0f - alpha);
-                        float dLa = gR0 * (T * col[0] - (fr0 - c0) * inv1m) + gR1 * (T * col[1] - (fr1 - c1) * inv1m) + gR2 * (T * col[2] - (fr2 - c2) * inv1m);
-                        dLa += gD * (T * h.t - (fD - cD) * inv1m);
-                        dLa += gA * (T - (fA - cA) * inv1m);
-                        dLa += gN0 * (T * nf0 - (fN0 - cN0) * inv1m) + gN1 * (T * nf1 - (fN1 - cN1) * inv1m) + gN2 * (T * nf2 - (fN2 - cN2) * inv1m);
-                        dLa += gX0 * (T * x0 - (fX0 - cX0) * inv1m) + gX1 * (T * x1 - (fX1 - cX1) * inv1m);
-                        dLa += -(fT * inv1m) * bgdot;
-                        dc0 = cl[0] ? 0.f : w * gR0; dc1 = cl[1] ? 0.f : w * gR1; dc2 = cl[2] ? 0.f : w * gR2;
-                        if (A.M > 0) {
-                            // dL/d(dir) = sum_k grad(basis_k) * (sh_k . dc): accumulate the 16 scalars, apply grad(basis) once per ray
-                            const float *sh = A.shs + (size_t)sid * A.M * 3;
-#pragma unroll
-                            for (int k = 0; k < 16; k++)
-                                if (k < nb) Sk[k] += sh[k * 3] * dc0 + sh[k * 3 + 1] * dc1 + sh[k * 3 + 2] * dc2;
-                        }
-                        if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * gX1); }
-                        const float dLG = s0.w * dLa;
-                        const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
-                        const float su = s1.w, sv = s2.w;
-                        const float qx = ox + h.t * dx - s0.x, qy = oy + h.t * dy - s0.y, qz = oz + h.t * dz - s0.z;
-                        // u = (a/su).q : dL/dq = dLu*(a/su) + dLv*(b/sv) ; dL/da = (dLu/su) q ; dL/dsu = -dLu*u/su
-                        const float dq0 = dLu * s1.x + dLv * s2.x, dq1 = dLu * s1.y + dLv * s2.y, dq2 = dLu * s1.z + dLv * s2.z;
-                        const float cu = dLu / su, cv = dLv / sv;
-                        const float dLt_tot = w * gD + dq0 * dx + dq1 * dy + dq2 * dz;
-                        const float kt = dLt_tot / h.denom;
-                        gv[0] = -dq0 + kt * s3.x; gv[1] = -dq1 + kt * s3.y; gv[2] = -dq2 + kt * s3.z;
-                        gv[3] = cu * qx; gv[4] = cu * qy; gv[5] = cu * qz;
-                        gv[6] = cv * qx; gv[7] = cv * qy; gv[8] = cv * qz;
-                        gv[9] = w * sgn * gN0 - kt * qx; gv[10] = w * sgn * gN1 - kt * qy; gv[11] = w * sgn * gN2 - kt * qz;
-                        gv[12] = -dLu * h.u / su * A.mod; gv[13] = -dLv * h.v / sv * A.mod;
-                        gv[14] = h.G * dLa;
-                        dO0 += dq0 - kt * s3.x; dO1 += dq1 - kt * s3.y; dO2 += dq2 - kt * s3.z;
-                        dD0 += h.t * (dq0 - kt * s3.x); dD1 += h.t * (dq1 - kt * s3.y); dD2 += h.t * (dq2 - kt * s3.z);
-                        T = test_T;
-                    }
+                    has = bwd_hit(A, B, acc, basis, nb, sid, dc0, dc1, dc2, gv);
+                    if (!has) done = true;
                 }
-                // ---- cooperative flush: one hit at a time, the WHOLE wavefront writes that surfel's contiguous gradient words:
-                // lanes 0..47 the (16,3) SH block, lanes 48..62 the 15-word geometry record -> 1 instruction, ~3 cache lines per hit
-                // (instead of 63 per-lane atomics that each touch 64 different lines).
-                const unsigned long long hm = __builtin_amdgcn_ballot_w64(has);
-                if (hm == 0) continue;
-                fld[0][lane] = __int_as_float(sid); fld[1][lane] = dc0; fld[2][lane] = dc1; fld[3][lane] = dc2;
-#pragma unroll
-                for (int k = 0; k < 15; k++) fld[4 + k][lane] = gv[k];
-                __syncthreads();
-                unsigned long long m = hm;
-                while (m) {
-                    const int l = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int hs = __float_as_int(fld[0][l]);
-                    float val = 0.f; float *dst = nullptr;
-                    if (A.M > 0) {
-                        const float x = fld[19][l], y = fld[20][l], z = fld[21][l];
-                        const float lin = form[0] + form[1] * x + form[2] * y + form[3] * z;
-                        const float quad = form[4] + form[5] * (x * x) + form[6] * (y * y) + form[7] * (z * z) + form[8] * (x * y) + form[9] * (y * z) + form[10] * (x * z);
-                        const float dcc = fc == 0 ? fld[1][l] : (fc == 1 ? fld[2][l] : fld[3][l]);
-                        val = lin * quad * dcc;
-                        dst = A.dshs + (size_t)hs * A.M * 3 + lane;
-                    } else {
-                        val = fld[1 + (lane < 3 ? lane : 0)][l];
-                        dst = A.dcolors + (size_t)hs * 3 + lane;
-                    }
-                    if (geo_lane) { val = fld[4 + (lane - 48)][l]; dst = A.geo_rec + (size_t)hs * GEO + (lane - 48); }
-                    if (sh_lane || geo_lane) atomic_add_f32(dst, val);
-                }
-                __syncthreads();
+                flush_hits(A, fld, lane, role, has, sid, dc0, dc1, dc2, gv);
             }
             if (!done) {
                 if (kb.n < KBUF) done = true;
                 else { tlo = kb.t[KBUF - 1]; idlo = kb.id[KBUF - 1]; }
             }
         }
-        if (valid) {
-            float dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
-            if (A.M > 0) {
-                float bgx[16], bgy[16], bgz[16];
-                sh_basis_grad(A.D, ux, uy, uz, bgx, bgy, bgz);
-#pragma unroll
-                for (int k = 0; k < 16; k++) { dd0 += bgx[k] * Sk[k]; dd1 += bgy[k] * Sk[k]; dd2 += bgz[k] * Sk[k]; }
+        if (valid) bwd_store_ray(A, r, B, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------- list path ---
+// MI355X-first variant of T2/T3 for bounce-free tracing (what EnvGS runs: max_trace_depth = 0).  HBM is plentiful
+// (288 GB), so instead of re-traversing the BVH in rounds of K hits -- and again in the backward -- the ray's hits
+// are collected ONCE, unordered, into a per-ray list in HBM (collect_hits: no K-buffer, few registers, high
+// occupancy), sorted by (t, id) per ray in LDS by the whole wavefront (sort_hit_lists), and then walked front to back
+// by the forward (composite_lists_fwd) and again by the backward (composite_lists_bwd), which never touches the BVH.
+// Rays whose list overflows `cap` fall back to the K-buffer kernels above (only_overflow mode).
+
+__global__ void __launch_bounds__(64)
+collect_hits(const TraceArgs A)
+{
+    // Shallow LDS stack (6 KB per wavefront -> ~26 wavefronts per CU instead of 10); the rare deeper pushes spill to a
+    // per-wavefront slab in HBM.  Traversal order is irrelevant here (hits are sorted afterwards), only completeness.
+    __shared__ int stk[LDS_STACK][64];
+    int *spill = A.stack_spill + (size_t)blockIdx.x * (STACK * 64);
+    const int lane = threadIdx.x;
+    unsigned visits = 0, rays_done = 0, found_tot = 0;
+    while (true) {
+        int base = 0;
+        if (lane == 0) base = (int)atomicAdd(A.counter, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= A.R) break;
+        const int r = base + lane;
+        const bool valid = r < A.R;
+        const int rr = valid ? r : 0;
+        const float ox = A.ray_o[3 * rr], oy = A.ray_o[3 * rr + 1], oz = A.ray_o[3 * rr + 2];
+        const float dx = A.ray_d[3 * rr], dy = A.ray_d[3 * rr + 1], dz = A.ray_d[3 * rr + 2];
+        const float tmin = A.start_from_first ? NEAR_N : 0.0f;
+        const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+        uint2 *list = A.hits + (size_t)rr * A.cap;
+        int n = 0;
+        int sp = 0;
+        int cur = (valid && A.P > 0) ? 0 : -1;
+        while (true) {
+            if (cur < 0) {
+                if (sp == 0) break;
+                --sp;
+                cur = sp < LDS_STACK ? stk[sp][lane] : spill[(sp - LDS_STACK) * 64 + lane];
             }
-            const float inv3 = il * il * il;
-            dD0 += ((dl2 - dx * dx) * dd0 - dy * dx * dd1 - dz * dx * dd2) * inv3;
-            dD1 += (-dx * dy * dd0 + (dl2 - dy * dy) * dd1 - dz * dy * dd2) * inv3;
-            dD2 += (-dx * dz * dd0 - dy * dz * dd1 + (dl2 - dz * dz) * dd2) * inv3;
-            A.dray_o[3 * r] = dO0; A.dray_o[3 * r + 1] = dO1; A.dray_o[3 * r + 2] = dO2;
-            A.dray_d[3 * r] = dD0; A.dray_d[3 * r + 1] = dD1; A.dray_d[3 * r + 2] = dD2;
+            const float4 *nd = A.nodes + (size_t)cur * 4;
+            visits++;
+            const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+            const int lc = __float_as_int(n3.x), rc = __float_as_int(n3.y);
+            float a0 = (n0.x - ox) * ix, a1 = (n0.w - ox) * ix, b0 = (n0.y - oy) * iy, b1 = (n1.x - oy) * iy, c0 = (n0.z - oz) * iz, c1 = (n1.y - oz) * iz;
+            const float tnL = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
+            const float tfL = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+            a0 = (n1.z - ox) * ix; a1 = (n2.y - ox) * ix; b0 = (n1.w - oy) * iy; b1 = (n2.z - oy) * iy; c0 = (n2.x - oz) * iz; c1 = (n2.w - oz) * iz;
+            const float tnR = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
+            const float tfR = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+            bool hitL = (tnL <= tfL) && (tfL >= tmin);
+            bool hitR = (tnR <= tfR) && (tfR >= tmin);
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const bool hit = side == 0 ? hitL : hitR;
+                const int ch = side == 0 ? lc : rc;
+                if (hit && ch < 0) {
+                    const int sid = ~ch;
+                    const float4 *sr = A.srec + (size_t)sid * 4;
+                    const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], sr[3], ox, oy, oz, dx, dy, dz);
+                    if (h.ok && h.t > tmin) {
+                        if (n < A.cap) list[n] = make_uint2(__float_as_uint(h.t), (unsigned)sid);
+                        n++;
+                    }
+                }
+            }
+            hitL = hitL && lc >= 0;
+            hitR = hitR && rc >= 0;
+            if (hitL && hitR) {
+                if (sp < LDS_STACK) stk[sp][lane] = rc; else if (sp < LDS_STACK + STACK) spill[(sp - LDS_STACK) * 64 + lane] = rc;
+                sp++;
+                cur = lc;
+            }
+            else if (hitL) cur = lc;
+            else if (hitR) cur = rc;
+            else cur = -1;
         }
+        if (valid) { A.hit_cnt[r] = n; rays_done++; found_tot += (unsigned)n; }
+        // wave max of n -> global max (adaptive cap of the next call)
+        int mx = n;
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        if (lane == 0) atomicMax((int *)(A.counter + 1), mx);
+    }
+    if (A.stats) {
+        const float fv = wave_sum((float)visits), ff = wave_sum((float)found_tot);
+        if (lane == 0) { atomicAdd(A.stats + 1, (unsigned long long)fv); atomicAdd(A.stats + 3, (unsigned long long)ff); }
+    }
+}
+
+// One wavefront sorts one ray's list at a time: bitonic network over keys (t bits << 32 | id) in LDS.
+// t > 0 always, so the IEEE bit pattern orders like the value; ties break on the surfel id, as in the oracle.
+constexpr int SORT_MAX = 1024;
+__global__ void __launch_bounds__(64)
+sort_hit_lists(const TraceArgs A)
+{
+    __shared__ unsigned long long keys[SORT_MAX];
+    const int lane = threadIdx.x;
+    for (int r = blockIdx.x; r < A.R; r += gridDim.x) {
+        const int n = A.hit_cnt[r];
+        if (n < 2 || n > A.cap) continue;
+        uint2 *list = A.hits + (size_t)r * A.cap;
+        int np = 2;
+        while (np < n) np <<= 1;
+        __syncthreads();
+        for (int i = lane; i < np; i += 64) {
+            unsigned long long k = ~0ull;
+            if (i < n) { const uint2 e = list[i]; k = ((unsigned long long)e.x << 32) | e.y; }
+            keys[i] = k;
+        }
+        __syncthreads();
+        for (int size = 2; size <= np; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = lane; i < (np >> 1); i += 64) {
+                    const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+                    const int hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const unsigned long long a = keys[lo], b = keys[hi];
+                    if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+                }
+                __syncthreads();
+            }
+        for (int i = lane; i < n; i += 64) { const unsigned long long k = keys[i]; list[i] = make_uint2((unsigned)(k >> 32), (unsigned)k); }
+    }
+}
+
+__global__ void __launch_bounds__(64)
+composite_lists_fwd(const TraceArgs A)
+{
+    const int lane = threadIdx.x;
+    unsigned st_hits = 0;
+    for (int base = blockIdx.x * 64; base < A.R; base += gridDim.x * 64) {
+        const int r = base + lane;
+        if (r >= A.R) continue;
+        const int n = A.hit_cnt[r];
+        if (n > A.cap) continue;                            // overflow: the K-buffer kernel owns this ray
+        const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
+        const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
+        float basis[16];
+        {
+            const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+            sh_basis(A.D, dx * il, dy * il, dz * il, basis);
+        }
+        const uint2 *list = A.hits + (size_t)r * A.cap;
+        float T = 1.0f, M1 = 0.f, M2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dpt = 0.f, acc = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, dist = 0.f, x0 = 0.f, x1 = 0.f;
+        int used = 0;
+        for (int k = 0; k < n; k++) {
+            const int sid = (int)list[k].y;
+            const float4 *sr = A.srec + (size_t)sid * 4;
+            const float4 s3 = sr[3];
+            const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], s3, ox, oy, oz, dx, dy, dz);
+            const float test_T = T * (1.0f - h.alpha);
+            if (test_T < T_EPS) break;
+            const float w = h.alpha * T;
+            float col[3]; bool cl[3];
+            surfel_color(A, sid, basis, col, cl);
+            const float tt = h.t > NEAR_N ? h.t : NEAR_N;
+            const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / tt);
+            dist += (m * m * (1.0f - T) + M2 - 2.0f * m * M1) * w;
+            M1 += m * w; M2 += m * m * w;
+            c0 += w * col[0]; c1 += w * col[1]; c2 += w * col[2];
+            dpt += w * h.t; acc += w;
+            const float sg = h.denom < 0.0f ? w : -w;
+            n0 += sg * s3.x; n1 += sg * s3.y; n2 += sg * s3.z;
+            if (A.has_others) { x0 += w * A.others[2 * sid]; x1 += w * A.others[2 * sid + 1]; }
+            atomic_add_f32(A.wet + sid, w);
+            T = test_T;
+            used++;
+        }
+        st_hits += (unsigned)used;
+        A.n_used[r] = used;
+        c0 += T * (0 < A.bg_len ? A.bg[0] : 0.f); c1 += T * (1 < A.bg_len ? A.bg[1] : 0.f); c2 += T * (2 < A.bg_len ? A.bg[2] : 0.f);
+        A.rgb[3 * r] = c0; A.rgb[3 * r + 1] = c1; A.rgb[3 * r + 2] = c2;
+        A.dpt[r] = dpt; A.acc[r] = acc; A.dist[r] = dist;
+        A.norm[3 * r] = n0; A.norm[3 * r + 1] = n1; A.norm[3 * r + 2] = n2;
+        A.aux[2 * r] = x0; A.aux[2 * r + 1] = x1;
+        A.final_T[r] = T;
+        float *m = A.mid + (size_t)r * MID;
+        m[0] = ox; m[1] = oy; m[2] = oz; m[3] = dx; m[4] = dy; m[5] = dz; m[6] = dpt; m[7] = acc;
+        m[8] = n0; m[9] = n1; m[10] = n2; m[11] = x0; m[12] = x1; m[13] = c0; m[14] = c1; m[15] = c2;
+    }
+    if (A.stats) {
+        // NB: lanes that `continue`d above are still here; wave_sum needs the full wavefront
+        const float fh = wave_sum((float)st_hits);
+        if (lane == 0) atomicAdd(A.stats + 0, (unsigned long long)fh);
+    }
+}
+
+__global__ void __launch_bounds__(64)
+composite_lists_bwd(const TraceArgs A)
+{
+    __shared__ float fld[NFLD][65];
+    const int lane = threadIdx.x;
+    const FlushRole role = flush_role(A, lane);
+    const int nb = (A.D + 1) * (A.D + 1);
+    for (int base = blockIdx.x * 64; base < A.R; base += gridDim.x * 64) {
+        const int r = base + lane;
+        const bool valid = r < A.R && A.hit_cnt[r < A.R ? r : 0] <= A.cap;
+        const int rr = r < A.R ? r : 0;
+        BwdRay B;
+        bwd_load_ray(A, rr, B);
+        BwdAcc acc;
+        bwd_init_acc(acc);
+        float basis[16];
+        sh_basis(A.D, B.ux, B.uy, B.uz, basis);
+        __syncthreads();
+        fld[19][lane] = B.ux; fld[20][lane] = B.uy; fld[21][lane] = B.uz;
+        const int n = valid ? A.n_used[rr] : 0;
+        const uint2 *list = A.hits + (size_t)rr * A.cap;
+        int nmax = n;
+        for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+        for (int k = 0; k < nmax; k++) {
+            bool has = false;
+            int sid = 0;
+            float dc0 = 0.f, dc1 = 0.f, dc2 = 0.f, gv[15];
+#pragma unroll
+            for (int q = 0; q < 15; q++) gv[q] = 0.f;
+            if (k < n) {
+                sid = (int)list[k].y;
+                has = bwd_hit(A, B, acc, basis, nb, sid, dc0, dc1, dc2, gv);
+            }
+            flush_hits(A, fld, lane, role, has, sid, dc0, dc1, dc2, gv);
+        }
+        if (valid) bwd_store_ray(A, r, B, acc);
     }
 }
 
@@ -584,7 +877,7 @@ finish_surfel_grads(int P, const float *__restrict__ rots, const float *__restri
     if (dgrads3D) { dgrads3D[3 * i] = g[0]; dgrads3D[3 * i + 1] = g[1]; dgrads3D[3 * i + 2] = g[2]; }
 }
 
-static int persistent_grid(int R)
+static int persistent_grid(int R, int per_cu = 8)
 {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -592,7 +885,15 @@ static int persistent_grid(int R)
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     const int want = (R + 63) / 64;
-    const int cap = cus * 8;
+    const int cap = cus * per_cu;
+    return want < cap ? (want > 0 ? want : 1) : cap;
+}
+
+// grid for a grid-stride kernel that handles `per_block` rays per block iteration
+static int stride_grid(int R, int per_block)
+{
+    const int want = (R + per_block - 1) / per_block;
+    const int cap = 256 * 32;
     return want < cap ? (want > 0 ? want : 1) : cap;
 }
 
@@ -609,11 +910,14 @@ static void ray_layout(const envgs_trace_cfg *cfg, int *rh, int *rw)
 
 extern "C" {
 
+size_t envgs_trace_stack_spill_ints(int32_t num_rays) { return (size_t)persistent_grid(num_rays, 24) * STACK * 64; }
+
 int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const float *ray_o, const float *ray_d,
                         const float *means3D, const float *scales, const float *rotations, const float *opacities,
                         const float *shs, const float *colors_precomp, const float *others_precomp, const float *bg,
                         float *srec, uint32_t *counters, float *rgb, float *dpt, float *acc, float *norm, float *dist,
-                        float *aux, float *mid, float *wet, float *final_T, void *stream_)
+                        float *aux, float *mid, float *wet, float *final_T, uint32_t *hit_lists, int32_t *hit_cnt, int32_t *n_used,
+                        int32_t cap, int32_t *stack_spill, void *stream_)
 {
     if (!cfg || cfg->P < 0 || cfg->num_rays < 0 || cfg->sh_degree < 0 || cfg->sh_degree > 3 || cfg->max_trace_depth < 0 || cfg->max_trace_depth > 7)
         return ENVGS_ERR_BAD_ARG;
@@ -645,8 +949,22 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     A.rgb = rgb; A.dpt = dpt; A.acc = acc; A.norm = norm; A.dist = dist; A.aux = aux; A.mid = mid; A.wet = wet; A.final_T = final_T;
     A.mod = cfg->scale_modifier;
     int rh, rw; ray_layout(cfg, &rh, &rw);
+    const bool lists = cap > 0 && cfg->max_trace_depth == 0 && cfg->P > 0 && hit_lists && hit_cnt && n_used && stack_spill;
+    if (cap > SORT_MAX) return ENVGS_ERR_BAD_ARG;
     ProfScope prof_(K_TRACE_FWD, stream);
-    hipLaunchKernelGGL(trace_fwd, dim3(persistent_grid(cfg->num_rays)), dim3(64), 0, stream, A, rh, rw);
+    if (lists) {
+        A.hits = (uint2 *)hit_lists; A.hit_cnt = hit_cnt; A.n_used = n_used; A.cap = cap; A.stack_spill = stack_spill;
+        { ProfScope p1(K_TRACE_COLLECT, stream); hipLaunchKernelGGL(collect_hits, dim3(persistent_grid(cfg->num_rays, 24)), dim3(64), 0, stream, A); }
+        ENVGS_CHECK_LAUNCH(dcfg, stream);
+        { ProfScope p2(K_TRACE_SORT, stream); hipLaunchKernelGGL(sort_hit_lists, dim3(stride_grid(cfg->num_rays, 1)), dim3(64), 0, stream, A); }
+        ENVGS_CHECK_LAUNCH(dcfg, stream);
+        { ProfScope p3(K_TRACE_COMPOSITE, stream); hipLaunchKernelGGL(composite_lists_fwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
+        ENVGS_CHECK_LAUNCH(dcfg, stream);
+        e = hipMemsetAsync(counters, 0, sizeof(uint32_t), stream);          // ray-fetch counter for the overflow pass
+        if (e != hipSuccess) return (int)e;
+        A.only_overflow = 1;
+    }
+    { ProfScope p4(K_TRACE_KBUF_FWD, stream); hipLaunchKernelGGL(trace_fwd, dim3(persistent_grid(cfg->num_rays)), dim3(64), 0, stream, A, rh, rw); }
     ENVGS_CHECK_LAUNCH(dcfg, stream);
     return 0;
 }
@@ -658,7 +976,8 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
                          const float *norm, const float *aux, const float *final_T, const float *dL_drgb, const float *dL_ddpt,
                          const float *dL_dacc, const float *dL_dnorm, const float *dL_daux, float *geo_rec, float *dmeans3D,
                          float *dgrads3D, float *dscales, float *drots, float *dopacities, float *dshs, float *dcolors,
-                         float *dothers, float *dray_o, float *dray_d, void *stream_)
+                         float *dothers, float *dray_o, float *dray_d, const uint32_t *hit_lists, const int32_t *hit_cnt,
+                         const int32_t *n_used, int32_t cap, void *stream_)
 {
     if (!cfg || cfg->P < 0 || cfg->num_rays < 0) return ENVGS_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
@@ -676,7 +995,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
         !dL_dacc || !dL_dnorm || !dL_daux || !geo_rec || !dmeans3D || !dscales || !drots || !dopacities || !dray_o || !dray_d || !rotations || !bg)
         return ENVGS_ERR_BAD_ARG;
     if (cfg->sh_coeffs > 0 ? (!shs || !dshs) : (!colors_precomp || !dcolors)) return ENVGS_ERR_BAD_ARG;
-    e = hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), stream);
+    e = hipMemsetAsync(counters, 0, sizeof(uint32_t), stream);      // only the ray-fetch counter: [1] (largest list) and the stats stay readable
     if (e != hipSuccess) return (int)e;
     TraceArgs A;
     A = TraceArgs{};
@@ -691,7 +1010,12 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     int rh, rw; ray_layout(cfg, &rh, &rw);
     {
         ProfScope prof_(K_TRACE_BWD, stream);
-        hipLaunchKernelGGL(trace_bwd, dim3(persistent_grid(cfg->num_rays)), dim3(64), 0, stream, A, rh, rw);
+        if (cap > 0 && cfg->max_trace_depth == 0 && hit_lists && hit_cnt && n_used) {
+            A.hits = (uint2 *)hit_lists; A.hit_cnt = (int *)hit_cnt; A.n_used = (int *)n_used; A.cap = cap;
+            { ProfScope p5(K_TRACE_LIST_BWD, stream); hipLaunchKernelGGL(composite_lists_bwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
+            A.only_overflow = 1;
+        }
+        { ProfScope p6(K_TRACE_KBUF_BWD, stream); hipLaunchKernelGGL(trace_bwd, dim3(persistent_grid(cfg->num_rays)), dim3(64), 0, stream, A, rh, rw); }
     }
     ENVGS_CHECK_LAUNCH(dcfg, stream);
     hipLaunchKernelGGL(finish_surfel_grads, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, rotations, geo_rec, dmeans3D, dscales,

@@ -86,8 +86,22 @@ def _cfg(settings, P, R, shs, others, start_from_first, ray_shape):
                          rh, rw, float(settings.scale_modifier), float(settings.specular_threshold))
 
 
+HIT_CAP = {"cap": 256}      # per-ray hit-list capacity of the list path; adapted from the largest list of the previous call
+
+
+def _next_cap():
+    if HIT_CAP.get("force"):                       # tests: pin the capacity (e.g. tiny, to exercise the overflow hand-off)
+        return int(HIT_CAP["force"])
+    c = LAST_STATS.get("counters")
+    if c is not None:
+        mx = int(c[1].item())                      # previous call has long finished; this read is the only host sync
+        want = ((int(mx * 1.2) + 8 + 63) // 64) * 64          # 20 % headroom, multiple of 64 entries (512 B)
+        HIT_CAP["cap"] = max(64, min(want, 1024))
+    return HIT_CAP["cap"]
+
+
 def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_precomp, opacities, scales, rotations, settings,
-                  start_from_first):
+                  start_from_first, use_lists=True):
     lib = _lib.load()
     dev = means3D.device
     lead = tuple(ray_o.shape[:-1])
@@ -104,14 +118,21 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     rgb = torch.empty(R, 3, **f32); dpt = torch.empty(R, 1, **f32); acc = torch.empty(R, 1, **f32)
     norm = torch.empty(R, 3, **f32); dist = torch.empty(R, 1, **f32); aux = torch.empty(R, 2, **f32)
     mid = torch.empty(R, 16 * ND, **f32); wet = torch.empty(P, 1, **f32); final_T = torch.empty(R, **f32)
+    cap = _next_cap() if (use_lists and ND == 1 and P > 0 and R > 0) else 0
+    hit_lists = torch.empty(R, cap, 2, dtype=torch.int32, device=dev) if cap else None
+    hit_cnt = torch.empty(R, dtype=torch.int32, device=dev) if cap else None
+    n_used = torch.empty(R, dtype=torch.int32, device=dev) if cap else None
+    spill = torch.empty(lib.envgs_trace_stack_spill_ints(R), dtype=torch.int32, device=dev) if cap else None
     p = _lib.ptr
     _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
                                        p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),
-                                       p(norm), p(dist), p(aux), p(mid), p(wet), p(final_T), _stream(dev)), "envgs_trace_forward")
+                                       p(norm), p(dist), p(aux), p(mid), p(wet), p(final_T), p(hit_lists), p(hit_cnt), p(n_used), cap,
+                                       p(spill), _stream(dev)), "envgs_trace_forward")
     LAST_STATS.update(P=P, R=R, counters=counters)
     saved = dict(cfg=cfg, nodes=nodes, ro=ro, rd=rd, means3D=means3D, scales=scales, rotations=rotations, opacities=opacities,
                  shs=shs, colors_precomp=colors_precomp, others=others_precomp, bg=bg, srec=srec, counters=counters,
-                 rgb=rgb, dpt=dpt, acc=acc, norm=norm, aux=aux, final_T=final_T, lead=lead)
+                 rgb=rgb, dpt=dpt, acc=acc, norm=norm, aux=aux, final_T=final_T, lead=lead,
+                 hit_lists=hit_lists, hit_cnt=hit_cnt, n_used=n_used, cap=cap)
     outs = (rgb.reshape(lead + (3,)), dpt.reshape(lead + (1,)), acc.reshape(lead + (1,)), norm.reshape(lead + (3,)),
             dist.reshape(lead + (1,)), aux.reshape(lead + (2,)), mid.reshape(lead + (16 * ND,)), wet)
     return outs, saved
@@ -139,7 +160,8 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
                                         p(s["opacities"]), p(shs), p(s["colors_precomp"]), p(others), p(s["bg"]), p(s["srec"]),
                                         p(s["counters"]), p(s["rgb"]), p(s["dpt"]), p(s["acc"]), p(s["norm"]), p(s["aux"]), p(s["final_T"]),
                                         p(g_rgb), p(g_dpt), p(g_acc), p(g_norm), p(g_aux), p(geo_rec), p(dmeans), p(dgrads3D), p(dscales),
-                                        p(drots), p(dopac), p(dshs), p(dcolors), p(dothers), p(dro), p(drd), _stream(dev)),
+                                        p(drots), p(dopac), p(dshs), p(dcolors), p(dothers), p(dro), p(drd), p(s["hit_lists"]), p(s["hit_cnt"]),
+                                        p(s["n_used"]), s["cap"], _stream(dev)),
                "envgs_trace_backward")
     lead = s["lead"]
     return dict(ray_o=dro.reshape(lead + (3,)), ray_d=drd.reshape(lead + (3,)), means3D=dmeans, grads3D=dgrads3D, shs=dshs,
@@ -212,5 +234,7 @@ def last_trace_counts():
     c = LAST_STATS.get("counters")
     if c is None:
         return None
-    v = c[2:8].cpu().view(torch.int64)
-    return dict(hits=int(v[0]), node_visits=int(v[1]), rounds=int(v[2]), rays=LAST_STATS["R"])
+    w = c.cpu()
+    v = w[2:10].view(torch.int64)
+    return dict(hits=int(v[0]), node_visits=int(v[1]), rounds=int(v[2]), found=int(v[3]), max_list=int(w[1]), cap=HIT_CAP["cap"],
+                rays=LAST_STATS["R"])

@@ -76,14 +76,23 @@ ENVGS_API int envgs_bvh_build(int32_t P, const float *vertices, float *nodes, vo
  * forward, words [2..7] hold three uint64 totals: composited hits, BVH node visits, traversal rounds (diagnostics that
  * the roofline accounting of bench.py needs: BASELINE.md section 4 "hits / node_visits are data dependent").
  * final_T (R): stage-0 transmittance, kept for the backward.
+ * List path (cap > 0, max_trace_depth == 0): hit_lists (R, cap, 2) uint32 = (t bits, surfel id) per hit, hit_cnt (R) hits
+ * found, n_used (R) hits composited.  Each ray's hits are collected in ONE unordered traversal, sorted by (t, id) in LDS and
+ * walked front to back; the backward walks the same lists and never touches the BVH.  Rays with more than `cap` (<= 1024)
+ * hits, and all rays when cap == 0 or bounces are requested, use the K-nearest-buffer traversal instead.  After the call
+ * counters[1] holds the largest hit_cnt (so the caller can size `cap` for the next call).
+ * stack_spill: envgs_trace_stack_spill_ints() int32 of scratch (deep-stack overflow space of the collection pass).
  */
+ENVGS_API size_t envgs_trace_stack_spill_ints(int32_t num_rays);
 ENVGS_API int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes,
                                   const float *ray_o, const float *ray_d,
                                   const float *means3D, const float *scales, const float *rotations, const float *opacities,
                                   const float *shs, const float *colors_precomp, const float *others_precomp, const float *bg,
                                   float *srec, uint32_t *counters,
                                   float *rgb, float *dpt, float *acc, float *norm, float *dist, float *aux, float *mid,
-                                  float *wet, float *final_T, void *stream);
+                                  float *wet, float *final_T,
+                                  uint32_t *hit_lists, int32_t *hit_cnt, int32_t *n_used, int32_t cap,
+                                  int32_t *stack_spill, void *stream);
 
 /*
  * SurfelTracer backward: gradients of stage 0 w.r.t. the surfel parameters AND the rays (reflected rays are
@@ -103,6 +112,7 @@ ENVGS_API int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *node
                                    float *geo_rec,
                                    float *dmeans3D, float *dgrads3D, float *dscales, float *drots, float *dopacities,
                                    float *dshs, float *dcolors, float *dothers, float *dray_o, float *dray_d,
+                                   const uint32_t *hit_lists, const int32_t *hit_cnt, const int32_t *n_used, int32_t cap,
                                    void *stream);
 
 #ifdef __cplusplus

@@ -123,3 +123,44 @@ def test_trace_edge_cases():
     with torch.inference_mode():
         rgb2, *_ = tracer(ro.to(dev)[None], rd.to(dev)[None], None, **kw)
     assert rgb2.shape == (1, 64, 3) and torch.isfinite(rgb2).all()
+
+
+@pytest.mark.parametrize("force_cap", [12, 20, 0])
+def test_trace_list_path_overflow_handoff(force_cap):
+    """Per-ray hit lists with a tiny capacity: rays that overflow must be handed to the K-buffer kernels and give the same
+    result as the oracle (forward and backward); force_cap=0 disables the list path entirely."""
+    from envgs_amd import tracing
+    from oracle import trace as otr
+    g, ro, rd = trace_scene(P=600, R=512, seed=11, camera=False)
+    g["scales"] = g["scales"] * 0.6
+    R = ro.shape[0]
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    gen = torch.Generator().manual_seed(3)
+    gr = [torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen),
+          torch.randn(R, 3, generator=gen), torch.randn(R, 2, generator=gen)]
+    old = dict(tracing.HIT_CAP)
+    orig_fwd = tracing.trace_forward
+    try:
+        if force_cap: tracing.HIT_CAP["force"] = force_cap
+        else: tracing.trace_forward = lambda *a, **k: orig_fwd(*a, **{**k, "use_lists": False})
+        outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, 3, True, False, grads=gr)
+        cnt = tracing.last_trace_counts()
+    finally:
+        tracing.HIT_CAP.clear(); tracing.HIT_CAP.update(old); tracing.trace_forward = orig_fwd
+    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
+    ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(),
+                            g["opacities"].numpy(), shs=g["shs"].numpy(), sh_degree=3, others=g["others"].numpy(), bg=bg.numpy(),
+                            start_from_first=False)
+    if force_cap:
+        assert cnt["max_list"] > force_cap                 # the overflow path really ran
+        assert (ref["nhits"] <= force_cap).any()           # and so did the list path
+    assert_close_frac(rgb, ref["rgb"], 1e-4, max_bad_frac=2e-3, flip_bound=0.05, what="rgb")
+    assert_close_frac(wet[:, 0], ref["wet"], 1e-4, max_bad_frac=2e-3, flip_bound=0.05, what="wet")
+    assert_close_frac(mid[:, 13:16], ref["rgb"], 1e-4, max_bad_frac=2e-3, flip_bound=0.05, what="mid.rgb")
+    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
+    chk = lambda a, b, nm: assert_close_frac(a, b, 1e-3, max_bad_frac=5e-3, flip_bound=0.2, what=nm)
+    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
+    chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
+    chk(L["rotations"].grad.cpu().numpy(), rb["drots"], "drots")
+    chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
+    chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
