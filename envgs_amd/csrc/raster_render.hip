@@ -54,7 +54,52 @@ struct TileLds {
     float4 rec[4][256];
     float col[C][256];
     uint32_t id[256];
+    uint32_t qmask[256];      // bit q set: quadrant (wavefront) q can see alpha >= 1/255 from this splat
 };
+
+// XCD-aware tile order: consecutive workgroup ids land on different XCDs (b % 8), each with a private L2.  Give every
+// XCD one contiguous run of tiles so neighbouring tiles -- which share most of their splats -- hit the same L2.
+__device__ __forceinline__ int xcd_tile(int b, int ntiles)
+{
+    const int per = (ntiles + 7) >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+
+// Exact wavefront-level culling.  A pixel composites a splat only if alpha = min(0.99, o*exp(-rho/2)) >= 1/255, i.e.
+// rho = min(rho3d, rho2d) <= tau = 2 ln(255 o).  {rho2d <= tau} is a disc of radius sqrt(tau/2) px around the centre;
+// {rho3d <= tau} is the projected ellipse of the uv-disc of radius sqrt(tau), whose screen AABB has the closed form of
+// the 3-sigma AABB with 9 replaced by tau (valid while the disc stays in front of the w = 0 plane, d < 0; otherwise no
+// culling).  A quadrant whose pixel rect misses the union of both boxes (plus a margin far above fp noise) cannot
+// contribute, so skipping it changes no result.
+__device__ __forceinline__ uint32_t quadrant_mask(const float4 r0, const float4 r1, const float4 r2, const float4 r3, int tile_px, int tile_py)
+{
+    const float Tux = r0.x, Tuy = r0.y, Tuz = r0.z, Tvx = r0.w, Tvy = r1.x, Tvz = r1.y, Twx = r1.z, Twy = r1.w, Twz = r2.x;
+    const float cx = r2.y, cy = r2.z, opa = r3.z;
+    const float tau = 2.0f * __logf(255.0f * opa);
+    if (!(tau >= 0.0f)) return 0u;
+    const float r2d = sqrtf(0.5f * tau);
+    float bx0 = cx - r2d, bx1 = cx + r2d, by0 = cy - r2d, by1 = cy + r2d;
+    const float d = tau * (Twx * Twx + Twy * Twy) - Twz * Twz;
+    if (!(d < 0.0f)) return 0xFu;
+    const float id = 1.0f / d;
+    const float f0 = tau * id, f2 = -id;
+    const float pxc = f0 * (Tux * Twx + Tuy * Twy) + f2 * (Tuz * Twz);
+    const float pyc = f0 * (Tvx * Twx + Tvy * Twy) + f2 * (Tvz * Twz);
+    const float hx = pxc * pxc - (f0 * (Tux * Tux + Tuy * Tuy) + f2 * (Tuz * Tuz));
+    const float hy = pyc * pyc - (f0 * (Tvx * Tvx + Tvy * Tvy) + f2 * (Tvz * Tvz));
+    const float ex = sqrtf(fmaxf(hx, 0.0f)), ey = sqrtf(fmaxf(hy, 0.0f));
+    bx0 = fminf(bx0, pxc - ex); bx1 = fmaxf(bx1, pxc + ex); by0 = fminf(by0, pyc - ey); by1 = fmaxf(by1, pyc + ey);
+    const float mx = 0.05f + 1e-3f * (bx1 - bx0), my = 0.05f + 1e-3f * (by1 - by0);
+    bx0 -= mx; bx1 += mx; by0 -= my; by1 += my;
+    if (!(bx0 <= bx1 && by0 <= by1)) return 0xFu;       // NaN guard: never cull on garbage
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float qx = (float)(tile_px + (q & 1) * 8), qy = (float)(tile_py + (q >> 1) * 8);
+        if (bx0 <= qx + 7.0f && bx1 >= qx && by0 <= qy + 7.0f && by1 >= qy) m |= 1u << q;
+    }
+    return m;
+}
 
 // ------------------------------------------------------------------------------------------ R6 ---
 template <int C>
@@ -65,8 +110,10 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
               int32_t *__restrict__ n_contrib, float *__restrict__ weight)
 {
     __shared__ TileLds<C> lds;
-    const int gx = (W + TILE - 1) / TILE;
-    const int tile = blockIdx.x;
+    __shared__ float wacc[256];            // per-splat weight summed over the 4 wavefronts before it leaves the CU
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int tile = xcd_tile(blockIdx.x, gx * gy);
+    if (tile >= gx * gy) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int pxi = tx * TILE + (wave & 1) * 8 + (lane & 7);
@@ -80,14 +127,17 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
     int32_t last = 0, medc = -1;
 #pragma unroll
     for (int c = 0; c < C; c++) Cacc[c] = 0.f;
+    wacc[tid] = 0.f;
 
     for (uint32_t base = r0; base < r1; base += 256) {
         if (__syncthreads_and(done)) break;
         if (base + tid < r1) {
             const uint32_t g = point_list[base + tid];
             const float4 *gp = reinterpret_cast<const float4 *>(geom + (size_t)g * GEOM);
+            const float4 a0 = gp[0], a1 = gp[1], a2 = gp[2], a3 = gp[3];
             lds.id[tid] = g;
-            lds.rec[0][tid] = gp[0]; lds.rec[1][tid] = gp[1]; lds.rec[2][tid] = gp[2]; lds.rec[3][tid] = gp[3];
+            lds.rec[0][tid] = a0; lds.rec[1][tid] = a1; lds.rec[2][tid] = a2; lds.rec[3][tid] = a3;
+            lds.qmask[tid] = quadrant_mask(a0, a1, a2, a3, tx * TILE, ty * TILE);
 #pragma unroll
             for (int c = 0; c < C; c++) lds.col[c][tid] = colors[(size_t)g * C + c];
         }
@@ -95,6 +145,7 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
         const int count = (int)min(256u, r1 - base);
         for (int j = 0; j < count; j++) {
             if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+            if (!((lds.qmask[j] >> wave) & 1u)) continue;          // wave-uniform: this quadrant cannot reach alpha >= 1/255
             const Hit h = eval_splat(lds.rec[0][j], lds.rec[1][j], lds.rec[2][j], lds.rec[3][j], px, py);
             bool contrib = !done && h.ok;
             const float test_T = T * (1.0f - h.alpha);
@@ -121,8 +172,13 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
             }
             if (__builtin_amdgcn_ballot_w64(contrib) != 0) {
                 const float ws = wave_sum(w);
-                if (lane == 0) atomic_add_f32(weight + lds.id[j], ws);
+                if (lane == 0) atomic_add_f32(&wacc[j], ws);          // LDS atomic: ds_add_f32
             }
+        }
+        __syncthreads();
+        if (tid < count) {
+            const float ws = wacc[tid];
+            if (ws != 0.0f) { atomic_add_f32(weight + lds.id[tid], ws); wacc[tid] = 0.f; }
         }
     }
 
@@ -150,9 +206,14 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
 {
     constexpr int V = 15 + C;          // gradient words per surfel
     __shared__ TileLds<C> lds;
+    // Per-batch gradient accumulator: the 4 wavefronts add their DPP-reduced words here (ds_add_f32), and the tile sends
+    // ONE global atomic per (splat, word).  The L2 atomic units retire roughly one dword per clock per channel
+    // (~0.12 T dword-atomics/s measured), so the number of global atomic dwords -- not bytes -- is what R7 pays for.
+    __shared__ float gacc[256][V];
     __shared__ int s_max_last;
-    const int gx = (W + TILE - 1) / TILE;
-    const int tile = blockIdx.x;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int tile = xcd_tile(blockIdx.x, gx * gy);
+    if (tile >= gx * gy) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int pxi = tx * TILE + (wave & 1) * 8 + (lane & 7);
@@ -189,6 +250,7 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
 
     // Entries behind the deepest last-contributor of this tile were never blended by any pixel: skip them.
     if (tid == 0) s_max_last = 0;
+    for (int i = tid; i < 256 * V; i += 256) (&gacc[0][0])[i] = 0.f;
     __syncthreads();
     {
         int m = last;
@@ -205,14 +267,17 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
         if (top - 1 - tid >= 0) {
             const uint32_t g = point_list[r0 + (uint32_t)(top - 1 - tid)];
             const float4 *gp = reinterpret_cast<const float4 *>(geom + (size_t)g * GEOM);
+            const float4 a0 = gp[0], a1 = gp[1], a2 = gp[2], a3 = gp[3];
             lds.id[tid] = g;
-            lds.rec[0][tid] = gp[0]; lds.rec[1][tid] = gp[1]; lds.rec[2][tid] = gp[2]; lds.rec[3][tid] = gp[3];
+            lds.rec[0][tid] = a0; lds.rec[1][tid] = a1; lds.rec[2][tid] = a2; lds.rec[3][tid] = a3;
+            lds.qmask[tid] = quadrant_mask(a0, a1, a2, a3, tx * TILE, ty * TILE);
 #pragma unroll
             for (int c = 0; c < C; c++) lds.col[c][tid] = colors[(size_t)g * C + c];
         }
         __syncthreads();
         const int count = min(256, top);
         for (int j = 0; j < count; j++) {
+            if (!((lds.qmask[j] >> wave) & 1u)) continue;
             const int ci = top - 1 - j;                       // 0-based position in the tile list
             const bool cand = ci < last;
             if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
@@ -281,11 +346,18 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
                 }
                 gv[12] = G * dL_dalpha;
             }
-            // wavefront reduction: lane v ends up owning the sum of word v, then one coalesced atomic
+            // wavefront reduction: lane v ends up owning the sum of word v, then one LDS atomic instruction
             float mine = 0.f;
 #pragma unroll
             for (int v = 0; v < V; v++) { const float sv = wave_sum(gv[v]); mine = (lane == v) ? sv : mine; }
-            if (lane < V) atomic_add_f32(grad_rec + (size_t)lds.id[j] * GREC + lane, mine);
+            if (lane < V) atomic_add_f32(&gacc[j][lane], mine);
+        }
+        __syncthreads();
+        // flush the batch: consecutive lanes own consecutive words, so one instruction covers ~3 whole 128 B records
+        for (int i = tid; i < count * V; i += 256) {
+            const int j = i / V, v = i - j * V;
+            const float val = gacc[j][v];
+            if (val != 0.0f) { atomic_add_f32(grad_rec + (size_t)lds.id[j] * GREC + v, val); gacc[j][v] = 0.f; }
         }
     }
 }
@@ -298,7 +370,7 @@ static int run_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const ui
 {
     const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
     ProfScope prof_(K_COMPOSITE_FWD, stream);
-    hipLaunchKernelGGL(composite_fwd<C>, dim3(gx * gy), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
+    hipLaunchKernelGGL(composite_fwd<C>, dim3(8 * ((gx * gy + 7) / 8)), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
                        point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;
@@ -327,7 +399,7 @@ static int run_bwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const ui
 {
     const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
     ProfScope prof_(K_COMPOSITE_BWD, stream);
-    hipLaunchKernelGGL(composite_bwd<C>, dim3(gx * gy), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
+    hipLaunchKernelGGL(composite_bwd<C>, dim3(8 * ((gx * gy + 7) / 8)), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
                        point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;
