@@ -19,6 +19,14 @@ class RasterCfg(ctypes.Structure):
                 ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float)]
 
 
+class TraceLists(ctypes.Structure):
+    """struct envgs_trace_lists (include/envgs_trace.h)."""
+    _fields_ = [("hit_lists", ctypes.c_void_p), ("hit_cnt", ctypes.c_void_p), ("n_used", ctypes.c_void_p), ("cap", ctypes.c_int32),
+                ("stack_spill", ctypes.c_void_p), ("surf_cnt", ctypes.c_void_p), ("surf_off", ctypes.c_void_p),
+                ("scan_temp", ctypes.c_void_p), ("scan_temp_bytes", ctypes.c_size_t), ("records", ctypes.c_void_p),
+                ("num_records", ctypes.c_uint64)]
+
+
 class TraceCfg(ctypes.Structure):
     """struct envgs_trace_cfg (include/envgs_trace.h)."""
     _fields_ = [("P", ctypes.c_int32), ("num_rays", ctypes.c_int32), ("sh_degree", ctypes.c_int32),
@@ -39,8 +47,8 @@ SYMBOLS = {
     "envgs_bvh_temp_bytes": (c_size_t, [ctypes.c_int32]),
     "envgs_bvh_build": (c_int, [ctypes.c_int32, _P, _P, _P, c_size_t, ctypes.c_int32, _P]),
     "envgs_trace_stack_spill_ints": (c_size_t, [ctypes.c_int32]),
-    "envgs_trace_forward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 22 + [_P, _P, _P, ctypes.c_int32, _P, _P]),
-    "envgs_trace_backward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 35 + [_P, _P, _P, ctypes.c_int32, _P]),
+    "envgs_trace_forward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 22 + [ctypes.POINTER(TraceLists), _P]),
+    "envgs_trace_backward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 35 + [ctypes.POINTER(TraceLists), _P]),
     "envgs_prof_enable": (None, [c_int]),
     "envgs_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     "envgs_prof_kernel_name": (ctypes.c_char_p, [c_int]),

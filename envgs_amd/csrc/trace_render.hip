@@ -13,6 +13,8 @@
 // oracle/surfel_trace_oracle.c ("parity unpinned": the OptiX sources are not in the reference tree).
 #include "common.h"
 
+#include <cstdlib>
+
 #include "../../include/envgs_trace.h"
 
 namespace envgs {
@@ -136,6 +138,11 @@ struct TraceArgs {
     int *hit_cnt;       // hits found per ray (may exceed cap: the ray then takes the K-buffer path)
     int *n_used;        // hits composited before termination
     int cap;
+    unsigned *surf_cnt;       // (P) composited hits per surfel (list path)
+    const unsigned *surf_off; // (P) inclusive scan of surf_cnt
+    float *records;           // (num_records, 24) per-hit gradient records grouped by surfel
+    unsigned long long num_records;
+    int exp;            // experiment switches (ENVGS_TRACE_EXP env var; 0 in production)
     int *stack_spill;   // collect_hits: (grid, STACK, 64) ints of stack overflow space
     int only_overflow;  // K-buffer kernels: process only rays whose hit_cnt exceeds cap
 };
@@ -519,7 +526,7 @@ __device__ __forceinline__ void flush_hits(const TraceArgs &A, float (*fld)[65],
                                            const bool has, const int sid, const float dc0, const float dc1, const float dc2, const float *gv)
 {
     const unsigned long long hm = __builtin_amdgcn_ballot_w64(has);
-    if (hm == 0) return;
+    if (hm == 0 || (A.exp & 4)) return;
     fld[0][lane] = __int_as_float(sid); fld[1][lane] = dc0; fld[2][lane] = dc1; fld[3][lane] = dc2;
 #pragma unroll
     for (int k = 0; k < 15; k++) fld[4 + k][lane] = gv[k];
@@ -542,7 +549,7 @@ __device__ __forceinline__ void flush_hits(const TraceArgs &A, float (*fld)[65],
             dst = A.dcolors + (size_t)hs * 3 + lane;
         }
         if (R.geo_lane) { val = fld[4 + (lane - 48)][l]; dst = A.geo_rec + (size_t)hs * GEO + (lane - 48); }
-        if (R.sh_lane || R.geo_lane) atomic_add_f32(dst, val);
+        if (((R.sh_lane && !(A.exp & 1)) || (R.geo_lane && !(A.exp & 2)))) atomic_add_f32(dst, val);
     }
     __syncthreads();
 }
@@ -767,7 +774,7 @@ composite_lists_fwd(const TraceArgs A)
             const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
             sh_basis(A.D, dx * il, dy * il, dz * il, basis);
         }
-        const uint2 *list = A.hits + (size_t)r * A.cap;
+        uint2 *list = A.hits + (size_t)r * A.cap;
         float T = 1.0f, M1 = 0.f, M2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dpt = 0.f, acc = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, dist = 0.f, x0 = 0.f, x1 = 0.f;
         int used = 0;
         for (int k = 0; k < n; k++) {
@@ -790,6 +797,7 @@ composite_lists_fwd(const TraceArgs A)
             n0 += sg * s3.x; n1 += sg * s3.y; n2 += sg * s3.z;
             if (A.has_others) { x0 += w * A.others[2 * sid]; x1 += w * A.others[2 * sid + 1]; }
             atomic_add_f32(A.wet + sid, w);
+            list[k].x = atomicAdd(A.surf_cnt + sid, 1u);     // this hit's slot among the surfel's hits (t is recomputed when needed)
             T = test_T;
             used++;
         }
@@ -848,6 +856,98 @@ composite_lists_bwd(const TraceArgs A)
             flush_hits(A, fld, lane, role, has, sid, dc0, dc1, dc2, gv);
         }
         if (valid) bwd_store_ray(A, r, B, acc);
+    }
+}
+
+// Atomic-free backward of the list path, stage 1: every lane walks its ray's list and writes one 96 B gradient record
+// per composited hit at  surf_off[sid] - surf_cnt[sid] + slot  -- i.e. the records land GROUPED BY SURFEL without any sort.
+constexpr int RECW = 24;      // floats per record: dir 3, dcolour 3, geometry 15, pad 3
+__global__ void __launch_bounds__(64)
+composite_lists_bwd_records(const TraceArgs A)
+{
+    const int lane = threadIdx.x;
+    const int nb = (A.D + 1) * (A.D + 1);
+    for (int base = blockIdx.x * 64; base < A.R; base += gridDim.x * 64) {
+        const int r = base + lane;
+        if (r >= A.R) continue;
+        if (A.hit_cnt[r] > A.cap) continue;                 // overflow rays: K-buffer backward (atomic flush)
+        BwdRay B;
+        bwd_load_ray(A, r, B);
+        BwdAcc acc;
+        bwd_init_acc(acc);
+        float basis[16];
+        sh_basis(A.D, B.ux, B.uy, B.uz, basis);
+        const int n = A.n_used[r];
+        const uint2 *list = A.hits + (size_t)r * A.cap;
+        for (int k = 0; k < n; k++) {
+            const uint2 e = list[k];
+            const int sid = (int)e.y;
+            float dc0, dc1, dc2, gv[15];
+            if (!bwd_hit(A, B, acc, basis, nb, sid, dc0, dc1, dc2, gv)) break;      // cannot happen: same arithmetic as the forward
+            const unsigned long long idx = (unsigned long long)(A.surf_off[sid] - A.surf_cnt[sid]) + e.x;
+            if (idx < A.num_records) {
+                float4 *o = reinterpret_cast<float4 *>(A.records + idx * RECW);
+                o[0] = make_float4(B.ux, B.uy, B.uz, dc0);
+                o[1] = make_float4(dc1, dc2, gv[0], gv[1]);
+                o[2] = make_float4(gv[2], gv[3], gv[4], gv[5]);
+                o[3] = make_float4(gv[6], gv[7], gv[8], gv[9]);
+                o[4] = make_float4(gv[10], gv[11], gv[12], gv[13]);
+                o[5] = make_float4(gv[14], 0.f, 0.f, 0.f);
+            }
+        }
+        bwd_store_ray(A, r, B, acc);
+    }
+}
+
+// Stage 2: one wavefront per surfel streams that surfel's contiguous records (coalesced 96 B reads), accumulates the (16,3)
+// SH gradient block and the 15 geometry words in registers, reduces across the wavefront with DPP and leaves as ONE
+// instruction per surfel -- the same word layout as the cooperative flush, so both paths add into the same buffers.
+__global__ void __launch_bounds__(256)
+reduce_surfel_records(const TraceArgs A)
+{
+    // 4 wavefronts share a surfel (hit counts per surfel are very uneven); each adds its partial with one instruction
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nb = (A.D + 1) * (A.D + 1);
+    for (int sid = blockIdx.x; sid < A.P; sid += gridDim.x) {
+        const unsigned cnt = A.surf_cnt[sid];
+        if (cnt <= (unsigned)wave * 64u) continue;
+        const unsigned long long start = (unsigned long long)(A.surf_off[sid] - cnt);
+        float sh[16][3], geo[15];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { sh[k][0] = 0.f; sh[k][1] = 0.f; sh[k][2] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 15; k++) geo[k] = 0.f;
+        for (unsigned i = wave * 64 + lane; i < cnt; i += 256) {
+            const unsigned long long idx = start + i;
+            if (idx >= A.num_records) break;
+            const float4 *rp = reinterpret_cast<const float4 *>(A.records + idx * RECW);
+            const float4 a0 = rp[0], a1 = rp[1], a2 = rp[2], a3 = rp[3], a4 = rp[4], a5 = rp[5];
+            const float dc0 = a0.w, dc1 = a1.x, dc2 = a1.y;
+            if (A.M > 0) {
+                float b[16];
+                sh_basis(A.D, a0.x, a0.y, a0.z, b);
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    if (k < nb) { sh[k][0] += b[k] * dc0; sh[k][1] += b[k] * dc1; sh[k][2] += b[k] * dc2; }
+            } else { sh[0][0] += dc0; sh[0][1] += dc1; sh[0][2] += dc2; }
+            geo[0] += a1.z; geo[1] += a1.w; geo[2] += a2.x; geo[3] += a2.y; geo[4] += a2.z; geo[5] += a2.w;
+            geo[6] += a3.x; geo[7] += a3.y; geo[8] += a3.z; geo[9] += a3.w; geo[10] += a4.x; geo[11] += a4.y;
+            geo[12] += a4.z; geo[13] += a4.w; geo[14] += a5.x;
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) { const float v = wave_sum(sh[k][c]); mine = (lane == k * 3 + c) ? v : mine; }
+#pragma unroll
+        for (int k = 0; k < 15; k++) { const float v = wave_sum(geo[k]); mine = (lane == 48 + k) ? v : mine; }
+        float *dst = nullptr;
+        bool act = false;
+        if (lane < 48) {
+            if (A.M > 0) { act = (lane / 3) < nb; dst = A.dshs + (size_t)sid * A.M * 3 + lane; }
+            else { act = lane < 3; dst = A.dcolors + (size_t)sid * 3 + lane; }
+        } else if (lane < 63) { act = true; dst = A.geo_rec + (size_t)sid * GEO + (lane - 48); }
+        if (act) atomic_add_f32(dst, mine);
     }
 }
 
@@ -916,8 +1016,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
                         const float *means3D, const float *scales, const float *rotations, const float *opacities,
                         const float *shs, const float *colors_precomp, const float *others_precomp, const float *bg,
                         float *srec, uint32_t *counters, float *rgb, float *dpt, float *acc, float *norm, float *dist,
-                        float *aux, float *mid, float *wet, float *final_T, uint32_t *hit_lists, int32_t *hit_cnt, int32_t *n_used,
-                        int32_t cap, int32_t *stack_spill, void *stream_)
+                        float *aux, float *mid, float *wet, float *final_T, const envgs_trace_lists *L, void *stream_)
 {
     if (!cfg || cfg->P < 0 || cfg->num_rays < 0 || cfg->sh_degree < 0 || cfg->sh_degree > 3 || cfg->max_trace_depth < 0 || cfg->max_trace_depth > 7)
         return ENVGS_ERR_BAD_ARG;
@@ -949,17 +1048,26 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     A.rgb = rgb; A.dpt = dpt; A.acc = acc; A.norm = norm; A.dist = dist; A.aux = aux; A.mid = mid; A.wet = wet; A.final_T = final_T;
     A.mod = cfg->scale_modifier;
     int rh, rw; ray_layout(cfg, &rh, &rw);
-    const bool lists = cap > 0 && cfg->max_trace_depth == 0 && cfg->P > 0 && hit_lists && hit_cnt && n_used && stack_spill;
-    if (cap > SORT_MAX) return ENVGS_ERR_BAD_ARG;
+    const bool lists = L && L->cap > 0 && cfg->max_trace_depth == 0 && cfg->P > 0 && L->hit_lists && L->hit_cnt && L->n_used &&
+                       L->stack_spill && L->surf_cnt && L->surf_off && L->scan_temp;
+    if (L && L->cap > SORT_MAX) return ENVGS_ERR_BAD_ARG;
     ProfScope prof_(K_TRACE_FWD, stream);
     if (lists) {
-        A.hits = (uint2 *)hit_lists; A.hit_cnt = hit_cnt; A.n_used = n_used; A.cap = cap; A.stack_spill = stack_spill;
+        if (L->scan_temp_bytes < scan_temp_bytes(cfg->P)) return ENVGS_ERR_TEMP_TOO_SMALL;
+        A.hits = (uint2 *)L->hit_lists; A.hit_cnt = L->hit_cnt; A.n_used = L->n_used; A.cap = L->cap; A.stack_spill = L->stack_spill;
+        A.surf_cnt = L->surf_cnt; A.surf_off = L->surf_off;
+        e = hipMemsetAsync(L->surf_cnt, 0, sizeof(unsigned) * (size_t)cfg->P, stream);
+        if (e != hipSuccess) return (int)e;
         { ProfScope p1(K_TRACE_COLLECT, stream); hipLaunchKernelGGL(collect_hits, dim3(persistent_grid(cfg->num_rays, 24)), dim3(64), 0, stream, A); }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
         { ProfScope p2(K_TRACE_SORT, stream); hipLaunchKernelGGL(sort_hit_lists, dim3(stride_grid(cfg->num_rays, 1)), dim3(64), 0, stream, A); }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
         { ProfScope p3(K_TRACE_COMPOSITE, stream); hipLaunchKernelGGL(composite_lists_fwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
+        {   // records of the backward are addressed through the inclusive scan of the per-surfel hit counts
+            const int rc = launch_scan(L->surf_cnt, L->surf_off, cfg->P, L->scan_temp, L->scan_temp_bytes, stream);
+            if (rc) return rc;
+        }
         e = hipMemsetAsync(counters, 0, sizeof(uint32_t), stream);          // ray-fetch counter for the overflow pass
         if (e != hipSuccess) return (int)e;
         A.only_overflow = 1;
@@ -976,8 +1084,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
                          const float *norm, const float *aux, const float *final_T, const float *dL_drgb, const float *dL_ddpt,
                          const float *dL_dacc, const float *dL_dnorm, const float *dL_daux, float *geo_rec, float *dmeans3D,
                          float *dgrads3D, float *dscales, float *drots, float *dopacities, float *dshs, float *dcolors,
-                         float *dothers, float *dray_o, float *dray_d, const uint32_t *hit_lists, const int32_t *hit_cnt,
-                         const int32_t *n_used, int32_t cap, void *stream_)
+                         float *dothers, float *dray_o, float *dray_d, const envgs_trace_lists *L, void *stream_)
 {
     if (!cfg || cfg->P < 0 || cfg->num_rays < 0) return ENVGS_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
@@ -1006,13 +1113,22 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     A.f_rgb = rgb; A.f_dpt = dpt; A.f_acc = acc; A.f_norm = norm; A.f_aux = aux; A.f_T = final_T;
     A.g_rgb = dL_drgb; A.g_dpt = dL_ddpt; A.g_acc = dL_dacc; A.g_norm = dL_dnorm; A.g_aux = dL_daux;
     A.geo_rec = geo_rec; A.dshs = dshs; A.dcolors = dcolors;
+    { const char *ev = getenv("ENVGS_TRACE_EXP"); A.exp = ev ? atoi(ev) : 0; }
     A.dothers = dothers; A.dray_o = dray_o; A.dray_d = dray_d; A.mod = cfg->scale_modifier;
     int rh, rw; ray_layout(cfg, &rh, &rw);
     {
         ProfScope prof_(K_TRACE_BWD, stream);
-        if (cap > 0 && cfg->max_trace_depth == 0 && hit_lists && hit_cnt && n_used) {
-            A.hits = (uint2 *)hit_lists; A.hit_cnt = (int *)hit_cnt; A.n_used = (int *)n_used; A.cap = cap;
-            { ProfScope p5(K_TRACE_LIST_BWD, stream); hipLaunchKernelGGL(composite_lists_bwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
+        if (L && L->cap > 0 && cfg->max_trace_depth == 0 && L->hit_lists && L->hit_cnt && L->n_used) {
+            A.hits = (uint2 *)L->hit_lists; A.hit_cnt = L->hit_cnt; A.n_used = L->n_used; A.cap = L->cap;
+            if (L->records && L->num_records > 0 && L->surf_cnt && L->surf_off && !(A.exp & 8)) {
+                // atomic-free: per-hit records grouped by surfel, then one wavefront per surfel reduces its segment
+                A.surf_cnt = L->surf_cnt; A.surf_off = L->surf_off; A.records = L->records; A.num_records = L->num_records;
+                { ProfScope p5(K_TRACE_LIST_BWD, stream); hipLaunchKernelGGL(composite_lists_bwd_records, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
+                { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 1)), dim3(256), 0, stream, A); }
+            } else {
+                ProfScope p5(K_TRACE_LIST_BWD, stream);
+                hipLaunchKernelGGL(composite_lists_bwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A);
+            }
             A.only_overflow = 1;
         }
         { ProfScope p6(K_TRACE_KBUF_BWD, stream); hipLaunchKernelGGL(trace_bwd, dim3(persistent_grid(cfg->num_rays)), dim3(64), 0, stream, A, rh, rw); }

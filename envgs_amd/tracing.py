@@ -86,7 +86,8 @@ def _cfg(settings, P, R, shs, others, start_from_first, ray_shape):
                          rh, rw, float(settings.scale_modifier), float(settings.specular_threshold))
 
 
-HIT_CAP = {"cap": 256}      # per-ray hit-list capacity of the list path; adapted from the largest list of the previous call
+HIT_CAP = {"cap": 512}
+USE_RECORDS = {"on": True}   # atomic-free backward (per-hit records grouped by surfel); False = cooperative atomic flush      # per-ray hit-list capacity of the list path; adapted from the largest list of the previous call
 
 
 def _next_cap():
@@ -119,20 +120,26 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     norm = torch.empty(R, 3, **f32); dist = torch.empty(R, 1, **f32); aux = torch.empty(R, 2, **f32)
     mid = torch.empty(R, 16 * ND, **f32); wet = torch.empty(P, 1, **f32); final_T = torch.empty(R, **f32)
     cap = _next_cap() if (use_lists and ND == 1 and P > 0 and R > 0) else 0
-    hit_lists = torch.empty(R, cap, 2, dtype=torch.int32, device=dev) if cap else None
-    hit_cnt = torch.empty(R, dtype=torch.int32, device=dev) if cap else None
-    n_used = torch.empty(R, dtype=torch.int32, device=dev) if cap else None
-    spill = torch.empty(lib.envgs_trace_stack_spill_ints(R), dtype=torch.int32, device=dev) if cap else None
+    lists = None
+    keep = {}
+    if cap:
+        i32 = dict(dtype=torch.int32, device=dev)
+        keep = dict(hit_lists=torch.empty(R, cap, 2, **i32), hit_cnt=torch.empty(R, **i32), n_used=torch.empty(R, **i32),
+                    spill=torch.empty(lib.envgs_trace_stack_spill_ints(R), **i32), surf_cnt=torch.empty(P, **i32),
+                    surf_off=torch.empty(P, **i32))
+        sb = lib.envgs_raster_scan_temp_bytes(P)
+        keep["scan_temp"] = torch.empty(max(sb, 1), dtype=torch.uint8, device=dev)
+        lists = _lib.TraceLists(keep["hit_lists"].data_ptr(), keep["hit_cnt"].data_ptr(), keep["n_used"].data_ptr(), cap,
+                                keep["spill"].data_ptr(), keep["surf_cnt"].data_ptr(), keep["surf_off"].data_ptr(),
+                                keep["scan_temp"].data_ptr(), sb, None, 0)
     p = _lib.ptr
     _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
                                        p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),
-                                       p(norm), p(dist), p(aux), p(mid), p(wet), p(final_T), p(hit_lists), p(hit_cnt), p(n_used), cap,
-                                       p(spill), _stream(dev)), "envgs_trace_forward")
+                                       p(norm), p(dist), p(aux), p(mid), p(wet), p(final_T), lists, _stream(dev)), "envgs_trace_forward")
     LAST_STATS.update(P=P, R=R, counters=counters)
     saved = dict(cfg=cfg, nodes=nodes, ro=ro, rd=rd, means3D=means3D, scales=scales, rotations=rotations, opacities=opacities,
                  shs=shs, colors_precomp=colors_precomp, others=others_precomp, bg=bg, srec=srec, counters=counters,
-                 rgb=rgb, dpt=dpt, acc=acc, norm=norm, aux=aux, final_T=final_T, lead=lead,
-                 hit_lists=hit_lists, hit_cnt=hit_cnt, n_used=n_used, cap=cap)
+                 rgb=rgb, dpt=dpt, acc=acc, norm=norm, aux=aux, final_T=final_T, lead=lead, lists=lists, keep=keep, cap=cap)
     outs = (rgb.reshape(lead + (3,)), dpt.reshape(lead + (1,)), acc.reshape(lead + (1,)), norm.reshape(lead + (3,)),
             dist.reshape(lead + (1,)), aux.reshape(lead + (2,)), mid.reshape(lead + (16 * ND,)), wet)
     return outs, saved
@@ -156,12 +163,21 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
     dro = torch.empty(R, 3, **f32); drd = torch.empty(R, 3, **f32)
     p = _lib.ptr
     s = saved
+    lists = s["lists"]
+    records = None
+    if lists is not None and USE_RECORDS["on"]:
+        # atomic-free backward: one 96 B record per composited hit, grouped by surfel.  The count is known on the device
+        # (inclusive scan of the per-surfel hit counts, done at the end of the forward); reading it is the one host sync here.
+        n_rec = int(s["keep"]["surf_off"][-1].item()) & 0xFFFFFFFF if P > 0 else 0
+        if n_rec > 0:
+            records = torch.empty(n_rec, 24, **f32)
+            lists.records = records.data_ptr()
+            lists.num_records = n_rec
     _lib.check(lib.envgs_trace_backward(cfg, p(s["nodes"]), p(s["ro"]), p(s["rd"]), p(s["means3D"]), p(s["scales"]), p(s["rotations"]),
                                         p(s["opacities"]), p(shs), p(s["colors_precomp"]), p(others), p(s["bg"]), p(s["srec"]),
                                         p(s["counters"]), p(s["rgb"]), p(s["dpt"]), p(s["acc"]), p(s["norm"]), p(s["aux"]), p(s["final_T"]),
                                         p(g_rgb), p(g_dpt), p(g_acc), p(g_norm), p(g_aux), p(geo_rec), p(dmeans), p(dgrads3D), p(dscales),
-                                        p(drots), p(dopac), p(dshs), p(dcolors), p(dothers), p(dro), p(drd), p(s["hit_lists"]), p(s["hit_cnt"]),
-                                        p(s["n_used"]), s["cap"], _stream(dev)),
+                                        p(drots), p(dopac), p(dshs), p(dcolors), p(dothers), p(dro), p(drd), lists, _stream(dev)),
                "envgs_trace_backward")
     lead = s["lead"]
     return dict(ray_o=dro.reshape(lead + (3,)), ray_d=drd.reshape(lead + (3,)), means3D=dmeans, grads3D=dgrads3D, shs=dshs,

@@ -59,6 +59,25 @@ typedef struct envgs_trace_cfg {
     float specular_threshold;
 } envgs_trace_cfg;
 
+/*
+ * Scratch of the list path (bounce-free tracing; all DEVICE pointers, caller-allocated).  HBM is used deliberately here
+ * (288 GB per MI355X): per-ray hit lists make the backward traversal-free, per-hit gradient records grouped by surfel make
+ * it atomic-free (the L2 atomic units retire ~0.15 T dword-atomics/s, which is what bounded a scatter-add backward).
+ */
+typedef struct envgs_trace_lists {
+    uint32_t *hit_lists;     /* (R, cap, 2): after the forward, word 0 = the hit's slot among its surfel's hits, word 1 = surfel id */
+    int32_t *hit_cnt;        /* (R) hits found; > cap => that ray took the K-buffer path */
+    int32_t *n_used;         /* (R) hits composited before termination */
+    int32_t cap;             /* list capacity per ray, <= 1024; 0 disables the list path */
+    int32_t *stack_spill;    /* envgs_trace_stack_spill_ints(R) int32 */
+    uint32_t *surf_cnt;      /* (P) composited hits per surfel (list path only) */
+    uint32_t *surf_off;      /* (P) inclusive prefix sum of surf_cnt; surf_off[P-1] = number of gradient records */
+    void *scan_temp;         /* envgs_raster_scan_temp_bytes(P) bytes */
+    size_t scan_temp_bytes;
+    float *records;          /* backward only: (num_records, 24) per-hit gradient records (96 B), grouped by surfel */
+    uint64_t num_records;    /* backward only: capacity of `records` in records (>= surf_off[P-1]) */
+} envgs_trace_lists;
+
 /* Scratch bytes for the Morton sort + build of P surfels. */
 ENVGS_API size_t envgs_bvh_temp_bytes(int32_t P);
 
@@ -76,12 +95,10 @@ ENVGS_API int envgs_bvh_build(int32_t P, const float *vertices, float *nodes, vo
  * forward, words [2..7] hold three uint64 totals: composited hits, BVH node visits, traversal rounds (diagnostics that
  * the roofline accounting of bench.py needs: BASELINE.md section 4 "hits / node_visits are data dependent").
  * final_T (R): stage-0 transmittance, kept for the backward.
- * List path (cap > 0, max_trace_depth == 0): hit_lists (R, cap, 2) uint32 = (t bits, surfel id) per hit, hit_cnt (R) hits
- * found, n_used (R) hits composited.  Each ray's hits are collected in ONE unordered traversal, sorted by (t, id) in LDS and
- * walked front to back; the backward walks the same lists and never touches the BVH.  Rays with more than `cap` (<= 1024)
- * hits, and all rays when cap == 0 or bounces are requested, use the K-nearest-buffer traversal instead.  After the call
- * counters[1] holds the largest hit_cnt (so the caller can size `cap` for the next call).
- * stack_spill: envgs_trace_stack_spill_ints() int32 of scratch (deep-stack overflow space of the collection pass).
+ * List path (lists != NULL, lists->cap > 0, max_trace_depth == 0): each ray's hits are collected in ONE unordered traversal,
+ * sorted by (t, id) in LDS and walked front to back; the backward walks the same lists and never touches the BVH.  Rays with
+ * more than `cap` hits, and all rays when lists == NULL or bounces are requested, use the K-nearest-buffer traversal instead.
+ * After the call counters[1] holds the largest hit_cnt (so the caller can size `cap` for the next call).
  */
 ENVGS_API size_t envgs_trace_stack_spill_ints(int32_t num_rays);
 ENVGS_API int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes,
@@ -90,9 +107,7 @@ ENVGS_API int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes
                                   const float *shs, const float *colors_precomp, const float *others_precomp, const float *bg,
                                   float *srec, uint32_t *counters,
                                   float *rgb, float *dpt, float *acc, float *norm, float *dist, float *aux, float *mid,
-                                  float *wet, float *final_T,
-                                  uint32_t *hit_lists, int32_t *hit_cnt, int32_t *n_used, int32_t cap,
-                                  int32_t *stack_spill, void *stream);
+                                  float *wet, float *final_T, const envgs_trace_lists *lists, void *stream);
 
 /*
  * SurfelTracer backward: gradients of stage 0 w.r.t. the surfel parameters AND the rays (reflected rays are
@@ -112,8 +127,7 @@ ENVGS_API int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *node
                                    float *geo_rec,
                                    float *dmeans3D, float *dgrads3D, float *dscales, float *drots, float *dopacities,
                                    float *dshs, float *dcolors, float *dothers, float *dray_o, float *dray_d,
-                                   const uint32_t *hit_lists, const int32_t *hit_cnt, const int32_t *n_used, int32_t cap,
-                                   void *stream);
+                                   const envgs_trace_lists *lists, void *stream);
 
 #ifdef __cplusplus
 }

@@ -125,8 +125,8 @@ def test_trace_edge_cases():
     assert rgb2.shape == (1, 64, 3) and torch.isfinite(rgb2).all()
 
 
-@pytest.mark.parametrize("force_cap", [12, 20, 0])
-def test_trace_list_path_overflow_handoff(force_cap):
+@pytest.mark.parametrize("force_cap,records", [(12, True), (20, False), (0, True), (512, False)])
+def test_trace_list_path_overflow_handoff(force_cap, records):
     """Per-ray hit lists with a tiny capacity: rays that overflow must be handed to the K-buffer kernels and give the same
     result as the oracle (forward and backward); force_cap=0 disables the list path entirely."""
     from envgs_amd import tracing
@@ -140,18 +140,20 @@ def test_trace_list_path_overflow_handoff(force_cap):
           torch.randn(R, 3, generator=gen), torch.randn(R, 2, generator=gen)]
     old = dict(tracing.HIT_CAP)
     orig_fwd = tracing.trace_forward
+    old_rec = tracing.USE_RECORDS["on"]
     try:
+        tracing.USE_RECORDS["on"] = records
         if force_cap: tracing.HIT_CAP["force"] = force_cap
         else: tracing.trace_forward = lambda *a, **k: orig_fwd(*a, **{**k, "use_lists": False})
         outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, 3, True, False, grads=gr)
         cnt = tracing.last_trace_counts()
     finally:
-        tracing.HIT_CAP.clear(); tracing.HIT_CAP.update(old); tracing.trace_forward = orig_fwd
+        tracing.HIT_CAP.clear(); tracing.HIT_CAP.update(old); tracing.trace_forward = orig_fwd; tracing.USE_RECORDS["on"] = old_rec
     rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
     ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(),
                             g["opacities"].numpy(), shs=g["shs"].numpy(), sh_degree=3, others=g["others"].numpy(), bg=bg.numpy(),
                             start_from_first=False)
-    if force_cap:
+    if force_cap and force_cap < 100:
         assert cnt["max_list"] > force_cap                 # the overflow path really ran
         assert (ref["nhits"] <= force_cap).any()           # and so did the list path
     assert_close_frac(rgb, ref["rgb"], 1e-4, max_bad_frac=2e-3, flip_bound=0.05, what="rgb")
