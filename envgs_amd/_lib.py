@@ -45,7 +45,7 @@ SYMBOLS = {
     "envgs_raster_bin_and_render": (c_int, [ctypes.POINTER(RasterCfg), c_uint32] + [_P] * 9 + [_P, c_size_t] + [_P] * 6 + [_P]),
     "envgs_raster_backward": (c_int, [ctypes.POINTER(RasterCfg), c_uint32] + [_P] * 28 + [_P]),
     "envgs_bvh_temp_bytes": (c_size_t, [ctypes.c_int32]),
-    "envgs_bvh_build": (c_int, [ctypes.c_int32, _P, _P, _P, c_size_t, ctypes.c_int32, _P]),
+    "envgs_bvh_build": (c_int, [ctypes.c_int32, _P, _P, _P, _P, c_size_t, ctypes.c_int32, _P]),
     "envgs_trace_stack_spill_ints": (c_size_t, [ctypes.c_int32]),
     "envgs_trace_forward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 22 + [ctypes.POINTER(TraceLists), _P]),
     "envgs_trace_backward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 35 + [ctypes.POINTER(TraceLists), _P]),

@@ -62,7 +62,8 @@ static BvhTemp carve(int P, void *base)
 
 // ---- 1. quad AABBs + per-block bounds -----------------------------------------------------------
 __global__ void __launch_bounds__(256)
-quad_boxes(int P, const float *__restrict__ verts, float *__restrict__ leaf_box, float *__restrict__ partial)
+quad_boxes(int P, const float *__restrict__ verts, const float *__restrict__ opac, float *__restrict__ leaf_box,
+           float *__restrict__ partial)
 {
     __shared__ float s_red[6][4];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -73,6 +74,26 @@ quad_boxes(int P, const float *__restrict__ verts, float *__restrict__ leaf_box,
         for (int k = 0; k < 4; k++)
 #pragma unroll
             for (int c = 0; c < 3; c++) { const float x = v[k * 3 + c]; mn[c] = fminf(mn[c], x); mx[c] = fmaxf(mx[c], x); }
+        if (opac) {
+            // Opacity-aware tightening.  A hit needs alpha = o*exp(-(u^2+v^2)/2) >= 1/255, i.e. u^2+v^2 <= tau = 2 ln(255 o): the
+            // contributing region is the 3-sigma quad INTERSECTED with the disc of radius sqrt(tau) (<= 3.33).  The disc's AABB has
+            // half extent sqrt(tau) * sqrt(a_c^2 + b_c^2) per axis; the quad corners give centre mu, 6a = v2 - v0, 6b = v0 - v1.
+            const float o = opac[i];
+            const float tau = 2.0f * __logf(255.0f * o);
+            if (!(tau > 0.0f)) {                 // can never contribute: park the box where no ray goes (and keep it out of the bounds)
+#pragma unroll
+                for (int c = 0; c < 3; c++) { mn[c] = 1.0e30f; mx[c] = 1.0e30f; }
+            } else {
+                const float rr = sqrtf(tau) * (1.0f + 1e-4f);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float mu = 0.5f * (v[c] + v[9 + c]);
+                    const float a = (v[6 + c] - v[c]) * (1.0f / 6.0f), b = (v[c] - v[3 + c]) * (1.0f / 6.0f);
+                    const float he = rr * sqrtf(a * a + b * b);
+                    mn[c] = fmaxf(mn[c], mu - he); mx[c] = fminf(mx[c], mu + he);
+                }
+            }
+        }
         // conservative pad: the hit test is analytic (|u|,|v| <= 3), the box comes from rounded vertices
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -82,7 +103,8 @@ quad_boxes(int P, const float *__restrict__ verts, float *__restrict__ leaf_box,
             leaf_box[(size_t)i * 6 + 3 + c] = mx[c];
         }
     }
-    // block reduction of the bounds (wave shuffles, then 4 partials through LDS)
+    // block reduction of the bounds (wave shuffles, then 4 partials through LDS); parked boxes do not count
+    if (mn[0] > 0.9e30f) { for (int c = 0; c < 3; c++) { mn[c] = 3.0e38f; mx[c] = -3.0e38f; } }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -248,7 +270,8 @@ extern "C" {
 
 size_t envgs_bvh_temp_bytes(int32_t P) { return carve(P, nullptr).total; }
 
-int envgs_bvh_build(int32_t P, const float *vertices, float *nodes, void *temp, size_t temp_bytes, int32_t debug, void *stream_)
+int envgs_bvh_build(int32_t P, const float *vertices, const float *opacities, float *nodes, void *temp, size_t temp_bytes, int32_t debug,
+                    void *stream_)
 {
     if (P < 0) return ENVGS_ERR_BAD_ARG;
     if (P == 0) return 0;
@@ -260,7 +283,7 @@ int envgs_bvh_build(int32_t P, const float *vertices, float *nodes, void *temp, 
     const envgs_raster_cfg *cfg = &dbg;
     ProfScope prof_(K_BVH_BUILD, stream);
     const int nblocks = (P + 255) / 256;
-    hipLaunchKernelGGL(quad_boxes, dim3(nblocks), dim3(256), 0, stream, P, vertices, t.leaf_box, t.partial);
+    hipLaunchKernelGGL(quad_boxes, dim3(nblocks), dim3(256), 0, stream, P, vertices, opacities, t.leaf_box, t.partial);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     if (P == 1) {
         hipLaunchKernelGGL(single_leaf_node, dim3(1), dim3(64), 0, stream, t.leaf_box, nodes);

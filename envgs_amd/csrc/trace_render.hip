@@ -796,8 +796,8 @@ composite_lists_fwd(const TraceArgs A)
             const float sg = h.denom < 0.0f ? w : -w;
             n0 += sg * s3.x; n1 += sg * s3.y; n2 += sg * s3.z;
             if (A.has_others) { x0 += w * A.others[2 * sid]; x1 += w * A.others[2 * sid + 1]; }
-            atomic_add_f32(A.wet + sid, w);
-            list[k].x = atomicAdd(A.surf_cnt + sid, 1u);     // this hit's slot among the surfel's hits (t is recomputed when needed)
+            if (!(A.exp & 16)) atomic_add_f32(A.wet + sid, w);
+            if (!(A.exp & 32)) list[k].x = atomicAdd(A.surf_cnt + sid, 1u);     // this hit's slot among the surfel's hits (t is recomputed when needed)
             T = test_T;
             used++;
         }
@@ -1047,6 +1047,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     A.bg = bg; A.ray_o = ray_o; A.ray_d = ray_d; A.counter = counters; A.stats = (unsigned long long *)(counters + 2);
     A.rgb = rgb; A.dpt = dpt; A.acc = acc; A.norm = norm; A.dist = dist; A.aux = aux; A.mid = mid; A.wet = wet; A.final_T = final_T;
     A.mod = cfg->scale_modifier;
+    { const char *ev = getenv("ENVGS_TRACE_EXP"); A.exp = ev ? atoi(ev) : 0; }
     int rh, rw; ray_layout(cfg, &rh, &rw);
     const bool lists = L && L->cap > 0 && cfg->max_trace_depth == 0 && cfg->P > 0 && L->hit_lists && L->hit_cnt && L->n_used &&
                        L->stack_spill && L->surf_cnt && L->surf_off && L->scan_temp;

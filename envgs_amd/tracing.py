@@ -58,8 +58,8 @@ def _stream(dev):
     return _lib.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-def build_bvh(vertices, debug=False):
-    """LBVH over the (4P,3) quad vertices.  Returns the (max(P-1,1),16) node tensor."""
+def build_bvh(vertices, opacities=None, debug=False):
+    """LBVH over the (4P,3) quad vertices (leaf boxes tightened by `opacities` when given).  Returns ((max(P-1,1),16) nodes, P)."""
     lib = _lib.load()
     v = _f32c(vertices.detach())
     if v.device.type != "cuda":
@@ -71,7 +71,10 @@ def build_bvh(vertices, debug=False):
     nodes = torch.empty(max(P - 1, 1), 16, dtype=torch.float32, device=dev)
     tb = lib.envgs_bvh_temp_bytes(P)
     temp = torch.empty(max(tb, 1), dtype=torch.uint8, device=dev)
-    _lib.check(lib.envgs_bvh_build(P, _lib.ptr(v), _lib.ptr(nodes), _lib.ptr(temp), tb, 1 if debug else 0, _stream(dev)),
+    op = None if opacities is None else _f32c(opacities.detach()).reshape(-1)
+    if op is not None and op.numel() != P:
+        raise RuntimeError("opacities (%d) do not match the %d surfels of the vertex buffer" % (op.numel(), P))
+    _lib.check(lib.envgs_bvh_build(P, _lib.ptr(v), _lib.ptr(op), _lib.ptr(nodes), _lib.ptr(temp), tb, 1 if debug else 0, _stream(dev)),
                "envgs_bvh_build")
     return nodes, P
 
@@ -213,13 +216,22 @@ class SurfelTracer(nn.Module):
         _lib.load()                       # fail at construction (optix_utils.py:24 creates the OptiX context here)
         self.nodes = None
         self.num_surfels = 0
+        self._pending = None
 
     def build_acceleration_structure(self, vertices, faces=None, rebuild=True):
-        """optix_utils.py:78.  `faces` must be the get_disks layout (2 triangles per 4 consecutive vertices)."""
+        """optix_utils.py:78.  `faces` must be the get_disks layout (2 triangles per 4 consecutive vertices).
+        The LBVH itself is built lazily by the next traced call, which knows the opacities and can bound every surfel by
+        the region where it can still contribute (tighter boxes, identical results)."""
         if faces is not None and faces.shape[0] * 2 != vertices.shape[0]:
             raise RuntimeError("faces (%d,3) do not match vertices (%d,3): expected 2 triangles per 4 vertices" % (faces.shape[0], vertices.shape[0]))
-        if rebuild or self.nodes is None:
-            self.nodes, self.num_surfels = build_bvh(vertices)
+        if vertices.dim() != 2 or vertices.shape[1] != 3 or vertices.shape[0] % 4 != 0:
+            raise RuntimeError("vertices must be (4P,3) in the get_disks layout, got %s" % (tuple(vertices.shape),))
+        if vertices.device.type != "cuda":
+            raise RuntimeError("envgs_amd tracer needs tensors on the GPU (got %s); there is no CPU path" % vertices.device)
+        if rebuild or (self.nodes is None and self._pending is None):
+            self._pending = vertices.detach()
+            self.nodes = None
+            self.num_surfels = vertices.shape[0] // 4
 
     def forward(self, ray_o, ray_d, v=None, *, means3D, grads3D=None, shs=None, colors_precomp=None, others_precomp=None,
                 opacities=None, scales=None, rotations=None, cov3D_precomp=None, tracer_settings=None, start_from_first=True):
@@ -230,13 +242,18 @@ class SurfelTracer(nn.Module):
                             'a precomputed screen-space transMat (cov3D_precomp) cannot be traced.')
         if scales is None or rotations is None:
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-        if self.nodes is None:
+        if self.nodes is None and self._pending is None:
             if v is None:
                 raise RuntimeError("SurfelTracer: no acceleration structure; call build_acceleration_structure first")
             self.build_acceleration_structure(v)
         if means3D.shape[0] != self.num_surfels:
             raise RuntimeError("SurfelTracer: acceleration structure holds %d surfels, call has %d (rebuild after densification)"
                                % (self.num_surfels, means3D.shape[0]))
+        if self.nodes is None:
+            if self._pending.shape[0] != 4 * means3D.shape[0]:
+                raise RuntimeError("SurfelTracer: acceleration structure was requested for %d surfels, call has %d" % (self._pending.shape[0] // 4, means3D.shape[0]))
+            self.nodes, self.num_surfels = build_bvh(self._pending, opacities)
+            self._pending = None
         if grads3D is None:
             grads3D = torch.zeros_like(means3D)
         e = torch.Tensor([])

@@ -61,7 +61,7 @@ def test_bad_arguments_are_rejected_before_any_gpu_work(lib):
         assert rc == -1
     tcfg = _lib.TraceCfg(10, 10, 9, 0, 0, 1, 0, 3, 0, 0, 0, 1.0, 0.0)      # sh_degree 9
     assert lib.envgs_trace_forward(tcfg, *([None] * 22), None, None) == -1
-    assert lib.envgs_bvh_build(-1, None, None, None, 0, 0, None) == -1
+    assert lib.envgs_bvh_build(-1, None, None, None, None, 0, 0, None) == -1
     assert lib.envgs_prof_kernel_name(6) == b"composite_bwd" and lib.envgs_prof_kernel_name(999) == b""
 
 
