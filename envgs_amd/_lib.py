@@ -22,7 +22,7 @@ class RasterCfg(ctypes.Structure):
 class TraceLists(ctypes.Structure):
     """struct envgs_trace_lists (include/envgs_trace.h)."""
     _fields_ = [("hit_lists", ctypes.c_void_p), ("hit_cnt", ctypes.c_void_p), ("n_used", ctypes.c_void_p), ("cap", ctypes.c_int32),
-                ("stack_spill", ctypes.c_void_p), ("surf_cnt", ctypes.c_void_p), ("surf_off", ctypes.c_void_p),
+                ("stack_spill", ctypes.c_void_p), ("surf_acc", ctypes.c_void_p), ("surf_cnt", ctypes.c_void_p), ("surf_off", ctypes.c_void_p),
                 ("scan_temp", ctypes.c_void_p), ("scan_temp_bytes", ctypes.c_size_t), ("records", ctypes.c_void_p),
                 ("num_records", ctypes.c_uint64)]
 

@@ -128,12 +128,13 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     if cap:
         i32 = dict(dtype=torch.int32, device=dev)
         keep = dict(hit_lists=torch.empty(R, cap, 2, **i32), hit_cnt=torch.empty(R, **i32), n_used=torch.empty(R, **i32),
-                    spill=torch.empty(lib.envgs_trace_stack_spill_ints(R), **i32), surf_cnt=torch.empty(P, **i32),
+                    spill=torch.empty(lib.envgs_trace_stack_spill_ints(R), **i32), surf_acc=torch.empty(P, dtype=torch.int64, device=dev),
+                    surf_cnt=torch.empty(P, **i32),
                     surf_off=torch.empty(P, **i32))
         sb = lib.envgs_raster_scan_temp_bytes(P)
         keep["scan_temp"] = torch.empty(max(sb, 1), dtype=torch.uint8, device=dev)
         lists = _lib.TraceLists(keep["hit_lists"].data_ptr(), keep["hit_cnt"].data_ptr(), keep["n_used"].data_ptr(), cap,
-                                keep["spill"].data_ptr(), keep["surf_cnt"].data_ptr(), keep["surf_off"].data_ptr(),
+                                keep["spill"].data_ptr(), keep["surf_acc"].data_ptr(), keep["surf_cnt"].data_ptr(), keep["surf_off"].data_ptr(),
                                 keep["scan_temp"].data_ptr(), sb, None, 0)
     p = _lib.ptr
     _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
