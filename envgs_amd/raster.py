@@ -51,9 +51,27 @@ def _stream(dev):
     return _lib.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+import weakref
+
+_DEG_CACHE = weakref.WeakKeyDictionary()
+
+
+def sh_degree_of(deg):
+    """settings.sh_degree is a 1-element tensor in the reference (a registered buffer on the GPU, gaussian2d_utils.py:294) and
+    reading it is a host sync.  The value is cached per tensor OBJECT and in-place version (the reference passes the same buffer
+    every iteration and bumps it in place once every 1000 iterations); a fresh tensor is always read."""
+    if not torch.is_tensor(deg):
+        return int(deg)
+    hit = _DEG_CACHE.get(deg)
+    if hit is not None and hit[0] == deg._version:
+        return hit[1]
+    v = int(deg.item())
+    _DEG_CACHE[deg] = (deg._version, v)
+    return v
+
+
 def _cfg(settings, P, C, sh_coeffs, bg_len):
-    deg = settings.sh_degree
-    deg = int(deg.item()) if torch.is_tensor(deg) else int(deg)
+    deg = sh_degree_of(settings.sh_degree)
     return _lib.RasterCfg(P, deg, sh_coeffs, C, int(settings.image_width), int(settings.image_height), bg_len,
                           1 if settings.debug else 0, float(settings.scale_modifier), float(settings.tanfovx),
                           float(settings.tanfovy))

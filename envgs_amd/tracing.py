@@ -80,8 +80,8 @@ def build_bvh(vertices, opacities=None, debug=False):
 
 
 def _cfg(settings, P, R, shs, others, start_from_first, ray_shape):
-    deg = settings.sh_degree
-    deg = int(deg.item()) if torch.is_tensor(deg) else int(deg)
+    from .raster import sh_degree_of
+    deg = sh_degree_of(settings.sh_degree)
     rh, rw = (int(ray_shape[0]), int(ray_shape[1])) if len(ray_shape) == 2 else (0, 0)
     bg_len = min(int(settings.bg.numel()), 3)
     return _lib.TraceCfg(P, R, deg, 0 if shs is None else int(shs.shape[1]), int(settings.max_trace_depth),
@@ -93,12 +93,24 @@ HIT_CAP = {"cap": 512}
 USE_RECORDS = {"on": True}   # atomic-free backward (per-hit records grouped by surfel); False = cooperative atomic flush      # per-ray hit-list capacity of the list path; adapted from the largest list of the previous call
 
 
-def _next_cap():
+_ASYNC = {}      # pinned host mirrors of two device counters + the events that say when they are valid
+
+
+def _mirror(name, dev):
+    m = _ASYNC.get((name, dev))
+    if m is None:
+        m = _ASYNC[(name, dev)] = dict(host=torch.zeros(1, dtype=torch.int32).pin_memory(), event=torch.cuda.Event(), valid=False)
+    return m
+
+
+def _next_cap(dev):
+    """Capacity of the per-ray hit lists: 20 % above the longest list of the PREVIOUS call, read through a pinned mirror that was
+    copied asynchronously at the end of that call -- no host sync on the hot path."""
     if HIT_CAP.get("force"):                       # tests: pin the capacity (e.g. tiny, to exercise the overflow hand-off)
         return int(HIT_CAP["force"])
-    c = LAST_STATS.get("counters")
-    if c is not None:
-        mx = int(c[1].item())                      # previous call has long finished; this read is the only host sync
+    m = _mirror("max_list", dev)
+    if m["valid"] and m["event"].query():
+        mx = int(m["host"][0])
         want = ((int(mx * 1.2) + 8 + 63) // 64) * 64          # 20 % headroom, multiple of 64 entries (512 B)
         HIT_CAP["cap"] = max(64, min(want, 1024))
     return HIT_CAP["cap"]
@@ -122,7 +134,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     rgb = torch.empty(R, 3, **f32); dpt = torch.empty(R, 1, **f32); acc = torch.empty(R, 1, **f32)
     norm = torch.empty(R, 3, **f32); dist = torch.empty(R, 1, **f32); aux = torch.empty(R, 2, **f32)
     mid = torch.empty(R, 16 * ND, **f32); wet = torch.empty(P, 1, **f32); final_T = torch.empty(R, **f32)
-    cap = _next_cap() if (use_lists and ND == 1 and P > 0 and R > 0) else 0
+    cap = _next_cap(dev) if (use_lists and ND == 1 and P > 0 and R > 0) else 0
     lists = None
     keep = {}
     if cap:
@@ -141,6 +153,13 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
                                        p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),
                                        p(norm), p(dist), p(aux), p(mid), p(wet), p(final_T), lists, _stream(dev)), "envgs_trace_forward")
     LAST_STATS.update(P=P, R=R, counters=counters)
+    if cap:
+        # asynchronous read-backs for later: the longest list (sizes the next call's cap) and the number of gradient records
+        m = _mirror("max_list", dev)
+        m["host"].copy_(counters[1:2], non_blocking=True); m["event"].record(torch.cuda.current_stream(dev)); m["valid"] = True
+        keep["n_rec_host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        keep["n_rec_host"].copy_(keep["surf_off"][P - 1:P], non_blocking=True)
+        keep["n_rec_event"] = torch.cuda.Event(); keep["n_rec_event"].record(torch.cuda.current_stream(dev))
     saved = dict(cfg=cfg, nodes=nodes, ro=ro, rd=rd, means3D=means3D, scales=scales, rotations=rotations, opacities=opacities,
                  shs=shs, colors_precomp=colors_precomp, others=others_precomp, bg=bg, srec=srec, counters=counters,
                  rgb=rgb, dpt=dpt, acc=acc, norm=norm, aux=aux, final_T=final_T, lead=lead, lists=lists, keep=keep, cap=cap)
@@ -172,7 +191,8 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
     if lists is not None and USE_RECORDS["on"]:
         # atomic-free backward: one 96 B record per composited hit, grouped by surfel.  The count is known on the device
         # (inclusive scan of the per-surfel hit counts, done at the end of the forward); reading it is the one host sync here.
-        n_rec = int(s["keep"]["surf_off"][-1].item()) & 0xFFFFFFFF if P > 0 else 0
+        s["keep"]["n_rec_event"].synchronize()         # copied at the end of the forward; long since complete
+        n_rec = int(s["keep"]["n_rec_host"][0]) & 0xFFFFFFFF if P > 0 else 0
         if n_rec > 0:
             records = torch.empty(n_rec, 24, **f32)
             lists.records = records.data_ptr()
