@@ -80,9 +80,9 @@ quad_boxes(int P, const float *__restrict__ verts, const float *__restrict__ opa
             // half extent sqrt(tau) * sqrt(a_c^2 + b_c^2) per axis; the quad corners give centre mu, 6a = v2 - v0, 6b = v0 - v1.
             const float o = opac[i];
             const float tau = 2.0f * __logf(255.0f * o);
-            if (!(tau > 0.0f)) {                 // can never contribute: park the box where no ray goes (and keep it out of the bounds)
+            if (!(tau > 0.0f)) {                 // can never contribute: shrink the box to the surfel's centre (keeps the tree tidy)
 #pragma unroll
-                for (int c = 0; c < 3; c++) { mn[c] = 1.0e30f; mx[c] = 1.0e30f; }
+                for (int c = 0; c < 3; c++) { const float mu = 0.5f * (v[c] + v[9 + c]); mn[c] = mu; mx[c] = mu; }
             } else {
                 const float rr = sqrtf(tau) * (1.0f + 1e-4f);
 #pragma unroll
@@ -103,8 +103,7 @@ quad_boxes(int P, const float *__restrict__ verts, const float *__restrict__ opa
             leaf_box[(size_t)i * 6 + 3 + c] = mx[c];
         }
     }
-    // block reduction of the bounds (wave shuffles, then 4 partials through LDS); parked boxes do not count
-    if (mn[0] > 0.9e30f) { for (int c = 0; c < 3; c++) { mn[c] = 3.0e38f; mx[c] = -3.0e38f; } }
+    // block reduction of the bounds (wave shuffles, then 4 partials through LDS)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int c = 0; c < 3; c++) {

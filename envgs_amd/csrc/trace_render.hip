@@ -643,15 +643,30 @@ trace_bwd(const TraceArgs A, const int ray_h, const int ray_w)
 // by the forward (composite_lists_fwd) and again by the backward (composite_lists_bwd), which never touches the BVH.
 // Rays whose list overflows `cap` fall back to the K-buffer kernels above (only_overflow mode).
 
+// Conservative termination bound for the unordered collection.  The ray's accepted hits are binned by distance into 16
+// half-octave bins (16 registers of optical depth -ln(1-alpha)); as soon as the bins up to edge e hold more optical depth than
+// the compositing can survive (T < 1e-4), every hit beyond e is provably after the terminating hit: it is dropped and BVH nodes
+// that start beyond e are pruned.  Exact (never drops a composited hit) and it removes most of the 3x over-collection of a fog.
+constexpr int NBIN = 16;
+constexpr float KILL_OD = 9.2104f * 1.03f + 0.05f;       // -ln(1e-4) with margin for fp32 product vs sum-of-logs
+
 __global__ void __launch_bounds__(64)
 collect_hits(const TraceArgs A)
 {
     // Shallow LDS stack (6 KB per wavefront -> ~26 wavefronts per CU instead of 10); the rare deeper pushes spill to a
-    // per-wavefront slab in HBM.  Traversal order is irrelevant here (hits are sorted afterwards), only completeness.
+    // per-wavefront slab in HBM.  Hits are sorted afterwards, so the visiting order only matters for how early the bound tightens.
     __shared__ int stk[LDS_STACK][64];
     int *spill = A.stack_spill + (size_t)blockIdx.x * (STACK * 64);
     const int lane = threadIdx.x;
     unsigned visits = 0, rays_done = 0, found_tot = 0;
+    // scene size from the root's two child boxes (uniform loads)
+    float diag = 1.0f;
+    if (A.P > 0) {
+        const float4 n0 = A.nodes[0], n1 = A.nodes[1], n2 = A.nodes[2];
+        const float ex = fmaxf(n0.w, n2.y) - fminf(n0.x, n1.z), ey = fmaxf(n1.x, n2.z) - fminf(n0.y, n1.w), ez = fmaxf(n1.y, n2.w) - fminf(n0.z, n2.x);
+        diag = sqrtf(ex * ex + ey * ey + ez * ez);
+        if (!(diag > 0.0f) || !(diag < 1.0e29f)) diag = 1.0f;
+    }
     while (true) {
         int base = 0;
         if (lane == 0) base = (int)atomicAdd(A.counter, 64u);
@@ -664,6 +679,12 @@ collect_hits(const TraceArgs A)
         const float dx = A.ray_d[3 * rr], dy = A.ray_d[3 * rr + 1], dz = A.ray_d[3 * rr + 2];
         const float tmin = A.start_from_first ? NEAR_N : 0.0f;
         const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+        const float t0 = diag / (256.0f * sqrtf(dx * dx + dy * dy + dz * dz));     // first bin edge, in units of |d|
+        const float inv_t0 = 1.0f / t0;
+        float od[NBIN];
+#pragma unroll
+        for (int b = 0; b < NBIN; b++) od[b] = 0.f;
+        float tkill = 3.0e38f;
         uint2 *list = A.hits + (size_t)rr * A.cap;
         int n = 0;
         int sp = 0;
@@ -684,8 +705,8 @@ collect_hits(const TraceArgs A)
             a0 = (n1.z - ox) * ix; a1 = (n2.y - ox) * ix; b0 = (n1.w - oy) * iy; b1 = (n2.z - oy) * iy; c0 = (n2.x - oz) * iz; c1 = (n2.w - oz) * iz;
             const float tnR = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
             const float tfR = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
-            bool hitL = (tnL <= tfL) && (tfL >= tmin);
-            bool hitR = (tnR <= tfR) && (tfR >= tmin);
+            bool hitL = (tnL <= tfL) && (tfL >= tmin) && (tnL <= tkill);
+            bool hitR = (tnR <= tfR) && (tfR >= tmin) && (tnR <= tkill);
 #pragma unroll
             for (int side = 0; side < 2; side++) {
                 const bool hit = side == 0 ? hitL : hitR;
@@ -694,18 +715,31 @@ collect_hits(const TraceArgs A)
                     const int sid = ~ch;
                     const float4 *sr = A.srec + (size_t)sid * 4;
                     const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], sr[3], ox, oy, oz, dx, dy, dz);
-                    if (h.ok && h.t > tmin) {
+                    if (h.ok && h.t > tmin && h.t <= tkill) {
                         if (n < A.cap) list[n] = make_uint2(__float_as_uint(h.t), (unsigned)sid);
                         n++;
+                        // bin (biased upwards: a hit may only ever be filed FARTHER than it is, which keeps the bound conservative)
+                        const float x = h.t * inv_t0;
+                        int b = x <= 1.0f ? 0 : (int)ceilf(2.0f * __log2f(x) + 1e-3f);
+                        b = b > NBIN - 1 ? NBIN - 1 : b;
+                        const float dep = -__logf(1.0f - h.alpha);
+#pragma unroll
+                        for (int q = 0; q < NBIN; q++) od[q] += (q == b) ? dep : 0.f;
+                        float cum = 0.f; int kb = NBIN - 1;
+#pragma unroll
+                        for (int q = 0; q < NBIN - 1; q++) { cum += od[q]; kb = (cum >= KILL_OD && kb == NBIN - 1) ? q : kb; }
+                        tkill = kb < NBIN - 1 ? t0 * exp2f(0.5f * (float)kb) : 3.0e38f;
                     }
                 }
             }
             hitL = hitL && lc >= 0;
             hitR = hitR && rc >= 0;
             if (hitL && hitR) {
-                if (sp < LDS_STACK) stk[sp][lane] = rc; else if (sp < LDS_STACK + STACK) spill[(sp - LDS_STACK) * 64 + lane] = rc;
+                const bool leftFirst = tnL <= tnR;
+                const int farc = leftFirst ? rc : lc;
+                if (sp < LDS_STACK) stk[sp][lane] = farc; else if (sp < LDS_STACK + STACK) spill[(sp - LDS_STACK) * 64 + lane] = farc;
                 sp++;
-                cur = lc;
+                cur = leftFirst ? lc : rc;
             }
             else if (hitL) cur = lc;
             else if (hitR) cur = rc;
