@@ -208,13 +208,21 @@ def main():
         roof = None
         if dom:
             A = kernels[dom]["GBps"]
+            traffic = None
+            try:                                   # HBM bytes per launch from the committed PMC passes (profiles/, same workload)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_envgs.json")))["kernels"]
+                if envgs and dom in pm:
+                    traffic = pm[dom]["hbm_bytes"]
+            except Exception:
+                traffic = None
             roof = {"kernel": dom, "bound": "hbm", "achieved": A, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(A / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(A / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "alg_bytes_per_launch": int(kernels[dom]["alg_MB"] * 1e6), "ms_per_launch": kernels[dom]["ms"],
                     "tile_instances_N": int(N_avg),
                     "note": "dominant kernel by HIP-event time; algorithmic bytes per DESIGN.md (raster: SURVEY.md 8d formulas; tracer: "
                             "byte model over the kernel's own hit / node-visit counters).  Gather-heavy and VALU/latency bound rather "
-                            "than streaming: the HBM fraction is reported as mandated, traffic=null until a PMC pass is committed"}
+                            "than streaming: the HBM fraction is reported as mandated; traffic = (2*FETCH_SIZE + WRITE_SIZE) per launch from "
+                            "profiles/r01_pmc_envgs.json (separate --pmc passes), null if that profile has no row for this kernel"}
             rb = kernels.get("composite_bwd")
             if rb and rb["GBps"]:
                 roof["raster_composite_bwd"] = {"achieved": rb["GBps"], "frac": round(rb["GBps"] / HBM_PEAK_GBS, 5), "ms_per_launch": rb["ms"]}
