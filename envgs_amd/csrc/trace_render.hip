@@ -21,6 +21,7 @@ namespace envgs {
 
 constexpr int KBUF = 16;            // hits buffered per round
 constexpr int STACK = 64;           // LBVH depth bound: 62-bit keys
+constexpr int NCOPY = 8;            // per-surfel hit counters are replicated NCOPY x (by ray index) to spread same-address atomics
 constexpr int LDS_STACK = 24;       // collect_hits keeps this many levels in LDS, the rest in an HBM slab
 constexpr int MAX_ROUNDS = 256;     // safety bound: 4096 hits per ray
 constexpr float UV_MAX = 3.0f;
@@ -796,98 +797,96 @@ sort_hit_lists(const TraceArgs A)
 __global__ void __launch_bounds__(64)
 composite_lists_fwd(const TraceArgs A)
 {
-    // (weight, surfel) of the last PEND composited hits per lane.  Memory operations retire in order (vmcnt), so an atomic inside the
-    // per-hit chain would add a full memory-side round trip to EVERY hit (measured: 3.3 ms -> 13 ms for this kernel); instead the
-    // hits are parked in LDS and registered PEND at a time, with all PEND returning atomics in flight together.
-    constexpr int PEND = 8;
-    __shared__ uint2 pend[PEND][64];
+    // Memory operations retire in order (vmcnt), so an atomic inside the per-hit chain adds a full memory-side round trip to EVERY hit
+    // (measured: 3.3 ms -> 13 ms for this kernel).  The per-surfel bookkeeping (hit slot + accumulated weight) is therefore done by
+    // register_hits below, a pure atomic stream; here each composited hit only parks its weight in the list entry's first word.
     const int lane = threadIdx.x;
-    const float wscale = __builtin_ldexpf(1.0f, A.wfrac);
     unsigned st_hits = 0;
     for (int base = blockIdx.x * 64; base < A.R; base += gridDim.x * 64) {
         const int r = base + lane;
-        const bool valid = r < A.R && A.hit_cnt[r < A.R ? r : 0] <= A.cap;      // overflow: the K-buffer kernel owns this ray
-        const int rr = r < A.R ? r : 0;
-        const int n = valid ? A.hit_cnt[rr] : 0;
-        const float ox = A.ray_o[3 * rr], oy = A.ray_o[3 * rr + 1], oz = A.ray_o[3 * rr + 2];
-        const float dx = A.ray_d[3 * rr], dy = A.ray_d[3 * rr + 1], dz = A.ray_d[3 * rr + 2];
+        if (r >= A.R) continue;
+        const int n = A.hit_cnt[r];
+        if (n > A.cap) continue;                            // overflow: the K-buffer kernel owns this ray
+        const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
+        const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
         float basis[16];
         {
             const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
             sh_basis(A.D, dx * il, dy * il, dz * il, basis);
         }
-        uint2 *list = A.hits + (size_t)rr * A.cap;
+        uint2 *list = A.hits + (size_t)r * A.cap;
         float T = 1.0f, M1 = 0.f, M2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dpt = 0.f, acc = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, dist = 0.f, x0 = 0.f, x1 = 0.f;
         int used = 0;
-        bool done = n == 0;
-        int nmax = n;
-        for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
-        for (int kb = 0; kb < nmax; kb += PEND) {
-            if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-#pragma unroll 1
-            for (int j = 0; j < PEND; j++) {
-                const int k = kb + j;
-                uint2 rec = make_uint2(0u, 0xFFFFFFFFu);
-                if (!done && k < n) {
-                    const int sid = (int)list[k].y;
-                    const float4 *sr = A.srec + (size_t)sid * 4;
-                    const float4 s3 = sr[3];
-                    const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], s3, ox, oy, oz, dx, dy, dz);
-                    const float test_T = T * (1.0f - h.alpha);
-                    if (test_T < T_EPS) done = true;
-                    else {
-                        const float w = h.alpha * T;
-                        float col[3]; bool cl[3];
-                        surfel_color(A, sid, basis, col, cl);
-                        const float tt = h.t > NEAR_N ? h.t : NEAR_N;
-                        const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / tt);
-                        dist += (m * m * (1.0f - T) + M2 - 2.0f * m * M1) * w;
-                        M1 += m * w; M2 += m * m * w;
-                        c0 += w * col[0]; c1 += w * col[1]; c2 += w * col[2];
-                        dpt += w * h.t; acc += w;
-                        const float sg = h.denom < 0.0f ? w : -w;
-                        n0 += sg * s3.x; n1 += sg * s3.y; n2 += sg * s3.z;
-                        if (A.has_others) { x0 += w * A.others[2 * sid]; x1 += w * A.others[2 * sid + 1]; }
-                        rec = make_uint2(__float_as_uint(w), (unsigned)sid);
-                        T = test_T;
-                        used++;
-                    }
-                } else if (k >= n) done = true;
-                pend[j][lane] = rec;
-            }
-            // register the parked hits: ONE returning 64-bit atomic per hit does count++ (old count = the hit's slot among the
-            // surfel's hits) and weight += w in 40-bit fixed point (rounded up, so any contribution keeps the surfel "visible")
-            unsigned long long old[PEND];
-#pragma unroll
-            for (int j = 0; j < PEND; j++) {
-                const uint2 rec = pend[j][lane];
-                old[j] = 0;
-                if (rec.y != 0xFFFFFFFFu) {
-                    const unsigned long long wq = (unsigned long long)ceilf(__uint_as_float(rec.x) * wscale);
-                    old[j] = atomicAdd(A.surf_acc + rec.y, (wq << 24) | 1ull);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < PEND; j++)
-                if (pend[j][lane].y != 0xFFFFFFFFu) list[kb + j].x = (unsigned)(old[j] & 0xFFFFFFull);
+        for (int k = 0; k < n; k++) {
+            const int sid = (int)list[k].y;
+            const float4 *sr = A.srec + (size_t)sid * 4;
+            const float4 s3 = sr[3];
+            const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], s3, ox, oy, oz, dx, dy, dz);
+            const float test_T = T * (1.0f - h.alpha);
+            if (test_T < T_EPS) break;
+            const float w = h.alpha * T;
+            float col[3]; bool cl[3];
+            surfel_color(A, sid, basis, col, cl);
+            const float tt = h.t > NEAR_N ? h.t : NEAR_N;
+            const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / tt);
+            dist += (m * m * (1.0f - T) + M2 - 2.0f * m * M1) * w;
+            M1 += m * w; M2 += m * m * w;
+            c0 += w * col[0]; c1 += w * col[1]; c2 += w * col[2];
+            dpt += w * h.t; acc += w;
+            const float sg = h.denom < 0.0f ? w : -w;
+            n0 += sg * s3.x; n1 += sg * s3.y; n2 += sg * s3.z;
+            if (A.has_others) { x0 += w * A.others[2 * sid]; x1 += w * A.others[2 * sid + 1]; }
+            list[k].x = __float_as_uint(w);
+            T = test_T;
+            used++;
         }
         st_hits += (unsigned)used;
-        if (valid) {
-            A.n_used[r] = used;
-            c0 += T * (0 < A.bg_len ? A.bg[0] : 0.f); c1 += T * (1 < A.bg_len ? A.bg[1] : 0.f); c2 += T * (2 < A.bg_len ? A.bg[2] : 0.f);
-            A.rgb[3 * r] = c0; A.rgb[3 * r + 1] = c1; A.rgb[3 * r + 2] = c2;
-            A.dpt[r] = dpt; A.acc[r] = acc; A.dist[r] = dist;
-            A.norm[3 * r] = n0; A.norm[3 * r + 1] = n1; A.norm[3 * r + 2] = n2;
-            A.aux[2 * r] = x0; A.aux[2 * r + 1] = x1;
-            A.final_T[r] = T;
-            float *m = A.mid + (size_t)r * MID;
-            m[0] = ox; m[1] = oy; m[2] = oz; m[3] = dx; m[4] = dy; m[5] = dz; m[6] = dpt; m[7] = acc;
-            m[8] = n0; m[9] = n1; m[10] = n2; m[11] = x0; m[12] = x1; m[13] = c0; m[14] = c1; m[15] = c2;
-        }
+        A.n_used[r] = used;
+        c0 += T * (0 < A.bg_len ? A.bg[0] : 0.f); c1 += T * (1 < A.bg_len ? A.bg[1] : 0.f); c2 += T * (2 < A.bg_len ? A.bg[2] : 0.f);
+        A.rgb[3 * r] = c0; A.rgb[3 * r + 1] = c1; A.rgb[3 * r + 2] = c2;
+        A.dpt[r] = dpt; A.acc[r] = acc; A.dist[r] = dist;
+        A.norm[3 * r] = n0; A.norm[3 * r + 1] = n1; A.norm[3 * r + 2] = n2;
+        A.aux[2 * r] = x0; A.aux[2 * r + 1] = x1;
+        A.final_T[r] = T;
+        float *m = A.mid + (size_t)r * MID;
+        m[0] = ox; m[1] = oy; m[2] = oz; m[3] = dx; m[4] = dy; m[5] = dz; m[6] = dpt; m[7] = acc;
+        m[8] = n0; m[9] = n1; m[10] = n2; m[11] = x0; m[12] = x1; m[13] = c0; m[14] = c1; m[15] = c2;
     }
     if (A.stats) {
         const float fh = wave_sum((float)st_hits);
         if (lane == 0) atomicAdd(A.stats + 0, (unsigned long long)fh);
+    }
+}
+
+// Register every composited hit with its surfel: ONE returning 64-bit atomic does count++ (the old count is the hit's slot among the
+// surfel's hits, which is where the backward will put its gradient record) and weight += w in 40-bit fixed point (rounded up, so any
+// contribution keeps the surfel "visible").  Nothing here depends on anything else, so 8 atomics per lane are kept in flight.
+__global__ void __launch_bounds__(256)
+register_hits(const TraceArgs A)
+{
+    constexpr int U = 8;
+    const float wscale = __builtin_ldexpf(1.0f, A.wfrac);
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < A.R; r += gridDim.x * 256) {
+        if (A.hit_cnt[r] > A.cap) continue;
+        const int n = A.n_used[r];
+        uint2 *list = A.hits + (size_t)r * A.cap;
+        for (int kb = 0; kb < n; kb += U) {
+            uint2 e[U];
+            unsigned long long old[U];
+#pragma unroll
+            for (int j = 0; j < U; j++) e[j] = (kb + j < n) ? list[kb + j] : make_uint2(0u, 0u);
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                old[j] = 0;
+                if (kb + j < n) {
+                    const unsigned long long wq = (unsigned long long)ceilf(__uint_as_float(e[j].x) * wscale);
+                    old[j] = atomicAdd(A.surf_acc + (size_t)e[j].y * NCOPY + (r & (NCOPY - 1)), (wq << 24) | 1ull);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < U; j++)
+                if (kb + j < n) list[kb + j].x = (unsigned)(old[j] & 0xFFFFFFull);
+        }
     }
 }
 
@@ -937,9 +936,14 @@ unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, 
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    const unsigned long long a = acc[i];
-    cnt[i] = (unsigned)(a & 0xFFFFFFull);
-    const float w = (float)((double)(a >> 24) / (double)(1ull << wfrac));
+    unsigned long long wsum = 0;
+#pragma unroll
+    for (int c = 0; c < NCOPY; c++) {
+        const unsigned long long a = acc[(size_t)i * NCOPY + c];
+        cnt[(size_t)i * NCOPY + c] = (unsigned)(a & 0xFFFFFFull);
+        wsum += a >> 24;
+    }
+    const float w = (float)((double)wsum / (double)(1ull << wfrac));
     if (w != 0.0f) wet[i] += w;
 }
 
@@ -968,7 +972,8 @@ composite_lists_bwd_records(const TraceArgs A)
             const int sid = (int)e.y;
             float dc0, dc1, dc2, gv[15];
             if (!bwd_hit(A, B, acc, basis, nb, sid, dc0, dc1, dc2, gv)) break;      // cannot happen: same arithmetic as the forward
-            const unsigned long long idx = (unsigned long long)(A.surf_off[sid] - A.surf_cnt[sid]) + e.x;
+            const size_t ci = (size_t)sid * NCOPY + (r & (NCOPY - 1));
+            const unsigned long long idx = (unsigned long long)(A.surf_off[ci] - A.surf_cnt[ci]) + e.x;
             if (idx < A.num_records) {
                 float4 *o = reinterpret_cast<float4 *>(A.records + idx * RECW);
                 o[0] = make_float4(B.ux, B.uy, B.uz, dc0);
@@ -993,9 +998,11 @@ reduce_surfel_records(const TraceArgs A)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nb = (A.D + 1) * (A.D + 1);
     for (int sid = blockIdx.x; sid < A.P; sid += gridDim.x) {
-        const unsigned cnt = A.surf_cnt[sid];
+        const unsigned end = A.surf_off[(size_t)sid * NCOPY + NCOPY - 1];
+        const unsigned begin = A.surf_off[(size_t)sid * NCOPY] - A.surf_cnt[(size_t)sid * NCOPY];     // the NCOPY sub-segments are adjacent
+        const unsigned cnt = end - begin;
         if (cnt <= (unsigned)wave * 64u) continue;
-        const unsigned long long start = (unsigned long long)(A.surf_off[sid] - cnt);
+        const unsigned long long start = (unsigned long long)begin;
         float sh[16][3], geo[15];
 #pragma unroll
         for (int k = 0; k < 16; k++) { sh[k][0] = 0.f; sh[k][1] = 0.f; sh[k][2] = 0.f; }
@@ -1138,7 +1145,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     if (L && L->cap > SORT_MAX) return ENVGS_ERR_BAD_ARG;
     ProfScope prof_(K_TRACE_FWD, stream);
     if (lists) {
-        if (L->scan_temp_bytes < scan_temp_bytes(cfg->P)) return ENVGS_ERR_TEMP_TOO_SMALL;
+        if (L->scan_temp_bytes < scan_temp_bytes(cfg->P * NCOPY)) return ENVGS_ERR_TEMP_TOO_SMALL;
         A.hits = (uint2 *)L->hit_lists; A.hit_cnt = L->hit_cnt; A.n_used = L->n_used; A.cap = L->cap; A.stack_spill = L->stack_spill;
         A.surf_cnt = L->surf_cnt; A.surf_off = L->surf_off; A.surf_acc = (unsigned long long *)L->surf_acc;
         {   // 40-bit fixed-point weight: enough integer bits that even a surfel seen with w = 1 by every ray cannot overflow
@@ -1146,7 +1153,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             while ((1ll << ib) <= (long long)cfg->num_rays) ib++;
             A.wfrac = 40 - ib > 30 ? 30 : 40 - ib;
         }
-        e = hipMemsetAsync(L->surf_acc, 0, sizeof(unsigned long long) * (size_t)cfg->P, stream);
+        e = hipMemsetAsync(L->surf_acc, 0, sizeof(unsigned long long) * (size_t)cfg->P * NCOPY, stream);
         if (e != hipSuccess) return (int)e;
         { ProfScope p1(K_TRACE_COLLECT, stream); hipLaunchKernelGGL(collect_hits, dim3(persistent_grid(cfg->num_rays, 24)), dim3(64), 0, stream, A); }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
@@ -1154,10 +1161,12 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         ENVGS_CHECK_LAUNCH(dcfg, stream);
         { ProfScope p3(K_TRACE_COMPOSITE, stream); hipLaunchKernelGGL(composite_lists_fwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
+        { ProfScope p8(K_TRACE_REGISTER, stream); hipLaunchKernelGGL(register_hits, dim3(stride_grid(cfg->num_rays, 256)), dim3(256), 0, stream, A); }
+        ENVGS_CHECK_LAUNCH(dcfg, stream);
         hipLaunchKernelGGL(unpack_surfel_acc, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, A.wfrac, A.surf_acc, L->surf_cnt, wet);
         ENVGS_CHECK_LAUNCH(dcfg, stream);
         {   // records of the backward are addressed through the inclusive scan of the per-surfel hit counts
-            const int rc = launch_scan(L->surf_cnt, L->surf_off, cfg->P, L->scan_temp, L->scan_temp_bytes, stream);
+            const int rc = launch_scan(L->surf_cnt, L->surf_off, cfg->P * NCOPY, L->scan_temp, L->scan_temp_bytes, stream);
             if (rc) return rc;
         }
         e = hipMemsetAsync(counters, 0, sizeof(uint32_t), stream);          // ray-fetch counter for the overflow pass

@@ -70,10 +70,11 @@ typedef struct envgs_trace_lists {
     int32_t *n_used;         /* (R) hits composited before termination */
     int32_t cap;             /* list capacity per ray, <= 1024; 0 disables the list path */
     int32_t *stack_spill;    /* envgs_trace_stack_spill_ints(R) int32 */
-    uint64_t *surf_acc;      /* (P) packed per-surfel accumulator of the forward: low 24 bits hit count, high 40 bits fixed-point weight */
-    uint32_t *surf_cnt;      /* (P) composited hits per surfel (list path only) */
-    uint32_t *surf_off;      /* (P) inclusive prefix sum of surf_cnt; surf_off[P-1] = number of gradient records */
-    void *scan_temp;         /* envgs_raster_scan_temp_bytes(P) bytes */
+    uint64_t *surf_acc;      /* (P,8) packed accumulators of the forward (8 copies per surfel, chosen by ray index, spread same-address
+                                atomics): low 24 bits hit count, high 40 bits fixed-point weight */
+    uint32_t *surf_cnt;      /* (P,8) composited hits per (surfel, copy) (list path only) */
+    uint32_t *surf_off;      /* (P,8) inclusive prefix sum of surf_cnt; the last entry = number of gradient records */
+    void *scan_temp;         /* envgs_raster_scan_temp_bytes(8*P) bytes */
     size_t scan_temp_bytes;
     float *records;          /* backward only: (num_records, 24) per-hit gradient records (96 B), grouped by surfel */
     uint64_t num_records;    /* backward only: capacity of `records` in records (>= surf_off[P-1]) */
