@@ -89,6 +89,7 @@ def _cfg(settings, P, R, shs, others, start_from_first, ray_shape):
                          rh, rw, float(settings.scale_modifier), float(settings.specular_threshold))
 
 
+NCOPY = 8                    # must equal NCOPY in csrc/trace_render.hip
 HIT_CAP = {"cap": 512}
 USE_RECORDS = {"on": True}   # atomic-free backward (per-hit records grouped by surfel); False = cooperative atomic flush      # per-ray hit-list capacity of the list path; adapted from the largest list of the previous call
 
@@ -140,10 +141,10 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     if cap:
         i32 = dict(dtype=torch.int32, device=dev)
         keep = dict(hit_lists=torch.empty(R, cap, 2, **i32), hit_cnt=torch.empty(R, **i32), n_used=torch.empty(R, **i32),
-                    spill=torch.empty(lib.envgs_trace_stack_spill_ints(R), **i32), surf_acc=torch.empty(P, 8, dtype=torch.int64, device=dev),
-                    surf_cnt=torch.empty(P, 8, **i32),
-                    surf_off=torch.empty(P, 8, **i32))
-        sb = lib.envgs_raster_scan_temp_bytes(8 * P)
+                    spill=torch.empty(lib.envgs_trace_stack_spill_ints(R), **i32), surf_acc=torch.empty(P, NCOPY, dtype=torch.int64, device=dev),
+                    surf_cnt=torch.empty(P, NCOPY, **i32),
+                    surf_off=torch.empty(P, NCOPY, **i32))
+        sb = lib.envgs_raster_scan_temp_bytes(NCOPY * P)
         keep["scan_temp"] = torch.empty(max(sb, 1), dtype=torch.uint8, device=dev)
         lists = _lib.TraceLists(keep["hit_lists"].data_ptr(), keep["hit_cnt"].data_ptr(), keep["n_used"].data_ptr(), cap,
                                 keep["spill"].data_ptr(), keep["surf_acc"].data_ptr(), keep["surf_cnt"].data_ptr(), keep["surf_off"].data_ptr(),
@@ -158,7 +159,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
         m = _mirror("max_list", dev)
         m["host"].copy_(counters[1:2], non_blocking=True); m["event"].record(torch.cuda.current_stream(dev)); m["valid"] = True
         keep["n_rec_host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
-        keep["n_rec_host"].copy_(keep["surf_off"].view(-1)[8 * P - 1:8 * P], non_blocking=True)
+        keep["n_rec_host"].copy_(keep["surf_off"].view(-1)[NCOPY * P - 1:NCOPY * P], non_blocking=True)
         keep["n_rec_event"] = torch.cuda.Event(); keep["n_rec_event"].record(torch.cuda.current_stream(dev))
     saved = dict(cfg=cfg, nodes=nodes, ro=ro, rd=rd, means3D=means3D, scales=scales, rotations=rotations, opacities=opacities,
                  shs=shs, colors_precomp=colors_precomp, others=others_precomp, bg=bg, srec=srec, counters=counters,
