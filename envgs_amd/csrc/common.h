@@ -47,6 +47,37 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 
+// Transpose-reduce of 4*N4 per-lane values over the wavefront in ~(2+1+1)*N4 + ... instructions instead of 7 per value:
+//   v_permlane32_swap pairs value i with value i+2*N4 (one add leaves i's 32 partial sums in the low half, the other's in the high half),
+//   v_permlane16_swap pairs again (each 16-lane row now owns ONE value), four DPP row rotations finish the row sums, and N4-1 selects
+//   merge the registers.  Result: lane r*16+k (k < N4) returns the sum over all 64 lanes of value k + r*N4.
+typedef unsigned envgs_u2 __attribute__((ext_vector_type(2)));
+template <int N4>
+__device__ __forceinline__ float wave_transpose_reduce(const float (&g)[4 * N4], const int lane)
+{
+    float z[2 * N4];
+#pragma unroll
+    for (int i = 0; i < 2 * N4; i++) {
+        const envgs_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(g[i]), __float_as_uint(g[i + 2 * N4]), false, false);
+        z[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    float w[N4];
+#pragma unroll
+    for (int k = 0; k < N4; k++) {
+        const envgs_u2 q = __builtin_amdgcn_permlane16_swap(__float_as_uint(z[k]), __float_as_uint(z[k + N4]), false, false);
+        float v = __uint_as_float(q.x) + __uint_as_float(q.y);
+        v += dpp_mov<0x128>(v);                // row_ror:8
+        v += dpp_mov<0x124>(v);                // row_ror:4
+        v += dpp_mov<0x122>(v);                // row_ror:2
+        v += dpp_mov<0x121>(v);                // row_ror:1
+        w[k] = v;
+    }
+    float out = w[0];
+#pragma unroll
+    for (int k = 1; k < N4; k++) out = ((lane & 15) == k) ? w[k] : out;
+    return out;
+}
+
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 __device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
