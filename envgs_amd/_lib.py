@@ -23,7 +23,9 @@ class TraceLists(ctypes.Structure):
     """struct envgs_trace_lists (include/envgs_trace.h)."""
     _fields_ = [("hit_lists", ctypes.c_void_p), ("hit_cnt", ctypes.c_void_p), ("n_used", ctypes.c_void_p), ("cap", ctypes.c_int32),
                 ("stack_spill", ctypes.c_void_p), ("surf_acc", ctypes.c_void_p), ("surf_cnt", ctypes.c_void_p), ("surf_off", ctypes.c_void_p),
-                ("scan_temp", ctypes.c_void_p), ("scan_temp_bytes", ctypes.c_size_t), ("records", ctypes.c_void_p),
+                ("scan_temp", ctypes.c_void_p), ("scan_temp_bytes", ctypes.c_size_t), ("ray_keys", ctypes.c_void_p),
+                ("ray_order", ctypes.c_void_p), ("ray_sort_temp", ctypes.c_void_p), ("ray_sort_temp_bytes", ctypes.c_size_t),
+                ("records", ctypes.c_void_p),
                 ("num_records", ctypes.c_uint64)]
 
 
@@ -47,6 +49,7 @@ SYMBOLS = {
     "envgs_bvh_temp_bytes": (c_size_t, [ctypes.c_int32]),
     "envgs_bvh_build": (c_int, [ctypes.c_int32, _P, _P, _P, _P, c_size_t, ctypes.c_int32, _P]),
     "envgs_trace_stack_spill_ints": (c_size_t, [ctypes.c_int32]),
+    "envgs_trace_ray_sort_temp_bytes": (c_size_t, [ctypes.c_int32]),
     "envgs_trace_forward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 22 + [ctypes.POINTER(TraceLists), _P]),
     "envgs_trace_backward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 35 + [ctypes.POINTER(TraceLists), _P]),
     "envgs_prof_enable": (None, [c_int]),

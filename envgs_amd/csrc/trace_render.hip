@@ -14,6 +14,8 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "../../include/envgs_trace.h"
 
@@ -145,6 +147,7 @@ struct TraceArgs {
     const unsigned *surf_off; // (P) inclusive scan of surf_cnt
     float *records;           // (num_records, 24) per-hit gradient records grouped by surfel
     unsigned long long num_records;
+    const unsigned *order;    // (R) ray permutation (coherence sort) or NULL
     int exp;            // experiment switches (ENVGS_TRACE_EXP env var; 0 in production)
     int *stack_spill;   // collect_hits: (grid, STACK, 64) ints of stack overflow space
     int only_overflow;  // K-buffer kernels: process only rays whose hit_cnt exceeds cap
@@ -636,6 +639,43 @@ trace_bwd(const TraceArgs A, const int ray_h, const int ray_w)
     }
 }
 
+// Rays are processed in a coherence-sorted order when A.order is set: 64 consecutive slots = one wavefront = rays with nearly the same
+// direction (and nearby origins), so its lanes walk nearly the same BVH nodes and hit the same surfels -- the loads coalesce.
+__device__ __forceinline__ int ray_of(const TraceArgs &A, int slot) { return slot < A.R ? (A.order ? (int)A.order[slot] : slot) : A.R; }
+
+// Sort key of a ray: octahedral direction (2 x 8 bits, Morton-interleaved) in the high bits, origin cell (3 x 5 bits) below.
+__global__ void __launch_bounds__(256)
+make_ray_keys(int R, const float *__restrict__ ray_o, const float *__restrict__ ray_d, const float4 *__restrict__ nodes, int P,
+              unsigned *__restrict__ keys, unsigned *__restrict__ vals)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float lo[3] = {-1.f, -1.f, -1.f}, ext[3] = {2.f, 2.f, 2.f};
+    if (P > 0) {
+        const float4 n0 = nodes[0], n1 = nodes[1], n2 = nodes[2];
+        lo[0] = fminf(n0.x, n1.z); lo[1] = fminf(n0.y, n1.w); lo[2] = fminf(n0.z, n2.x);
+        ext[0] = fmaxf(n0.w, n2.y) - lo[0]; ext[1] = fmaxf(n1.x, n2.z) - lo[1]; ext[2] = fmaxf(n1.y, n2.w) - lo[2];
+    }
+    const float dx = ray_d[3 * r], dy = ray_d[3 * r + 1], dz = ray_d[3 * r + 2];
+    const float inv = 1.0f / (fabsf(dx) + fabsf(dy) + fabsf(dz) + 1e-30f);
+    float u = dx * inv, v = dy * inv;
+    if (dz < 0.f) { const float uu = (1.f - fabsf(v)) * (u >= 0.f ? 1.f : -1.f), vv = (1.f - fabsf(u)) * (v >= 0.f ? 1.f : -1.f); u = uu; v = vv; }
+    const unsigned qu = (unsigned)fminf(fmaxf((u * 0.5f + 0.5f) * 256.f, 0.f), 255.f), qv = (unsigned)fminf(fmaxf((v * 0.5f + 0.5f) * 256.f, 0.f), 255.f);
+    unsigned dkey = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) dkey |= ((qu >> b) & 1u) << (2 * b) | ((qv >> b) & 1u) << (2 * b + 1);
+    unsigned okey = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float t = ext[c] > 0.f ? (ray_o[3 * r + c] - lo[c]) / ext[c] : 0.f;
+        const unsigned q = (unsigned)fminf(fmaxf(t * 32.f, 0.f), 31.f);
+#pragma unroll
+        for (int b = 0; b < 5; b++) okey |= ((q >> b) & 1u) << (3 * b + c);
+    }
+    keys[r] = (dkey << 15) | okey;
+    vals[r] = (unsigned)r;
+}
+
 // ---------------------------------------------------------------------------------- list path ---
 // MI355X-first variant of T2/T3 for bounce-free tracing (what EnvGS runs: max_trace_depth = 0).  HBM is plentiful
 // (288 GB), so instead of re-traversing the BVH in rounds of K hits -- and again in the backward -- the ray's hits
@@ -673,7 +713,7 @@ collect_hits(const TraceArgs A)
         if (lane == 0) base = (int)atomicAdd(A.counter, 64u);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= A.R) break;
-        const int r = base + lane;
+        const int r = ray_of(A, base + lane);
         const bool valid = r < A.R;
         const int rr = valid ? r : 0;
         const float ox = A.ray_o[3 * rr], oy = A.ray_o[3 * rr + 1], oz = A.ray_o[3 * rr + 2];
@@ -803,7 +843,7 @@ composite_lists_fwd(const TraceArgs A)
     const int lane = threadIdx.x;
     unsigned st_hits = 0;
     for (int base = blockIdx.x * 64; base < A.R; base += gridDim.x * 64) {
-        const int r = base + lane;
+        const int r = ray_of(A, base + lane);
         if (r >= A.R) continue;
         const int n = A.hit_cnt[r];
         if (n > A.cap) continue;                            // overflow: the K-buffer kernel owns this ray
@@ -898,7 +938,7 @@ composite_lists_bwd(const TraceArgs A)
     const FlushRole role = flush_role(A, lane);
     const int nb = (A.D + 1) * (A.D + 1);
     for (int base = blockIdx.x * 64; base < A.R; base += gridDim.x * 64) {
-        const int r = base + lane;
+        const int r = ray_of(A, base + lane);
         const bool valid = r < A.R && A.hit_cnt[r < A.R ? r : 0] <= A.cap;
         const int rr = r < A.R ? r : 0;
         BwdRay B;
@@ -956,7 +996,7 @@ composite_lists_bwd_records(const TraceArgs A)
     const int lane = threadIdx.x;
     const int nb = (A.D + 1) * (A.D + 1);
     for (int base = blockIdx.x * 64; base < A.R; base += gridDim.x * 64) {
-        const int r = base + lane;
+        const int r = ray_of(A, base + lane);
         if (r >= A.R) continue;
         if (A.hit_cnt[r] > A.cap) continue;                 // overflow rays: K-buffer backward (atomic flush)
         BwdRay B;
@@ -1101,6 +1141,14 @@ static void ray_layout(const envgs_trace_cfg *cfg, int *rh, int *rw)
 
 extern "C" {
 
+size_t envgs_trace_ray_sort_temp_bytes(int32_t num_rays)
+{
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned *)nullptr, (unsigned *)nullptr, (const unsigned *)nullptr, (unsigned *)nullptr,
+                                    (size_t)(num_rays > 0 ? num_rays : 1), 0u, 31u);
+    return bytes;
+}
+
 size_t envgs_trace_stack_spill_ints(int32_t num_rays) { return (size_t)persistent_grid(num_rays, 24) * STACK * 64; }
 
 int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const float *ray_o, const float *ray_d,
@@ -1148,6 +1196,16 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         if (L->scan_temp_bytes < scan_temp_bytes(cfg->P * NCOPY)) return ENVGS_ERR_TEMP_TOO_SMALL;
         A.hits = (uint2 *)L->hit_lists; A.hit_cnt = L->hit_cnt; A.n_used = L->n_used; A.cap = L->cap; A.stack_spill = L->stack_spill;
         A.surf_cnt = L->surf_cnt; A.surf_off = L->surf_off; A.surf_acc = (unsigned long long *)L->surf_acc;
+        if (L->ray_keys && L->ray_order && L->ray_sort_temp && !(A.exp & 64)) {
+            // coherence sort of the rays (keys / values double-buffered in ray_keys / ray_order: 2R words each)
+            const int R = cfg->num_rays;
+            hipLaunchKernelGGL(make_ray_keys, dim3((R + 255) / 256), dim3(256), 0, stream, R, ray_o, ray_d, A.nodes, cfg->P, L->ray_keys, L->ray_order);
+            ENVGS_CHECK_LAUNCH(dcfg, stream);
+            size_t tb = L->ray_sort_temp_bytes;
+            e = rocprim::radix_sort_pairs(L->ray_sort_temp, tb, L->ray_keys, L->ray_keys + R, L->ray_order, L->ray_order + R, (size_t)R, 0u, 31u, stream);
+            if (e != hipSuccess) return (int)e;
+            A.order = L->ray_order + R;
+        }
         {   // 40-bit fixed-point weight: enough integer bits that even a surfel seen with w = 1 by every ray cannot overflow
             int ib = 1;
             while ((1ll << ib) <= (long long)cfg->num_rays) ib++;
@@ -1221,6 +1279,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
         ProfScope prof_(K_TRACE_BWD, stream);
         if (L && L->cap > 0 && cfg->max_trace_depth == 0 && L->hit_lists && L->hit_cnt && L->n_used) {
             A.hits = (uint2 *)L->hit_lists; A.hit_cnt = L->hit_cnt; A.n_used = L->n_used; A.cap = L->cap;
+            if (L->ray_keys && L->ray_order && L->ray_sort_temp && !(A.exp & 64)) A.order = L->ray_order + cfg->num_rays;
             if (L->records && L->num_records > 0 && L->surf_cnt && L->surf_off && !(A.exp & 8)) {
                 // atomic-free: per-hit records grouped by surfel, then one wavefront per surfel reduces its segment
                 A.surf_cnt = L->surf_cnt; A.surf_off = L->surf_off; A.records = L->records; A.num_records = L->num_records;

@@ -91,6 +91,7 @@ def _cfg(settings, P, R, shs, others, start_from_first, ray_shape):
 
 NCOPY = 8                    # must equal NCOPY in csrc/trace_render.hip
 HIT_CAP = {"cap": 512}
+SORT_RAYS = {"on": True}     # coherence-sort the rays (direction, origin) before tracing
 USE_RECORDS = {"on": True}   # atomic-free backward (per-hit records grouped by surfel); False = cooperative atomic flush      # per-ray hit-list capacity of the list path; adapted from the largest list of the previous call
 
 
@@ -146,9 +147,14 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
                     surf_off=torch.empty(P, NCOPY, **i32))
         sb = lib.envgs_raster_scan_temp_bytes(NCOPY * P)
         keep["scan_temp"] = torch.empty(max(sb, 1), dtype=torch.uint8, device=dev)
+        rb = lib.envgs_trace_ray_sort_temp_bytes(R)
+        keep.update(ray_keys=torch.empty(2 * R, **i32), ray_order=torch.empty(2 * R, **i32),
+                    ray_sort_temp=torch.empty(max(rb, 1), dtype=torch.uint8, device=dev))
+        srt = SORT_RAYS["on"]
         lists = _lib.TraceLists(keep["hit_lists"].data_ptr(), keep["hit_cnt"].data_ptr(), keep["n_used"].data_ptr(), cap,
                                 keep["spill"].data_ptr(), keep["surf_acc"].data_ptr(), keep["surf_cnt"].data_ptr(), keep["surf_off"].data_ptr(),
-                                keep["scan_temp"].data_ptr(), sb, None, 0)
+                                keep["scan_temp"].data_ptr(), sb, keep["ray_keys"].data_ptr() if srt else None,
+                                keep["ray_order"].data_ptr() if srt else None, keep["ray_sort_temp"].data_ptr() if srt else None, rb, None, 0)
     p = _lib.ptr
     _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
                                        p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),

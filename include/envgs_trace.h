@@ -76,6 +76,10 @@ typedef struct envgs_trace_lists {
     uint32_t *surf_off;      /* (P,8) inclusive prefix sum of surf_cnt; the last entry = number of gradient records */
     void *scan_temp;         /* envgs_raster_scan_temp_bytes(8*P) bytes */
     size_t scan_temp_bytes;
+    uint32_t *ray_keys;      /* (2R) scratch of the ray coherence sort (keys, double buffered); NULL disables the sort */
+    uint32_t *ray_order;     /* (2R) ray permutation (double buffered); the second half holds the order the kernels use */
+    void *ray_sort_temp;     /* envgs_trace_ray_sort_temp_bytes(R) bytes */
+    size_t ray_sort_temp_bytes;
     float *records;          /* backward only: (num_records, 24) per-hit gradient records (96 B), grouped by surfel */
     uint64_t num_records;    /* backward only: capacity of `records` in records (>= surf_off[P-1]) */
 } envgs_trace_lists;
@@ -105,6 +109,7 @@ ENVGS_API int envgs_bvh_build(int32_t P, const float *vertices, const float *opa
  * After the call counters[1] holds the largest hit_cnt (so the caller can size `cap` for the next call).
  */
 ENVGS_API size_t envgs_trace_stack_spill_ints(int32_t num_rays);
+ENVGS_API size_t envgs_trace_ray_sort_temp_bytes(int32_t num_rays);
 ENVGS_API int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes,
                                   const float *ray_o, const float *ray_d,
                                   const float *means3D, const float *scales, const float *rotations, const float *opacities,
