@@ -684,6 +684,35 @@ make_ray_keys(int R, const float *__restrict__ ray_o, const float *__restrict__ 
 // by the forward (composite_lists_fwd) and again by the backward (composite_lists_bwd), which never touches the BVH.
 // Rays whose list overflows `cap` fall back to the K-buffer kernels above (only_overflow mode).
 
+// XCD-affine batch fetch.  Rays are coherence-sorted, so a contiguous run of 64-ray batches covers one region of direction space;
+// each of the 8 XCDs (private 4 MB L2) takes its own contiguous eighth of the batches, so the BVH nodes and surfel records that
+// region touches stay in THAT L2 instead of streaming from the Infinity Cache for every XCD.  An XCD that runs dry steals.
+// workgroup b of a grid whose size is a multiple of 8: workgroups that share an XCD (b % 8) get one contiguous run of block slots
+__device__ __forceinline__ int xcd_block(int b, int nblocks) { return (b & 7) * (nblocks >> 3) + (b >> 3); }
+
+__device__ __forceinline__ int xcc_id()
+{
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return (int)(v & 7u);
+}
+
+__device__ __forceinline__ int fetch_batch(unsigned *ctr /*8 counters*/, int nbatch, int home, int lane)
+{
+    const int per = (nbatch + 7) >> 3;
+    int b = -1;
+    if (lane == 0) {
+        for (int k = 0; k < 8 && b < 0; k++) {
+            const int x = (home + k) & 7;
+            const int lo = x * per, hi = min(lo + per, nbatch);
+            if (lo >= hi) continue;
+            const int i = (int)atomicAdd(ctr + x, 1u);
+            if (lo + i < hi) b = lo + i;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(b);
+}
+
 // Conservative termination bound for the unordered collection.  The ray's accepted hits are binned by distance into 16
 // half-octave bins (16 registers of optical depth -ln(1-alpha)); as soon as the bins up to edge e hold more optical depth than
 // the compositing can survive (T < 1e-4), every hit beyond e is provably after the terminating hit: it is dropped and BVH nodes
@@ -708,11 +737,12 @@ collect_hits(const TraceArgs A)
         diag = sqrtf(ex * ex + ey * ey + ez * ez);
         if (!(diag > 0.0f) || !(diag < 1.0e29f)) diag = 1.0f;
     }
+    const int home = xcc_id();
+    const int nbatch = (A.R + 63) >> 6;
     while (true) {
-        int base = 0;
-        if (lane == 0) base = (int)atomicAdd(A.counter, 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= A.R) break;
+        const int batch = fetch_batch(A.counter + 16, nbatch, home, lane);
+        if (batch < 0) break;
+        const int base = batch << 6;
         const int r = ray_of(A, base + lane);
         const bool valid = r < A.R;
         const int rr = valid ? r : 0;
@@ -752,13 +782,14 @@ collect_hits(const TraceArgs A)
             for (int side = 0; side < 2; side++) {
                 const bool hit = side == 0 ? hitL : hitR;
                 const int ch = side == 0 ? lc : rc;
-                if (hit && ch < 0) {
+                if (hit && ch < 0 && !(A.exp & 128)) {
                     const int sid = ~ch;
                     const float4 *sr = A.srec + (size_t)sid * 4;
                     const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], sr[3], ox, oy, oz, dx, dy, dz);
                     if (h.ok && h.t > tmin && h.t <= tkill) {
                         if (n < A.cap) list[n] = make_uint2(__float_as_uint(h.t), (unsigned)sid);
                         n++;
+                        if (A.exp & 256) continue;
                         // bin (biased upwards: a hit may only ever be filed FARTHER than it is, which keeps the bound conservative)
                         const float x = h.t * inv_t0;
                         int b = x <= 1.0f ? 0 : (int)ceilf(2.0f * __log2f(x) + 1e-3f);
@@ -1125,7 +1156,8 @@ static int stride_grid(int R, int per_block)
 {
     const int want = (R + per_block - 1) / per_block;
     const int cap = 256 * 32;
-    return want < cap ? (want > 0 ? want : 1) : cap;
+    const int g = want < cap ? (want > 0 ? want : 1) : cap;
+    return (g + 7) & ~7;                 // multiple of 8: xcd_block() needs it
 }
 
 }  // namespace envgs
@@ -1167,7 +1199,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     hipStream_t stream = (hipStream_t)stream_;
     envgs_raster_cfg dbg; dbg.debug = cfg->debug;
     const envgs_raster_cfg *dcfg = &dbg;
-    hipError_t e = hipMemsetAsync(counters, 0, 16 * sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(counters, 0, 32 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
     if (cfg->P > 0) {
         e = hipMemsetAsync(wet, 0, sizeof(float) * (size_t)cfg->P, stream);
