@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--gaussians", type=int, default=300000)
     ap.add_argument("--env-gaussians", type=int, default=163840)
     ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--torch-glue", action="store_true", help="keep the reference's torch expressions for the caller-side glue (default: fused HIP, SURVEY 8(f).1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the same view traced by the brute-force CPU oracle (bounded sample)")
@@ -117,6 +118,7 @@ def main():
         import diff_surfel_rasterization_wet_ch05 as pkg
         import diff_surfel_tracing as tpkg
         from envgs_amd import envgs_step
+        envgs_step.FUSED["on"] = not args.torch_glue
         tracer = tpkg.SurfelTracer()
         rays = [synth.get_rays(c) for c in cams]
         env_bg = torch.zeros(3, device=dev)
@@ -239,6 +241,7 @@ def main():
                                     "Ref-NeRF toaster-like base 2DGS raster only (BASELINE configs[1]), SH deg 3 in-kernel"),
                        "gaussians": P, "env_gaussians": (args.env_gaussians if envgs else 0), "resolution": [H, W], "channels": C, "views": 8,
                        "parallelism": "dp%d (camera batch sharded, flat grad all-reduce)" % world,
+                       "caller_glue": ("torch (reference expressions)" if (not envgs or args.torch_glue) else "fused HIP (envgs_amd.fused)"),
                        "allreduce_bytes_per_step": int(ar_bytes)},
             "train_mpix_per_s": round(value * HW / 1e6, 2),
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "trace_counts": tcounts,

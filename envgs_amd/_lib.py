@@ -52,6 +52,10 @@ SYMBOLS = {
     "envgs_trace_ray_sort_temp_bytes": (c_size_t, [ctypes.c_int32]),
     "envgs_trace_forward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 22 + [ctypes.POINTER(TraceLists), _P]),
     "envgs_trace_backward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 35 + [ctypes.POINTER(TraceLists), _P]),
+    "envgs_sh_colors_forward": (c_int, [ctypes.c_int32] * 4 + [_P] * 7 + [_P]),
+    "envgs_sh_colors_backward": (c_int, [ctypes.c_int32] * 4 + [_P] * 9 + [_P]),
+    "envgs_reflect_forward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float] + [_P] * 8 + [_P]),
+    "envgs_reflect_backward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float] + [_P] * 11 + [_P]),
     "envgs_prof_enable": (None, [c_int]),
     "envgs_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     "envgs_prof_kernel_name": (ctypes.c_char_p, [c_int]),

@@ -1,0 +1,247 @@
+// glue.hip -- fused caller-side glue (include/envgs_glue.h): per-surfel SH -> colour channels and per-pixel reflected-ray
+// construction, forward and backward, one HBM pass each (the reference spends ~125 torch launches on the same expressions).
+#include "common.h"
+
+#include "../../include/envgs_glue.h"
+
+namespace envgs {
+
+constexpr float gC0 = 0.28209479177387814f;
+constexpr float gC1 = 0.4886025119029199f;
+__device__ __constant__ float gC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                        -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ float gC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                        0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                        -0.5900435899266435f};
+
+__device__ __forceinline__ void basis16(int D, float x, float y, float z, float *b)
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) b[k] = 0.f;
+    b[0] = gC0;
+    if (D > 0) {
+        b[1] = -gC1 * y; b[2] = gC1 * z; b[3] = -gC1 * x;
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = gC2[0] * xy; b[5] = gC2[1] * yz; b[6] = gC2[2] * (2.0f * zz - xx - yy); b[7] = gC2[3] * xz; b[8] = gC2[4] * (xx - yy);
+            if (D > 2) {
+                b[9] = gC3[0] * y * (3.0f * xx - yy); b[10] = gC3[1] * xy * z; b[11] = gC3[2] * y * (4.0f * zz - xx - yy);
+                b[12] = gC3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy); b[13] = gC3[4] * x * (4.0f * zz - xx - yy);
+                b[14] = gC3[5] * z * (xx - yy); b[15] = gC3[6] * x * (xx - 3.0f * yy);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void basis16_grad(int D, float x, float y, float z, float *gx, float *gy, float *gz)
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) { gx[k] = 0.f; gy[k] = 0.f; gz[k] = 0.f; }
+    if (D > 0) {
+        gy[1] = -gC1; gz[2] = gC1; gx[3] = -gC1;
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            gx[4] = gC2[0] * y; gy[4] = gC2[0] * x;
+            gy[5] = gC2[1] * z; gz[5] = gC2[1] * y;
+            gx[6] = gC2[2] * -2.f * x; gy[6] = gC2[2] * -2.f * y; gz[6] = gC2[2] * 4.f * z;
+            gx[7] = gC2[3] * z; gz[7] = gC2[3] * x;
+            gx[8] = gC2[4] * 2.f * x; gy[8] = gC2[4] * -2.f * y;
+            if (D > 2) {
+                gx[9] = gC3[0] * 6.f * xy; gy[9] = gC3[0] * 3.f * (xx - yy);
+                gx[10] = gC3[1] * yz; gy[10] = gC3[1] * xz; gz[10] = gC3[1] * xy;
+                gx[11] = gC3[2] * -2.f * xy; gy[11] = gC3[2] * (4.f * zz - xx - 3.f * yy); gz[11] = gC3[2] * 8.f * yz;
+                gx[12] = gC3[3] * -6.f * xz; gy[12] = gC3[3] * -6.f * yz; gz[12] = gC3[3] * 3.f * (2.f * zz - xx - yy);
+                gx[13] = gC3[4] * (4.f * zz - 3.f * xx - yy); gy[13] = gC3[4] * -2.f * xy; gz[13] = gC3[4] * 8.f * xz;
+                gx[14] = gC3[5] * 2.f * xz; gy[14] = gC3[5] * -2.f * yz; gz[14] = gC3[5] * (xx - yy);
+                gx[15] = gC3[6] * 3.f * (xx - yy); gy[15] = gC3[6] * -6.f * xy;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sh_colors_fwd(int P, int D, int M, int S, const float *__restrict__ means, const float *__restrict__ shs, const float *__restrict__ campos,
+              const float *__restrict__ spec, const float *__restrict__ rough, float *__restrict__ colors, uint8_t *__restrict__ clamped)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int C = 3 + S + 1;
+    const float dx = means[3 * i] - campos[0], dy = means[3 * i + 1] - campos[1], dz = means[3 * i + 2] - campos[2];
+    const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    float b[16];
+    basis16(D, dx * il, dy * il, dz * il, b);
+    const float *sh = shs + (size_t)i * M * 3;
+    const int nb = (D + 1) * (D + 1);
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (k < nb) { r0 += b[k] * sh[k * 3]; r1 += b[k] * sh[k * 3 + 1]; r2 += b[k] * sh[k * 3 + 2]; }
+    r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+    clamped[3 * i] = r0 < 0.f; clamped[3 * i + 1] = r1 < 0.f; clamped[3 * i + 2] = r2 < 0.f;
+    float *o = colors + (size_t)i * C;
+    o[0] = fmaxf(r0, 0.f); o[1] = fmaxf(r1, 0.f); o[2] = fmaxf(r2, 0.f);
+    for (int s = 0; s < S; s++) o[3 + s] = spec[(size_t)i * S + s];
+    o[3 + S] = rough[i];
+}
+
+__global__ void __launch_bounds__(256)
+sh_colors_bwd(int P, int D, int M, int S, const float *__restrict__ means, const float *__restrict__ shs, const float *__restrict__ campos,
+              const uint8_t *__restrict__ clamped, const float *__restrict__ dcolors, float *__restrict__ dmeans, float *__restrict__ dshs,
+              float *__restrict__ dspec, float *__restrict__ drough)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int C = 3 + S + 1;
+    const float *g = dcolors + (size_t)i * C;
+    const float g0 = clamped[3 * i] ? 0.f : g[0], g1 = clamped[3 * i + 1] ? 0.f : g[1], g2 = clamped[3 * i + 2] ? 0.f : g[2];
+    const float dx = means[3 * i] - campos[0], dy = means[3 * i + 1] - campos[1], dz = means[3 * i + 2] - campos[2];
+    const float sum2 = dx * dx + dy * dy + dz * dz, il = 1.0f / sqrtf(sum2);
+    const float x = dx * il, y = dy * il, z = dz * il;
+    float b[16], gx[16], gy[16], gz[16];
+    basis16(D, x, y, z, b);
+    basis16_grad(D, x, y, z, gx, gy, gz);
+    const float *sh = shs + (size_t)i * M * 3;
+    float *dsh = dshs + (size_t)i * M * 3;
+    const int nb = (D + 1) * (D + 1);
+    float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+    for (int k = 0; k < M; k++) {
+        if (k < nb && k < 16) {
+            dsh[k * 3] = b[k] * g0; dsh[k * 3 + 1] = b[k] * g1; dsh[k * 3 + 2] = b[k] * g2;
+            const float sd = sh[k * 3] * g0 + sh[k * 3 + 1] * g1 + sh[k * 3 + 2] * g2;
+            ddx += gx[k] * sd; ddy += gy[k] * sd; ddz += gz[k] * sd;
+        } else { dsh[k * 3] = 0.f; dsh[k * 3 + 1] = 0.f; dsh[k * 3 + 2] = 0.f; }
+    }
+    const float inv3 = il * il * il;
+    dmeans[3 * i] = ((sum2 - dx * dx) * ddx - dy * dx * ddy - dz * dx * ddz) * inv3;
+    dmeans[3 * i + 1] = (-dx * dy * ddx + (sum2 - dy * dy) * ddy - dz * dy * ddz) * inv3;
+    dmeans[3 * i + 2] = (-dx * dz * ddx - dy * dz * ddy + (sum2 - dz * dz) * ddz) * inv3;
+    for (int s = 0; s < S; s++) dspec[(size_t)i * S + s] = g[3 + s];
+    drough[i] = g[3 + S];
+}
+
+// ------------------------------------------------------------------------------------------------ reflect
+__global__ void __launch_bounds__(256)
+reflect_fwd(int HW, float ratio, const float *__restrict__ allmap, const float *__restrict__ ray_o, const float *__restrict__ ray_d,
+            const float *__restrict__ V, float *__restrict__ nw, float *__restrict__ depth, float *__restrict__ ref_o, float *__restrict__ ref_d)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float Dw = allmap[p], A = allmap[HW + p], n0 = allmap[2 * HW + p], n1 = allmap[3 * HW + p], n2 = allmap[4 * HW + p], med = allmap[5 * HW + p];
+    // normal_world_c = sum_k n_view_k * V[c][k]   (V = world_view_transform, rows 0..2 = R^T)
+    const float w0 = n0 * V[0] + n1 * V[1] + n2 * V[2], w1 = n0 * V[4] + n1 * V[5] + n2 * V[6], w2 = n0 * V[8] + n1 * V[9] + n2 * V[10];
+    float de = Dw / A;
+    if (!(fabsf(de) <= 3.0e38f)) de = 0.f;                                   // nan_to_num(., 0, 0)
+    float dm = med;
+    if (!(fabsf(dm) <= 3.0e38f)) dm = 0.f;
+    const float dep = de * (1.0f - ratio) + dm * ratio;
+    nw[p] = w0; nw[HW + p] = w1; nw[2 * HW + p] = w2;
+    depth[p] = dep;
+    const float len = sqrtf(w0 * w0 + w1 * w1 + w2 * w2), il = 1.0f / (len + 1e-8f);     // math_utils.normalize: x / (|x| + 1e-8)
+    const float u0 = w0 * il, u1 = w1 * il, u2 = w2 * il;
+    const float o0 = ray_o[3 * p], o1 = ray_o[3 * p + 1], o2 = ray_o[3 * p + 2];
+    const float d0 = ray_d[3 * p], d1 = ray_d[3 * p + 1], d2 = ray_d[3 * p + 2];
+    const float dn = d0 * u0 + d1 * u1 + d2 * u2;
+    ref_d[3 * p] = d0 - 2.0f * dn * u0; ref_d[3 * p + 1] = d1 - 2.0f * dn * u1; ref_d[3 * p + 2] = d2 - 2.0f * dn * u2;
+    ref_o[3 * p] = o0 + d0 * dep; ref_o[3 * p + 1] = o1 + d1 * dep; ref_o[3 * p + 2] = o2 + d2 * dep;
+}
+
+__global__ void __launch_bounds__(256)
+reflect_bwd(int HW, float ratio, const float *__restrict__ allmap, const float *__restrict__ ray_o, const float *__restrict__ ray_d,
+            const float *__restrict__ V, const float *__restrict__ dnw, const float *__restrict__ ddepth, const float *__restrict__ dref_o,
+            const float *__restrict__ dref_d, float *__restrict__ dallmap, float *__restrict__ dray_o, float *__restrict__ dray_d)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float Dw = allmap[p], A = allmap[HW + p], n0 = allmap[2 * HW + p], n1 = allmap[3 * HW + p], n2 = allmap[4 * HW + p], med = allmap[5 * HW + p];
+    const float w0 = n0 * V[0] + n1 * V[1] + n2 * V[2], w1 = n0 * V[4] + n1 * V[5] + n2 * V[6], w2 = n0 * V[8] + n1 * V[9] + n2 * V[10];
+    const float d0 = ray_d[3 * p], d1 = ray_d[3 * p + 1], d2 = ray_d[3 * p + 2];
+    const float go0 = dref_o ? dref_o[3 * p] : 0.f, go1 = dref_o ? dref_o[3 * p + 1] : 0.f, go2 = dref_o ? dref_o[3 * p + 2] : 0.f;
+    const float gd0 = dref_d ? dref_d[3 * p] : 0.f, gd1 = dref_d ? dref_d[3 * p + 1] : 0.f, gd2 = dref_d ? dref_d[3 * p + 2] : 0.f;
+    float de = Dw / A; const bool de_ok = fabsf(de) <= 3.0e38f; if (!de_ok) de = 0.f;
+    float dm = med; const bool dm_ok = fabsf(dm) <= 3.0e38f; if (!dm_ok) dm = 0.f;
+    const float dep = de * (1.0f - ratio) + dm * ratio;
+    // ref_o = o + d*dep
+    float gdep = (ddepth ? ddepth[p] : 0.f) + go0 * d0 + go1 * d1 + go2 * d2;
+    // ref_d = d - 2 (d.u) u,  u = w / max(|w|, eps)
+    const float len = sqrtf(w0 * w0 + w1 * w1 + w2 * w2), il = 1.0f / (len + 1e-8f);
+    const float u0 = w0 * il, u1 = w1 * il, u2 = w2 * il;
+    const float dn = d0 * u0 + d1 * u1 + d2 * u2, gu_dot = gd0 * u0 + gd1 * u1 + gd2 * u2;
+    // dL/du = -2 [ (g.u) d + (d.u) g ]
+    const float gu0 = -2.0f * (gu_dot * d0 + dn * gd0), gu1 = -2.0f * (gu_dot * d1 + dn * gd1), gu2 = -2.0f * (gu_dot * d2 + dn * gd2);
+    // u = w / (|w| + eps):  dL/dw = gu/(|w|+eps) - (gu.w) w / (|w| (|w|+eps)^2)
+    float gw0 = gu0 * il, gw1 = gu1 * il, gw2 = gu2 * il;
+    if (len > 0.0f) {
+        const float k = (gu0 * w0 + gu1 * w1 + gu2 * w2) * il * il / len;
+        gw0 -= k * w0; gw1 -= k * w1; gw2 -= k * w2;
+    }
+    if (dnw) { gw0 += dnw[p]; gw1 += dnw[HW + p]; gw2 += dnw[2 * HW + p]; }
+    // w = V3x3 n_view  ->  dL/dn_k = sum_c gw_c V[c][k]
+    dallmap[2 * HW + p] = gw0 * V[0] + gw1 * V[4] + gw2 * V[8];
+    dallmap[3 * HW + p] = gw0 * V[1] + gw1 * V[5] + gw2 * V[9];
+    dallmap[4 * HW + p] = gw0 * V[2] + gw1 * V[6] + gw2 * V[10];
+    const float gde = de_ok ? gdep * (1.0f - ratio) : 0.f;
+    dallmap[p] = gde / A;
+    dallmap[HW + p] = -gde * Dw / (A * A);
+    if (!de_ok) { dallmap[p] = 0.f; dallmap[HW + p] = 0.f; }
+    dallmap[5 * HW + p] = dm_ok ? gdep * ratio : 0.f;
+    dallmap[6 * HW + p] = 0.f;
+    if (dray_o) { dray_o[3 * p] = go0; dray_o[3 * p + 1] = go1; dray_o[3 * p + 2] = go2; }
+    if (dray_d) {
+        // ref_d: (I - 2 u u^T) g ; ref_o: dep * g_o
+        dray_d[3 * p] = gd0 - 2.0f * gu_dot * u0 + dep * go0;
+        dray_d[3 * p + 1] = gd1 - 2.0f * gu_dot * u1 + dep * go1;
+        dray_d[3 * p + 2] = gd2 - 2.0f * gu_dot * u2 + dep * go2;
+    }
+}
+
+}  // namespace envgs
+
+using namespace envgs;
+
+extern "C" {
+
+int envgs_sh_colors_forward(int32_t P, int32_t D, int32_t M, int32_t S, const float *means3D, const float *shs, const float *campos,
+                            const float *specular, const float *roughness, float *colors, uint8_t *clamped, void *stream)
+{
+    if (P < 0 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || (S != 1 && S != 3)) return ENVGS_ERR_BAD_ARG;
+    if (P == 0) return 0;
+    if (!means3D || !shs || !campos || !specular || !roughness || !colors || !clamped) return ENVGS_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sh_colors_fwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, D, M, S, means3D, shs, campos, specular,
+                       roughness, colors, clamped);
+    return (int)hipGetLastError();
+}
+
+int envgs_sh_colors_backward(int32_t P, int32_t D, int32_t M, int32_t S, const float *means3D, const float *shs, const float *campos,
+                             const uint8_t *clamped, const float *dcolors, float *dmeans3D, float *dshs, float *dspecular,
+                             float *droughness, void *stream)
+{
+    if (P < 0 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || (S != 1 && S != 3)) return ENVGS_ERR_BAD_ARG;
+    if (P == 0) return 0;
+    if (!means3D || !shs || !campos || !clamped || !dcolors || !dmeans3D || !dshs || !dspecular || !droughness) return ENVGS_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sh_colors_bwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, D, M, S, means3D, shs, campos, clamped,
+                       dcolors, dmeans3D, dshs, dspecular, droughness);
+    return (int)hipGetLastError();
+}
+
+int envgs_reflect_forward(int32_t H, int32_t W, float depth_ratio, const float *allmap, const float *ray_o, const float *ray_d,
+                          const float *viewmatrix, float *normal_world, float *depth, float *ref_o, float *ref_d, void *stream)
+{
+    if (H <= 0 || W <= 0 || !allmap || !ray_o || !ray_d || !viewmatrix || !normal_world || !depth || !ref_o || !ref_d) return ENVGS_ERR_BAD_ARG;
+    const int HW = H * W;
+    hipLaunchKernelGGL(reflect_fwd, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, HW, depth_ratio, allmap, ray_o, ray_d, viewmatrix,
+                       normal_world, depth, ref_o, ref_d);
+    return (int)hipGetLastError();
+}
+
+int envgs_reflect_backward(int32_t H, int32_t W, float depth_ratio, const float *allmap, const float *ray_o, const float *ray_d,
+                           const float *viewmatrix, const float *dnormal_world, const float *ddepth, const float *dref_o,
+                           const float *dref_d, float *dallmap, float *dray_o, float *dray_d, void *stream)
+{
+    if (H <= 0 || W <= 0 || !allmap || !ray_o || !ray_d || !viewmatrix || !dallmap) return ENVGS_ERR_BAD_ARG;
+    const int HW = H * W;
+    hipLaunchKernelGGL(reflect_bwd, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, HW, depth_ratio, allmap, ray_o, ray_d, viewmatrix,
+                       dnormal_world, ddepth, dref_o, dref_d, dallmap, dray_o, dray_d);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

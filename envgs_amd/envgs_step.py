@@ -38,6 +38,9 @@ def eval_sh(deg, sh, dirs):
     return r
 
 
+FUSED = {"on": False}      # True: use envgs_amd.fused (HIP) for the SH colours and the reflected-ray construction instead of torch
+
+
 def base_pass(pkg, cam, base, bg, sh_degree, scale_modifier=1.0):
     """render() of gaussian2d_utils.py with pipe.convert_SHs_python=True and render_reflection (ch05)."""
     dev = base["means3D"].device
@@ -46,14 +49,21 @@ def base_pass(pkg, cam, base, bg, sh_degree, scale_modifier=1.0):
         scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
         sh_degree=sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
     means2D = torch.zeros_like(base["means3D"], requires_grad=True, device=dev) + 0
-    shs_view = base["shs"].transpose(1, 2)
-    dir_pp = base["means3D"] - cam.camera_center[None]
-    dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
-    colors = torch.clamp_min(eval_sh(int(sh_degree), shs_view, dir_pp) + 0.5, 0.0)
-    colors = torch.cat([colors, base["specular"], base["roughness"]], dim=-1)
+    if FUSED["on"]:
+        from . import fused
+        colors = fused.sh_colors(base["means3D"], base["shs"], cam.camera_center, sh_degree, base["specular"], base["roughness"])
+    else:
+        shs_view = base["shs"].transpose(1, 2)
+        dir_pp = base["means3D"] - cam.camera_center[None]
+        dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+        colors = torch.clamp_min(eval_sh(int(sh_degree), shs_view, dir_pp) + 0.5, 0.0)
+        colors = torch.cat([colors, base["specular"], base["roughness"]], dim=-1)
     img, radii, allmap, weight = pkg.GaussianRasterizer(raster_settings=st)(
         means3D=base["means3D"], means2D=means2D, shs=None, colors_precomp=colors, opacities=base["opacities"],
         scales=base["scales"], rotations=base["rotations"], cov3D_precomp=None)
+    if FUSED["on"]:
+        return dict(rgb=img[:3], spec=img[3:4], rough=img[4:5], alpha=allmap[1:2], radii=radii, weight=weight, means2D=means2D,
+                    allmap=allmap)
     alpha = allmap[1:2]
     # view -> world: the reference writes this as a (HW,3)@(3,3) matmul (gaussian2d_utils.py:1123); hipBLASLt picks a 4 ms GEMM for
     # that shape on this stack, so the same 9 multiply-adds are written elementwise here (the glue is next to fuse)
@@ -86,8 +96,16 @@ def envgs_forward(pkg, tpkg, tracer, cam, rays, base, env, bg, env_bg, sh_degree
     H, W = cam.image_height, cam.image_width
     b = base_pass(pkg, cam, base, bg, sh_degree)
     ray_o, ray_d = rays
+    if FUSED["on"]:
+        from . import fused
+        nw, dep, ref_o, ref_d = fused.reflect(b["allmap"], ray_o, ray_d, cam.world_view_transform, 0.0)
+        b["normal"], b["depth"] = nw, dep
+        rgb_env, dpt, acc, norm, dist, aux, mid, wet = env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree)
+        spec = b["spec"].permute(1, 2, 0)
+        rgb = (1 - spec) * b["rgb"].permute(1, 2, 0) + spec * rgb_env
+        return dict(rgb=rgb, base=b, rgb_env=rgb_env, env_wet=wet, ref_o=ref_o, ref_d=ref_d)
     nrm = b["normal"].permute(1, 2, 0)
-    nrm = nrm / nrm.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    nrm = nrm / (nrm.norm(dim=-1, keepdim=True) + 1e-8)            # easyvolcap/utils/math_utils.py:6-8
     ref_d = ray_d - 2 * (ray_d * nrm).sum(-1, keepdim=True) * nrm
     ref_o = ray_o + ray_d * b["depth"].permute(1, 2, 0)
     rgb_env, dpt, acc, norm, dist, aux, mid, wet = env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree)

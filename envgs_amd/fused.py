@@ -1,0 +1,95 @@
+"""Fused caller-side glue (include/envgs_glue.h): drop-in replacements for the torch expressions the
+reference evaluates between its two extension calls.  Optional -- the extensions do not need them.
+
+    sh_colors(means3D, shs, campos, sh_degree, specular, roughness) -> (P, 3+S+1)
+        == cat([clamp_min(eval_sh(deg, shs^T, normalize(xyz - campos)) + 0.5, 0), specular, roughness], -1)     gaussian2d_utils.py:1071-1084
+    reflect(allmap, ray_o, ray_d, viewmatrix, depth_ratio=0.0) -> normal_world (3,H,W), depth (1,H,W), ref_o (H,W,3), ref_d (H,W,3)
+        == gaussian2d_utils.py:1119-1136 + envgs_sampler.py:420-431
+"""
+import torch
+
+from . import _lib
+from .raster import sh_degree_of
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _stream(dev):
+    return _lib.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class _ShColors(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, shs, campos, deg, specular, roughness):
+        lib = _lib.load()
+        if means3D.device.type != "cuda":
+            raise RuntimeError("envgs_amd.fused needs tensors on the GPU; there is no CPU path")
+        means3D, shs, specular, roughness = _f32c(means3D), _f32c(shs), _f32c(specular), _f32c(roughness)
+        campos = _f32c(campos).reshape(-1)
+        P, M, S = means3D.shape[0], shs.shape[1], specular.shape[1]
+        colors = torch.empty(P, 3 + S + 1, dtype=torch.float32, device=means3D.device)
+        clamped = torch.empty(P, 3, dtype=torch.uint8, device=means3D.device)
+        p = _lib.ptr
+        _lib.check(lib.envgs_sh_colors_forward(P, deg, M, S, p(means3D), p(shs), p(campos), p(specular), p(roughness), p(colors), p(clamped),
+                                               _stream(means3D.device)), "envgs_sh_colors_forward")
+        ctx.save_for_backward(means3D, shs, campos, clamped)
+        ctx.meta = (P, deg, M, S)
+        return colors
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        means3D, shs, campos, clamped = ctx.saved_tensors
+        P, deg, M, S = ctx.meta
+        g = _f32c(g)
+        dm = torch.empty_like(means3D); dsh = torch.empty_like(shs)
+        dsp = torch.empty(P, S, dtype=torch.float32, device=g.device); dr = torch.empty(P, 1, dtype=torch.float32, device=g.device)
+        p = _lib.ptr
+        _lib.check(lib.envgs_sh_colors_backward(P, deg, M, S, p(means3D), p(shs), p(campos), p(clamped), p(g), p(dm), p(dsh), p(dsp), p(dr),
+                                                _stream(g.device)), "envgs_sh_colors_backward")
+        return dm, dsh, None, None, dsp, dr
+
+
+def sh_colors(means3D, shs, campos, sh_degree, specular, roughness):
+    return _ShColors.apply(means3D, shs, campos, sh_degree_of(sh_degree), specular, roughness)
+
+
+class _Reflect(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, allmap, ray_o, ray_d, viewmatrix, depth_ratio):
+        lib = _lib.load()
+        if allmap.device.type != "cuda":
+            raise RuntimeError("envgs_amd.fused needs tensors on the GPU; there is no CPU path")
+        allmap, ray_o, ray_d, viewmatrix = _f32c(allmap), _f32c(ray_o), _f32c(ray_d), _f32c(viewmatrix)
+        _, H, W = allmap.shape
+        f32 = dict(dtype=torch.float32, device=allmap.device)
+        nw = torch.empty(3, H, W, **f32); dep = torch.empty(1, H, W, **f32)
+        ref_o = torch.empty(H, W, 3, **f32); ref_d = torch.empty(H, W, 3, **f32)
+        p = _lib.ptr
+        _lib.check(lib.envgs_reflect_forward(H, W, float(depth_ratio), p(allmap), p(ray_o), p(ray_d), p(viewmatrix), p(nw), p(dep), p(ref_o),
+                                             p(ref_d), _stream(allmap.device)), "envgs_reflect_forward")
+        ctx.save_for_backward(allmap, ray_o, ray_d, viewmatrix)
+        ctx.ratio = float(depth_ratio)
+        ctx.need = (ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return nw, dep, ref_o, ref_d
+
+    @staticmethod
+    def backward(ctx, g_nw, g_dep, g_ro, g_rd):
+        lib = _lib.load()
+        allmap, ray_o, ray_d, viewmatrix = ctx.saved_tensors
+        _, H, W = allmap.shape
+        c = lambda g: None if g is None else _f32c(g)
+        g_nw, g_dep, g_ro, g_rd = c(g_nw), c(g_dep), c(g_ro), c(g_rd)
+        dall = torch.empty_like(allmap)
+        dro = torch.empty_like(ray_o) if ctx.need[0] else None
+        drd = torch.empty_like(ray_d) if ctx.need[1] else None
+        p = _lib.ptr
+        _lib.check(lib.envgs_reflect_backward(H, W, ctx.ratio, p(allmap), p(ray_o), p(ray_d), p(viewmatrix), p(g_nw), p(g_dep), p(g_ro), p(g_rd),
+                                              p(dall), p(dro), p(drd), _stream(allmap.device)), "envgs_reflect_backward")
+        return dall, dro, drd, None, None
+
+
+def reflect(allmap, ray_o, ray_d, viewmatrix, depth_ratio=0.0):
+    return _Reflect.apply(allmap, ray_o, ray_d, viewmatrix, depth_ratio)

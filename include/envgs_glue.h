@@ -1,0 +1,54 @@
+/*
+ * envgs_glue.h -- C-ABI of the fused caller-side glue (the first "next" row after the two extensions).
+ *
+ * Between its two extension calls the reference runs ~25 full-image and ~100 per-surfel torch kernels:
+ *   - SH -> 5/7-channel colours in Python when pipe.convert_SHs_python is set (EnvGS base pass):
+ *       easyvolcap/utils/gaussian2d_utils.py:1071-1084 (+ eval_sh, easyvolcap/utils/sh_utils.py:642-727)
+ *   - reflected-ray construction from the base pass' maps:
+ *       gaussian2d_utils.py:1119-1136 (normal view->world, depth = expected/alpha mixed with the median by depth_ratio),
+ *       easyvolcap/models/samplers/envgs_sampler.py:420-431 (ref_d = d - 2(d.n)n, ref_o = o + d*depth)
+ * These entry points compute exactly those expressions (and their gradients) in ONE kernel each.  They are optional: the two
+ * extensions do not depend on them, and the unchanged reference loop simply keeps using its torch code.
+ * Conventions as in envgs_raster.h (device pointers, hipStream_t as void*, 0 = ok).
+ */
+#ifndef ENVGS_GLUE_H
+#define ENVGS_GLUE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "envgs_raster.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * colours (P, 3+S+1) = [ clamp_min(eval_sh(deg, shs, normalize(means3D - campos)) + 0.5, 0), specular (P,S), roughness (P,1) ].
+ * shs is (P, sh_coeffs, 3) (the get_features layout); clamped (P,3) uint8 is kept for the backward.
+ */
+ENVGS_API int envgs_sh_colors_forward(int32_t P, int32_t sh_degree, int32_t sh_coeffs, int32_t spec_channels,
+                                      const float *means3D, const float *shs, const float *campos, const float *specular,
+                                      const float *roughness, float *colors, uint8_t *clamped, void *stream);
+ENVGS_API int envgs_sh_colors_backward(int32_t P, int32_t sh_degree, int32_t sh_coeffs, int32_t spec_channels,
+                                       const float *means3D, const float *shs, const float *campos, const uint8_t *clamped,
+                                       const float *dcolors, float *dmeans3D, float *dshs, float *dspecular, float *droughness,
+                                       void *stream);
+
+/*
+ * Per pixel, from allmap (7,H,W) [0 depth*alpha, 1 alpha, 2-4 view normal, 5 median depth], rays (H,W,3) and the view matrix
+ * (4,4, row-vector convention as everywhere): normal_world (3,H,W), depth (1,H,W), ref_o (H,W,3), ref_d (H,W,3).
+ */
+ENVGS_API int envgs_reflect_forward(int32_t H, int32_t W, float depth_ratio, const float *allmap, const float *ray_o,
+                                    const float *ray_d, const float *viewmatrix, float *normal_world, float *depth,
+                                    float *ref_o, float *ref_d, void *stream);
+/* dallmap (7,H,W) is WRITTEN (channels 0-5; channel 6 = 0); dray_o / dray_d (H,W,3) may be NULL. */
+ENVGS_API int envgs_reflect_backward(int32_t H, int32_t W, float depth_ratio, const float *allmap, const float *ray_o,
+                                     const float *ray_d, const float *viewmatrix, const float *dnormal_world, const float *ddepth,
+                                     const float *dref_o, const float *dref_d, float *dallmap, float *dray_o, float *dray_d,
+                                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENVGS_GLUE_H */

@@ -39,11 +39,16 @@ def _run(pkg, tpkg, tracer, dev):
     return out, g
 
 
-def test_full_envgs_step_matches_oracle_end_to_end():
+@pytest.mark.parametrize("fused_glue", [False, True])
+def test_full_envgs_step_matches_oracle_end_to_end(fused_glue):
     import diff_surfel_rasterization_wet_ch05 as pkg
     import diff_surfel_tracing as tpkg
     from tests.oracle_packages import make_raster_pkg, make_trace_pkg
-    out_h, g_h = _run(pkg, tpkg, tpkg.SurfelTracer(), torch.device("cuda:0"))
+    envgs_step.FUSED["on"] = fused_glue              # HIP run: torch glue or the fused HIP glue (envgs_amd.fused)
+    try:
+        out_h, g_h = _run(pkg, tpkg, tpkg.SurfelTracer(), torch.device("cuda:0"))
+    finally:
+        envgs_step.FUSED["on"] = False
     opkg, otpkg = make_raster_pkg(5), make_trace_pkg()
     out_o, g_o = _run(opkg, otpkg, otpkg.SurfelTracer(), torch.device("cpu"))
     c = lambda t: t.detach().cpu().numpy()
