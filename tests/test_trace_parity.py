@@ -204,3 +204,40 @@ def test_trace_baseline_size_env_set_sample_vs_oracle():
     chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
     chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
     chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
+
+
+def test_trace_clustered_surfels_deep_tree():
+    """Thousands of surfels packed into a tiny cluster (identical Morton prefixes -> a very deep LBVH: exercises the HBM stack-spill
+    path of the collection pass and the index tie-break of the Karras build) plus a sparse far set; also exact ties in t (coplanar
+    surfels) ordered by surfel id."""
+    from oracle import trace as otr
+    gen = torch.Generator().manual_seed(21)
+    Pc, Pf = 3000, 200
+    means = torch.cat([torch.tensor([0.0, 0.0, 5.0]) + 0.02 * torch.randn(Pc, 3, generator=gen), (torch.rand(Pf, 3, generator=gen) * 2 - 1) * 30])
+    means[:50] = means[0]                                              # 50 exactly coincident centres
+    P = Pc + Pf
+    scales = torch.cat([0.3 + 0.3 * torch.rand(Pc, 2, generator=gen), 2 + 2 * torch.rand(Pf, 2, generator=gen)])
+    q = torch.randn(P, 4, generator=gen); q[:50] = q[0]                # ... and coplanar: identical t for every ray
+    rots = q / q.norm(dim=-1, keepdim=True)
+    opac = torch.sigmoid(torch.randn(P, 1, generator=gen) - 2.5)       # faint: long lists through the cluster
+    g = dict(means3D=means, scales=scales, rotations=rots, opacities=opac, shs=torch.randn(P, 16, 3, generator=gen) * 0.3,
+             others=torch.rand(P, 2, generator=gen), colors_precomp=torch.rand(P, 3, generator=gen))
+    R = 512
+    ro = torch.randn(R, 3, generator=gen) * 0.2
+    tgt = torch.tensor([0.0, 0.0, 5.0]) + 0.3 * torch.randn(R, 3, generator=gen)
+    rd = tgt - ro; rd = rd / rd.norm(dim=-1, keepdim=True)
+    bg = torch.tensor([0.2, 0.2, 0.2])
+    gr = [torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen), torch.randn(R, 3, generator=gen), torch.zeros(R, 2)]
+    outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, 2, True, False, grads=gr)
+    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
+    ref = otr.trace_forward(ro.numpy(), rd.numpy(), means.numpy(), scales.numpy(), rots.numpy(), opac.numpy(), shs=g["shs"].numpy(), sh_degree=2,
+                            others=g["others"].numpy(), bg=bg.numpy(), start_from_first=False)
+    assert ref["nhits"].max() > 200
+    for a, b, nm in ((rgb, ref["rgb"], "rgb"), (dpt[:, 0], ref["dpt"], "dpt"), (acc[:, 0], ref["acc"], "acc"), (wet[:, 0], ref["wet"], "wet")):
+        assert_close_frac(a, b, 2e-4, max_bad_frac=5e-3, flip_bound=0.1, what=nm)
+    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
+    chk = lambda a, b, nm: assert_close_frac(a, b, 2e-3, max_bad_frac=5e-3, flip_bound=0.3, what=nm)
+    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
+    chk(L["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"], "dopac")
+    chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
+    chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
