@@ -1,0 +1,61 @@
+"""Turn the rocprofv3 outputs merged under gpurun_out/ into the small tracked summaries in profiles/ (run after a profiling gpurun call)."""
+import collections, csv, json, os, re, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def short(n):
+    m = re.search(r'radix_sort_onesweep_iteration|radix_sort_onesweep_global_offsets|scan_impl|init_lookback_scan_state|radix_sort_block_sort|radix_sort_merge', n)
+    if m: return 'rocprim::' + m.group(0)
+    n = re.sub(r'\(.*', '', n.replace('void ', '')).replace('at::native::', 'at::')
+    return n[:90].replace(',', ';')
+
+
+def stats(tag, steps, desc):
+    path = os.path.join(ROOT, 'gpurun_out', 'p_%s' % tag, '%s_kernel_stats.csv' % tag)
+    if not os.path.exists(path): return
+    rows = list(csv.DictReader(open(path)))
+    tot = sum(float(r['TotalDurationNs']) for r in rows)
+    with open(os.path.join(ROOT, 'profiles', '%s_%s_kernel_stats.csv' % (TAG, tag)), 'w') as f:
+        f.write("# rocprofv3 --kernel-trace --stats --output-format csv (MI355X)  -- %s\n" % desc)
+        f.write("# %d steps incl. warm-up; sum of all kernel time = %.3f ms per step\n" % (steps, tot / steps / 1e6))
+        f.write("name,calls,total_ns,avg_ns,pct,ms_per_step\n")
+        for r in rows[:32]:
+            f.write("%s,%s,%s,%.0f,%s,%.4f\n" % (short(r['Name']), r['Calls'], r['TotalDurationNs'], float(r['AverageNs']), r['Percentage'], float(r['TotalDurationNs']) / steps / 1e6))
+
+
+def pmc():
+    def load(path, cname):
+        d = collections.defaultdict(list)
+        if not os.path.exists(path): return d
+        for r in csv.DictReader(open(path)):
+            if r['Counter_Name'] == cname:
+                d[re.sub(r'\(.*', '', r['Kernel_Name'].replace('void ', ''))].append(float(r['Counter_Value']))
+        return d
+    f = load(os.path.join(ROOT, 'gpurun_out/pmc_fetch/f_counter_collection.csv'), 'FETCH_SIZE')
+    w = load(os.path.join(ROOT, 'gpurun_out/pmc_write/w_counter_collection.csv'), 'WRITE_SIZE')
+    names = {'envgs::composite_fwd<5>': 'composite_fwd', 'envgs::composite_bwd<5>': 'composite_bwd', 'envgs::project_surfels': 'project_surfels',
+             'envgs::project_surfels_bwd': 'project_surfels_bwd', 'envgs::emit_tile_keys': 'emit_tile_keys', 'envgs::find_tile_ranges': 'find_tile_ranges',
+             'envgs::collect_hits': 'trace.collect_hits', 'envgs::sort_hit_lists': 'trace.sort_hit_lists', 'envgs::composite_lists_fwd': 'trace.composite_lists_fwd',
+             'envgs::register_hits': 'trace.register_hits', 'envgs::composite_lists_bwd_records': 'trace.composite_lists_bwd',
+             'envgs::reduce_surfel_records': 'trace.reduce_surfel_records'}
+    out = {"_how": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / rocprofv3 --pmc WRITE_SIZE --kernel-trace (two separate passes, no other trace domains) -- "
+                   "python bench.py --steps 3 --warmup 1 --no-cpu-baseline on MI355X; per-launch averages. Units per MI355X_MICROARCH.md: counters are KB; on gfx950 "
+                   "FETCH_SIZE reports 1/2 of the bytes of 16 B/lane reads, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024. WRITE_SIZE is uncalibrated "
+                   "(scattered 4-8 B stores are counted at 32 B granularity).", "kernels": {}}
+    for k, v in names.items():
+        if k in f:
+            fv = sum(f[k]) / len(f[k]); wv = sum(w[k]) / len(w[k]) if k in w else 0
+            out["kernels"][v] = {"FETCH_SIZE_KB": round(fv, 1), "WRITE_SIZE_KB": round(wv, 1), "hbm_bytes": int((2 * fv + wv) * 1024)}
+    if out["kernels"]:
+        json.dump(out, open(os.path.join(ROOT, 'profiles', '%s_pmc_envgs.json' % TAG), 'w'), indent=1)
+
+
+stats('envgs', 24, 'full EnvGS step: 300k base surfels ch05 raster + 163840 env surfels LBVH trace, 800x800; python bench.py --steps 20 --warmup 4 --no-cpu-baseline')
+stats('raster', 34, 'raster only: 300k surfels, SH deg 3 in-kernel, 800x800; python bench.py --workload raster --steps 30 --warmup 4 --no-cpu-baseline')
+pmc()
+for n in ('envgs', 'raster'):
+    src = os.path.join(ROOT, 'gpurun_out', 'bench_%s_final.json' % n)
+    if os.path.exists(src) and os.path.getsize(src) > 10:
+        open(os.path.join(ROOT, 'profiles', '%s_bench_%s.json' % (TAG, n)), 'w').write(open(src).read())
