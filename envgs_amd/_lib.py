@@ -19,6 +19,12 @@ class RasterCfg(ctypes.Structure):
                 ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float)]
 
 
+class AdamTensor(ctypes.Structure):
+    """struct envgs_adam_tensor (include/envgs_optim.h)."""
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("numel", ctypes.c_int64), ("lr", ctypes.c_float), ("step", ctypes.c_float)]
+
+
 class TraceLists(ctypes.Structure):
     """struct envgs_trace_lists (include/envgs_trace.h)."""
     _fields_ = [("hit_lists", ctypes.c_void_p), ("hit_cnt", ctypes.c_void_p), ("n_used", ctypes.c_void_p), ("cap", ctypes.c_int32),
@@ -56,6 +62,7 @@ SYMBOLS = {
     "envgs_sh_colors_backward": (c_int, [ctypes.c_int32] * 4 + [_P] * 9 + [_P]),
     "envgs_reflect_forward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float] + [_P] * 8 + [_P]),
     "envgs_reflect_backward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float] + [_P] * 11 + [_P]),
+    "envgs_fused_adam": (c_int, [ctypes.c_int32, ctypes.POINTER(AdamTensor), ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
     "envgs_prof_enable": (None, [c_int]),
     "envgs_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     "envgs_prof_kernel_name": (ctypes.c_char_p, [c_int]),

@@ -20,7 +20,7 @@ class _Cfg(ctypes.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("surfel_raster_oracle.c", "surfel_trace_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("surfel_raster_oracle.c", "surfel_trace_oracle.c", "adam_oracle.c")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
