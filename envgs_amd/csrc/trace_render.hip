@@ -929,34 +929,70 @@ composite_lists_fwd(const TraceArgs A)
     }
 }
 
-// Register every composited hit with its surfel: ONE returning 64-bit atomic does count++ (the old count is the hit's slot among the
-// surfel's hits, which is where the backward will put its gradient record) and weight += w in 40-bit fixed point (rounded up, so any
-// contribution keeps the surfel "visible").  Nothing here depends on anything else, so 8 atomics per lane are kept in flight.
-__global__ void __launch_bounds__(256)
+// Register every composited hit with its surfel: count++ (the old count is the hit's slot among the surfel's hits, which is where the
+// backward will put its gradient record) and weight += w in 40-bit fixed point (rounded up, so any contribution keeps the surfel
+// "visible"), both in ONE returning 64-bit atomic.  Device-scope atomics run at ~10 G/s on this chip whatever their width or scope, so
+// the kernel issues as few as possible: the 64 rays of a (coherence-sorted) batch mostly composite the SAME surfels (measured: 27 hits
+// per distinct surfel per batch), so a wavefront first merges its batch in an LDS hash table (ds_cmpst / ds_add: count -> rank inside
+// the batch, weight sum), then spends one global atomic per DISTINCT surfel and hands slot = returned base + rank back to the lists.
+constexpr int RH_TAB = 1024;
+__global__ void __launch_bounds__(64)
 register_hits(const TraceArgs A)
 {
-    constexpr int U = 8;
+    __shared__ int key[RH_TAB];
+    __shared__ unsigned cnt[RH_TAB];                 // hits of this surfel in the batch; after the flush: slot of the first of them
+    __shared__ unsigned long long wsum[RH_TAB];
+    const int lane = threadIdx.x;
     const float wscale = __builtin_ldexpf(1.0f, A.wfrac);
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < A.R; r += gridDim.x * 256) {
-        if (A.hit_cnt[r] > A.cap) continue;
-        const int n = A.n_used[r];
-        uint2 *list = A.hits + (size_t)r * A.cap;
+    for (int base = blockIdx.x * 64; base < A.R; base += gridDim.x * 64) {
+        const int copy = (base >> 6) & (NCOPY - 1);
+        __syncthreads();
+        for (int i = lane; i < RH_TAB; i += 64) { key[i] = -1; cnt[i] = 0u; wsum[i] = 0ull; }
+        __syncthreads();
+        const int r = ray_of(A, base + lane);
+        int n = 0;
+        uint2 *list = A.hits;
+        if (r < A.R && A.hit_cnt[r] <= A.cap) { n = A.n_used[r]; list = A.hits + (size_t)r * A.cap; }
+        constexpr int U = 4;
         for (int kb = 0; kb < n; kb += U) {
             uint2 e[U];
-            unsigned long long old[U];
 #pragma unroll
             for (int j = 0; j < U; j++) e[j] = (kb + j < n) ? list[kb + j] : make_uint2(0u, 0u);
 #pragma unroll
             for (int j = 0; j < U; j++) {
-                old[j] = 0;
-                if (kb + j < n) {
-                    const unsigned long long wq = (unsigned long long)ceilf(__uint_as_float(e[j].x) * wscale);
-                    old[j] = atomicAdd(A.surf_acc + (size_t)e[j].y * NCOPY + (r & (NCOPY - 1)), (wq << 24) | 1ull);
+                if (kb + j >= n) break;
+                const unsigned long long wq = (unsigned long long)ceilf(__uint_as_float(e[j].x) * wscale);
+                unsigned h = (e[j].y * 2654435761u) >> 22;
+                bool ok = false;
+                for (int t = 0; t < 24; t++) {
+                    const int old = atomicCAS(&key[h], -1, (int)e[j].y);
+                    if (old == -1 || old == (int)e[j].y) { ok = true; break; }
+                    h = (h + 1) & (RH_TAB - 1);
                 }
+                unsigned x;
+                if (ok) {
+                    const unsigned rank = atomicAdd(&cnt[h], 1u);
+                    atomicAdd(&wsum[h], wq);
+                    x = (h << 8) | rank;                                  // rank < 64: a ray meets a planar surfel once
+                } else {                                                  // table full around h: register this hit directly
+                    const unsigned long long old = atomicAdd(A.surf_acc + (size_t)e[j].y * NCOPY + copy, (wq << 24) | 1ull);
+                    x = 0x80000000u | (unsigned)(old & 0xFFFFFFull);
+                }
+                list[kb + j].x = x;
             }
-#pragma unroll
-            for (int j = 0; j < U; j++)
-                if (kb + j < n) list[kb + j].x = (unsigned)(old[j] & 0xFFFFFFull);
+        }
+        __syncthreads();
+        for (int i = lane; i < RH_TAB; i += 64) {
+            const int sid = key[i];
+            if (sid >= 0) {
+                const unsigned long long old = atomicAdd(A.surf_acc + (size_t)sid * NCOPY + copy, (wsum[i] << 24) | (unsigned long long)cnt[i]);
+                cnt[i] = (unsigned)(old & 0xFFFFFFull);
+            }
+        }
+        __syncthreads();
+        for (int k = 0; k < n; k++) {
+            const unsigned x = list[k].x;
+            list[k].x = (x >> 31) ? (x & 0xFFFFFFu) : cnt[x >> 8] + (x & 255u);
         }
     }
 }
@@ -1043,7 +1079,7 @@ composite_lists_bwd_records(const TraceArgs A)
             const int sid = (int)e.y;
             float dc0, dc1, dc2, gv[15];
             if (!bwd_hit(A, B, acc, basis, nb, sid, dc0, dc1, dc2, gv)) break;      // cannot happen: same arithmetic as the forward
-            const size_t ci = (size_t)sid * NCOPY + (r & (NCOPY - 1));
+            const size_t ci = (size_t)sid * NCOPY + ((base >> 6) & (NCOPY - 1));
             const unsigned long long idx = (unsigned long long)(A.surf_off[ci] - A.surf_cnt[ci]) + e.x;
             if (idx < A.num_records) {
                 float4 *o = reinterpret_cast<float4 *>(A.records + idx * RECW);
@@ -1251,7 +1287,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         ENVGS_CHECK_LAUNCH(dcfg, stream);
         { ProfScope p3(K_TRACE_COMPOSITE, stream); hipLaunchKernelGGL(composite_lists_fwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
-        { ProfScope p8(K_TRACE_REGISTER, stream); hipLaunchKernelGGL(register_hits, dim3(stride_grid(cfg->num_rays, 256)), dim3(256), 0, stream, A); }
+        { ProfScope p8(K_TRACE_REGISTER, stream); hipLaunchKernelGGL(register_hits, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
         hipLaunchKernelGGL(unpack_surfel_acc, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, A.wfrac, A.surf_acc, L->surf_cnt, wet);
         ENVGS_CHECK_LAUNCH(dcfg, stream);
