@@ -236,10 +236,26 @@ struct StageSums { float rgb[3], dpt, acc, nrm[3], dist, aux[2], T, M1, M2; };
 __device__ __forceinline__ void surfel_color(const TraceArgs &A, int sid, const float *basis, float *col, bool *cl)
 {
     if (A.M > 0) {
-        const float *sh = A.shs + (size_t)sid * A.M * 3;
         const int nb = (A.D + 1) * (A.D + 1);
         float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-        for (int k = 0; k < nb; k++) { const float b = basis[k]; r0 += b * sh[k * 3]; r1 += b * sh[k * 3 + 1]; r2 += b * sh[k * 3 + 2]; }
+        if (A.M == 16) {
+            // the usual layout (16 coefficients x RGB = 192 B, 16 B aligned): 12 x 16 B loads instead of 48 x 4 B gathers
+            const float4 *s4 = reinterpret_cast<const float4 *>(A.shs + (size_t)sid * 48);
+            const int nq = (nb * 3 + 3) >> 2;
+            float v[48];
+#pragma unroll
+            for (int q = 0; q < 12; q++) {
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < nq) x = s4[q];
+                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k < nb) { const float b = basis[k]; r0 += b * v[k * 3]; r1 += b * v[k * 3 + 1]; r2 += b * v[k * 3 + 2]; }
+        } else {
+            const float *sh = A.shs + (size_t)sid * A.M * 3;
+            for (int k = 0; k < nb; k++) { const float b = basis[k]; r0 += b * sh[k * 3]; r1 += b * sh[k * 3 + 1]; r2 += b * sh[k * 3 + 2]; }
+        }
         r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
         cl[0] = r0 < 0.f; cl[1] = r1 < 0.f; cl[2] = r2 < 0.f;
         col[0] = cl[0] ? 0.f : r0; col[1] = cl[1] ? 0.f : r1; col[2] = cl[2] ? 0.f : r2;
@@ -981,6 +997,130 @@ sort_hit_lists(const TraceArgs A)
     }
 }
 
+// Inclusive scans over the wavefront (Hillis-Steele on ds_bpermute; a handful per 64 hits).
+__device__ __forceinline__ float wave_scan_add(float v, const int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); v += lane >= o ? t : 0.f; }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_mul(float v, const int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); v *= lane >= o ? t : 1.f; }
+    return v;
+}
+__device__ __forceinline__ float wave_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+
+// Sort AND composite, one wavefront per ray, one LANE per hit.  The lane-per-ray walk (composite_lists_fwd) is a chain of dependent
+// gathers -- list entry -> surfel record + SH block -> blend -> next entry -- whose length is the ray's hit count; here the 64 hits of
+// a chunk fetch their records independently (all gathers in flight at once) and the front-to-back recurrences (transmittance product,
+// the two distortion moments) become wavefront scans.  The sorted list is written back only up to the terminating hit.
+__global__ void __launch_bounds__(64)
+sort_composite_fwd(const TraceArgs A)
+{
+    __shared__ unsigned long long keys[SORT_MAX];
+    const int lane = threadIdx.x;
+    unsigned st_hits = 0;
+    for (int slot = blockIdx.x; slot < A.R; slot += gridDim.x) {
+        const int r = ray_of(A, slot);
+        const int n = A.hit_cnt[r];
+        if (n > A.cap) continue;                            // overflow: the K-buffer kernel owns this ray
+        uint2 *list = A.hits + (size_t)r * A.cap;
+        __syncthreads();
+        if (n >= 2) {
+            int np = 2;
+            while (np < n) np <<= 1;
+            for (int i = lane; i < np; i += 64) {
+                unsigned long long k = ~0ull;
+                if (i < n) { const uint2 e = list[i]; k = ((unsigned long long)e.x << 32) | e.y; }
+                keys[i] = k;
+            }
+            __syncthreads();
+            for (int size = 2; size <= np; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int i = lane; i < (np >> 1); i += 64) {
+                        const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+                        const int hi = lo + stride;
+                        const bool up = ((lo & size) == 0);
+                        const unsigned long long a = keys[lo], b = keys[hi];
+                        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+                    }
+                    __syncthreads();
+                }
+        } else if (n == 1 && lane == 0) {
+            const uint2 e = list[0];
+            keys[0] = ((unsigned long long)e.x << 32) | e.y;
+        }
+        __syncthreads();
+        const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
+        const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
+        float basis[16];
+        {
+            const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+            sh_basis(A.D, dx * il, dy * il, dz * il, basis);
+        }
+        float T = 1.0f, M1 = 0.f, M2 = 0.f;                 // carried across chunks (wave-uniform)
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, dpt = 0.f, acc = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, dist = 0.f, x0 = 0.f, x1 = 0.f;   // per-lane partial sums
+        int used = 0;
+        for (int cb = 0; cb < n; cb += 64) {
+            const int i = cb + lane;
+            const bool has = i < n;
+            int sid = 0;
+            float alpha = 0.f, t = 0.f, sg = 0.f;
+            float4 s3 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has) {
+                sid = (int)(unsigned)keys[i];
+                const float4 *sr = A.srec + (size_t)sid * 4;
+                s3 = sr[3];
+                const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], s3, ox, oy, oz, dx, dy, dz);
+                alpha = h.alpha; t = h.t; sg = h.denom < 0.0f ? 1.f : -1.f;
+            }
+            const float P = wave_scan_mul(1.0f - alpha, lane);              // prod_{j<=i} (1 - alpha_j) within the chunk
+            float Pex = __shfl_up(P, 1); Pex = lane == 0 ? 1.f : Pex;
+            const float test_T = T * P, Tb = T * Pex;                       // transmittance after / before this hit
+            const unsigned long long stop = __ballot(has && test_T < T_EPS);
+            const int f = stop ? (int)__builtin_ctzll(stop) : 64;           // first terminating lane: it and everything behind is dropped
+            const bool use = has && lane < f;
+            const float w = use ? alpha * Tb : 0.f;
+            float col[3] = {0.f, 0.f, 0.f}; bool cl[3];
+            if (use) surfel_color(A, sid, basis, col, cl);
+            const float tt = t > NEAR_N ? t : NEAR_N;
+            const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / tt);
+            const float mw = m * w, mmw = m * m * w;
+            const float S1 = wave_scan_add(mw, lane), S2 = wave_scan_add(mmw, lane);
+            const float M1b = M1 + (S1 - mw), M2b = M2 + (S2 - mmw);        // moments before this hit
+            dist += (m * m * (1.0f - Tb) + M2b - 2.0f * m * M1b) * w;
+            c0 += w * col[0]; c1 += w * col[1]; c2 += w * col[2];
+            dpt += w * t; acc += w;
+            n0 += sg * w * s3.x; n1 += sg * w * s3.y; n2 += sg * w * s3.z;
+            if (A.has_others && use) { x0 += w * A.others[2 * sid]; x1 += w * A.others[2 * sid + 1]; }
+            if (use) list[i] = make_uint2(__float_as_uint(w), (unsigned)sid);
+            const int nu = f < 64 ? f : min(64, n - cb);                    // hits of this chunk that were blended
+            used += nu;
+            M1 += wave_bcast(S1, 63); M2 += wave_bcast(S2, 63);
+            if (nu > 0) T = T * wave_bcast(P, nu - 1);
+            if (f < 64) break;
+        }
+        st_hits += (unsigned)used;
+        c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2); dpt = wave_sum(dpt); acc = wave_sum(acc);
+        n0 = wave_sum(n0); n1 = wave_sum(n1); n2 = wave_sum(n2); dist = wave_sum(dist); x0 = wave_sum(x0); x1 = wave_sum(x1);
+        if (lane == 0) {
+            A.n_used[r] = used;
+            c0 += T * (0 < A.bg_len ? A.bg[0] : 0.f); c1 += T * (1 < A.bg_len ? A.bg[1] : 0.f); c2 += T * (2 < A.bg_len ? A.bg[2] : 0.f);
+            A.rgb[3 * r] = c0; A.rgb[3 * r + 1] = c1; A.rgb[3 * r + 2] = c2;
+            A.dpt[r] = dpt; A.acc[r] = acc; A.dist[r] = dist;
+            A.norm[3 * r] = n0; A.norm[3 * r + 1] = n1; A.norm[3 * r + 2] = n2;
+            A.aux[2 * r] = x0; A.aux[2 * r + 1] = x1;
+            A.final_T[r] = T;
+            float *mm = A.mid + (size_t)r * MID;
+            mm[0] = ox; mm[1] = oy; mm[2] = oz; mm[3] = dx; mm[4] = dy; mm[5] = dz; mm[6] = dpt; mm[7] = acc;
+            mm[8] = n0; mm[9] = n1; mm[10] = n2; mm[11] = x0; mm[12] = x1; mm[13] = c0; mm[14] = c1; mm[15] = c2;
+        }
+    }
+    if (A.stats && lane == 0) atomicAdd(A.stats + 0, (unsigned long long)st_hits);
+}
+
 __global__ void __launch_bounds__(64)
 composite_lists_fwd(const TraceArgs A)
 {
@@ -1405,9 +1545,14 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
                 hipLaunchKernelGGL(collect_hits, dim3(persistent_grid(cfg->num_rays, 24)), dim3(64), 0, stream, A);
         }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
-        { ProfScope p2(K_TRACE_SORT, stream); hipLaunchKernelGGL(sort_hit_lists, dim3(stride_grid(cfg->num_rays, 1)), dim3(64), 0, stream, A); }
-        ENVGS_CHECK_LAUNCH(dcfg, stream);
-        { ProfScope p3(K_TRACE_COMPOSITE, stream); hipLaunchKernelGGL(composite_lists_fwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
+        if (!(A.exp & 1024)) {
+            ProfScope p2(K_TRACE_SORT, stream);
+            hipLaunchKernelGGL(sort_composite_fwd, dim3(stride_grid(cfg->num_rays, 1)), dim3(64), 0, stream, A);
+        } else {
+            { ProfScope p2(K_TRACE_SORT, stream); hipLaunchKernelGGL(sort_hit_lists, dim3(stride_grid(cfg->num_rays, 1)), dim3(64), 0, stream, A); }
+            ENVGS_CHECK_LAUNCH(dcfg, stream);
+            { ProfScope p3(K_TRACE_COMPOSITE, stream); hipLaunchKernelGGL(composite_lists_fwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
+        }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
         { ProfScope p8(K_TRACE_REGISTER, stream); hipLaunchKernelGGL(register_hits, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
