@@ -233,6 +233,28 @@ __device__ __forceinline__ void traverse(const TraceArgs &A, int (*stk)[64], con
 
 struct StageSums { float rgb[3], dpt, acc, nrm[3], dist, aux[2], T, M1, M2; };
 
+// SH block of one surfel into registers (zeros beyond the active degree).
+__device__ __forceinline__ void load_sh(const TraceArgs &A, const int sid, const int nb, float *v)
+{
+    if (A.M == 16) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(A.shs + (size_t)sid * 48);
+        const int nq = (nb * 3 + 3) >> 2;
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < nq) x = s4[q];
+            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+        }
+    } else {
+        const float *sh = A.shs + (size_t)sid * A.M * 3;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const bool in = k < nb;
+            v[k * 3] = in ? sh[k * 3] : 0.f; v[k * 3 + 1] = in ? sh[k * 3 + 1] : 0.f; v[k * 3 + 2] = in ? sh[k * 3 + 2] : 0.f;
+        }
+    }
+}
+
 __device__ __forceinline__ void surfel_color(const TraceArgs &A, int sid, const float *basis, float *col, bool *cl)
 {
     if (A.M > 0) {
@@ -481,7 +503,17 @@ __device__ __forceinline__ bool bwd_hit(const TraceArgs &A, const BwdRay &B, Bwd
     const float T = a.T;
     const float w = alpha * T;
     float col[3]; bool cl[3];
-    surfel_color(A, sid, basis, col, cl);
+    float shv[48];
+    if (A.M > 0) {
+        load_sh(A, sid, nb, shv);
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k < nb) { const float b = basis[k]; r0 += b * shv[k * 3]; r1 += b * shv[k * 3 + 1]; r2 += b * shv[k * 3 + 2]; }
+        r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+        cl[0] = r0 < 0.f; cl[1] = r1 < 0.f; cl[2] = r2 < 0.f;
+        col[0] = cl[0] ? 0.f : r0; col[1] = cl[1] ? 0.f : r1; col[2] = cl[2] ? 0.f : r2;
+    } else surfel_color(A, sid, basis, col, cl);
     const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
     const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
     const float x0 = A.has_others ? A.others[2 * sid] : 0.f, x1 = A.has_others ? A.others[2 * sid + 1] : 0.f;
@@ -499,10 +531,9 @@ __device__ __forceinline__ bool bwd_hit(const TraceArgs &A, const BwdRay &B, Bwd
     dc0 = cl[0] ? 0.f : w * B.gR0; dc1 = cl[1] ? 0.f : w * B.gR1; dc2 = cl[2] ? 0.f : w * B.gR2;
     if (A.M > 0) {
         // dL/d(dir) = sum_k grad(basis_k) * (sh_k . dc): accumulate the 16 scalars, apply grad(basis) once per ray
-        const float *sh = A.shs + (size_t)sid * A.M * 3;
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            if (k < nb) a.Sk[k] += sh[k * 3] * dc0 + sh[k * 3 + 1] * dc1 + sh[k * 3 + 2] * dc2;
+            if (k < nb) a.Sk[k] += shv[k * 3] * dc0 + shv[k * 3 + 1] * dc1 + shv[k * 3 + 2] * dc2;
     }
     if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * B.gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * B.gX1); }
     const float dLG = s0.w * dLa;
@@ -1351,6 +1382,123 @@ composite_lists_bwd_records(const TraceArgs A)
     }
 }
 
+// Backward of the list path, one wavefront per ray, one LANE per hit (the counterpart of sort_composite_fwd): every hit's records are
+// gathered independently, the ten running sums and the transmittance product of the lane-per-ray form become wavefront scans, and each
+// lane writes its hit's 96 B gradient record at  surf_off - surf_cnt + slot  (grouped by surfel, no sort, no atomics).
+__global__ void __launch_bounds__(64)
+composite_bwd_scan_records(const TraceArgs A)
+{
+    const int lane = threadIdx.x;
+    const int nb = (A.D + 1) * (A.D + 1);
+    for (int slot = blockIdx.x; slot < A.R; slot += gridDim.x) {
+        const int r = ray_of(A, slot);
+        if (A.hit_cnt[r] > A.cap) continue;                 // overflow rays: K-buffer backward (atomic flush)
+        BwdRay B;
+        bwd_load_ray(A, r, B);
+        float basis[16];
+        sh_basis(A.D, B.ux, B.uy, B.uz, basis);
+        const int n = A.n_used[r];
+        const uint2 *list = A.hits + (size_t)r * A.cap;
+        const int copy = (slot >> 6) & (NCOPY - 1);
+        float T = 1.0f, C[10];
+#pragma unroll
+        for (int j = 0; j < 10; j++) C[j] = 0.f;
+        float Sk[16], dO0 = 0.f, dO1 = 0.f, dO2 = 0.f, dD0 = 0.f, dD1 = 0.f, dD2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) Sk[k] = 0.f;
+        for (int cb = 0; cb < n; cb += 64) {
+            const int i = cb + lane;
+            const bool has = i < n;
+            uint2 e = make_uint2(0u, 0u);
+            if (has) e = list[i];
+            const int sid = (int)e.y;
+            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+            SurfHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.G = 0.f; h.alpha = 0.f; h.denom = 1.f; h.ok = false;
+            float col[3] = {0.f, 0.f, 0.f}; bool cl[3] = {false, false, false};
+            float shv[48];
+            float x0 = 0.f, x1 = 0.f;
+            if (has) {
+                const float4 *sr = A.srec + (size_t)sid * 4;
+                s0 = sr[0]; s1 = sr[1]; s2 = sr[2]; s3 = sr[3];
+                h = hit_surfel(s0, s1, s2, s3, B.ox, B.oy, B.oz, B.dx, B.dy, B.dz);
+                if (A.M > 0) {
+                    load_sh(A, sid, nb, shv);
+                    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        if (k < nb) { const float b = basis[k]; r0 += b * shv[k * 3]; r1 += b * shv[k * 3 + 1]; r2 += b * shv[k * 3 + 2]; }
+                    r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+                    cl[0] = r0 < 0.f; cl[1] = r1 < 0.f; cl[2] = r2 < 0.f;
+                    col[0] = cl[0] ? 0.f : r0; col[1] = cl[1] ? 0.f : r1; col[2] = cl[2] ? 0.f : r2;
+                } else {
+                    col[0] = A.colors[3 * sid]; col[1] = A.colors[3 * sid + 1]; col[2] = A.colors[3 * sid + 2];
+                }
+                if (A.has_others) { x0 = A.others[2 * sid]; x1 = A.others[2 * sid + 1]; }
+            }
+            const float alpha = has ? h.alpha : 0.f;
+            const float P = wave_scan_mul(1.0f - alpha, lane);
+            float Pex = __shfl_up(P, 1); Pex = lane == 0 ? 1.f : Pex;
+            const float Tb = T * Pex;
+            const float w = alpha * Tb;
+            const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
+            const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
+            float S[10] = {w * col[0], w * col[1], w * col[2], w * h.t, w, w * nf0, w * nf1, w * nf2, w * x0, w * x1};
+#pragma unroll
+            for (int j = 0; j < 10; j++) S[j] = C[j] + wave_scan_add(S[j], lane);      // inclusive: this hit already added
+            if (has) {
+                const float inv1m = 1.0f / (1.0f - alpha);
+                float dLa = B.gR0 * (Tb * col[0] - (B.fr0 - S[0]) * inv1m) + B.gR1 * (Tb * col[1] - (B.fr1 - S[1]) * inv1m) + B.gR2 * (Tb * col[2] - (B.fr2 - S[2]) * inv1m);
+                dLa += B.gD * (Tb * h.t - (B.fD - S[3]) * inv1m);
+                dLa += B.gA * (Tb - (B.fA - S[4]) * inv1m);
+                dLa += B.gN0 * (Tb * nf0 - (B.fN0 - S[5]) * inv1m) + B.gN1 * (Tb * nf1 - (B.fN1 - S[6]) * inv1m) + B.gN2 * (Tb * nf2 - (B.fN2 - S[7]) * inv1m);
+                dLa += B.gX0 * (Tb * x0 - (B.fX0 - S[8]) * inv1m) + B.gX1 * (Tb * x1 - (B.fX1 - S[9]) * inv1m);
+                dLa += -(B.fT * inv1m) * B.bgdot;
+                const float dc0 = cl[0] ? 0.f : w * B.gR0, dc1 = cl[1] ? 0.f : w * B.gR1, dc2 = cl[2] ? 0.f : w * B.gR2;
+                if (A.M > 0) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        if (k < nb) Sk[k] += shv[k * 3] * dc0 + shv[k * 3 + 1] * dc1 + shv[k * 3 + 2] * dc2;
+                }
+                if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * B.gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * B.gX1); }
+                const float dLG = s0.w * dLa;
+                const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
+                const float su = s1.w, sv = s2.w;
+                const float qx = B.ox + h.t * B.dx - s0.x, qy = B.oy + h.t * B.dy - s0.y, qz = B.oz + h.t * B.dz - s0.z;
+                const float dq0 = dLu * s1.x + dLv * s2.x, dq1 = dLu * s1.y + dLv * s2.y, dq2 = dLu * s1.z + dLv * s2.z;
+                const float cu = dLu / su, cv = dLv / sv;
+                const float dLt_tot = w * B.gD + dq0 * B.dx + dq1 * B.dy + dq2 * B.dz;
+                const float kt = dLt_tot / h.denom;
+                const size_t ci = (size_t)sid * NCOPY + copy;
+                const unsigned long long idx = (unsigned long long)(A.surf_off[ci] - A.surf_cnt[ci]) + e.x;
+                if (idx < A.num_records) {
+                    float4 *o = reinterpret_cast<float4 *>(A.records + idx * RECW);
+                    o[0] = make_float4(B.ux, B.uy, B.uz, dc0);
+                    o[1] = make_float4(dc1, dc2, -dq0 + kt * s3.x, -dq1 + kt * s3.y);
+                    o[2] = make_float4(-dq2 + kt * s3.z, cu * qx, cu * qy, cu * qz);
+                    o[3] = make_float4(cv * qx, cv * qy, cv * qz, w * sgn * B.gN0 - kt * qx);
+                    o[4] = make_float4(w * sgn * B.gN1 - kt * qy, w * sgn * B.gN2 - kt * qz, -dLu * h.u / su * A.mod, -dLv * h.v / sv * A.mod);
+                    o[5] = make_float4(h.G * dLa, 0.f, 0.f, 0.f);
+                }
+                const float e0 = dq0 - kt * s3.x, e1 = dq1 - kt * s3.y, e2 = dq2 - kt * s3.z;
+                dO0 += e0; dO1 += e1; dO2 += e2;
+                dD0 += h.t * e0; dD1 += h.t * e1; dD2 += h.t * e2;
+            }
+#pragma unroll
+            for (int j = 0; j < 10; j++) C[j] = wave_bcast(S[j], 63);
+            T = T * wave_bcast(P, 63);
+        }
+        BwdAcc acc;
+        bwd_init_acc(acc);
+        acc.dO0 = wave_sum(dO0); acc.dO1 = wave_sum(dO1); acc.dO2 = wave_sum(dO2);
+        acc.dD0 = wave_sum(dD0); acc.dD1 = wave_sum(dD1); acc.dD2 = wave_sum(dD2);
+        if (A.M > 0) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc.Sk[k] = k < nb ? wave_sum(Sk[k]) : 0.f;
+        }
+        if (lane == 0) bwd_store_ray(A, r, B, acc);
+    }
+}
+
 // Stage 2: one wavefront per surfel streams that surfel's contiguous records (coalesced 96 B reads), accumulates the (16,3)
 // SH gradient block and the 15 geometry words in registers, reduces across the wavefront with DPP and leaves as ONE
 // instruction per surfel -- the same word layout as the cooperative flush, so both paths add into the same buffers.
@@ -1618,7 +1766,11 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
             if (L->records && L->num_records > 0 && L->surf_cnt && L->surf_off && !(A.exp & 8)) {
                 // atomic-free: per-hit records grouped by surfel, then one wavefront per surfel reduces its segment
                 A.surf_cnt = L->surf_cnt; A.surf_off = L->surf_off; A.records = L->records; A.num_records = L->num_records;
-                { ProfScope p5(K_TRACE_LIST_BWD, stream); hipLaunchKernelGGL(composite_lists_bwd_records, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
+                {
+                    ProfScope p5(K_TRACE_LIST_BWD, stream);
+                    if (A.exp & 2048) hipLaunchKernelGGL(composite_bwd_scan_records, dim3(stride_grid(cfg->num_rays, 1)), dim3(64), 0, stream, A);
+                    else hipLaunchKernelGGL(composite_lists_bwd_records, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A);
+                }
                 { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 1)), dim3(256), 0, stream, A); }
             } else {
                 ProfScope p5(K_TRACE_LIST_BWD, stream);
