@@ -32,7 +32,8 @@ class TraceLists(ctypes.Structure):
                 ("scan_temp", ctypes.c_void_p), ("scan_temp_bytes", ctypes.c_size_t), ("ray_keys", ctypes.c_void_p),
                 ("ray_order", ctypes.c_void_p), ("ray_sort_temp", ctypes.c_void_p), ("ray_sort_temp_bytes", ctypes.c_size_t),
                 ("records", ctypes.c_void_p),
-                ("num_records", ctypes.c_uint64)]
+                ("num_records", ctypes.c_uint64), ("hit_state", ctypes.c_void_p), ("entries", ctypes.c_void_p), ("pairs", ctypes.c_void_p),
+                ("n_entries", ctypes.c_void_p)]
 
 
 class TraceCfg(ctypes.Structure):

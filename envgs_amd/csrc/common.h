@@ -47,11 +47,63 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 
+typedef unsigned envgs_u2 __attribute__((ext_vector_type(2)));
+
+// Sum 64 per-lane values over the wavefront, value v ending in lane v (a full 64 x 64 transpose-reduce in ~140 instructions):
+// v_permlane32_swap and v_permlane16_swap fold the four 16-lane rows together two values per instruction (row r then owns values
+// 16r..16r+15), and inside a row a butterfly halves the value count per step -- each lane keeps the half its own lane-id bit selects and
+// receives the partner's contribution to that half through DPP (row_mirror, row_half_mirror, quad reversals pair lanes across bit 3,2,1,0).
+__device__ __forceinline__ float wave_reduce64(const float (&g)[64], const int lane)
+{
+    float z[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const envgs_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(g[i]), __float_as_uint(g[i + 32]), false, false);
+        z[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    float w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const envgs_u2 q = __builtin_amdgcn_permlane16_swap(__float_as_uint(z[k]), __float_as_uint(z[k + 16]), false, false);
+        w[k] = __uint_as_float(q.x) + __uint_as_float(q.y);
+    }
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = (b3 ? w[k + 8] : w[k]) + dpp_mov<0x140>(b3 ? w[k] : w[k + 8]);       // partner lane ^ 15
+    float b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) b[k] = (b2 ? a[k + 4] : a[k]) + dpp_mov<0x141>(b2 ? a[k] : a[k + 4]);       // partner lane ^ 7
+    float c[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) c[k] = (b1 ? b[k + 2] : b[k]) + dpp_mov<0x1B>(b1 ? b[k] : b[k + 2]);        // partner lane ^ 3
+    return (b0 ? c[1] : c[0]) + dpp_mov<0xB1>(b0 ? c[0] : c[1]);                                            // partner lane ^ 1
+}
+
+// Inclusive scans over the 64 lanes (DPP only: row_shr 1,2,4,8 inside each 16-lane row, then row_bcast15 / row_bcast31 carry the row
+// totals forward).  `IDENT` fills lanes whose source falls outside the row / the selected rows.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_fill(float v, float ident) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_scan_add(float v) {
+    v += dpp_fill<0x111>(v, 0.f); v += dpp_fill<0x112>(v, 0.f); v += dpp_fill<0x114>(v, 0.f); v += dpp_fill<0x118>(v, 0.f);
+    v += dpp_fill<0x142, 0xa>(v, 0.f);
+    v += dpp_fill<0x143, 0xc>(v, 0.f);
+    return v;
+}
+__device__ __forceinline__ float wave_scan_mul(float v) {
+    v *= dpp_fill<0x111>(v, 1.f); v *= dpp_fill<0x112>(v, 1.f); v *= dpp_fill<0x114>(v, 1.f); v *= dpp_fill<0x118>(v, 1.f);
+    v *= dpp_fill<0x142, 0xa>(v, 1.f);
+    v *= dpp_fill<0x143, 0xc>(v, 1.f);
+    return v;
+}
+__device__ __forceinline__ float wave_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+
 // Transpose-reduce of 4*N4 per-lane values over the wavefront in ~(2+1+1)*N4 + ... instructions instead of 7 per value:
 //   v_permlane32_swap pairs value i with value i+2*N4 (one add leaves i's 32 partial sums in the low half, the other's in the high half),
 //   v_permlane16_swap pairs again (each 16-lane row now owns ONE value), four DPP row rotations finish the row sums, and N4-1 selects
 //   merge the registers.  Result: lane r*16+k (k < N4) returns the sum over all 64 lanes of value k + r*N4.
-typedef unsigned envgs_u2 __attribute__((ext_vector_type(2)));
 template <int N4>
 __device__ __forceinline__ float wave_transpose_reduce(const float (&g)[4 * N4], const int lane)
 {

@@ -151,6 +151,10 @@ struct TraceArgs {
     int exp;            // experiment switches (ENVGS_TRACE_EXP env var; 0 in production)
     int *stack_spill;   // collect_hits: (grid, STACK, 64) ints of stack overflow space
     int only_overflow;  // K-buffer kernels: process only rays whose hit_cnt exceeds cap
+    unsigned long long *entries;  // (batches, 64*cap) distinct (batch, surfel) entries, see register_hits
+    unsigned *pairs;              // (batches, 64*cap) (lane << 16 | k) of every composited hit, grouped by entry
+    int *n_entries;               // (batches, 2) table entries, single entries
+    float4 *state;      // (R, cap, 3) per composited hit: transmittance before it, the ten prefix sums after it, alpha (for the backward)
 };
 
 // K-nearest buffer ordered by (t, id); insertion is a fully unrolled compare-exchange chain (registers only).
@@ -992,58 +996,8 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
     }
 }
 
-// One wavefront sorts one ray's list at a time: bitonic network over keys (t bits << 32 | id) in LDS.
-// t > 0 always, so the IEEE bit pattern orders like the value; ties break on the surfel id, as in the oracle.
 constexpr int SORT_MAX = 1024;
-__global__ void __launch_bounds__(64)
-sort_hit_lists(const TraceArgs A)
-{
-    __shared__ unsigned long long keys[SORT_MAX];
-    const int lane = threadIdx.x;
-    for (int r = blockIdx.x; r < A.R; r += gridDim.x) {
-        const int n = A.hit_cnt[r];
-        if (n < 2 || n > A.cap) continue;
-        uint2 *list = A.hits + (size_t)r * A.cap;
-        int np = 2;
-        while (np < n) np <<= 1;
-        __syncthreads();
-        for (int i = lane; i < np; i += 64) {
-            unsigned long long k = ~0ull;
-            if (i < n) { const uint2 e = list[i]; k = ((unsigned long long)e.x << 32) | e.y; }
-            keys[i] = k;
-        }
-        __syncthreads();
-        for (int size = 2; size <= np; size <<= 1)
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int i = lane; i < (np >> 1); i += 64) {
-                    const int lo = ((i / stride) * (stride << 1)) + (i % stride);
-                    const int hi = lo + stride;
-                    const bool up = ((lo & size) == 0);
-                    const unsigned long long a = keys[lo], b = keys[hi];
-                    if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
-                }
-                __syncthreads();
-            }
-        for (int i = lane; i < n; i += 64) { const unsigned long long k = keys[i]; list[i] = make_uint2((unsigned)(k >> 32), (unsigned)k); }
-    }
-}
-
-// Inclusive scans over the wavefront (Hillis-Steele on ds_bpermute; a handful per 64 hits).
-__device__ __forceinline__ float wave_scan_add(float v, const int lane)
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); v += lane >= o ? t : 0.f; }
-    return v;
-}
-__device__ __forceinline__ float wave_scan_mul(float v, const int lane)
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); v *= lane >= o ? t : 1.f; }
-    return v;
-}
-__device__ __forceinline__ float wave_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-
-// Sort AND composite, one wavefront per ray, one LANE per hit.  The lane-per-ray walk (composite_lists_fwd) is a chain of dependent
+// Sort AND composite, one wavefront per ray, one LANE per hit.  A lane-per-ray walk is a chain of dependent
 // gathers -- list entry -> surfel record + SH block -> blend -> next entry -- whose length is the ray's hit count; here the 64 hits of
 // a chunk fetch their records independently (all gathers in flight at once) and the front-to-back recurrences (transmittance product,
 // the two distortion moments) become wavefront scans.  The sorted list is written back only up to the terminating hit.
@@ -1091,9 +1045,14 @@ sort_composite_fwd(const TraceArgs A)
             const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
             sh_basis(A.D, dx * il, dy * il, dz * il, basis);
         }
-        float T = 1.0f, M1 = 0.f, M2 = 0.f;                 // carried across chunks (wave-uniform)
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f, dpt = 0.f, acc = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, dist = 0.f, x0 = 0.f, x1 = 0.f;   // per-lane partial sums
+        // carried across chunks (wave-uniform): transmittance, the two distortion moments, and the ten blended sums
+        // [rgb 3, depth, acc, normal 3, aux 2] -- kept as running PREFIX sums because the backward needs them per hit
+        float T = 1.0f, M1 = 0.f, M2 = 0.f, C[10];
+#pragma unroll
+        for (int j = 0; j < 10; j++) C[j] = 0.f;
+        float dist = 0.f;                                   // per-lane partial sum
         int used = 0;
+        float4 *state = A.state ? A.state + (size_t)r * A.cap * 3 : nullptr;
         for (int cb = 0; cb < n; cb += 64) {
             const int i = cb + lane;
             const bool has = i < n;
@@ -1107,8 +1066,8 @@ sort_composite_fwd(const TraceArgs A)
                 const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], s3, ox, oy, oz, dx, dy, dz);
                 alpha = h.alpha; t = h.t; sg = h.denom < 0.0f ? 1.f : -1.f;
             }
-            const float P = wave_scan_mul(1.0f - alpha, lane);              // prod_{j<=i} (1 - alpha_j) within the chunk
-            float Pex = __shfl_up(P, 1); Pex = lane == 0 ? 1.f : Pex;
+            const float P = wave_scan_mul(1.0f - alpha);                    // prod_{j<=i} (1 - alpha_j) within the chunk
+            const float Pex = dpp_fill<0x138>(P, 1.f);                      // wave_shr:1
             const float test_T = T * P, Tb = T * Pex;                       // transmittance after / before this hit
             const unsigned long long stop = __ballot(has && test_T < T_EPS);
             const int f = stop ? (int)__builtin_ctzll(stop) : 64;           // first terminating lane: it and everything behind is dropped
@@ -1119,122 +1078,77 @@ sort_composite_fwd(const TraceArgs A)
             const float tt = t > NEAR_N ? t : NEAR_N;
             const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / tt);
             const float mw = m * w, mmw = m * m * w;
-            const float S1 = wave_scan_add(mw, lane), S2 = wave_scan_add(mmw, lane);
+            const float S1 = wave_scan_add(mw), S2 = wave_scan_add(mmw);
             const float M1b = M1 + (S1 - mw), M2b = M2 + (S2 - mmw);        // moments before this hit
             dist += (m * m * (1.0f - Tb) + M2b - 2.0f * m * M1b) * w;
-            c0 += w * col[0]; c1 += w * col[1]; c2 += w * col[2];
-            dpt += w * t; acc += w;
-            n0 += sg * w * s3.x; n1 += sg * w * s3.y; n2 += sg * w * s3.z;
-            if (A.has_others && use) { x0 += w * A.others[2 * sid]; x1 += w * A.others[2 * sid + 1]; }
-            if (use) list[i] = make_uint2(__float_as_uint(w), (unsigned)sid);
+            float x0 = 0.f, x1 = 0.f;
+            if (A.has_others && use) { x0 = A.others[2 * sid]; x1 = A.others[2 * sid + 1]; }
+            float S[10] = {w * col[0], w * col[1], w * col[2], w * t, w, sg * w * s3.x, sg * w * s3.y, sg * w * s3.z, w * x0, w * x1};
+#pragma unroll
+            for (int j = 0; j < 10; j++) S[j] = C[j] + wave_scan_add(S[j]);               // inclusive: this hit already added
+            if (use) {
+                list[i] = make_uint2(__float_as_uint(w), (unsigned)sid);
+                if (state) {
+                    float4 *o = state + (size_t)i * 3;
+                    o[0] = make_float4(Tb, S[0], S[1], S[2]);
+                    o[1] = make_float4(S[3], S[4], S[5], S[6]);
+                    o[2] = make_float4(S[7], S[8], S[9], alpha);
+                }
+            }
             const int nu = f < 64 ? f : min(64, n - cb);                    // hits of this chunk that were blended
             used += nu;
             M1 += wave_bcast(S1, 63); M2 += wave_bcast(S2, 63);
+#pragma unroll
+            for (int j = 0; j < 10; j++) C[j] = wave_bcast(S[j], 63);
             if (nu > 0) T = T * wave_bcast(P, nu - 1);
             if (f < 64) break;
         }
         st_hits += (unsigned)used;
-        c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2); dpt = wave_sum(dpt); acc = wave_sum(acc);
-        n0 = wave_sum(n0); n1 = wave_sum(n1); n2 = wave_sum(n2); dist = wave_sum(dist); x0 = wave_sum(x0); x1 = wave_sum(x1);
+        dist = wave_sum(dist);
         if (lane == 0) {
             A.n_used[r] = used;
-            c0 += T * (0 < A.bg_len ? A.bg[0] : 0.f); c1 += T * (1 < A.bg_len ? A.bg[1] : 0.f); c2 += T * (2 < A.bg_len ? A.bg[2] : 0.f);
+            const float c0 = C[0] + T * (0 < A.bg_len ? A.bg[0] : 0.f), c1 = C[1] + T * (1 < A.bg_len ? A.bg[1] : 0.f), c2 = C[2] + T * (2 < A.bg_len ? A.bg[2] : 0.f);
             A.rgb[3 * r] = c0; A.rgb[3 * r + 1] = c1; A.rgb[3 * r + 2] = c2;
-            A.dpt[r] = dpt; A.acc[r] = acc; A.dist[r] = dist;
-            A.norm[3 * r] = n0; A.norm[3 * r + 1] = n1; A.norm[3 * r + 2] = n2;
-            A.aux[2 * r] = x0; A.aux[2 * r + 1] = x1;
+            A.dpt[r] = C[3]; A.acc[r] = C[4]; A.dist[r] = dist;
+            A.norm[3 * r] = C[5]; A.norm[3 * r + 1] = C[6]; A.norm[3 * r + 2] = C[7];
+            A.aux[2 * r] = C[8]; A.aux[2 * r + 1] = C[9];
             A.final_T[r] = T;
             float *mm = A.mid + (size_t)r * MID;
-            mm[0] = ox; mm[1] = oy; mm[2] = oz; mm[3] = dx; mm[4] = dy; mm[5] = dz; mm[6] = dpt; mm[7] = acc;
-            mm[8] = n0; mm[9] = n1; mm[10] = n2; mm[11] = x0; mm[12] = x1; mm[13] = c0; mm[14] = c1; mm[15] = c2;
+            mm[0] = ox; mm[1] = oy; mm[2] = oz; mm[3] = dx; mm[4] = dy; mm[5] = dz; mm[6] = C[3]; mm[7] = C[4];
+            mm[8] = C[5]; mm[9] = C[6]; mm[10] = C[7]; mm[11] = C[8]; mm[12] = C[9]; mm[13] = c0; mm[14] = c1; mm[15] = c2;
         }
     }
     if (A.stats && lane == 0) atomicAdd(A.stats + 0, (unsigned long long)st_hits);
 }
 
-__global__ void __launch_bounds__(64)
-composite_lists_fwd(const TraceArgs A)
-{
-    // Memory operations retire in order (vmcnt), so an atomic inside the per-hit chain adds a full memory-side round trip to EVERY hit
-    // (measured: 3.3 ms -> 13 ms for this kernel).  The per-surfel bookkeeping (hit slot + accumulated weight) is therefore done by
-    // register_hits below, a pure atomic stream; here each composited hit only parks its weight in the list entry's first word.
-    const int lane = threadIdx.x;
-    unsigned st_hits = 0;
-    for (int base = blockIdx.x * 64; base < A.R; base += gridDim.x * 64) {
-        const int r = ray_of(A, base + lane);
-        if (r >= A.R) continue;
-        const int n = A.hit_cnt[r];
-        if (n > A.cap) continue;                            // overflow: the K-buffer kernel owns this ray
-        const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
-        const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
-        float basis[16];
-        {
-            const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-            sh_basis(A.D, dx * il, dy * il, dz * il, basis);
-        }
-        uint2 *list = A.hits + (size_t)r * A.cap;
-        float T = 1.0f, M1 = 0.f, M2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dpt = 0.f, acc = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, dist = 0.f, x0 = 0.f, x1 = 0.f;
-        int used = 0;
-        for (int k = 0; k < n; k++) {
-            const int sid = (int)list[k].y;
-            const float4 *sr = A.srec + (size_t)sid * 4;
-            const float4 s3 = sr[3];
-            const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], s3, ox, oy, oz, dx, dy, dz);
-            const float test_T = T * (1.0f - h.alpha);
-            if (test_T < T_EPS) break;
-            const float w = h.alpha * T;
-            float col[3]; bool cl[3];
-            surfel_color(A, sid, basis, col, cl);
-            const float tt = h.t > NEAR_N ? h.t : NEAR_N;
-            const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / tt);
-            dist += (m * m * (1.0f - T) + M2 - 2.0f * m * M1) * w;
-            M1 += m * w; M2 += m * m * w;
-            c0 += w * col[0]; c1 += w * col[1]; c2 += w * col[2];
-            dpt += w * h.t; acc += w;
-            const float sg = h.denom < 0.0f ? w : -w;
-            n0 += sg * s3.x; n1 += sg * s3.y; n2 += sg * s3.z;
-            if (A.has_others) { x0 += w * A.others[2 * sid]; x1 += w * A.others[2 * sid + 1]; }
-            list[k].x = __float_as_uint(w);
-            T = test_T;
-            used++;
-        }
-        st_hits += (unsigned)used;
-        A.n_used[r] = used;
-        c0 += T * (0 < A.bg_len ? A.bg[0] : 0.f); c1 += T * (1 < A.bg_len ? A.bg[1] : 0.f); c2 += T * (2 < A.bg_len ? A.bg[2] : 0.f);
-        A.rgb[3 * r] = c0; A.rgb[3 * r + 1] = c1; A.rgb[3 * r + 2] = c2;
-        A.dpt[r] = dpt; A.acc[r] = acc; A.dist[r] = dist;
-        A.norm[3 * r] = n0; A.norm[3 * r + 1] = n1; A.norm[3 * r + 2] = n2;
-        A.aux[2 * r] = x0; A.aux[2 * r + 1] = x1;
-        A.final_T[r] = T;
-        float *m = A.mid + (size_t)r * MID;
-        m[0] = ox; m[1] = oy; m[2] = oz; m[3] = dx; m[4] = dy; m[5] = dz; m[6] = dpt; m[7] = acc;
-        m[8] = n0; m[9] = n1; m[10] = n2; m[11] = x0; m[12] = x1; m[13] = c0; m[14] = c1; m[15] = c2;
-    }
-    if (A.stats) {
-        const float fh = wave_sum((float)st_hits);
-        if (lane == 0) atomicAdd(A.stats + 0, (unsigned long long)fh);
-    }
-}
-
-// Register every composited hit with its surfel: count++ (the old count is the hit's slot among the surfel's hits, which is where the
-// backward will put its gradient record) and weight += w in 40-bit fixed point (rounded up, so any contribution keeps the surfel
-// "visible"), both in ONE returning 64-bit atomic.  Device-scope atomics run at ~10 G/s on this chip whatever their width or scope, so
-// the kernel issues as few as possible: the 64 rays of a (coherence-sorted) batch mostly composite the SAME surfels (measured: 27 hits
-// per distinct surfel per batch), so a wavefront first merges its batch in an LDS hash table (ds_cmpst / ds_add: count -> rank inside
-// the batch, weight sum), then spends one global atomic per DISTINCT surfel and hands slot = returned base + rank back to the lists.
+// Register every composited hit with its surfel, per BATCH of 64 coherence-sorted rays.  The rays of a batch mostly composite the SAME
+// surfels (measured: 27 hits per distinct surfel per batch), and device-scope atomics run at ~10 G/s on this chip whatever their width
+// or scope, so a wavefront first merges its batch in an LDS hash table (ds_cmpst / ds_add: hit count, weight sum in 40-bit fixed point)
+// and then spends ONE global 64-bit atomic per DISTINCT surfel: weight += sum (rounded up, so any contribution keeps the surfel
+// "visible") and entry count += 1, whose old value is the slot of this (batch, surfel) ENTRY among the surfel's entries -- where the
+// backward will put the entry's gradient record.  Outputs for the backward, per batch b (region = 64*cap slots):
+//   entries[b][e]  e < D: the distinct surfels of the table, packed  sid | (hits-1) << 24 | slot << 32 ; singles that found no room in
+//                  the table are filed from the TOP of the region downwards (n_entries[2b] = D, n_entries[2b+1] = singles)
+//   pairs[b][...]  (lane << 16 | k) of every hit, grouped by entry in entry order (singles again from the top)
 constexpr int RH_TAB = 1024;
 __global__ void __launch_bounds__(64)
 register_hits(const TraceArgs A)
 {
     __shared__ int key[RH_TAB];
-    __shared__ unsigned cnt[RH_TAB];                 // hits of this surfel in the batch; after the flush: slot of the first of them
+    __shared__ unsigned cnt[RH_TAB];                 // hits of this surfel in the batch; after the flush: offset of its first pair
     __shared__ unsigned long long wsum[RH_TAB];
+    __shared__ unsigned nfail;
     const int lane = threadIdx.x;
     const float wscale = __builtin_ldexpf(1.0f, A.wfrac);
+    const size_t region = (size_t)64 * A.cap;
     for (int base = blockIdx.x * 64; base < A.R; base += gridDim.x * 64) {
-        const int copy = (base >> 6) & (NCOPY - 1);
+        const int batch = base >> 6;
+        const int copy = batch & (NCOPY - 1);
+        unsigned long long *ent = A.entries ? A.entries + (size_t)batch * region : nullptr;
+        unsigned *prs = A.pairs ? A.pairs + (size_t)batch * region : nullptr;
         __syncthreads();
         for (int i = lane; i < RH_TAB; i += 64) { key[i] = -1; cnt[i] = 0u; wsum[i] = 0ull; }
+        if (lane == 0) nfail = 0u;
         __syncthreads();
         const int r = ray_of(A, base + lane);
         int n = 0;
@@ -1256,31 +1170,46 @@ register_hits(const TraceArgs A)
                     if (old == -1 || old == (int)e[j].y) { ok = true; break; }
                     h = (h + 1) & (RH_TAB - 1);
                 }
-                unsigned x;
+                unsigned x = 0xFFFFFFFFu;
                 if (ok) {
                     const unsigned rank = atomicAdd(&cnt[h], 1u);
                     atomicAdd(&wsum[h], wq);
                     x = (h << 8) | rank;                                  // rank < 64: a ray meets a planar surfel once
-                } else {                                                  // table full around h: register this hit directly
+                } else {                                                  // table full around h: an entry of its own
                     const unsigned long long old = atomicAdd(A.surf_acc + (size_t)e[j].y * NCOPY + copy, (wq << 24) | 1ull);
-                    x = 0x80000000u | (unsigned)(old & 0xFFFFFFull);
+                    const unsigned f = atomicAdd(&nfail, 1u);
+                    if (ent) ent[region - 1 - f] = (unsigned long long)e[j].y | ((old & 0xFFFFFFull) << 32);
+                    if (prs) prs[region - 1 - f] = ((unsigned)lane << 16) | (unsigned)(kb + j);
                 }
                 list[kb + j].x = x;
             }
         }
         __syncthreads();
-        for (int i = lane; i < RH_TAB; i += 64) {
-            const int sid = key[i];
-            if (sid >= 0) {
-                const unsigned long long old = atomicAdd(A.surf_acc + (size_t)sid * NCOPY + copy, (wsum[i] << 24) | (unsigned long long)cnt[i]);
-                cnt[i] = (unsigned)(old & 0xFFFFFFull);
+        unsigned carry_d = 0u, carry_off = 0u;
+        for (int c = 0; c < RH_TAB; c += 64) {
+            const int h = c + lane;
+            const int sid = key[h];
+            const bool occ = sid >= 0;
+            const unsigned long long mask = __ballot(occ);
+            const unsigned cn = occ ? cnt[h] : 0u;
+            const float incl = wave_scan_add((float)cn);                 // exact: at most 64*cap < 2^24 hits per batch
+            const unsigned offh = carry_off + (unsigned)incl - cn;
+            if (occ) {
+                const unsigned d = carry_d + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                const unsigned long long old = atomicAdd(A.surf_acc + (size_t)sid * NCOPY + copy, (wsum[h] << 24) | 1ull);
+                if (ent) ent[d] = (unsigned long long)(unsigned)sid | ((unsigned long long)(cn - 1u) << 24) | ((old & 0xFFFFFFull) << 32);
+                cnt[h] = offh;
             }
+            carry_d += (unsigned)__popcll(mask);
+            carry_off += (unsigned)wave_bcast(incl, 63);
         }
         __syncthreads();
-        for (int k = 0; k < n; k++) {
-            const unsigned x = list[k].x;
-            list[k].x = (x >> 31) ? (x & 0xFFFFFFu) : cnt[x >> 8] + (x & 255u);
-        }
+        if (A.n_entries && lane == 0) { A.n_entries[2 * batch] = (int)carry_d; A.n_entries[2 * batch + 1] = (int)nfail; }
+        if (prs)
+            for (int k = 0; k < n; k++) {
+                const unsigned x = list[k].x;
+                if (x != 0xFFFFFFFFu) prs[cnt[x >> 8] + (x & 255u)] = ((unsigned)lane << 16) | (unsigned)k;
+            }
     }
 }
 
@@ -1341,208 +1270,260 @@ unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, 
     if (w != 0.0f) wet[i] += w;
 }
 
-// Atomic-free backward of the list path, stage 1: every lane walks its ray's list and writes one 96 B gradient record
-// per composited hit at  surf_off[sid] - surf_cnt[sid] + slot  -- i.e. the records land GROUPED BY SURFEL without any sort.
-constexpr int RECW = 24;      // floats per record: dir 3, dcolour 3, geometry 15, pad 3
+// Backward of the list path, SURFEL-MAJOR per batch (the tracer's counterpart of the rasterizer's tile backward): one wavefront owns a
+// batch of 64 coherence-sorted rays, LANE = RAY.  It walks the batch's entries (distinct surfels); the surfel's record and SH block are
+// staged through LDS 16 entries ahead (coalesced, off the critical path) and read back as broadcasts, each ray that composited the surfel
+// fetches the per-hit state the forward stored (transmittance before the hit, the ten prefix sums after it), evaluates its gradient
+// independently of every other hit, and the 63 gradient words (48 SH + 15 geometry) are transpose-reduced over the wavefront into ONE
+// 256 B record per (batch, surfel) written by the 64 lanes as one coalesced line pair.  ~27x fewer records than one per hit, no
+// per-hit gathers of surfel data, no dependent chain along the ray, no atomics.
+constexpr int BS_GROUP = 16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int RECW = 64;      // floats per (batch, surfel) gradient record: 48 SH (or 3 colour) + 15 geometry + pad
 __global__ void __launch_bounds__(64)
-composite_lists_bwd_records(const TraceArgs A)
+batch_surfel_bwd(const TraceArgs A)
 {
+    __shared__ float4 sdat[2][BS_GROUP][16];               // per entry: surfel record (4 x 16 B) + SH block (12 x 16 B)
+    __shared__ unsigned long long sdesc[2][BS_GROUP];      // sid | (hits-1) << 24 ; record index << 32
+    __shared__ unsigned short kmat[2][BS_GROUP][64];       // per entry and ray: list position of the hit + 1, 0 = the ray did not blend it
+    __shared__ unsigned spb[2][BS_GROUP];                  // per entry: index of its first pair
+    __shared__ unsigned scn[2][BS_GROUP];                  // per entry: hits
+    __shared__ float btile[64][16];                        // B operand of the reduction MFMAs: 16 words per ray
     const int lane = threadIdx.x;
     const int nb = (A.D + 1) * (A.D + 1);
-    for (int base = blockIdx.x * 64; base < A.R; base += gridDim.x * 64) {
+    const size_t region = (size_t)64 * A.cap;
+    const int nbatch = (A.R + 63) >> 6;
+    for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+        const int base = batch << 6;
+        const int copy = batch & (NCOPY - 1);
         const int r = ray_of(A, base + lane);
-        if (r >= A.R) continue;
-        if (A.hit_cnt[r] > A.cap) continue;                 // overflow rays: K-buffer backward (atomic flush)
+        const bool valid = r < A.R && A.hit_cnt[r < A.R ? r : 0] <= A.cap;
+        const int rr = r < A.R ? r : 0;
         BwdRay B;
-        bwd_load_ray(A, r, B);
-        BwdAcc acc;
-        bwd_init_acc(acc);
+        bwd_load_ray(A, rr, B);
         float basis[16];
-        sh_basis(A.D, B.ux, B.uy, B.uz, basis);
-        const int n = A.n_used[r];
-        const uint2 *list = A.hits + (size_t)r * A.cap;
-        for (int k = 0; k < n; k++) {
-            const uint2 e = list[k];
-            const int sid = (int)e.y;
-            float dc0, dc1, dc2, gv[15];
-            if (!bwd_hit(A, B, acc, basis, nb, sid, dc0, dc1, dc2, gv)) break;      // cannot happen: same arithmetic as the forward
-            const size_t ci = (size_t)sid * NCOPY + ((base >> 6) & (NCOPY - 1));
-            const unsigned long long idx = (unsigned long long)(A.surf_off[ci] - A.surf_cnt[ci]) + e.x;
-            if (idx < A.num_records) {
-                float4 *o = reinterpret_cast<float4 *>(A.records + idx * RECW);
-                o[0] = make_float4(B.ux, B.uy, B.uz, dc0);
-                o[1] = make_float4(dc1, dc2, gv[0], gv[1]);
-                o[2] = make_float4(gv[2], gv[3], gv[4], gv[5]);
-                o[3] = make_float4(gv[6], gv[7], gv[8], gv[9]);
-                o[4] = make_float4(gv[10], gv[11], gv[12], gv[13]);
-                o[5] = make_float4(gv[14], 0.f, 0.f, 0.f);
-            }
-        }
-        bwd_store_ray(A, r, B, acc);
-    }
-}
-
-// Backward of the list path, one wavefront per ray, one LANE per hit (the counterpart of sort_composite_fwd): every hit's records are
-// gathered independently, the ten running sums and the transmittance product of the lane-per-ray form become wavefront scans, and each
-// lane writes its hit's 96 B gradient record at  surf_off - surf_cnt + slot  (grouped by surfel, no sort, no atomics).
-__global__ void __launch_bounds__(64)
-composite_bwd_scan_records(const TraceArgs A)
-{
-    const int lane = threadIdx.x;
-    const int nb = (A.D + 1) * (A.D + 1);
-    for (int slot = blockIdx.x; slot < A.R; slot += gridDim.x) {
-        const int r = ray_of(A, slot);
-        if (A.hit_cnt[r] > A.cap) continue;                 // overflow rays: K-buffer backward (atomic flush)
-        BwdRay B;
-        bwd_load_ray(A, r, B);
-        float basis[16];
-        sh_basis(A.D, B.ux, B.uy, B.uz, basis);
-        const int n = A.n_used[r];
-        const uint2 *list = A.hits + (size_t)r * A.cap;
-        const int copy = (slot >> 6) & (NCOPY - 1);
-        float T = 1.0f, C[10];
 #pragma unroll
-        for (int j = 0; j < 10; j++) C[j] = 0.f;
+        for (int k = 0; k < 16; k++) basis[k] = 0.f;
+        sh_basis(A.D, B.ux, B.uy, B.uz, basis);
+        if (A.M == 0) basis[0] = kC0;
+        // A operand of the reduction MFMAs, constant for the batch: lane l holds basis_{l & 15} of ray 4s + (l >> 4)
+        float Areg[16];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) btile[lane][k] = (valid && k < nb) ? basis[k] : (k == 0 ? kC0 : 0.f);
+        __syncthreads();
+#pragma unroll
+        for (int sI = 0; sI < 16; sI++) Areg[sI] = btile[4 * sI + (lane >> 4)][lane & 15];
         float Sk[16], dO0 = 0.f, dO1 = 0.f, dO2 = 0.f, dD0 = 0.f, dD1 = 0.f, dD2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; k++) Sk[k] = 0.f;
-        for (int cb = 0; cb < n; cb += 64) {
-            const int i = cb + lane;
-            const bool has = i < n;
-            uint2 e = make_uint2(0u, 0u);
-            if (has) e = list[i];
-            const int sid = (int)e.y;
-            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-            SurfHit h; h.t = 0.f; h.u = 0.f; h.v = 0.f; h.G = 0.f; h.alpha = 0.f; h.denom = 1.f; h.ok = false;
-            float col[3] = {0.f, 0.f, 0.f}; bool cl[3] = {false, false, false};
-            float shv[48];
-            float x0 = 0.f, x1 = 0.f;
-            if (has) {
-                const float4 *sr = A.srec + (size_t)sid * 4;
-                s0 = sr[0]; s1 = sr[1]; s2 = sr[2]; s3 = sr[3];
-                h = hit_surfel(s0, s1, s2, s3, B.ox, B.oy, B.oz, B.dx, B.dy, B.dz);
-                if (A.M > 0) {
-                    load_sh(A, sid, nb, shv);
-                    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        const float4 *state = A.state + (size_t)rr * A.cap * 3;
+        const unsigned long long *ent = A.entries + (size_t)batch * region;
+        const unsigned *prs = A.pairs + (size_t)batch * region;
+        const int D = A.n_entries[2 * batch], NE = D + A.n_entries[2 * batch + 1];
+        unsigned poff = 0u;                                  // pairs of the table entries staged so far
+        // Stage one group of entries, a whole group ahead of its use: 4 lanes per entry fetch the surfel record and SH block, then the
+        // group's (lane, k) pairs (one contiguous run) are scattered into kmat -- so the main loop touches no global memory except
+        // each ray's per-hit state.
+        auto stage = [&](int g, int buf) {
+            const int el = lane >> 2, part = lane & 3;
+            const int e = g * BS_GROUP + el;
+            unsigned long long d = 0ull;
+            if (e < NE) {
+                d = e < D ? ent[e] : ent[region - 1 - (size_t)(e - D)];
+                const int sid = (int)(d & 0xFFFFFFull);
+                sdat[buf][el][part] = A.srec[(size_t)sid * 4 + part];
+                if (A.M == 16) {
+                    const float4 *s4 = reinterpret_cast<const float4 *>(A.shs + (size_t)sid * 48);
 #pragma unroll
-                    for (int k = 0; k < 16; k++)
-                        if (k < nb) { const float b = basis[k]; r0 += b * shv[k * 3]; r1 += b * shv[k * 3 + 1]; r2 += b * shv[k * 3 + 2]; }
-                    r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
-                    cl[0] = r0 < 0.f; cl[1] = r1 < 0.f; cl[2] = r2 < 0.f;
-                    col[0] = cl[0] ? 0.f : r0; col[1] = cl[1] ? 0.f : r1; col[2] = cl[2] ? 0.f : r2;
+                    for (int q = 0; q < 3; q++) sdat[buf][el][4 + part * 3 + q] = s4[part * 3 + q];
                 } else {
-                    col[0] = A.colors[3 * sid]; col[1] = A.colors[3 * sid + 1]; col[2] = A.colors[3 * sid + 2];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        float v[4];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const int idx = (part * 3 + q) * 4 + c;
+                            v[c] = A.M > 0 ? (idx < nb * 3 ? A.shs[(size_t)sid * A.M * 3 + idx] : 0.f) : (idx < 3 ? A.colors[(size_t)sid * 3 + idx] : 0.f);
+                        }
+                        sdat[buf][el][4 + part * 3 + q] = make_float4(v[0], v[1], v[2], v[3]);
+                    }
                 }
-                if (A.has_others) { x0 = A.others[2 * sid]; x1 = A.others[2 * sid + 1]; }
+                if (part == 0) {
+                    const size_t ci = (size_t)sid * NCOPY + copy;
+                    const unsigned rec = A.surf_off[ci] - A.surf_cnt[ci] + (unsigned)(d >> 32);
+                    sdesc[buf][el] = (d & 0x3FFFFFFFull) | ((unsigned long long)rec << 32);
+                }
             }
-            const float alpha = has ? h.alpha : 0.f;
-            const float P = wave_scan_mul(1.0f - alpha, lane);
-            float Pex = __shfl_up(P, 1); Pex = lane == 0 ? 1.f : Pex;
-            const float Tb = T * Pex;
-            const float w = alpha * Tb;
-            const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
-            const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
-            float S[10] = {w * col[0], w * col[1], w * col[2], w * h.t, w, w * nf0, w * nf1, w * nf2, w * x0, w * x1};
-#pragma unroll
-            for (int j = 0; j < 10; j++) S[j] = C[j] + wave_scan_add(S[j], lane);      // inclusive: this hit already added
-            if (has) {
-                const float inv1m = 1.0f / (1.0f - alpha);
-                float dLa = B.gR0 * (Tb * col[0] - (B.fr0 - S[0]) * inv1m) + B.gR1 * (Tb * col[1] - (B.fr1 - S[1]) * inv1m) + B.gR2 * (Tb * col[2] - (B.fr2 - S[2]) * inv1m);
-                dLa += B.gD * (Tb * h.t - (B.fD - S[3]) * inv1m);
-                dLa += B.gA * (Tb - (B.fA - S[4]) * inv1m);
-                dLa += B.gN0 * (Tb * nf0 - (B.fN0 - S[5]) * inv1m) + B.gN1 * (Tb * nf1 - (B.fN1 - S[6]) * inv1m) + B.gN2 * (Tb * nf2 - (B.fN2 - S[7]) * inv1m);
-                dLa += B.gX0 * (Tb * x0 - (B.fX0 - S[8]) * inv1m) + B.gX1 * (Tb * x1 - (B.fX1 - S[9]) * inv1m);
-                dLa += -(B.fT * inv1m) * B.bgdot;
-                const float dc0 = cl[0] ? 0.f : w * B.gR0, dc1 = cl[1] ? 0.f : w * B.gR1, dc2 = cl[2] ? 0.f : w * B.gR2;
-                if (A.M > 0) {
-#pragma unroll
-                    for (int k = 0; k < 16; k++)
-                        if (k < nb) Sk[k] += shv[k * 3] * dc0 + shv[k * 3 + 1] * dc1 + shv[k * 3 + 2] * dc2;
-                }
-                if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * B.gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * B.gX1); }
-                const float dLG = s0.w * dLa;
-                const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
-                const float su = s1.w, sv = s2.w;
-                const float qx = B.ox + h.t * B.dx - s0.x, qy = B.oy + h.t * B.dy - s0.y, qz = B.oz + h.t * B.dz - s0.z;
-                const float dq0 = dLu * s1.x + dLv * s2.x, dq1 = dLu * s1.y + dLv * s2.y, dq2 = dLu * s1.z + dLv * s2.z;
-                const float cu = dLu / su, cv = dLv / sv;
-                const float dLt_tot = w * B.gD + dq0 * B.dx + dq1 * B.dy + dq2 * B.dz;
-                const float kt = dLt_tot / h.denom;
-                const size_t ci = (size_t)sid * NCOPY + copy;
-                const unsigned long long idx = (unsigned long long)(A.surf_off[ci] - A.surf_cnt[ci]) + e.x;
-                if (idx < A.num_records) {
-                    float4 *o = reinterpret_cast<float4 *>(A.records + idx * RECW);
-                    o[0] = make_float4(B.ux, B.uy, B.uz, dc0);
-                    o[1] = make_float4(dc1, dc2, -dq0 + kt * s3.x, -dq1 + kt * s3.y);
-                    o[2] = make_float4(-dq2 + kt * s3.z, cu * qx, cu * qy, cu * qz);
-                    o[3] = make_float4(cv * qx, cv * qy, cv * qz, w * sgn * B.gN0 - kt * qx);
-                    o[4] = make_float4(w * sgn * B.gN1 - kt * qy, w * sgn * B.gN2 - kt * qz, -dLu * h.u / su * A.mod, -dLv * h.v / sv * A.mod);
-                    o[5] = make_float4(h.G * dLa, 0.f, 0.f, 0.f);
-                }
-                const float e0 = dq0 - kt * s3.x, e1 = dq1 - kt * s3.y, e2 = dq2 - kt * s3.z;
-                dO0 += e0; dO1 += e1; dO2 += e2;
-                dD0 += h.t * e0; dD1 += h.t * e1; dD2 += h.t * e2;
+            if (part == 0) scn[buf][el] = e < NE ? (unsigned)((d >> 24) & 63ull) + 1u : 0u;
+            {   // clear kmat[buf]: 2 KB = 32 B per lane
+                uint4 *km = reinterpret_cast<uint4 *>(&kmat[buf][0][0]);
+                km[lane * 2] = make_uint4(0u, 0u, 0u, 0u); km[lane * 2 + 1] = make_uint4(0u, 0u, 0u, 0u);
             }
+            __syncthreads();
+            // prefix of the hit counts (every lane reads the 16 counts as broadcasts) and each entry's first pair
+            unsigned pref[BS_GROUP + 1];
+            pref[0] = 0u;
 #pragma unroll
-            for (int j = 0; j < 10; j++) C[j] = wave_bcast(S[j], 63);
-            T = T * wave_bcast(P, 63);
-        }
-        BwdAcc acc;
-        bwd_init_acc(acc);
-        acc.dO0 = wave_sum(dO0); acc.dO1 = wave_sum(dO1); acc.dO2 = wave_sum(dO2);
-        acc.dD0 = wave_sum(dD0); acc.dD1 = wave_sum(dD1); acc.dD2 = wave_sum(dD2);
-        if (A.M > 0) {
+            for (int q = 0; q < BS_GROUP; q++) pref[q + 1] = pref[q] + scn[buf][q];
+            unsigned tab_before = 0u;                        // hits of the group's TABLE entries before entry q (singles live elsewhere)
 #pragma unroll
-            for (int k = 0; k < 16; k++) acc.Sk[k] = k < nb ? wave_sum(Sk[k]) : 0.f;
+            for (int q = 0; q < BS_GROUP; q++) {
+                const int eq = g * BS_GROUP + q;
+                if (lane == q) spb[buf][q] = eq < D ? poff + tab_before : (unsigned)(region - 1 - (size_t)(eq - D));
+                if (eq < D) tab_before += scn[buf][q];
+            }
+            __syncthreads();
+            const unsigned total = pref[BS_GROUP];
+            for (unsigned q = lane; q < total; q += 64) {
+                int eli = 0;
+#pragma unroll
+                for (int t = 1; t < BS_GROUP; t++) eli += q >= pref[t] ? 1 : 0;
+                const unsigned pr = prs[spb[buf][eli] + (q - pref[eli])];
+                kmat[buf][eli][pr >> 16] = (unsigned short)((pr & 0xFFFFu) + 1u);
+            }
+            poff += tab_before;
+        };
+        __syncthreads();
+        stage(0, 0);
+        for (int g = 0; g * BS_GROUP < NE; g++) {
+            const int buf = g & 1;
+            __syncthreads();                                   // group g staged; group g-1 fully consumed
+            if ((g + 1) * BS_GROUP < NE) stage(g + 1, buf ^ 1);
+            const int ne = min(BS_GROUP, NE - g * BS_GROUP);
+            // software pipeline over the entries: the per-hit state of entry el+1 is in flight while entry el is evaluated
+            int k1 = valid ? (int)kmat[buf][0][lane] : 0;
+            float4 st0 = make_float4(0.f, 0.f, 0.f, 0.f), st1 = st0, st2 = st0;
+            if (k1 > 0) { const float4 *sp = state + (size_t)(k1 - 1) * 3; st0 = sp[0]; st1 = sp[1]; st2 = sp[2]; }
+            for (int el = 0; el < ne; el++) {
+                const unsigned long long d = sdesc[buf][el];
+                const int sid = (int)(d & 0xFFFFFFull);
+                const unsigned long long rec = d >> 32;
+                const bool act = k1 > 0;
+                const float4 c0 = st0, c1 = st1, c2 = st2;
+                if (el + 1 < ne) {
+                    k1 = valid ? (int)kmat[buf][el + 1][lane] : 0;
+                    if (k1 > 0) { const float4 *sp = state + (size_t)(k1 - 1) * 3; st0 = sp[0]; st1 = sp[1]; st2 = sp[2]; }
+                }
+                // this ray's 16 B-matrix words: dL/dcolour (3) and the first 13 geometry words; the last two geometry words go by wave_sum
+                float bv[16], g13 = 0.f, g14 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; q++) bv[q] = 0.f;
+                if (act) {
+                    const float4 s0 = sdat[buf][el][0], s1 = sdat[buf][el][1], s2 = sdat[buf][el][2], s3 = sdat[buf][el][3];
+                    const SurfHit h = hit_surfel(s0, s1, s2, s3, B.ox, B.oy, B.oz, B.dx, B.dy, B.dz);
+                    float col[3]; bool cl[3] = {false, false, false};
+                    if (A.M > 0) {
+                        float rc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int q4 = 0; q4 < 12; q4++) {
+                            const float4 x = sdat[buf][el][4 + q4];
+                            const float xe[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                            for (int e = 0; e < 4; e++) { const int idx = 4 * q4 + e; if (idx / 3 < nb) rc[idx % 3] += basis[idx / 3] * xe[e]; }
+                        }
+#pragma unroll
+                        for (int c = 0; c < 3; c++) { const float v = rc[c] + 0.5f; cl[c] = v < 0.f; col[c] = cl[c] ? 0.f : v; }
+                    } else { const float4 x = sdat[buf][el][4]; col[0] = x.x; col[1] = x.y; col[2] = x.z; }
+                    const float x0 = A.has_others ? A.others[2 * sid] : 0.f, x1 = A.has_others ? A.others[2 * sid + 1] : 0.f;
+                    const float alpha = h.alpha, Tb = c0.x;
+                    const float w = alpha * Tb;
+                    const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
+                    const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
+                    const float inv1m = 1.0f / (1.0f - alpha);
+                    float dLa = B.gR0 * (Tb * col[0] - (B.fr0 - c0.y) * inv1m) + B.gR1 * (Tb * col[1] - (B.fr1 - c0.z) * inv1m) + B.gR2 * (Tb * col[2] - (B.fr2 - c0.w) * inv1m);
+                    dLa += B.gD * (Tb * h.t - (B.fD - c1.x) * inv1m);
+                    dLa += B.gA * (Tb - (B.fA - c1.y) * inv1m);
+                    dLa += B.gN0 * (Tb * nf0 - (B.fN0 - c1.z) * inv1m) + B.gN1 * (Tb * nf1 - (B.fN1 - c1.w) * inv1m) + B.gN2 * (Tb * nf2 - (B.fN2 - c2.x) * inv1m);
+                    dLa += B.gX0 * (Tb * x0 - (B.fX0 - c2.y) * inv1m) + B.gX1 * (Tb * x1 - (B.fX1 - c2.z) * inv1m);
+                    dLa += -(B.fT * inv1m) * B.bgdot;
+                    const float dc[3] = {cl[0] ? 0.f : w * B.gR0, cl[1] ? 0.f : w * B.gR1, cl[2] ? 0.f : w * B.gR2};
+                    if (A.M > 0) {
+#pragma unroll
+                        for (int q4 = 0; q4 < 12; q4++) {
+                            const float4 x = sdat[buf][el][4 + q4];
+                            const float xe[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                            for (int e = 0; e < 4; e++) { const int idx = 4 * q4 + e; if (idx / 3 < nb) Sk[idx / 3] += xe[e] * dc[idx % 3]; }
+                        }
+                    }
+                    if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * B.gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * B.gX1); }
+                    const float dLG = s0.w * dLa;
+                    const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
+                    const float su = s1.w, sv = s2.w;
+                    const float qx = B.ox + h.t * B.dx - s0.x, qy = B.oy + h.t * B.dy - s0.y, qz = B.oz + h.t * B.dz - s0.z;
+                    const float dq0 = dLu * s1.x + dLv * s2.x, dq1 = dLu * s1.y + dLv * s2.y, dq2 = dLu * s1.z + dLv * s2.z;
+                    const float cu = dLu / su, cv = dLv / sv;
+                    const float dLt_tot = w * B.gD + dq0 * B.dx + dq1 * B.dy + dq2 * B.dz;
+                    const float kt = dLt_tot / h.denom;
+                    bv[0] = dc[0]; bv[1] = dc[1]; bv[2] = dc[2];
+                    bv[3] = -dq0 + kt * s3.x; bv[4] = -dq1 + kt * s3.y; bv[5] = -dq2 + kt * s3.z;
+                    bv[6] = cu * qx; bv[7] = cu * qy; bv[8] = cu * qz;
+                    bv[9] = cv * qx; bv[10] = cv * qy; bv[11] = cv * qz;
+                    bv[12] = w * sgn * B.gN0 - kt * qx; bv[13] = w * sgn * B.gN1 - kt * qy; bv[14] = w * sgn * B.gN2 - kt * qz;
+                    bv[15] = -dLu * h.u / su * A.mod;
+                    g13 = -dLv * h.v / sv * A.mod;
+                    g14 = h.G * dLa;
+                    const float e0 = dq0 - kt * s3.x, e1 = dq1 - kt * s3.y, e2 = dq2 - kt * s3.z;
+                    dO0 += e0; dO1 += e1; dO2 += e2;
+                    dD0 += h.t * e0; dD1 += h.t * e1; dD2 += h.t * e2;
+                }
+                // Sum over the 64 rays on the matrix cores: D[16 x 16] = basis^T[16 x 64 rays] . B[64 rays x 16], K = 64 in 16 exact-f32
+                // MFMAs.  Columns 0-2 are the (16,3) SH gradient block; basis_0 is the constant C0 for every ray, so row 0 of the
+                // other 13 columns is C0 x (the plain sum of a geometry word).
+                __syncthreads();                               // previous entry's B tile fully read
+                {
+                    float4 *bt = reinterpret_cast<float4 *>(&btile[lane][0]);
+                    bt[0] = make_float4(bv[0], bv[1], bv[2], bv[3]); bt[1] = make_float4(bv[4], bv[5], bv[6], bv[7]);
+                    bt[2] = make_float4(bv[8], bv[9], bv[10], bv[11]); bt[3] = make_float4(bv[12], bv[13], bv[14], bv[15]);
+                }
+                __syncthreads();
+                f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sI = 0; sI < 16; sI++)
+                    acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI], btile[4 * sI + (lane >> 4)][lane & 15], acc4, 0, 0, 0);
+                const float s13 = wave_sum(g13), s14 = wave_sum(g14);
+                if (rec < A.num_records) {
+                    float *ro = A.records + rec * RECW;
+                    const int n = lane & 15, mrow = (lane >> 4) * 4;
+                    if (A.M > 0) {
+                        if (n < 3) { ro[(mrow + 0) * 3 + n] = acc4[0]; ro[(mrow + 1) * 3 + n] = acc4[1]; ro[(mrow + 2) * 3 + n] = acc4[2]; ro[(mrow + 3) * 3 + n] = acc4[3]; }
+                    } else if (lane < 3) ro[lane] = acc4[0] * (1.0f / kC0);
+                    if (lane >= 3 && lane < 16) ro[48 + lane - 3] = acc4[0] * (1.0f / kC0);
+                    if (lane == 0) { ro[61] = s13; ro[62] = s14; }
+                }
+            }
         }
-        if (lane == 0) bwd_store_ray(A, r, B, acc);
+        if (valid) {
+            BwdAcc acc;
+            bwd_init_acc(acc);
+            acc.dO0 = dO0; acc.dO1 = dO1; acc.dO2 = dO2; acc.dD0 = dD0; acc.dD1 = dD1; acc.dD2 = dD2;
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc.Sk[k] = Sk[k];
+            bwd_store_ray(A, r, B, acc);
+        }
     }
 }
 
-// Stage 2: one wavefront per surfel streams that surfel's contiguous records (coalesced 96 B reads), accumulates the (16,3)
-// SH gradient block and the 15 geometry words in registers, reduces across the wavefront with DPP and leaves as ONE
-// instruction per surfel -- the same word layout as the cooperative flush, so both paths add into the same buffers.
+// Stage 2: sum each surfel's (batch, surfel) records -- 256 B lines, word v of every record belongs to lane v -- and add the result
+// to the gradient buffers (the same word layout as the cooperative flush, so the K-buffer path may add into the same buffers).
 __global__ void __launch_bounds__(256)
 reduce_surfel_records(const TraceArgs A)
 {
-    // 4 wavefronts share a surfel (hit counts per surfel are very uneven); each adds its partial with one instruction
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nb = (A.D + 1) * (A.D + 1);
-    for (int sid = blockIdx.x; sid < A.P; sid += gridDim.x) {
+    for (int sid = blockIdx.x * 4 + wave; sid < A.P; sid += gridDim.x * 4) {
         const unsigned end = A.surf_off[(size_t)sid * NCOPY + NCOPY - 1];
         const unsigned begin = A.surf_off[(size_t)sid * NCOPY] - A.surf_cnt[(size_t)sid * NCOPY];     // the NCOPY sub-segments are adjacent
-        const unsigned cnt = end - begin;
-        if (cnt <= (unsigned)wave * 64u) continue;
-        const unsigned long long start = (unsigned long long)begin;
-        float sh[16][3], geo[15];
-#pragma unroll
-        for (int k = 0; k < 16; k++) { sh[k][0] = 0.f; sh[k][1] = 0.f; sh[k][2] = 0.f; }
-#pragma unroll
-        for (int k = 0; k < 15; k++) geo[k] = 0.f;
-        for (unsigned i = wave * 64 + lane; i < cnt; i += 256) {
-            const unsigned long long idx = start + i;
-            if (idx >= A.num_records) break;
-            const float4 *rp = reinterpret_cast<const float4 *>(A.records + idx * RECW);
-            const float4 a0 = rp[0], a1 = rp[1], a2 = rp[2], a3 = rp[3], a4 = rp[4], a5 = rp[5];
-            const float dc0 = a0.w, dc1 = a1.x, dc2 = a1.y;
-            if (A.M > 0) {
-                float b[16];
-                sh_basis(A.D, a0.x, a0.y, a0.z, b);
-#pragma unroll
-                for (int k = 0; k < 16; k++)
-                    if (k < nb) { sh[k][0] += b[k] * dc0; sh[k][1] += b[k] * dc1; sh[k][2] += b[k] * dc2; }
-            } else { sh[0][0] += dc0; sh[0][1] += dc1; sh[0][2] += dc2; }
-            geo[0] += a1.z; geo[1] += a1.w; geo[2] += a2.x; geo[3] += a2.y; geo[4] += a2.z; geo[5] += a2.w;
-            geo[6] += a3.x; geo[7] += a3.y; geo[8] += a3.z; geo[9] += a3.w; geo[10] += a4.x; geo[11] += a4.y;
-            geo[12] += a4.z; geo[13] += a4.w; geo[14] += a5.x;
+        if (end <= begin) continue;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        unsigned long long i = begin;
+        for (; i + 4 <= end && i + 4 <= A.num_records; i += 4) {
+            a0 += A.records[i * RECW + lane]; a1 += A.records[(i + 1) * RECW + lane];
+            a2 += A.records[(i + 2) * RECW + lane]; a3 += A.records[(i + 3) * RECW + lane];
         }
-        float mine = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) { const float v = wave_sum(sh[k][c]); mine = (lane == k * 3 + c) ? v : mine; }
-#pragma unroll
-        for (int k = 0; k < 15; k++) { const float v = wave_sum(geo[k]); mine = (lane == 48 + k) ? v : mine; }
+        for (; i < end && i < A.num_records; i++) a0 += A.records[i * RECW + lane];
+        const float mine = (a0 + a1) + (a2 + a3);
         float *dst = nullptr;
         bool act = false;
         if (lane < 48) {
@@ -1693,14 +1674,8 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
                 hipLaunchKernelGGL(collect_hits, dim3(persistent_grid(cfg->num_rays, 24)), dim3(64), 0, stream, A);
         }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
-        if (!(A.exp & 1024)) {
-            ProfScope p2(K_TRACE_SORT, stream);
-            hipLaunchKernelGGL(sort_composite_fwd, dim3(stride_grid(cfg->num_rays, 1)), dim3(64), 0, stream, A);
-        } else {
-            { ProfScope p2(K_TRACE_SORT, stream); hipLaunchKernelGGL(sort_hit_lists, dim3(stride_grid(cfg->num_rays, 1)), dim3(64), 0, stream, A); }
-            ENVGS_CHECK_LAUNCH(dcfg, stream);
-            { ProfScope p3(K_TRACE_COMPOSITE, stream); hipLaunchKernelGGL(composite_lists_fwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
-        }
+        A.state = (float4 *)L->hit_state; A.entries = (unsigned long long *)L->entries; A.pairs = L->pairs; A.n_entries = L->n_entries;
+        { ProfScope p2(K_TRACE_SORT, stream); hipLaunchKernelGGL(sort_composite_fwd, dim3(stride_grid(cfg->num_rays, 1)), dim3(64), 0, stream, A); }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
         { ProfScope p8(K_TRACE_REGISTER, stream); hipLaunchKernelGGL(register_hits, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
@@ -1763,15 +1738,12 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
         if (L && L->cap > 0 && cfg->max_trace_depth == 0 && L->hit_lists && L->hit_cnt && L->n_used) {
             A.hits = (uint2 *)L->hit_lists; A.hit_cnt = L->hit_cnt; A.n_used = L->n_used; A.cap = L->cap;
             if (L->ray_keys && L->ray_order && L->ray_sort_temp && !(A.exp & 64)) A.order = L->ray_order + cfg->num_rays;
-            if (L->records && L->num_records > 0 && L->surf_cnt && L->surf_off && !(A.exp & 8)) {
-                // atomic-free: per-hit records grouped by surfel, then one wavefront per surfel reduces its segment
+            if (L->records && L->num_records > 0 && L->surf_cnt && L->surf_off && L->hit_state && L->entries && L->pairs && L->n_entries && !(A.exp & 8)) {
+                // atomic-free: one record per (batch, surfel) entry, grouped by surfel; then each surfel's records are summed
                 A.surf_cnt = L->surf_cnt; A.surf_off = L->surf_off; A.records = L->records; A.num_records = L->num_records;
-                {
-                    ProfScope p5(K_TRACE_LIST_BWD, stream);
-                    if (A.exp & 2048) hipLaunchKernelGGL(composite_bwd_scan_records, dim3(stride_grid(cfg->num_rays, 1)), dim3(64), 0, stream, A);
-                    else hipLaunchKernelGGL(composite_lists_bwd_records, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A);
-                }
-                { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 1)), dim3(256), 0, stream, A); }
+                A.state = (float4 *)L->hit_state; A.entries = (unsigned long long *)L->entries; A.pairs = L->pairs; A.n_entries = L->n_entries;
+                { ProfScope p5(K_TRACE_LIST_BWD, stream); hipLaunchKernelGGL(batch_surfel_bwd, dim3(stride_grid((cfg->num_rays + 63) / 64, 1)), dim3(64), 0, stream, A); }
+                { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 4)), dim3(256), 0, stream, A); }
             } else {
                 ProfScope p5(K_TRACE_LIST_BWD, stream);
                 hipLaunchKernelGGL(composite_lists_bwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A);

@@ -92,7 +92,7 @@ def _cfg(settings, P, R, shs, others, start_from_first, ray_shape):
 NCOPY = 8                    # must equal NCOPY in csrc/trace_render.hip
 HIT_CAP = {"cap": 512}
 SORT_RAYS = {"on": True}     # coherence-sort the rays (direction, origin) before tracing
-USE_RECORDS = {"on": True}   # atomic-free backward (per-hit records grouped by surfel); False = cooperative atomic flush      # per-ray hit-list capacity of the list path; adapted from the largest list of the previous call
+USE_RECORDS = {"on": True}   # atomic-free backward (one record per (batch, surfel) entry, grouped by surfel); False = cooperative atomic flush
 
 
 _ASYNC = {}      # pinned host mirrors of two device counters + the events that say when they are valid
@@ -119,7 +119,7 @@ def _next_cap(dev):
 
 
 def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_precomp, opacities, scales, rotations, settings,
-                  start_from_first, use_lists=True):
+                  start_from_first, use_lists=True, need_grad=True):
     lib = _lib.load()
     dev = means3D.device
     lead = tuple(ray_o.shape[:-1])
@@ -151,10 +151,16 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
         keep.update(ray_keys=torch.empty(2 * R, **i32), ray_order=torch.empty(2 * R, **i32),
                     ray_sort_temp=torch.empty(max(rb, 1), dtype=torch.uint8, device=dev))
         srt = SORT_RAYS["on"]
+        if need_grad and USE_RECORDS["on"]:
+            # what the record backward needs from the forward: per-hit state, and the (batch, surfel) entries with their (lane, k) pairs
+            nbatch = (R + 63) // 64
+            keep.update(hit_state=torch.empty(R, cap, 12, **f32), entries=torch.empty(nbatch, 64 * cap, dtype=torch.int64, device=dev),
+                        pairs=torch.empty(nbatch, 64 * cap, **i32), n_entries=torch.empty(nbatch, 2, **i32))
         lists = _lib.TraceLists(keep["hit_lists"].data_ptr(), keep["hit_cnt"].data_ptr(), keep["n_used"].data_ptr(), cap,
                                 keep["spill"].data_ptr(), keep["surf_acc"].data_ptr(), keep["surf_cnt"].data_ptr(), keep["surf_off"].data_ptr(),
                                 keep["scan_temp"].data_ptr(), sb, keep["ray_keys"].data_ptr() if srt else None,
-                                keep["ray_order"].data_ptr() if srt else None, keep["ray_sort_temp"].data_ptr() if srt else None, rb, None, 0)
+                                keep["ray_order"].data_ptr() if srt else None, keep["ray_sort_temp"].data_ptr() if srt else None, rb, None, 0,
+                                *[(keep[k].data_ptr() if k in keep else None) for k in ("hit_state", "entries", "pairs", "n_entries")])
     p = _lib.ptr
     _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
                                        p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),
@@ -195,13 +201,13 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
     s = saved
     lists = s["lists"]
     records = None
-    if lists is not None and USE_RECORDS["on"]:
-        # atomic-free backward: one 96 B record per composited hit, grouped by surfel.  The count is known on the device
-        # (inclusive scan of the per-surfel hit counts, done at the end of the forward); reading it is the one host sync here.
+    if lists is not None and USE_RECORDS["on"] and "hit_state" in s["keep"]:
+        # atomic-free backward: one 256 B record per (batch, surfel) entry, grouped by surfel.  The count is known on the device
+        # (inclusive scan of the per-surfel entry counts, done at the end of the forward); reading it is the one host sync here.
         s["keep"]["n_rec_event"].synchronize()         # copied at the end of the forward; long since complete
         n_rec = int(s["keep"]["n_rec_host"][0]) & 0xFFFFFFFF if P > 0 else 0
         if n_rec > 0:
-            records = torch.empty(n_rec, 24, **f32)
+            records = torch.empty(n_rec, 64, **f32)
             lists.records = records.data_ptr()
             lists.num_records = n_rec
     _lib.check(lib.envgs_trace_backward(cfg, p(s["nodes"]), p(s["ro"]), p(s["rd"]), p(s["means3D"]), p(s["scales"]), p(s["rotations"]),
@@ -221,7 +227,7 @@ class _TraceSurfels(torch.autograd.Function):
                 cov3D_precomp, tracer_settings, start_from_first, nodes):
         none = lambda t: None if (t is None or t.numel() == 0) else t
         outs, saved = trace_forward(nodes, ray_o, ray_d, means3D, none(shs), none(colors_precomp), none(others_precomp), opacities,
-                                    scales, rotations, tracer_settings, start_from_first)
+                                    scales, rotations, tracer_settings, start_from_first, need_grad=any(ctx.needs_input_grad))
         ctx.saved = saved
         ctx.in_dtypes = tuple(None if t is None else t.dtype for t in (ray_o, ray_d, means3D, grads3D, shs, colors_precomp,
                                                                         others_precomp, opacities, scales, rotations))

@@ -61,18 +61,19 @@ typedef struct envgs_trace_cfg {
 
 /*
  * Scratch of the list path (bounce-free tracing; all DEVICE pointers, caller-allocated).  HBM is used deliberately here
- * (288 GB per MI355X): per-ray hit lists make the backward traversal-free, per-hit gradient records grouped by surfel make
+ * (288 GB per MI355X): per-ray hit lists make the backward traversal-free, per-(batch, surfel) gradient records grouped by surfel make
  * it atomic-free (the L2 atomic units retire ~0.15 T dword-atomics/s, which is what bounded a scatter-add backward).
  */
 typedef struct envgs_trace_lists {
-    uint32_t *hit_lists;     /* (R, cap, 2): after the forward, word 0 = the hit's slot among its surfel's hits, word 1 = surfel id */
+    uint32_t *hit_lists;     /* (R, cap, 2): after the forward the first n_used entries are sorted by (t, id); word 1 = surfel id */
     int32_t *hit_cnt;        /* (R) hits found; > cap => that ray took the K-buffer path */
     int32_t *n_used;         /* (R) hits composited before termination */
     int32_t cap;             /* list capacity per ray, <= 1024; 0 disables the list path */
     int32_t *stack_spill;    /* envgs_trace_stack_spill_ints(R) int32 */
     uint64_t *surf_acc;      /* (P,8) packed accumulators of the forward (8 copies per surfel, chosen by ray index, spread same-address
                                 atomics): low 24 bits hit count, high 40 bits fixed-point weight */
-    uint32_t *surf_cnt;      /* (P,8) composited hits per (surfel, copy) (list path only) */
+    uint32_t *surf_cnt;      /* (P,8) (batch, surfel) entries per (surfel, copy) (list path only); a batch = 64 consecutive rays of the
+                                coherence-sorted order */
     uint32_t *surf_off;      /* (P,8) inclusive prefix sum of surf_cnt; the last entry = number of gradient records */
     void *scan_temp;         /* envgs_raster_scan_temp_bytes(8*P) bytes */
     size_t scan_temp_bytes;
@@ -80,8 +81,13 @@ typedef struct envgs_trace_lists {
     uint32_t *ray_order;     /* (2R) ray permutation (double buffered); the second half holds the order the kernels use */
     void *ray_sort_temp;     /* envgs_trace_ray_sort_temp_bytes(R) bytes */
     size_t ray_sort_temp_bytes;
-    float *records;          /* backward only: (num_records, 24) per-hit gradient records (96 B), grouped by surfel */
+    float *records;          /* backward only: (num_records, 64) one 256 B gradient record per (batch, surfel) entry, grouped by surfel */
     uint64_t num_records;    /* backward only: capacity of `records` in records (>= surf_off[P-1]) */
+    float *hit_state;        /* (R, cap, 12) written by the forward for the backward: transmittance before each composited hit and the
+                                ten prefix sums after it; NULL = forward only (then no record backward) */
+    uint64_t *entries;       /* (ceil(R/64), 64*cap) distinct surfels of every batch, packed id | hits-1 << 24 | slot << 32 */
+    uint32_t *pairs;         /* (ceil(R/64), 64*cap) (lane << 16 | list position) of every composited hit, grouped by entry */
+    int32_t *n_entries;      /* (ceil(R/64), 2) entries merged in the batch's table, single entries filed from the top */
 } envgs_trace_lists;
 
 /* Scratch bytes for the Morton sort + build of P surfels. */
