@@ -1280,7 +1280,7 @@ unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, 
 constexpr int BS_GROUP = 16;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int RECW = 64;      // floats per (batch, surfel) gradient record: 48 SH (or 3 colour) + 15 geometry + pad
-__global__ void __launch_bounds__(64)
+__global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64)
 batch_surfel_bwd(const TraceArgs A)
 {
     __shared__ float4 sdat[2][BS_GROUP][16];               // per entry: surfel record (4 x 16 B) + SH block (12 x 16 B)
@@ -1288,7 +1288,7 @@ batch_surfel_bwd(const TraceArgs A)
     __shared__ unsigned short kmat[2][BS_GROUP][64];       // per entry and ray: list position of the hit + 1, 0 = the ray did not blend it
     __shared__ unsigned spb[2][BS_GROUP];                  // per entry: index of its first pair
     __shared__ unsigned scn[2][BS_GROUP];                  // per entry: hits
-    __shared__ float btile[64][16];                        // B operand of the reduction MFMAs: 16 words per ray
+    __shared__ float btile[16][64];                        // B operand of the reduction MFMAs: 16 words per ray, swizzled (see below)
     const int lane = threadIdx.x;
     const int nb = (A.D + 1) * (A.D + 1);
     const size_t region = (size_t)64 * A.cap;
@@ -1299,21 +1299,30 @@ batch_surfel_bwd(const TraceArgs A)
         const int r = ray_of(A, base + lane);
         const bool valid = r < A.R && A.hit_cnt[r < A.R ? r : 0] <= A.cap;
         const int rr = r < A.R ? r : 0;
-        BwdRay B;
-        bwd_load_ray(A, rr, B);
-        float basis[16];
+        // Per-ray constants.  The suffix terms of dL/dalpha only ever appear as  sum_j g_j (final_j - prefix_j)  (+ the background term), so
+        // the twelve final sums fold into ONE scalar F = sum_j g_j final_j + T_final (bg . g_rgb): 17 live registers instead of 33.
+        float basis[16], Box, Boy, Boz, Bdx, Bdy, Bdz, gR0, gR1, gR2, gD, gA, gN0, gN1, gN2, gX0, gX1, Fsum;
+        {
+            BwdRay B;
+            bwd_load_ray(A, rr, B);
 #pragma unroll
-        for (int k = 0; k < 16; k++) basis[k] = 0.f;
-        sh_basis(A.D, B.ux, B.uy, B.uz, basis);
-        if (A.M == 0) basis[0] = kC0;
+            for (int k = 0; k < 16; k++) basis[k] = 0.f;
+            sh_basis(A.D, B.ux, B.uy, B.uz, basis);
+            if (A.M == 0) basis[0] = kC0;
+            Box = B.ox; Boy = B.oy; Boz = B.oz; Bdx = B.dx; Bdy = B.dy; Bdz = B.dz;
+            gR0 = B.gR0; gR1 = B.gR1; gR2 = B.gR2; gD = B.gD; gA = B.gA; gN0 = B.gN0; gN1 = B.gN1; gN2 = B.gN2; gX0 = B.gX0; gX1 = B.gX1;
+            Fsum = B.gR0 * B.fr0 + B.gR1 * B.fr1 + B.gR2 * B.fr2 + B.gD * B.fD + B.gA * B.fA + B.gN0 * B.fN0 + B.gN1 * B.fN1 + B.gN2 * B.fN2 +
+                   B.gX0 * B.fX0 + B.gX1 * B.fX1 + B.fT * B.bgdot;
+        }
         // A operand of the reduction MFMAs, constant for the batch: lane l holds basis_{l & 15} of ray 4s + (l >> 4)
         float Areg[16];
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; k++) btile[lane][k] = (valid && k < nb) ? basis[k] : (k == 0 ? kC0 : 0.f);
+        for (int k = 0; k < 16; k++) btile[k][(lane + 2 * k) & 63] = (valid && k < nb) ? basis[k] : (k == 0 ? kC0 : 0.f);
         __syncthreads();
 #pragma unroll
-        for (int sI = 0; sI < 16; sI++) Areg[sI] = btile[4 * sI + (lane >> 4)][lane & 15];
+        for (int sI = 0; sI < 16; sI++) Areg[sI] = btile[lane & 15][(4 * sI + (lane >> 4) + 2 * (lane & 15)) & 63];
+        __syncthreads();
         float Sk[16], dO0 = 0.f, dO1 = 0.f, dO2 = 0.f, dD0 = 0.f, dD1 = 0.f, dD2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; k++) Sk[k] = 0.f;
@@ -1336,7 +1345,15 @@ batch_surfel_bwd(const TraceArgs A)
                 if (A.M == 16) {
                     const float4 *s4 = reinterpret_cast<const float4 *>(A.shs + (size_t)sid * 48);
 #pragma unroll
-                    for (int q = 0; q < 3; q++) sdat[buf][el][4 + part * 3 + q] = s4[part * 3 + q];
+                    for (int q = 0; q < 3; q++) {
+                        float4 x = s4[part * 3 + q];
+                        const int i0 = (part * 3 + q) * 4;             // words beyond the active degree are staged as zeros: the entry
+                        if (i0 + 0 >= nb * 3) x.x = 0.f;               // loop then needs no degree checks
+                        if (i0 + 1 >= nb * 3) x.y = 0.f;
+                        if (i0 + 2 >= nb * 3) x.z = 0.f;
+                        if (i0 + 3 >= nb * 3) x.w = 0.f;
+                        sdat[buf][el][4 + part * 3 + q] = x;
+                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 3; q++) {
@@ -1393,25 +1410,23 @@ batch_surfel_bwd(const TraceArgs A)
             const int ne = min(BS_GROUP, NE - g * BS_GROUP);
             // software pipeline over the entries: the per-hit state of entry el+1 is in flight while entry el is evaluated
             int k1 = valid ? (int)kmat[buf][0][lane] : 0;
-            float4 st0 = make_float4(0.f, 0.f, 0.f, 0.f), st1 = st0, st2 = st0;
-            if (k1 > 0) { const float4 *sp = state + (size_t)(k1 - 1) * 3; st0 = sp[0]; st1 = sp[1]; st2 = sp[2]; }
+            float4 st0, st1, st2;
+            { const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) * 3 : A.state; st0 = sp[0]; st1 = sp[1]; st2 = sp[2]; }      // unconditional (idle lanes share one address): no branch, no wait
             for (int el = 0; el < ne; el++) {
                 const unsigned long long d = sdesc[buf][el];
                 const int sid = (int)(d & 0xFFFFFFull);
                 const unsigned long long rec = d >> 32;
                 const bool act = k1 > 0;
-                const float4 c0 = st0, c1 = st1, c2 = st2;
-                if (el + 1 < ne) {
-                    k1 = valid ? (int)kmat[buf][el + 1][lane] : 0;
-                    if (k1 > 0) { const float4 *sp = state + (size_t)(k1 - 1) * 3; st0 = sp[0]; st1 = sp[1]; st2 = sp[2]; }
-                }
-                // this ray's 16 B-matrix words: dL/dcolour (3) and the first 13 geometry words; the last two geometry words go by wave_sum
-                float bv[16], g13 = 0.f, g14 = 0.f;
-#pragma unroll
-                for (int q = 0; q < 16; q++) bv[q] = 0.f;
+                // this ray's 16 B-matrix words -- dL/dcolour (3) and the first 13 geometry words -- go straight to the LDS tile (zeros from
+                // rays that did not blend this surfel); the last two geometry words are summed with DPP.  Tile layout: word n of ray j at
+                // n*64 + ((j + 2n) & 63): conflict-free both for these writes (fixed n, 64 rays) and for the MFMA operand reads (16 words
+                // x 4 rays).  One wavefront per workgroup: its LDS operations execute in program order, so no barrier is needed -- and a
+                // barrier's vmcnt(0) would drain the state prefetch that is in flight.
+                float g13 = 0.f, g14 = 0.f;
+#define BT(n) btile[(n)][(lane + 2 * (n)) & 63]
                 if (act) {
                     const float4 s0 = sdat[buf][el][0], s1 = sdat[buf][el][1], s2 = sdat[buf][el][2], s3 = sdat[buf][el][3];
-                    const SurfHit h = hit_surfel(s0, s1, s2, s3, B.ox, B.oy, B.oz, B.dx, B.dy, B.dz);
+                    const SurfHit h = hit_surfel(s0, s1, s2, s3, Box, Boy, Boz, Bdx, Bdy, Bdz);
                     float col[3]; bool cl[3] = {false, false, false};
                     if (A.M > 0) {
                         float rc[3] = {0.f, 0.f, 0.f};
@@ -1420,68 +1435,79 @@ batch_surfel_bwd(const TraceArgs A)
                             const float4 x = sdat[buf][el][4 + q4];
                             const float xe[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-                            for (int e = 0; e < 4; e++) { const int idx = 4 * q4 + e; if (idx / 3 < nb) rc[idx % 3] += basis[idx / 3] * xe[e]; }
+                            for (int e = 0; e < 4; e++) { const int idx = 4 * q4 + e; rc[idx % 3] += basis[idx / 3] * xe[e]; }
                         }
 #pragma unroll
                         for (int c = 0; c < 3; c++) { const float v = rc[c] + 0.5f; cl[c] = v < 0.f; col[c] = cl[c] ? 0.f : v; }
                     } else { const float4 x = sdat[buf][el][4]; col[0] = x.x; col[1] = x.y; col[2] = x.z; }
                     const float x0 = A.has_others ? A.others[2 * sid] : 0.f, x1 = A.has_others ? A.others[2 * sid + 1] : 0.f;
-                    const float alpha = h.alpha, Tb = c0.x;
+                    const float alpha = h.alpha, Tb = st0.x;
                     const float w = alpha * Tb;
                     const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
                     const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
-                    const float inv1m = 1.0f / (1.0f - alpha);
-                    float dLa = B.gR0 * (Tb * col[0] - (B.fr0 - c0.y) * inv1m) + B.gR1 * (Tb * col[1] - (B.fr1 - c0.z) * inv1m) + B.gR2 * (Tb * col[2] - (B.fr2 - c0.w) * inv1m);
-                    dLa += B.gD * (Tb * h.t - (B.fD - c1.x) * inv1m);
-                    dLa += B.gA * (Tb - (B.fA - c1.y) * inv1m);
-                    dLa += B.gN0 * (Tb * nf0 - (B.fN0 - c1.z) * inv1m) + B.gN1 * (Tb * nf1 - (B.fN1 - c1.w) * inv1m) + B.gN2 * (Tb * nf2 - (B.fN2 - c2.x) * inv1m);
-                    dLa += B.gX0 * (Tb * x0 - (B.fX0 - c2.y) * inv1m) + B.gX1 * (Tb * x1 - (B.fX1 - c2.z) * inv1m);
-                    dLa += -(B.fT * inv1m) * B.bgdot;
-                    const float dc[3] = {cl[0] ? 0.f : w * B.gR0, cl[1] ? 0.f : w * B.gR1, cl[2] ? 0.f : w * B.gR2};
+                    const float inv1m = __frcp_rn(1.0f - alpha);
+                    const float gv_ = gR0 * col[0] + gR1 * col[1] + gR2 * col[2] + gD * h.t + gA + gN0 * nf0 + gN1 * nf1 + gN2 * nf2 + gX0 * x0 + gX1 * x1;
+                    const float gS = gR0 * st0.y + gR1 * st0.z + gR2 * st0.w + gD * st1.x + gA * st1.y + gN0 * st1.z + gN1 * st1.w + gN2 * st2.x +
+                                     gX0 * st2.y + gX1 * st2.z;
+                    const float dLa = Tb * gv_ - (Fsum - gS) * inv1m;
+                    const float dc[3] = {cl[0] ? 0.f : w * gR0, cl[1] ? 0.f : w * gR1, cl[2] ? 0.f : w * gR2};
                     if (A.M > 0) {
 #pragma unroll
                         for (int q4 = 0; q4 < 12; q4++) {
                             const float4 x = sdat[buf][el][4 + q4];
                             const float xe[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-                            for (int e = 0; e < 4; e++) { const int idx = 4 * q4 + e; if (idx / 3 < nb) Sk[idx / 3] += xe[e] * dc[idx % 3]; }
+                            for (int e = 0; e < 4; e++) { const int idx = 4 * q4 + e; Sk[idx / 3] += xe[e] * dc[idx % 3]; }
                         }
                     }
-                    if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * B.gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * B.gX1); }
+                    if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * gX1); }
                     const float dLG = s0.w * dLa;
                     const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
-                    const float su = s1.w, sv = s2.w;
-                    const float qx = B.ox + h.t * B.dx - s0.x, qy = B.oy + h.t * B.dy - s0.y, qz = B.oz + h.t * B.dz - s0.z;
+                    const float isu = __frcp_rn(s1.w), isv = __frcp_rn(s2.w);
+                    const float qx = Box + h.t * Bdx - s0.x, qy = Boy + h.t * Bdy - s0.y, qz = Boz + h.t * Bdz - s0.z;
                     const float dq0 = dLu * s1.x + dLv * s2.x, dq1 = dLu * s1.y + dLv * s2.y, dq2 = dLu * s1.z + dLv * s2.z;
-                    const float cu = dLu / su, cv = dLv / sv;
-                    const float dLt_tot = w * B.gD + dq0 * B.dx + dq1 * B.dy + dq2 * B.dz;
-                    const float kt = dLt_tot / h.denom;
-                    bv[0] = dc[0]; bv[1] = dc[1]; bv[2] = dc[2];
-                    bv[3] = -dq0 + kt * s3.x; bv[4] = -dq1 + kt * s3.y; bv[5] = -dq2 + kt * s3.z;
-                    bv[6] = cu * qx; bv[7] = cu * qy; bv[8] = cu * qz;
-                    bv[9] = cv * qx; bv[10] = cv * qy; bv[11] = cv * qz;
-                    bv[12] = w * sgn * B.gN0 - kt * qx; bv[13] = w * sgn * B.gN1 - kt * qy; bv[14] = w * sgn * B.gN2 - kt * qz;
-                    bv[15] = -dLu * h.u / su * A.mod;
-                    g13 = -dLv * h.v / sv * A.mod;
-                    g14 = h.G * dLa;
+                    const float cu = dLu * isu, cv = dLv * isv;
+                    const float dLt_tot = w * gD + dq0 * Bdx + dq1 * Bdy + dq2 * Bdz;
+                    const float kt = dLt_tot * __frcp_rn(h.denom);
+                    BT(0) = dc[0]; BT(1) = dc[1]; BT(2) = dc[2];
                     const float e0 = dq0 - kt * s3.x, e1 = dq1 - kt * s3.y, e2 = dq2 - kt * s3.z;
+                    BT(3) = -e0; BT(4) = -e1; BT(5) = -e2;
+                    BT(6) = cu * qx; BT(7) = cu * qy; BT(8) = cu * qz;
+                    BT(9) = cv * qx; BT(10) = cv * qy; BT(11) = cv * qz;
+                    const float ws = w * sgn;
+                    BT(12) = ws * gN0 - kt * qx; BT(13) = ws * gN1 - kt * qy; BT(14) = ws * gN2 - kt * qz;
+                    BT(15) = -cu * h.u * A.mod;
+                    g13 = -cv * h.v * A.mod;
+                    g14 = h.G * dLa;
                     dO0 += e0; dO1 += e1; dO2 += e2;
                     dD0 += h.t * e0; dD1 += h.t * e1; dD2 += h.t * e2;
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 16; n++) BT(n) = 0.f;
+                }
+#undef BT
+                if (el + 1 < ne) {                           // next entry's state: in flight during the reduction below
+                    k1 = valid ? (int)kmat[buf][el + 1][lane] : 0;
+                    const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) * 3 : A.state;
+                    st0 = sp[0]; st1 = sp[1]; st2 = sp[2];
                 }
                 // Sum over the 64 rays on the matrix cores: D[16 x 16] = basis^T[16 x 64 rays] . B[64 rays x 16], K = 64 in 16 exact-f32
-                // MFMAs.  Columns 0-2 are the (16,3) SH gradient block; basis_0 is the constant C0 for every ray, so row 0 of the
-                // other 13 columns is C0 x (the plain sum of a geometry word).
-                __syncthreads();                               // previous entry's B tile fully read
+                // MFMAs (four independent chains: the dependent latency is 40 cycles).  Columns 0-2 are the (16,3) SH gradient block;
+                // basis_0 is the constant C0 for every ray, so row 0 of the other 13 columns is C0 x (the plain sum of a geometry word).
+                f32x4 acc4 = {0.f, 0.f, 0.f, 0.f}, accB = acc4, accC = acc4, accD = acc4;
                 {
-                    float4 *bt = reinterpret_cast<float4 *>(&btile[lane][0]);
-                    bt[0] = make_float4(bv[0], bv[1], bv[2], bv[3]); bt[1] = make_float4(bv[4], bv[5], bv[6], bv[7]);
-                    bt[2] = make_float4(bv[8], bv[9], bv[10], bv[11]); bt[3] = make_float4(bv[12], bv[13], bv[14], bv[15]);
-                }
-                __syncthreads();
-                f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+                    const int n = lane & 15, j = lane >> 4;
+                    const float *brow = &btile[n][0];
+                    const int rot = 2 * n + j;
 #pragma unroll
-                for (int sI = 0; sI < 16; sI++)
-                    acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI], btile[4 * sI + (lane >> 4)][lane & 15], acc4, 0, 0, 0);
+                    for (int sI = 0; sI < 16; sI += 4) {
+                        acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI], brow[(4 * sI + rot) & 63], acc4, 0, 0, 0);
+                        accB = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 1], brow[(4 * sI + 4 + rot) & 63], accB, 0, 0, 0);
+                        accC = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 2], brow[(4 * sI + 8 + rot) & 63], accC, 0, 0, 0);
+                        accD = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 3], brow[(4 * sI + 12 + rot) & 63], accD, 0, 0, 0);
+                    }
+                }
+                acc4 = (acc4 + accB) + (accC + accD);
                 const float s13 = wave_sum(g13), s14 = wave_sum(g14);
                 if (rec < A.num_records) {
                     float *ro = A.records + rec * RECW;
@@ -1495,6 +1521,8 @@ batch_surfel_bwd(const TraceArgs A)
             }
         }
         if (valid) {
+            BwdRay B;
+            bwd_load_ray(A, r, B);
             BwdAcc acc;
             bwd_init_acc(acc);
             acc.dO0 = dO0; acc.dO1 = dO1; acc.dO2 = dO2; acc.dD0 = dD0; acc.dD1 = dD1; acc.dD2 = dD2;
