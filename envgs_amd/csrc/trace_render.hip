@@ -1533,32 +1533,80 @@ batch_surfel_bwd(const TraceArgs A)
     }
 }
 
-// Stage 2: sum each surfel's (batch, surfel) records -- 256 B lines, word v of every record belongs to lane v -- and add the result
-// to the gradient buffers (the same word layout as the cooperative flush, so the K-buffer path may add into the same buffers).
+// Stage 2: sum each surfel's (batch, surfel) records into the (zeroed) gradient buffers -- plain stores, every word has one owner; the
+// K-buffer pass for overflowed rays runs afterwards and adds to the same buffers atomically.  16 lanes per surfel, 16 B per lane = one
+// 256 B record per load instruction; the typical surfel has ~15 records, but a few are seen by thousands of batches: those are deferred
+// and summed by the whole workgroup (16 records per instruction) so that no lane group walks a megabyte on its own.
+constexpr int RED_LONG = 96;
+__device__ __forceinline__ void reduce_store(const TraceArgs &A, const int sid, const int q, const int nb, const float *v)
+{
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int wd = 4 * q + e;
+        if (wd < 48) {
+            if (A.M > 0) { if (wd / 3 < nb) A.dshs[(size_t)sid * A.M * 3 + wd] = v[e]; }
+            else if (wd < 3) A.dcolors[(size_t)sid * 3 + wd] = v[e];
+        } else if (wd < 63) A.geo_rec[(size_t)sid * GEO + (wd - 48)] = v[e];
+    }
+}
 __global__ void __launch_bounds__(256)
 reduce_surfel_records(const TraceArgs A)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int longs[64];
+    __shared__ int nlong;
+    __shared__ float4 part[16][16];
+    const int sub = threadIdx.x >> 4, q = threadIdx.x & 15;               // 16 surfels per workgroup
     const int nb = (A.D + 1) * (A.D + 1);
-    for (int sid = blockIdx.x * 4 + wave; sid < A.P; sid += gridDim.x * 4) {
+    const float4 *rp = reinterpret_cast<const float4 *>(A.records) + q;
+    if (threadIdx.x == 0) nlong = 0;
+    __syncthreads();
+    for (int sid0 = blockIdx.x * 16; sid0 < A.P; sid0 += gridDim.x * 16) {
+        const int sid = sid0 + sub;
+        if (sid >= A.P) continue;
         const unsigned end = A.surf_off[(size_t)sid * NCOPY + NCOPY - 1];
         const unsigned begin = A.surf_off[(size_t)sid * NCOPY] - A.surf_cnt[(size_t)sid * NCOPY];     // the NCOPY sub-segments are adjacent
         if (end <= begin) continue;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        unsigned long long i = begin;
-        for (; i + 4 <= end && i + 4 <= A.num_records; i += 4) {
-            a0 += A.records[i * RECW + lane]; a1 += A.records[(i + 1) * RECW + lane];
-            a2 += A.records[(i + 2) * RECW + lane]; a3 += A.records[(i + 3) * RECW + lane];
+        if (end - begin > (unsigned)RED_LONG) {
+            int k = 0;
+            if (q == 0) k = atomicAdd(&nlong, 1);
+            k = __shfl(k, 0, 16);
+            if (k < 64) { if (q == 0) longs[k] = sid; continue; }          // (list full: fall through and do it the slow way)
         }
-        for (; i < end && i < A.num_records; i++) a0 += A.records[i * RECW + lane];
-        const float mine = (a0 + a1) + (a2 + a3);
-        float *dst = nullptr;
-        bool act = false;
-        if (lane < 48) {
-            if (A.M > 0) { act = (lane / 3) < nb; dst = A.dshs + (size_t)sid * A.M * 3 + lane; }
-            else { act = lane < 3; dst = A.dcolors + (size_t)sid * 3 + lane; }
-        } else if (lane < 63) { act = true; dst = A.geo_rec + (size_t)sid * GEO + (lane - 48); }
-        if (act) atomic_add_f32(dst, mine);
+        const unsigned long long hi = end < A.num_records ? end : A.num_records;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        unsigned long long i = begin;
+        for (; i + 4 <= hi; i += 4) {
+            const float4 x0 = rp[i * 16], x1 = rp[(i + 1) * 16], x2 = rp[(i + 2) * 16], x3 = rp[(i + 3) * 16];
+            a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w; a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+            a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w; a3.x += x3.x; a3.y += x3.y; a3.z += x3.z; a3.w += x3.w;
+        }
+        for (; i < hi; i++) { const float4 x0 = rp[i * 16]; a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w; }
+        const float v[4] = {(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w)};
+        reduce_store(A, sid, q, nb, v);
+    }
+    __syncthreads();
+    const int nl = nlong < 64 ? nlong : 64;
+    for (int k = 0; k < nl; k++) {
+        const int sid = longs[k];
+        const unsigned end = A.surf_off[(size_t)sid * NCOPY + NCOPY - 1];
+        const unsigned begin = A.surf_off[(size_t)sid * NCOPY] - A.surf_cnt[(size_t)sid * NCOPY];
+        const unsigned long long hi = end < A.num_records ? end : A.num_records;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        unsigned long long i = (unsigned long long)begin + sub;
+        for (; i + 16 < hi; i += 32) {
+            const float4 x0 = rp[i * 16], x1 = rp[(i + 16) * 16];
+            a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w; a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+        }
+        if (i < hi) { const float4 x0 = rp[i * 16]; a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w; }
+        __syncthreads();
+        part[sub][q] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+        __syncthreads();
+        if (sub == 0) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 16; g++) { const float4 x = part[g][q]; v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w; }
+            reduce_store(A, sid, q, nb, v);
+        }
     }
 }
 
@@ -1771,7 +1819,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
                 A.surf_cnt = L->surf_cnt; A.surf_off = L->surf_off; A.records = L->records; A.num_records = L->num_records;
                 A.state = (float4 *)L->hit_state; A.entries = (unsigned long long *)L->entries; A.pairs = L->pairs; A.n_entries = L->n_entries;
                 { ProfScope p5(K_TRACE_LIST_BWD, stream); hipLaunchKernelGGL(batch_surfel_bwd, dim3(stride_grid((cfg->num_rays + 63) / 64, 1)), dim3(64), 0, stream, A); }
-                { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 4)), dim3(256), 0, stream, A); }
+                { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, stream, A); }
             } else {
                 ProfScope p5(K_TRACE_LIST_BWD, stream);
                 hipLaunchKernelGGL(composite_lists_bwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A);
