@@ -997,126 +997,176 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
 }
 
 constexpr int SORT_MAX = 1024;
+// Cross-lane fetch of a 32-bit value from lane ^ S (S < 64): DPP quad permutes for 1 and 2, ds_swizzle (crossbar only, no LDS memory)
+// for 4, 8, 16, v_permlane32_swap for 32.
+template <int S>
+__device__ __forceinline__ unsigned xlane(unsigned v)
+{
+    if constexpr (S == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);
+    else if constexpr (S == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);
+    else if constexpr (S == 32) {
+        const envgs_u2 r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (threadIdx.x & 32) ? r.x : r.y;
+    } else return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (S << 10));
+}
+
+// One compare-exchange layer of the bitonic network over E*64 keys held as E registers per lane (element e*64 + lane).
+template <int E, int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_layer(unsigned long long (&k)[E], const int lane)
+{
+    if constexpr (STRIDE >= 64) {
+        constexpr int SE = STRIDE / 64;
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            if ((e & SE) == 0) {
+                const bool up = ((e * 64) & SIZE) == 0;                   // SIZE >= 128 here: decided by the register index alone
+                const unsigned long long a = k[e], b = k[e | SE];
+                const bool sw = (a > b) == up;
+                k[e] = sw ? b : a; k[e | SE] = sw ? a : b;
+            }
+    } else {
+        const bool lower = (lane & STRIDE) == 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const bool up = SIZE < 64 ? ((lane & SIZE) == 0) : (((e * 64) & SIZE) == 0);
+            const unsigned long long mine = k[e];
+            const unsigned long long p = ((unsigned long long)xlane<STRIDE>((unsigned)(mine >> 32)) << 32) | xlane<STRIDE>((unsigned)mine);
+            const bool keepmin = lower == up;
+            k[e] = ((p < mine) == keepmin) ? p : mine;
+        }
+    }
+}
+template <int E, int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_merge(unsigned long long (&k)[E], const int lane)
+{
+    bitonic_layer<E, SIZE, STRIDE>(k, lane);
+    if constexpr (STRIDE > 1) bitonic_merge<E, SIZE, STRIDE / 2>(k, lane);
+}
+template <int E, int SIZE>
+__device__ __forceinline__ void bitonic_sort(unsigned long long (&k)[E], const int lane)
+{
+    if constexpr (SIZE > 2) bitonic_sort<E, SIZE / 2>(k, lane);
+    bitonic_merge<E, SIZE, SIZE / 2>(k, lane);
+}
+
 // Sort AND composite, one wavefront per ray, one LANE per hit.  A lane-per-ray walk is a chain of dependent
 // gathers -- list entry -> surfel record + SH block -> blend -> next entry -- whose length is the ray's hit count; here the 64 hits of
 // a chunk fetch their records independently (all gathers in flight at once) and the front-to-back recurrences (transmittance product,
-// the two distortion moments) become wavefront scans.  The sorted list is written back only up to the terminating hit.
+// the two distortion moments, the ten blended sums) become wavefront scans.  The (t, id) keys are sorted IN REGISTERS -- E keys per
+// lane, a bitonic network whose cross-lane layers use DPP / ds_swizzle / permlane32 and whose long strides are register-to-register --
+// so the sorted chunk c is simply register c: no LDS, no barriers, no bank conflicts.  The sorted list is written back only up to the
+// terminating hit.
+template <int E>
+__device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int r, const int n, const int lane, unsigned &st_hits)
+{
+    uint2 *list = A.hits + (size_t)r * A.cap;
+    unsigned long long kreg[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int i = e * 64 + lane;
+        unsigned long long kk = ~0ull;
+        if (i < n) { const uint2 q = list[i]; kk = ((unsigned long long)q.x << 32) | q.y; }
+        kreg[e] = kk;
+    }
+    bitonic_sort<E, E * 64>(kreg, lane);
+    const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
+    const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
+    float basis[16];
+    {
+        const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        sh_basis(A.D, dx * il, dy * il, dz * il, basis);
+    }
+    // carried across chunks (wave-uniform): transmittance, the two distortion moments, and the ten blended sums
+    // [rgb 3, depth, acc, normal 3, aux 2] -- kept as running PREFIX sums because the backward needs them per hit
+    float T = 1.0f, M1 = 0.f, M2 = 0.f, C[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) C[j] = 0.f;
+    float dist = 0.f;                                   // per-lane partial sum
+    int used = 0;
+    float4 *state = A.state ? A.state + (size_t)r * A.cap * 3 : nullptr;
+#pragma unroll
+    for (int ce = 0; ce < E; ce++) {
+        const int cb = ce * 64;
+        if (cb >= n) break;
+        const int i = cb + lane;
+        const bool has = i < n;
+        int sid = 0;
+        float alpha = 0.f, t = 0.f, sg = 0.f;
+        float4 s3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has) {
+            sid = (int)(unsigned)kreg[ce];
+            const float4 *sr = A.srec + (size_t)sid * 4;
+            s3 = sr[3];
+            const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], s3, ox, oy, oz, dx, dy, dz);
+            alpha = h.alpha; t = h.t; sg = h.denom < 0.0f ? 1.f : -1.f;
+        }
+        const float P = wave_scan_mul(1.0f - alpha);                    // prod_{j<=i} (1 - alpha_j) within the chunk
+        const float Pex = dpp_fill<0x138>(P, 1.f);                      // wave_shr:1
+        const float test_T = T * P, Tb = T * Pex;                       // transmittance after / before this hit
+        const unsigned long long stop = __ballot(has && test_T < T_EPS);
+        const int f = stop ? (int)__builtin_ctzll(stop) : 64;           // first terminating lane: it and everything behind is dropped
+        const bool use = has && lane < f;
+        const float w = use ? alpha * Tb : 0.f;
+        float col[3] = {0.f, 0.f, 0.f}; bool cl[3];
+        if (use) surfel_color(A, sid, basis, col, cl);
+        const float tt = t > NEAR_N ? t : NEAR_N;
+        const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / tt);
+        const float mw = m * w, mmw = m * m * w;
+        const float S1 = wave_scan_add(mw), S2 = wave_scan_add(mmw);
+        const float M1b = M1 + (S1 - mw), M2b = M2 + (S2 - mmw);        // moments before this hit
+        dist += (m * m * (1.0f - Tb) + M2b - 2.0f * m * M1b) * w;
+        float x0 = 0.f, x1 = 0.f;
+        if (A.has_others && use) { x0 = A.others[2 * sid]; x1 = A.others[2 * sid + 1]; }
+        float S[10] = {w * col[0], w * col[1], w * col[2], w * t, w, sg * w * s3.x, sg * w * s3.y, sg * w * s3.z, w * x0, w * x1};
+#pragma unroll
+        for (int j = 0; j < 10; j++) S[j] = C[j] + wave_scan_add(S[j]);               // inclusive: this hit already added
+        if (use) {
+            list[i] = make_uint2(__float_as_uint(w), (unsigned)sid);
+            if (state) {
+                float4 *o = state + (size_t)i * 3;
+                o[0] = make_float4(Tb, S[0], S[1], S[2]);
+                o[1] = make_float4(S[3], S[4], S[5], S[6]);
+                o[2] = make_float4(S[7], S[8], S[9], alpha);
+            }
+        }
+        const int nu = f < 64 ? f : min(64, n - cb);                    // hits of this chunk that were blended
+        used += nu;
+        M1 += wave_bcast(S1, 63); M2 += wave_bcast(S2, 63);
+#pragma unroll
+        for (int j = 0; j < 10; j++) C[j] = wave_bcast(S[j], 63);
+        if (nu > 0) T = T * wave_bcast(P, nu - 1);
+        if (f < 64) break;
+    }
+    st_hits += (unsigned)used;
+    dist = wave_sum(dist);
+    if (lane == 0) {
+        A.n_used[r] = used;
+        const float c0 = C[0] + T * (0 < A.bg_len ? A.bg[0] : 0.f), c1 = C[1] + T * (1 < A.bg_len ? A.bg[1] : 0.f), c2 = C[2] + T * (2 < A.bg_len ? A.bg[2] : 0.f);
+        A.rgb[3 * r] = c0; A.rgb[3 * r + 1] = c1; A.rgb[3 * r + 2] = c2;
+        A.dpt[r] = C[3]; A.acc[r] = C[4]; A.dist[r] = dist;
+        A.norm[3 * r] = C[5]; A.norm[3 * r + 1] = C[6]; A.norm[3 * r + 2] = C[7];
+        A.aux[2 * r] = C[8]; A.aux[2 * r + 1] = C[9];
+        A.final_T[r] = T;
+        float *mm = A.mid + (size_t)r * MID;
+        mm[0] = ox; mm[1] = oy; mm[2] = oz; mm[3] = dx; mm[4] = dy; mm[5] = dz; mm[6] = C[3]; mm[7] = C[4];
+        mm[8] = C[5]; mm[9] = C[6]; mm[10] = C[7]; mm[11] = C[8]; mm[12] = C[9]; mm[13] = c0; mm[14] = c1; mm[15] = c2;
+    }
+}
+
 __global__ void __launch_bounds__(64)
 sort_composite_fwd(const TraceArgs A)
 {
-    __shared__ unsigned long long keys[SORT_MAX];
     const int lane = threadIdx.x;
     unsigned st_hits = 0;
     for (int slot = blockIdx.x; slot < A.R; slot += gridDim.x) {
         const int r = ray_of(A, slot);
         const int n = A.hit_cnt[r];
         if (n > A.cap) continue;                            // overflow: the K-buffer kernel owns this ray
-        uint2 *list = A.hits + (size_t)r * A.cap;
-        __syncthreads();
-        if (n >= 2) {
-            int np = 2;
-            while (np < n) np <<= 1;
-            for (int i = lane; i < np; i += 64) {
-                unsigned long long k = ~0ull;
-                if (i < n) { const uint2 e = list[i]; k = ((unsigned long long)e.x << 32) | e.y; }
-                keys[i] = k;
-            }
-            __syncthreads();
-            for (int size = 2; size <= np; size <<= 1)
-                for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                    for (int i = lane; i < (np >> 1); i += 64) {
-                        const int lo = ((i / stride) * (stride << 1)) + (i % stride);
-                        const int hi = lo + stride;
-                        const bool up = ((lo & size) == 0);
-                        const unsigned long long a = keys[lo], b = keys[hi];
-                        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
-                    }
-                    __syncthreads();
-                }
-        } else if (n == 1 && lane == 0) {
-            const uint2 e = list[0];
-            keys[0] = ((unsigned long long)e.x << 32) | e.y;
-        }
-        __syncthreads();
-        const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
-        const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
-        float basis[16];
-        {
-            const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-            sh_basis(A.D, dx * il, dy * il, dz * il, basis);
-        }
-        // carried across chunks (wave-uniform): transmittance, the two distortion moments, and the ten blended sums
-        // [rgb 3, depth, acc, normal 3, aux 2] -- kept as running PREFIX sums because the backward needs them per hit
-        float T = 1.0f, M1 = 0.f, M2 = 0.f, C[10];
-#pragma unroll
-        for (int j = 0; j < 10; j++) C[j] = 0.f;
-        float dist = 0.f;                                   // per-lane partial sum
-        int used = 0;
-        float4 *state = A.state ? A.state + (size_t)r * A.cap * 3 : nullptr;
-        for (int cb = 0; cb < n; cb += 64) {
-            const int i = cb + lane;
-            const bool has = i < n;
-            int sid = 0;
-            float alpha = 0.f, t = 0.f, sg = 0.f;
-            float4 s3 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (has) {
-                sid = (int)(unsigned)keys[i];
-                const float4 *sr = A.srec + (size_t)sid * 4;
-                s3 = sr[3];
-                const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], s3, ox, oy, oz, dx, dy, dz);
-                alpha = h.alpha; t = h.t; sg = h.denom < 0.0f ? 1.f : -1.f;
-            }
-            const float P = wave_scan_mul(1.0f - alpha);                    // prod_{j<=i} (1 - alpha_j) within the chunk
-            const float Pex = dpp_fill<0x138>(P, 1.f);                      // wave_shr:1
-            const float test_T = T * P, Tb = T * Pex;                       // transmittance after / before this hit
-            const unsigned long long stop = __ballot(has && test_T < T_EPS);
-            const int f = stop ? (int)__builtin_ctzll(stop) : 64;           // first terminating lane: it and everything behind is dropped
-            const bool use = has && lane < f;
-            const float w = use ? alpha * Tb : 0.f;
-            float col[3] = {0.f, 0.f, 0.f}; bool cl[3];
-            if (use) surfel_color(A, sid, basis, col, cl);
-            const float tt = t > NEAR_N ? t : NEAR_N;
-            const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / tt);
-            const float mw = m * w, mmw = m * m * w;
-            const float S1 = wave_scan_add(mw), S2 = wave_scan_add(mmw);
-            const float M1b = M1 + (S1 - mw), M2b = M2 + (S2 - mmw);        // moments before this hit
-            dist += (m * m * (1.0f - Tb) + M2b - 2.0f * m * M1b) * w;
-            float x0 = 0.f, x1 = 0.f;
-            if (A.has_others && use) { x0 = A.others[2 * sid]; x1 = A.others[2 * sid + 1]; }
-            float S[10] = {w * col[0], w * col[1], w * col[2], w * t, w, sg * w * s3.x, sg * w * s3.y, sg * w * s3.z, w * x0, w * x1};
-#pragma unroll
-            for (int j = 0; j < 10; j++) S[j] = C[j] + wave_scan_add(S[j]);               // inclusive: this hit already added
-            if (use) {
-                list[i] = make_uint2(__float_as_uint(w), (unsigned)sid);
-                if (state) {
-                    float4 *o = state + (size_t)i * 3;
-                    o[0] = make_float4(Tb, S[0], S[1], S[2]);
-                    o[1] = make_float4(S[3], S[4], S[5], S[6]);
-                    o[2] = make_float4(S[7], S[8], S[9], alpha);
-                }
-            }
-            const int nu = f < 64 ? f : min(64, n - cb);                    // hits of this chunk that were blended
-            used += nu;
-            M1 += wave_bcast(S1, 63); M2 += wave_bcast(S2, 63);
-#pragma unroll
-            for (int j = 0; j < 10; j++) C[j] = wave_bcast(S[j], 63);
-            if (nu > 0) T = T * wave_bcast(P, nu - 1);
-            if (f < 64) break;
-        }
-        st_hits += (unsigned)used;
-        dist = wave_sum(dist);
-        if (lane == 0) {
-            A.n_used[r] = used;
-            const float c0 = C[0] + T * (0 < A.bg_len ? A.bg[0] : 0.f), c1 = C[1] + T * (1 < A.bg_len ? A.bg[1] : 0.f), c2 = C[2] + T * (2 < A.bg_len ? A.bg[2] : 0.f);
-            A.rgb[3 * r] = c0; A.rgb[3 * r + 1] = c1; A.rgb[3 * r + 2] = c2;
-            A.dpt[r] = C[3]; A.acc[r] = C[4]; A.dist[r] = dist;
-            A.norm[3 * r] = C[5]; A.norm[3 * r + 1] = C[6]; A.norm[3 * r + 2] = C[7];
-            A.aux[2 * r] = C[8]; A.aux[2 * r + 1] = C[9];
-            A.final_T[r] = T;
-            float *mm = A.mid + (size_t)r * MID;
-            mm[0] = ox; mm[1] = oy; mm[2] = oz; mm[3] = dx; mm[4] = dy; mm[5] = dz; mm[6] = C[3]; mm[7] = C[4];
-            mm[8] = C[5]; mm[9] = C[6]; mm[10] = C[7]; mm[11] = C[8]; mm[12] = C[9]; mm[13] = c0; mm[14] = c1; mm[15] = c2;
-        }
+        if (n <= 64) sort_composite_ray<1>(A, r, n, lane, st_hits);
+        else if (n <= 128) sort_composite_ray<2>(A, r, n, lane, st_hits);
+        else if (n <= 256) sort_composite_ray<4>(A, r, n, lane, st_hits);
+        else if (n <= 512) sort_composite_ray<8>(A, r, n, lane, st_hits);
+        else sort_composite_ray<16>(A, r, n, lane, st_hits);
     }
     if (A.stats && lane == 0) atomicAdd(A.stats + 0, (unsigned long long)st_hits);
 }
