@@ -47,18 +47,19 @@ def algorithmic_bytes(kernel, P, N, HW, C, sh_in_kernel):
 
 
 def trace_algorithmic_bytes(kernel, tc, P_env, R):
-    """DESIGN.md "tracer byte model": per-launch algorithmic bytes of the list-path tracer kernels from the kernel's own counters.
-    node visit = one 64 B node; leaf test / composited hit reads the 64 B surfel record; SH degree 3 = 192 B per shaded hit;
-    a backward hit read-modify-writes 63 gradient words (48 SH + 15 geometry)."""
+    """DESIGN.md "tracer byte model" = SURVEY.md 8(d)'s per-unit figures x the kernel's own counters: a node visit of a ray = one 64 B
+    node; a leaf test / composited hit reads the 64 B surfel record; SH degree 3 = 192 B per shaded hit; a backward hit
+    read-modify-writes 63 gradient words (48 SH + 15 geometry).  These are per-RAY units: the packet / batch kernels serve most of them
+    from one fetch per 64 rays, so bytes/time can exceed the HBM peak -- `traffic` (PMC) is what actually crossed the HBM interface."""
     hits, visits, found = tc["hits"], tc["node_visits"], tc["found"]
     if kernel == "trace.collect_hits":
         return visits * 64 + found * (64 + 8) + R * 24
-    if kernel == "trace.sort_hit_lists":
-        return found * 16
-    if kernel == "trace.composite_lists_fwd":
-        return hits * (8 + 64 + 192) + R * (24 + 4 * (11 + 16 + 1))
-    if kernel == "trace.composite_lists_bwd":
-        return hits * (8 + 64 + 192 + 8 * 63) + R * (24 + 4 * 12 + 4 * 12 + 24)
+    if kernel == "trace.sort_composite_fwd":
+        return found * 16 + hits * (8 + 64 + 192 + 48) + R * (24 + 4 * (11 + 16 + 1))
+    if kernel == "trace.register_hits":
+        return hits * (8 + 4 + 4)
+    if kernel == "trace.batch_surfel_bwd":
+        return hits * (8 + 48 + 64 + 192 + 8 * 63) + R * (24 + 4 * 12 + 4 * 12 + 24)
     if kernel == "bvh_build":
         return P_env * (48 + 24 + 6 * 16 + 64 + 64)
     return 0
