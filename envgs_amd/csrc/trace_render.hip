@@ -1187,7 +1187,8 @@ register_hits(const TraceArgs A)
     __shared__ int key[RH_TAB];
     __shared__ unsigned cnt[RH_TAB];                 // hits of this surfel in the batch; after the flush: offset of its first pair
     __shared__ unsigned long long wsum[RH_TAB];
-    __shared__ unsigned nfail;
+    __shared__ unsigned nfail, ndense;
+    __shared__ unsigned short hod[RH_TAB];           // table slot of the d-th distinct surfel, in order of first appearance
     const int lane = threadIdx.x;
     const float wscale = __builtin_ldexpf(1.0f, A.wfrac);
     const size_t region = (size_t)64 * A.cap;
@@ -1198,7 +1199,7 @@ register_hits(const TraceArgs A)
         unsigned *prs = A.pairs ? A.pairs + (size_t)batch * region : nullptr;
         __syncthreads();
         for (int i = lane; i < RH_TAB; i += 64) { key[i] = -1; cnt[i] = 0u; wsum[i] = 0ull; }
-        if (lane == 0) nfail = 0u;
+        if (lane == 0) { nfail = 0u; ndense = 0u; }
         __syncthreads();
         const int r = ray_of(A, base + lane);
         int n = 0;
@@ -1217,6 +1218,7 @@ register_hits(const TraceArgs A)
                 bool ok = false;
                 for (int t = 0; t < 24; t++) {
                     const int old = atomicCAS(&key[h], -1, (int)e[j].y);
+                    if (old == -1) hod[atomicAdd(&ndense, 1u)] = (unsigned short)h;      // first to see this surfel: entries keep this order
                     if (old == -1 || old == (int)e[j].y) { ok = true; break; }
                     h = (h + 1) & (RH_TAB - 1);
                 }
@@ -1235,24 +1237,26 @@ register_hits(const TraceArgs A)
             }
         }
         __syncthreads();
-        unsigned carry_d = 0u, carry_off = 0u;
-        for (int c = 0; c < RH_TAB; c += 64) {
-            const int h = c + lane;
-            const int sid = key[h];
-            const bool occ = sid >= 0;
-            const unsigned long long mask = __ballot(occ);
+        // Flush in order of FIRST APPEARANCE along the rays (~ front to back): the backward then meets each ray's hits in roughly ascending
+        // list position, so the per-hit state it gathers is consumed cache line by cache line instead of at random.
+        const unsigned D = ndense;
+        unsigned carry_off = 0u;
+        for (unsigned c = 0; c < D; c += 64) {
+            const unsigned d = c + lane;
+            const bool occ = d < D;
+            const int h = occ ? (int)hod[d] : 0;
+            const int sid = occ ? key[h] : 0;
             const unsigned cn = occ ? cnt[h] : 0u;
             const float incl = wave_scan_add((float)cn);                 // exact: at most 64*cap < 2^24 hits per batch
             const unsigned offh = carry_off + (unsigned)incl - cn;
             if (occ) {
-                const unsigned d = carry_d + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
                 const unsigned long long old = atomicAdd(A.surf_acc + (size_t)sid * NCOPY + copy, (wsum[h] << 24) | 1ull);
                 if (ent) ent[d] = (unsigned long long)(unsigned)sid | ((unsigned long long)(cn - 1u) << 24) | ((old & 0xFFFFFFull) << 32);
                 cnt[h] = offh;
             }
-            carry_d += (unsigned)__popcll(mask);
             carry_off += (unsigned)wave_bcast(incl, 63);
         }
+        const unsigned carry_d = D;
         __syncthreads();
         if (A.n_entries && lane == 0) { A.n_entries[2 * batch] = (int)carry_d; A.n_entries[2 * batch + 1] = (int)nfail; }
         if (prs)
