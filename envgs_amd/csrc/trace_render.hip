@@ -154,7 +154,7 @@ struct TraceArgs {
     unsigned long long *entries;  // (batches, 64*cap) distinct (batch, surfel) entries, see register_hits
     unsigned *pairs;              // (batches, 64*cap) (lane << 16 | k) of every composited hit, grouped by entry
     int *n_entries;               // (batches, 2) table entries, single entries
-    float4 *state;      // (R, cap, 3) per composited hit: transmittance before it, the ten prefix sums after it, alpha (for the backward)
+    float4 *state;      // (R, cap, 2 | 3) x 16 B per composited hit: transmittance before it and the prefix sums after it (for the backward)
 };
 
 // K-nearest buffer ordered by (t, id); insertion is a fully unrolled compare-exchange chain (registers only).
@@ -1083,7 +1083,8 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
     for (int j = 0; j < 10; j++) C[j] = 0.f;
     float dist = 0.f;                                   // per-lane partial sum
     int used = 0;
-    float4 *state = A.state ? A.state + (size_t)r * A.cap * 3 : nullptr;
+    const int sstr = A.has_others ? 3 : 2;              // per-hit state row: 32 B, or 48 B when the two `others` sums are needed too
+    float4 *state = A.state ? A.state + (size_t)r * A.cap * sstr : nullptr;
 #pragma unroll
     for (int ce = 0; ce < E; ce++) {
         const int cb = ce * 64;
@@ -1123,10 +1124,11 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
         if (use) {
             list[i] = make_uint2(__float_as_uint(w), (unsigned)sid);
             if (state) {
-                float4 *o = state + (size_t)i * 3;
+                // (the acc sum S[4] is not stored: sum_{j<=k} w_j = 1 - T_before * (1 - alpha), which the backward rebuilds)
+                float4 *o = state + (size_t)i * sstr;
                 o[0] = make_float4(Tb, S[0], S[1], S[2]);
-                o[1] = make_float4(S[3], S[4], S[5], S[6]);
-                o[2] = make_float4(S[7], S[8], S[9], alpha);
+                o[1] = make_float4(S[3], S[5], S[6], S[7]);
+                if (A.has_others) o[2] = make_float4(S[8], S[9], 0.f, 0.f);
             }
         }
         const int nu = f < 64 ? f : min(64, n - cb);                    // hits of this chunk that were blended
@@ -1380,7 +1382,8 @@ batch_surfel_bwd(const TraceArgs A)
         float Sk[16], dO0 = 0.f, dO1 = 0.f, dO2 = 0.f, dD0 = 0.f, dD1 = 0.f, dD2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; k++) Sk[k] = 0.f;
-        const float4 *state = A.state + (size_t)rr * A.cap * 3;
+        const int sstr = A.has_others ? 3 : 2;
+        const float4 *state = A.state + (size_t)rr * A.cap * sstr;
         const unsigned long long *ent = A.entries + (size_t)batch * region;
         const unsigned *prs = A.pairs + (size_t)batch * region;
         const int D = A.n_entries[2 * batch], NE = D + A.n_entries[2 * batch + 1];
@@ -1464,8 +1467,8 @@ batch_surfel_bwd(const TraceArgs A)
             const int ne = min(BS_GROUP, NE - g * BS_GROUP);
             // software pipeline over the entries: the per-hit state of entry el+1 is in flight while entry el is evaluated
             int k1 = valid ? (int)kmat[buf][0][lane] : 0;
-            float4 st0, st1, st2;
-            { const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) * 3 : A.state; st0 = sp[0]; st1 = sp[1]; st2 = sp[2]; }      // unconditional (idle lanes share one address): no branch, no wait
+            float4 st0, st1, st2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            { const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) * sstr : A.state; st0 = sp[0]; st1 = sp[1]; if (A.has_others) st2 = sp[2]; }      // unconditional (idle lanes share one address): no branch, no wait
             for (int el = 0; el < ne; el++) {
                 const unsigned long long d = sdesc[buf][el];
                 const int sid = (int)(d & 0xFFFFFFull);
@@ -1501,8 +1504,8 @@ batch_surfel_bwd(const TraceArgs A)
                     const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
                     const float inv1m = __frcp_rn(1.0f - alpha);
                     const float gv_ = gR0 * col[0] + gR1 * col[1] + gR2 * col[2] + gD * h.t + gA + gN0 * nf0 + gN1 * nf1 + gN2 * nf2 + gX0 * x0 + gX1 * x1;
-                    const float gS = gR0 * st0.y + gR1 * st0.z + gR2 * st0.w + gD * st1.x + gA * st1.y + gN0 * st1.z + gN1 * st1.w + gN2 * st2.x +
-                                     gX0 * st2.y + gX1 * st2.z;
+                    const float gS = gR0 * st0.y + gR1 * st0.z + gR2 * st0.w + gD * st1.x + gA * (1.0f - Tb * (1.0f - alpha)) + gN0 * st1.y + gN1 * st1.z +
+                                     gN2 * st1.w + gX0 * st2.x + gX1 * st2.y;
                     const float dLa = Tb * gv_ - (Fsum - gS) * inv1m;
                     const float dc[3] = {cl[0] ? 0.f : w * gR0, cl[1] ? 0.f : w * gR1, cl[2] ? 0.f : w * gR2};
                     if (A.M > 0) {
@@ -1542,8 +1545,8 @@ batch_surfel_bwd(const TraceArgs A)
 #undef BT
                 if (el + 1 < ne) {                           // next entry's state: in flight during the reduction below
                     k1 = valid ? (int)kmat[buf][el + 1][lane] : 0;
-                    const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) * 3 : A.state;
-                    st0 = sp[0]; st1 = sp[1]; st2 = sp[2];
+                    const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) * sstr : A.state;
+                    st0 = sp[0]; st1 = sp[1]; if (A.has_others) st2 = sp[2];
                 }
                 // Sum over the 64 rays on the matrix cores: D[16 x 16] = basis^T[16 x 64 rays] . B[64 rays x 16], K = 64 in 16 exact-f32
                 // MFMAs (four independent chains: the dependent latency is 40 cycles).  Columns 0-2 are the (16,3) SH gradient block;

@@ -154,7 +154,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
         if need_grad and USE_RECORDS["on"]:
             # what the record backward needs from the forward: per-hit state, and the (batch, surfel) entries with their (lane, k) pairs
             nbatch = (R + 63) // 64
-            keep.update(hit_state=torch.empty(R, cap, 12, **f32), entries=torch.empty(nbatch, 64 * cap, dtype=torch.int64, device=dev),
+            keep.update(hit_state=torch.empty(R, cap, 12 if others_precomp is not None else 8, **f32), entries=torch.empty(nbatch, 64 * cap, dtype=torch.int64, device=dev),
                         pairs=torch.empty(nbatch, 64 * cap, **i32), n_entries=torch.empty(nbatch, 2, **i32))
         lists = _lib.TraceLists(keep["hit_lists"].data_ptr(), keep["hit_cnt"].data_ptr(), keep["n_used"].data_ptr(), cap,
                                 keep["spill"].data_ptr(), keep["surf_acc"].data_ptr(), keep["surf_cnt"].data_ptr(), keep["surf_off"].data_ptr(),

@@ -83,8 +83,8 @@ typedef struct envgs_trace_lists {
     size_t ray_sort_temp_bytes;
     float *records;          /* backward only: (num_records, 64) one 256 B gradient record per (batch, surfel) entry, grouped by surfel */
     uint64_t num_records;    /* backward only: capacity of `records` in records (>= surf_off[P-1]) */
-    float *hit_state;        /* (R, cap, 12) written by the forward for the backward: transmittance before each composited hit and the
-                                ten prefix sums after it; NULL = forward only (then no record backward) */
+    float *hit_state;        /* (R, cap, 8) -- (R, cap, 12) with has_others -- written by the forward for the backward: transmittance
+                                before each composited hit and the prefix sums after it; NULL = forward only (then no record backward) */
     uint64_t *entries;       /* (ceil(R/64), 64*cap) distinct surfels of every batch, packed id | hits-1 << 24 | slot << 32 */
     uint32_t *pairs;         /* (ceil(R/64), 64*cap) (lane << 16 | list position) of every composited hit, grouped by entry */
     int32_t *n_entries;      /* (ceil(R/64), 2) entries merged in the batch's table, single entries filed from the top */
