@@ -165,7 +165,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
                                        p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),
                                        p(norm), p(dist), p(aux), p(mid), p(wet), p(final_T), lists, _stream(dev)), "envgs_trace_forward")
-    LAST_STATS.update(P=P, R=R, counters=counters)
+    LAST_STATS.update(P=P, R=R, counters=counters, n_entries=keep.get("n_entries"))
     if cap:
         # asynchronous read-backs for later: the longest list (sizes the next call's cap) and the number of gradient records
         m = _mirror("max_list", dev)
@@ -294,6 +294,16 @@ class SurfelTracer(nn.Module):
         return _TraceSurfels.apply(ray_o, ray_d, v, means3D, grads3D, e if shs is None else shs,
                                    e if colors_precomp is None else colors_precomp, e if others_precomp is None else others_precomp,
                                    opacities, scales, rotations, None, tracer_settings, bool(start_from_first), self.nodes)
+
+
+def last_entry_counts():
+    """Diagnostics of the last list-path forward that prepared a record backward: (entries merged in the per-batch tables,
+    single entries that found no room in a table).  Host sync."""
+    ne = LAST_STATS.get("n_entries")
+    if ne is None:
+        return 0, 0
+    v = ne.sum(0).cpu()
+    return int(v[0]), int(v[1])
 
 
 def last_trace_counts():

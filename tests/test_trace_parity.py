@@ -241,3 +241,50 @@ def test_trace_clustered_surfels_deep_tree():
     chk(L["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"], "dopac")
     chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
     chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
+
+
+@pytest.mark.parametrize("sort_rays", [True, False])
+def test_trace_batch_table_overflow_and_unsorted_rays(sort_rays):
+    """Incoherent rays through a dense set: a 64-ray batch blends far more distinct surfels than its 1024-slot merge table holds, so part
+    of the hits become single entries (filed from the top of the batch's region) -- forward weights and every gradient must still match
+    the oracle; with the coherence sort disabled the per-ray collection kernel feeds the same batch kernels."""
+    from oracle import trace as otr
+    from envgs_amd import tracing
+    gen = torch.Generator().manual_seed(33)
+    P, R = 6000, 1000                                                   # R is not a multiple of 64: a ragged last batch
+    means = (torch.rand(P, 3, generator=gen) * 2 - 1) * 2.0
+    scales = 0.12 + 0.1 * torch.rand(P, 2, generator=gen)
+    q = torch.randn(P, 4, generator=gen)
+    g = dict(means3D=means, scales=scales, rotations=q / q.norm(dim=-1, keepdim=True), opacities=torch.sigmoid(torch.randn(P, 1, generator=gen) - 2.0),
+             shs=torch.randn(P, 16, 3, generator=gen) * 0.3, others=torch.rand(P, 2, generator=gen), colors_precomp=torch.rand(P, 3, generator=gen))
+    ro = (torch.rand(R, 3, generator=gen) * 2 - 1) * 2.0
+    rd = torch.randn(R, 3, generator=gen); rd = rd / rd.norm(dim=-1, keepdim=True)
+    bg = torch.tensor([0.1, 0.0, 0.2])
+    gr = [torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen), torch.randn(R, 3, generator=gen),
+          torch.randn(R, 2, generator=gen)]
+    old = tracing.SORT_RAYS["on"]
+    try:
+        tracing.SORT_RAYS["on"] = sort_rays
+        outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, 3, True, False, grads=gr)
+        table, singles = tracing.last_entry_counts()
+        cnt = tracing.last_trace_counts()
+    finally:
+        tracing.SORT_RAYS["on"] = old
+    assert table > 0 and singles > 0, (table, singles)                 # both kinds of entries were produced
+    assert table + singles <= cnt["hits"]
+    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
+    ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(), g["opacities"].numpy(),
+                            shs=g["shs"].numpy(), sh_degree=3, others=g["others"].numpy(), bg=bg.numpy(), start_from_first=False)
+    for a, b, nm in ((rgb, ref["rgb"], "rgb"), (dpt[:, 0], ref["dpt"], "dpt"), (acc[:, 0], ref["acc"], "acc"), (aux, ref["aux"], "aux"),
+                     (wet[:, 0], ref["wet"], "wet")):
+        assert_close_frac(a, b, 2e-4, max_bad_frac=2e-3, flip_bound=0.05, what=nm)
+    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
+    chk = lambda a, b, nm: assert_close_frac(a, b, 1e-3, max_bad_frac=5e-3, flip_bound=0.3, what=nm)
+    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
+    chk(L["scales"].grad.cpu().numpy(), rb["dscales"], "dscales")
+    chk(L["rotations"].grad.cpu().numpy(), rb["drots"], "drots")
+    chk(L["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"], "dopac")
+    chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
+    chk(L["others"].grad.cpu().numpy(), rb["dothers"], "dothers")
+    chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
+    chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
