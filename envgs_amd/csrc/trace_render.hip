@@ -1155,12 +1155,14 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
     }
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 sort_composite_fwd(const TraceArgs A)
 {
-    const int lane = threadIdx.x;
+    // 4 wavefronts per workgroup take 4 CONSECUTIVE rays of the coherence-sorted order: they blend mostly the same surfels at the same
+    // time, so the records / SH blocks one of them pulls into this CU's L1 serve the others
+    const int lane = threadIdx.x & 63;
     unsigned st_hits = 0;
-    for (int slot = blockIdx.x; slot < A.R; slot += gridDim.x) {
+    for (int slot = blockIdx.x * 4 + (threadIdx.x >> 6); slot < A.R; slot += gridDim.x * 4) {
         const int r = ray_of(A, slot);
         const int n = A.hit_cnt[r];
         if (n > A.cap) continue;                            // overflow: the K-buffer kernel owns this ray
@@ -1808,7 +1810,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
         A.state = (float4 *)L->hit_state; A.entries = (unsigned long long *)L->entries; A.pairs = L->pairs; A.n_entries = L->n_entries;
-        { ProfScope p2(K_TRACE_SORT, stream); hipLaunchKernelGGL(sort_composite_fwd, dim3(stride_grid(cfg->num_rays, 1)), dim3(64), 0, stream, A); }
+        { ProfScope p2(K_TRACE_SORT, stream); hipLaunchKernelGGL(sort_composite_fwd, dim3(stride_grid(cfg->num_rays, 4)), dim3(256), 0, stream, A); }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
         { ProfScope p8(K_TRACE_REGISTER, stream); hipLaunchKernelGGL(register_hits, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
         ENVGS_CHECK_LAUNCH(dcfg, stream);
