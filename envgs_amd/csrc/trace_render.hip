@@ -151,6 +151,9 @@ struct TraceArgs {
     int exp;            // experiment switches (ENVGS_TRACE_EXP env var; 0 in production)
     int *stack_spill;   // collect_hits: (grid, STACK, 64) ints of stack overflow space
     int only_overflow;  // K-buffer kernels: process only rays whose hit_cnt exceeds cap
+    int batch0, batch1; // list-path forward kernels: the range of 64-ray batches this launch owns (segments run on two streams)
+    int seg;            // segment index: selects the batch-fetch counters and the stack-spill slab
+    int spill_stride;   // stack-spill slabs per segment
     unsigned long long *entries;  // (batches, 64*cap) distinct (batch, surfel) entries, see register_hits
     unsigned *pairs;              // (batches, 64*cap) (lane << 16 | k) of every composited hit, grouped by entry
     int *n_entries;               // (batches, 2) table entries, single entries
@@ -777,7 +780,7 @@ collect_hits(const TraceArgs A)
     // Shallow LDS stack (6 KB per wavefront -> ~26 wavefronts per CU instead of 10); the rare deeper pushes spill to a
     // per-wavefront slab in HBM.  Hits are sorted afterwards, so the visiting order only matters for how early the bound tightens.
     __shared__ int stk[LDS_STACK][64];
-    int *spill = A.stack_spill + (size_t)blockIdx.x * (STACK * 64);
+    int *spill = A.stack_spill + ((size_t)A.seg * A.spill_stride + blockIdx.x) * (STACK * 64);
     const int lane = threadIdx.x;
     unsigned visits = 0, rays_done = 0, found_tot = 0;
     // scene size from the root's two child boxes (uniform loads)
@@ -789,10 +792,11 @@ collect_hits(const TraceArgs A)
         if (!(diag > 0.0f) || !(diag < 1.0e29f)) diag = 1.0f;
     }
     const int home = xcc_id();
-    const int nbatch = (A.R + 63) >> 6;
+    const int nbatch = A.batch1 - A.batch0;
     while (true) {
-        const int batch = fetch_batch(A.counter + 16, nbatch, home, lane);
-        if (batch < 0) break;
+        const int fb = fetch_batch(A.counter + 32 + 8 * A.seg, nbatch, home, lane);
+        if (fb < 0) break;
+        const int batch = A.batch0 + fb;
         const int base = batch << 6;
         const int r = ray_of(A, base + lane);
         const bool valid = r < A.R;
@@ -891,7 +895,7 @@ __global__ void __launch_bounds__(64)
 collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ srec)
 {
     __shared__ int stk[PSTACK];
-    int *spill = A.stack_spill + (size_t)blockIdx.x * (STACK * 64);
+    int *spill = A.stack_spill + ((size_t)A.seg * A.spill_stride + blockIdx.x) * (STACK * 64);
     const int lane = threadIdx.x;
     unsigned visits = 0, found_tot = 0;
     float diag = 1.0f;
@@ -902,10 +906,11 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
         if (!(diag > 0.0f) || !(diag < 1.0e29f)) diag = 1.0f;
     }
     const int home = xcc_id();
-    const int nbatch = (A.R + 63) >> 6;
+    const int nbatch = A.batch1 - A.batch0;
     while (true) {
-        const int batch = fetch_batch(A.counter + 16, nbatch, home, lane);
-        if (batch < 0) break;
+        const int fb = fetch_batch(A.counter + 32 + 8 * A.seg, nbatch, home, lane);
+        if (fb < 0) break;
+        const int batch = A.batch0 + fb;
         const int base = batch << 6;
         const int r = ray_of(A, base + lane);
         const bool valid = r < A.R;
@@ -1162,7 +1167,8 @@ sort_composite_fwd(const TraceArgs A)
     // time, so the records / SH blocks one of them pulls into this CU's L1 serve the others
     const int lane = threadIdx.x & 63;
     unsigned st_hits = 0;
-    for (int slot = blockIdx.x * 4 + (threadIdx.x >> 6); slot < A.R; slot += gridDim.x * 4) {
+    const int slot_end = min(A.R, A.batch1 * 64);
+    for (int slot = A.batch0 * 64 + blockIdx.x * 4 + (threadIdx.x >> 6); slot < slot_end; slot += gridDim.x * 4) {
         const int r = ray_of(A, slot);
         const int n = A.hit_cnt[r];
         if (n > A.cap) continue;                            // overflow: the K-buffer kernel owns this ray
@@ -1196,7 +1202,7 @@ register_hits(const TraceArgs A)
     const int lane = threadIdx.x;
     const float wscale = __builtin_ldexpf(1.0f, A.wfrac);
     const size_t region = (size_t)64 * A.cap;
-    for (int base = blockIdx.x * 64; base < A.R; base += gridDim.x * 64) {
+    for (int base = (A.batch0 + (int)blockIdx.x) * 64; base < min(A.R, A.batch1 * 64); base += gridDim.x * 64) {
         const int batch = base >> 6;
         const int copy = batch & (NCOPY - 1);
         unsigned long long *ent = A.entries ? A.entries + (size_t)batch * region : nullptr;
@@ -1755,7 +1761,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     hipStream_t stream = (hipStream_t)stream_;
     envgs_raster_cfg dbg; dbg.debug = cfg->debug;
     const envgs_raster_cfg *dcfg = &dbg;
-    hipError_t e = hipMemsetAsync(counters, 0, 32 * sizeof(uint32_t), stream);
+    hipError_t e = hipMemsetAsync(counters, 0, 96 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return (int)e;
     if (cfg->P > 0) {
         e = hipMemsetAsync(wet, 0, sizeof(float) * (size_t)cfg->P, stream);
@@ -1801,19 +1807,53 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         }
         e = hipMemsetAsync(L->surf_acc, 0, sizeof(unsigned long long) * (size_t)cfg->P * NCOPY, stream);
         if (e != hipSuccess) return (int)e;
-        {
-            ProfScope p1(K_TRACE_COLLECT, stream);
-            if (A.order && !(A.exp & 512))
-                hipLaunchKernelGGL(collect_hits_packet, dim3(persistent_grid(cfg->num_rays, 24)), dim3(64), 0, stream, A, A.nodes, A.srec);
-            else
-                hipLaunchKernelGGL(collect_hits, dim3(persistent_grid(cfg->num_rays, 24)), dim3(64), 0, stream, A);
-        }
-        ENVGS_CHECK_LAUNCH(dcfg, stream);
         A.state = (float4 *)L->hit_state; A.entries = (unsigned long long *)L->entries; A.pairs = L->pairs; A.n_entries = L->n_entries;
-        { ProfScope p2(K_TRACE_SORT, stream); hipLaunchKernelGGL(sort_composite_fwd, dim3(stride_grid(cfg->num_rays, 4)), dim3(256), 0, stream, A); }
-        ENVGS_CHECK_LAUNCH(dcfg, stream);
-        { ProfScope p8(K_TRACE_REGISTER, stream); hipLaunchKernelGGL(register_hits, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A); }
-        ENVGS_CHECK_LAUNCH(dcfg, stream);
+        // The ray batches are split into two segments that run collect -> sort+composite -> register on two streams: the collection
+        // kernel is a persistent grid whose wavefronts drain over the time of one whole batch, and the second segment's wavefronts
+        // (and the first segment's next kernel) move into the CUs it leaves idle.
+        const int nbatch_all = (cfg->num_rays + 63) / 64;
+        int nseg = 2;                                         // measured: 1 -> 18.3 ms / step, 2 -> 17.5, 4 -> 19.4 (each collection launch lasts at least one batch)
+        { const char *sv = getenv("ENVGS_SEGMENTS"); if (sv) nseg = atoi(sv); }
+        if (nseg > 8) nseg = 8;
+        while (nseg > 1 && nbatch_all / nseg < 256) nseg >>= 1;
+        if (nseg < 1) nseg = 1;
+        hipStream_t aux = nullptr;
+        static hipStream_t s_aux = nullptr;
+        static hipEvent_t s_fork = nullptr, s_join = nullptr;
+        if (nseg > 1) {
+            if (!s_aux) {
+                if (hipStreamCreateWithFlags(&s_aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s_fork, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&s_join, hipEventDisableTiming) != hipSuccess) { s_aux = nullptr; nseg = 1; }
+            }
+            if (nseg > 1) {
+                aux = s_aux;
+                if (hipEventRecord(s_fork, stream) != hipSuccess || hipStreamWaitEvent(aux, s_fork, 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+            }
+        }
+        for (int sg = 0; sg < nseg; sg++) {                   // even segments on the caller's stream, odd ones on the auxiliary stream
+            hipStream_t st = (sg & 1) ? aux : stream;
+            TraceArgs S = A;
+            S.seg = sg;
+            S.spill_stride = persistent_grid(cfg->num_rays, 32);
+            S.batch0 = (int)((long long)nbatch_all * sg / nseg);
+            S.batch1 = (int)((long long)nbatch_all * (sg + 1) / nseg);
+            const int rays_seg = (S.batch1 - S.batch0) * 64;
+            {
+                ProfScope p1(K_TRACE_COLLECT, st);
+                if (S.order && !(S.exp & 512))
+                    hipLaunchKernelGGL(collect_hits_packet, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S, S.nodes, S.srec);
+                else
+                    hipLaunchKernelGGL(collect_hits, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S);
+            }
+            ENVGS_CHECK_LAUNCH(dcfg, st);
+            { ProfScope p2(K_TRACE_SORT, st); hipLaunchKernelGGL(sort_composite_fwd, dim3(stride_grid(rays_seg, 4)), dim3(256), 0, st, S); }
+            ENVGS_CHECK_LAUNCH(dcfg, st);
+            { ProfScope p8(K_TRACE_REGISTER, st); hipLaunchKernelGGL(register_hits, dim3(stride_grid(rays_seg, 64)), dim3(64), 0, st, S); }
+            ENVGS_CHECK_LAUNCH(dcfg, st);
+        }
+        if (nseg > 1) {
+            if (hipEventRecord(s_join, aux) != hipSuccess || hipStreamWaitEvent(stream, s_join, 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+        }
         hipLaunchKernelGGL(unpack_surfel_acc, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, A.wfrac, A.surf_acc, L->surf_cnt, wet);
         ENVGS_CHECK_LAUNCH(dcfg, stream);
         {   // records of the backward are addressed through the inclusive scan of the per-surfel hit counts

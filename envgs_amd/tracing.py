@@ -132,7 +132,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     ND = cfg.max_trace_depth + 1
     f32 = dict(dtype=torch.float32, device=dev)
     srec = torch.empty(max(P, 1), 16, **f32)
-    counters = torch.empty(32, dtype=torch.int32, device=dev)
+    counters = torch.empty(96, dtype=torch.int32, device=dev)
     rgb = torch.empty(R, 3, **f32); dpt = torch.empty(R, 1, **f32); acc = torch.empty(R, 1, **f32)
     norm = torch.empty(R, 3, **f32); dist = torch.empty(R, 1, **f32); aux = torch.empty(R, 2, **f32)
     mid = torch.empty(R, 16 * ND, **f32); wet = torch.empty(P, 1, **f32); final_T = torch.empty(R, **f32)

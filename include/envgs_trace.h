@@ -105,7 +105,7 @@ ENVGS_API int envgs_bvh_build(int32_t P, const float *vertices, const float *opa
 
 /*
  * SurfelTracer.forward (optix_utils.py:188-201): trace R rays through the surfel set, composite front to back.
- * srec (P,16) is scratch written here (and read again by the backward).  counters: 32 uint32 of scratch; after the
+ * srec (P,16) is scratch written here (and read again by the backward).  counters: 96 uint32 of scratch; after the
  * forward, words [2..7] hold three uint64 totals: composited hits, BVH node visits, traversal rounds (diagnostics that
  * the roofline accounting of bench.py needs: BASELINE.md section 4 "hits / node_visits are data dependent").
  * final_T (R): stage-0 transmittance, kept for the backward.
