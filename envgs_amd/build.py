@@ -16,7 +16,9 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fvisibility=hidden",
           "-Wall", "-Wno-unused-function"]
 # per-file extra flags; raster_project.hip feeds bit-exact integer keys -> no FMA contraction there
-EXTRA = {"raster_project.hip": ["-ffp-contract=off"]}
+# trace_render.hip: the SLP vectoriser pairs scalar fp32 ops into v_pk_* and then spends two v_mov per packed op assembling register pairs
+# (batch_surfel_bwd: 89 v_mov per entry, 255 VGPRs; without it 17 and 221)
+EXTRA = {"raster_project.hip": ["-ffp-contract=off"], "trace_render.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():

@@ -1510,7 +1510,7 @@ batch_surfel_bwd(const TraceArgs A)
                     const float w = alpha * Tb;
                     const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
                     const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
-                    const float inv1m = __frcp_rn(1.0f - alpha);
+                    const float inv1m = __builtin_amdgcn_rcpf(1.0f - alpha);          // v_rcp_f32 (1 ulp): gradient-only terms need no IEEE division
                     const float gv_ = gR0 * col[0] + gR1 * col[1] + gR2 * col[2] + gD * h.t + gA + gN0 * nf0 + gN1 * nf1 + gN2 * nf2 + gX0 * x0 + gX1 * x1;
                     const float gS = gR0 * st0.y + gR1 * st0.z + gR2 * st0.w + gD * st1.x + gA * (1.0f - Tb * (1.0f - alpha)) + gN0 * st1.y + gN1 * st1.z +
                                      gN2 * st1.w + gX0 * st2.x + gX1 * st2.y;
@@ -1528,12 +1528,12 @@ batch_surfel_bwd(const TraceArgs A)
                     if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * gX1); }
                     const float dLG = s0.w * dLa;
                     const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
-                    const float isu = __frcp_rn(s1.w), isv = __frcp_rn(s2.w);
+                    const float isu = __builtin_amdgcn_rcpf(s1.w), isv = __builtin_amdgcn_rcpf(s2.w);
                     const float qx = Box + h.t * Bdx - s0.x, qy = Boy + h.t * Bdy - s0.y, qz = Boz + h.t * Bdz - s0.z;
                     const float dq0 = dLu * s1.x + dLv * s2.x, dq1 = dLu * s1.y + dLv * s2.y, dq2 = dLu * s1.z + dLv * s2.z;
                     const float cu = dLu * isu, cv = dLv * isv;
                     const float dLt_tot = w * gD + dq0 * Bdx + dq1 * Bdy + dq2 * Bdz;
-                    const float kt = dLt_tot * __frcp_rn(h.denom);
+                    const float kt = dLt_tot * __builtin_amdgcn_rcpf(h.denom);
                     BT(0) = dc[0]; BT(1) = dc[1]; BT(2) = dc[2];
                     const float e0 = dq0 - kt * s3.x, e1 = dq1 - kt * s3.y, e2 = dq2 - kt * s3.z;
                     BT(3) = -e0; BT(4) = -e1; BT(5) = -e2;
@@ -1818,16 +1818,22 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         while (nseg > 1 && nbatch_all / nseg < 256) nseg >>= 1;
         if (nseg < 1) nseg = 1;
         hipStream_t aux = nullptr;
-        static hipStream_t s_aux = nullptr;
-        static hipEvent_t s_fork = nullptr, s_join = nullptr;
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr;
         if (nseg > 1) {
-            if (!s_aux) {
-                if (hipStreamCreateWithFlags(&s_aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s_fork, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&s_join, hipEventDisableTiming) != hipSuccess) { s_aux = nullptr; nseg = 1; }
+            // one auxiliary stream + fork / join events per device, created on first use (one process drives one GPU in this design,
+            // but nothing here assumes it)
+            static hipStream_t s_aux[16] = {};
+            static hipEvent_t s_fork[16] = {}, s_join[16] = {};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) nseg = 1;
+            else if (!s_aux[dev]) {
+                if (hipStreamCreateWithFlags(&s_aux[dev], hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&s_fork[dev], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&s_join[dev], hipEventDisableTiming) != hipSuccess) { s_aux[dev] = nullptr; nseg = 1; }
             }
             if (nseg > 1) {
-                aux = s_aux;
-                if (hipEventRecord(s_fork, stream) != hipSuccess || hipStreamWaitEvent(aux, s_fork, 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+                aux = s_aux[dev]; ev_fork = s_fork[dev]; ev_join = s_join[dev];
+                if (hipEventRecord(ev_fork, stream) != hipSuccess || hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
             }
         }
         for (int sg = 0; sg < nseg; sg++) {                   // even segments on the caller's stream, odd ones on the auxiliary stream
@@ -1852,7 +1858,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             ENVGS_CHECK_LAUNCH(dcfg, st);
         }
         if (nseg > 1) {
-            if (hipEventRecord(s_join, aux) != hipSuccess || hipStreamWaitEvent(stream, s_join, 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+            if (hipEventRecord(ev_join, aux) != hipSuccess || hipStreamWaitEvent(stream, ev_join, 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
         }
         hipLaunchKernelGGL(unpack_surfel_acc, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, A.wfrac, A.surf_acc, L->surf_cnt, wet);
         ENVGS_CHECK_LAUNCH(dcfg, stream);
