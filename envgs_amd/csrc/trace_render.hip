@@ -768,7 +768,7 @@ __device__ __forceinline__ int fetch_batch(unsigned *ctr /*8 counters*/, int nba
 }
 
 // Conservative termination bound for the unordered collection.  The ray's accepted hits are binned by distance into 16
-// half-octave bins (16 registers of optical depth -ln(1-alpha)); as soon as the bins up to edge e hold more optical depth than
+// linear bins over its chord through the scene box (16 registers of optical depth -ln(1-alpha)); as soon as the bins up to edge e hold more optical depth than
 // the compositing can survive (T < 1e-4), every hit beyond e is provably after the terminating hit: it is dropped and BVH nodes
 // that start beyond e are pruned.  Exact (never drops a composited hit) and it removes most of the 3x over-collection of a fog.
 constexpr int NBIN = 16;
@@ -783,13 +783,12 @@ collect_hits(const TraceArgs A)
     int *spill = A.stack_spill + ((size_t)A.seg * A.spill_stride + blockIdx.x) * (STACK * 64);
     const int lane = threadIdx.x;
     unsigned visits = 0, rays_done = 0, found_tot = 0;
-    // scene size from the root's two child boxes (uniform loads)
-    float diag = 1.0f;
+    // the scene box = union of the root's two child boxes (uniform loads)
+    float rlx = 0.f, rly = 0.f, rlz = 0.f, rhx = 0.f, rhy = 0.f, rhz = 0.f;
     if (A.P > 0) {
         const float4 n0 = A.nodes[0], n1 = A.nodes[1], n2 = A.nodes[2];
-        const float ex = fmaxf(n0.w, n2.y) - fminf(n0.x, n1.z), ey = fmaxf(n1.x, n2.z) - fminf(n0.y, n1.w), ez = fmaxf(n1.y, n2.w) - fminf(n0.z, n2.x);
-        diag = sqrtf(ex * ex + ey * ey + ez * ez);
-        if (!(diag > 0.0f) || !(diag < 1.0e29f)) diag = 1.0f;
+        rlx = fminf(n0.x, n1.z); rly = fminf(n0.y, n1.w); rlz = fminf(n0.z, n2.x);
+        rhx = fmaxf(n0.w, n2.y); rhy = fmaxf(n1.x, n2.z); rhz = fmaxf(n1.y, n2.w);
     }
     const int home = xcc_id();
     const int nbatch = A.batch1 - A.batch0;
@@ -805,8 +804,18 @@ collect_hits(const TraceArgs A)
         const float dx = A.ray_d[3 * rr], dy = A.ray_d[3 * rr + 1], dz = A.ray_d[3 * rr + 2];
         const float tmin = A.start_from_first ? NEAR_N : 0.0f;
         const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-        const float t0 = diag / (256.0f * sqrtf(dx * dx + dy * dy + dz * dz));     // first bin edge, in units of |d|
-        const float inv_t0 = 1.0f / t0;
+        // bins: LINEAR in t over the ray's chord through the scene box (a fog terminates after a roughly constant optical depth, i.e. at a
+        // roughly constant fraction of the chord: 16 linear bins resolve that point to 1/15 of the chord, half-octave bins to +41 %)
+        float tA, bin_w, inv_bin_w;
+        {
+            const float a0 = (rlx - ox) * ix, a1 = (rhx - ox) * ix, b0 = (rly - oy) * iy, b1 = (rhy - oy) * iy, c0 = (rlz - oz) * iz, c1 = (rhz - oz) * iz;
+            const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1)), tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+            tA = fmaxf(tn, tmin);
+            float span = tf - tA;
+            if (!(span > 0.0f) || !(span < 1.0e30f)) span = 1.0f;               // the ray misses the scene (or a degenerate box): nothing to bin
+            bin_w = span * (1.00001f / (float)(NBIN - 1));
+            inv_bin_w = 1.0f / bin_w;
+        }
         float od[NBIN];
 #pragma unroll
         for (int b = 0; b < NBIN; b++) od[b] = 0.f;
@@ -846,8 +855,8 @@ collect_hits(const TraceArgs A)
                         n++;
                         if (A.exp & 256) continue;
                         // bin (biased upwards: a hit may only ever be filed FARTHER than it is, which keeps the bound conservative)
-                        const float x = h.t * inv_t0;
-                        int b = x <= 1.0f ? 0 : (int)ceilf(2.0f * __log2f(x) + 1e-3f);
+                        const float x = (h.t - tA) * inv_bin_w;
+                        int b = x <= 0.0f ? 0 : (int)ceilf(x + 1e-3f);
                         b = b > NBIN - 1 ? NBIN - 1 : b;
                         const float dep = -__logf(1.0f - h.alpha);
 #pragma unroll
@@ -855,7 +864,7 @@ collect_hits(const TraceArgs A)
                         float cum = 0.f; int kb = NBIN - 1;
 #pragma unroll
                         for (int q = 0; q < NBIN - 1; q++) { cum += od[q]; kb = (cum >= KILL_OD && kb == NBIN - 1) ? q : kb; }
-                        tkill = kb < NBIN - 1 ? t0 * exp2f(0.5f * (float)kb) : 3.0e38f;
+                        tkill = kb < NBIN - 1 ? tA + (float)kb * bin_w : 3.0e38f;
                     }
                 }
             }
@@ -898,12 +907,11 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
     int *spill = A.stack_spill + ((size_t)A.seg * A.spill_stride + blockIdx.x) * (STACK * 64);
     const int lane = threadIdx.x;
     unsigned visits = 0, found_tot = 0;
-    float diag = 1.0f;
+    float rlx, rly, rlz, rhx, rhy, rhz;                   // the scene box = union of the root's two child boxes
     {
         const float4 n0 = nodes[0], n1 = nodes[1], n2 = nodes[2];
-        const float ex = fmaxf(n0.w, n2.y) - fminf(n0.x, n1.z), ey = fmaxf(n1.x, n2.z) - fminf(n0.y, n1.w), ez = fmaxf(n1.y, n2.w) - fminf(n0.z, n2.x);
-        diag = sqrtf(ex * ex + ey * ey + ez * ez);
-        if (!(diag > 0.0f) || !(diag < 1.0e29f)) diag = 1.0f;
+        rlx = fminf(n0.x, n1.z); rly = fminf(n0.y, n1.w); rlz = fminf(n0.z, n2.x);
+        rhx = fmaxf(n0.w, n2.y); rhy = fmaxf(n1.x, n2.z); rhz = fmaxf(n1.y, n2.w);
     }
     const int home = xcc_id();
     const int nbatch = A.batch1 - A.batch0;
@@ -919,8 +927,18 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
         const float dx = A.ray_d[3 * rr], dy = A.ray_d[3 * rr + 1], dz = A.ray_d[3 * rr + 2];
         const float tmin = A.start_from_first ? NEAR_N : 0.0f;
         const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-        const float t0 = diag / (256.0f * sqrtf(dx * dx + dy * dy + dz * dz));
-        const float inv_t0 = 1.0f / t0;
+        // bins: LINEAR in t over the ray's chord through the scene box (a fog terminates after a roughly constant optical depth, i.e. at a
+        // roughly constant fraction of the chord: 16 linear bins resolve that point to 1/15 of the chord, half-octave bins to +41 %)
+        float tA, bin_w, inv_bin_w;
+        {
+            const float a0 = (rlx - ox) * ix, a1 = (rhx - ox) * ix, b0 = (rly - oy) * iy, b1 = (rhy - oy) * iy, c0 = (rlz - oz) * iz, c1 = (rhz - oz) * iz;
+            const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1)), tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+            tA = fmaxf(tn, tmin);
+            float span = tf - tA;
+            if (!(span > 0.0f) || !(span < 1.0e30f)) span = 1.0f;               // the ray misses the scene (or a degenerate box): nothing to bin
+            bin_w = span * (1.00001f / (float)(NBIN - 1));
+            inv_bin_w = 1.0f / bin_w;
+        }
         float od[NBIN];
 #pragma unroll
         for (int b = 0; b < NBIN; b++) od[b] = 0.f;
@@ -962,8 +980,8 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
                     if (hit && h.ok && h.t > tmin && h.t <= tkill) {
                         if (n < A.cap) list[n] = make_uint2(__float_as_uint(h.t), (unsigned)sid);
                         n++;
-                        const float x = h.t * inv_t0;
-                        int b = x <= 1.0f ? 0 : (int)ceilf(2.0f * __log2f(x) + 1e-3f);
+                        const float x = (h.t - tA) * inv_bin_w;
+                        int b = x <= 0.0f ? 0 : (int)ceilf(x + 1e-3f);
                         b = b > NBIN - 1 ? NBIN - 1 : b;
                         const float dep = -__logf(1.0f - h.alpha);
 #pragma unroll
@@ -971,7 +989,7 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
                         float cum = 0.f; int kb = NBIN - 1;
 #pragma unroll
                         for (int q = 0; q < NBIN - 1; q++) { cum += od[q]; kb = (cum >= KILL_OD && kb == NBIN - 1) ? q : kb; }
-                        tkill = kb < NBIN - 1 ? t0 * exp2f(0.5f * (float)kb) : 3.0e38f;
+                        tkill = kb < NBIN - 1 ? tA + (float)kb * bin_w : 3.0e38f;
                     }
                 }
             }
