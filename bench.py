@@ -221,6 +221,8 @@ def main():
                 nz = sum(int((g_ != 0).sum()) for g_ in last_grads if g_ is not None)
                 tot = sum(g_.numel() for g_ in last_grads if g_ is not None)
                 ab = 28 * nz + 4 * (tot - nz)
+            per_step = max(1, round(c_.value / max(n_acc["steps"], 1)))      # the tracer forward runs its kernels once per batch segment
+            ab = ab / per_step                                               # (2 segments on 2 streams, overlapping): bytes per LAUNCH
             kernels[name] = {"ms": round(ms, 4), "launches": c_.value, "alg_MB": round(ab / 1e6, 2),
                              "GBps": round(ab / 1e9 / (ms / 1e3), 1) if ab and ms > 0 else None}
 
