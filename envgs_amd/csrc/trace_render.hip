@@ -942,7 +942,8 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
         float od[NBIN];
 #pragma unroll
         for (int b = 0; b < NBIN; b++) od[b] = 0.f;
-        float tkill = 3.0e38f;
+        float tkill = 3.0e38f, odtot = 0.f;
+        int pend = 0;
         uint2 *list = A.hits + (size_t)rr * A.cap;
         int n = 0;
         int sp = 0;
@@ -986,11 +987,18 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
                         const float dep = -__logf(1.0f - h.alpha);
 #pragma unroll
                         for (int q = 0; q < NBIN; q++) od[q] += (q == b) ? dep : 0.f;
-                        float cum = 0.f; int kb = NBIN - 1;
-#pragma unroll
-                        for (int q = 0; q < NBIN - 1; q++) { cum += od[q]; kb = (cum >= KILL_OD && kb == NBIN - 1) ? q : kb; }
-                        tkill = kb < NBIN - 1 ? tA + (float)kb * bin_w : 3.0e38f;
+                        odtot += dep;
                     }
+                    pend++;
+                }
+            }
+            if (pend >= 3) {               // refresh the bound every third leaf test (a stale bound only collects a little more)
+                pend = 0;
+                if (__ballot(odtot >= KILL_OD) != 0ull) {
+                    float cum = 0.f; int kb = NBIN - 1;
+#pragma unroll
+                    for (int q = 0; q < NBIN - 1; q++) { cum += od[q]; kb = (cum >= KILL_OD && kb == NBIN - 1) ? q : kb; }
+                    tkill = kb < NBIN - 1 ? tA + (float)kb * bin_w : 3.0e38f;
                 }
             }
             const bool goL = lc >= 0 && mL != 0ull, goR = rc >= 0 && mR != 0ull;
