@@ -148,7 +148,8 @@ struct TraceArgs {
     float *records;           // (num_records, 24) per-hit gradient records grouped by surfel
     unsigned long long num_records;
     const unsigned *order;    // (R) ray permutation (coherence sort) or NULL
-    int exp;            // experiment switches (ENVGS_TRACE_EXP env var; 0 in production)
+    int exp;            // diagnostic switches (ENVGS_TRACE_EXP env var; 0 in production): 8 = atomic-flush backward instead of records,
+                        // 64 = no coherence sort of the rays, 512 = per-ray collection kernel even when the rays are sorted
     int *stack_spill;   // collect_hits: (grid, STACK, 64) ints of stack overflow space
     int only_overflow;  // K-buffer kernels: process only rays whose hit_cnt exceeds cap
     int batch0, batch1; // list-path forward kernels: the range of 64-ray batches this launch owns (segments run on two streams)
@@ -312,6 +313,8 @@ trace_fwd(const TraceArgs A, const int ray_h, const int ray_w)
 {
     __shared__ int stk[STACK][64];
     const int lane = threadIdx.x;
+    // overflow pass after the list path: counter[1] holds the longest list of this call -- nothing overflowed, nothing to do
+    if (A.only_overflow && (int)__hip_atomic_load(A.counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= A.cap) return;
     while (true) {
         int base = 0;
         if (lane == 0) base = (int)atomicAdd(A.counter, 64u);
@@ -586,7 +589,7 @@ __device__ __forceinline__ void flush_hits(const TraceArgs &A, float (*fld)[65],
                                            const bool has, const int sid, const float dc0, const float dc1, const float dc2, const float *gv)
 {
     const unsigned long long hm = __builtin_amdgcn_ballot_w64(has);
-    if (hm == 0 || (A.exp & 4)) return;
+    if (hm == 0) return;
     fld[0][lane] = __int_as_float(sid); fld[1][lane] = dc0; fld[2][lane] = dc1; fld[3][lane] = dc2;
 #pragma unroll
     for (int k = 0; k < 15; k++) fld[4 + k][lane] = gv[k];
@@ -609,7 +612,7 @@ __device__ __forceinline__ void flush_hits(const TraceArgs &A, float (*fld)[65],
             dst = A.dcolors + (size_t)hs * 3 + lane;
         }
         if (R.geo_lane) { val = fld[4 + (lane - 48)][l]; dst = A.geo_rec + (size_t)hs * GEO + (lane - 48); }
-        if (((R.sh_lane && !(A.exp & 1)) || (R.geo_lane && !(A.exp & 2)))) atomic_add_f32(dst, val);
+        if (R.sh_lane || R.geo_lane) atomic_add_f32(dst, val);
     }
     __syncthreads();
 }
@@ -638,6 +641,7 @@ trace_bwd(const TraceArgs A, const int ray_h, const int ray_w)
     __shared__ int stk[STACK][64];
     __shared__ float fld[NFLD][65];                 // row stride 65: lanes 48..62 read 15 different rows of one column conflict-free
     const int lane = threadIdx.x;
+    if (A.only_overflow && (int)__hip_atomic_load(A.counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= A.cap) return;
     const FlushRole role = flush_role(A, lane);
     const int nb = (A.D + 1) * (A.D + 1);
     while (true) {
@@ -846,14 +850,13 @@ collect_hits(const TraceArgs A)
             for (int side = 0; side < 2; side++) {
                 const bool hit = side == 0 ? hitL : hitR;
                 const int ch = side == 0 ? lc : rc;
-                if (hit && ch < 0 && !(A.exp & 128)) {
+                if (hit && ch < 0) {
                     const int sid = ~ch;
                     const float4 *sr = A.srec + (size_t)sid * 4;
                     const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], sr[3], ox, oy, oz, dx, dy, dz);
                     if (h.ok && h.t > tmin && h.t <= tkill) {
                         if (n < A.cap) list[n] = make_uint2(__float_as_uint(h.t), (unsigned)sid);
                         n++;
-                        if (A.exp & 256) continue;
                         // bin (biased upwards: a hit may only ever be filed FARTHER than it is, which keeps the bound conservative)
                         const float x = (h.t - tA) * inv_bin_w;
                         int b = x <= 0.0f ? 0 : (int)ceilf(x + 1e-3f);
