@@ -1189,6 +1189,9 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
     }
 }
 
+// EMAX = list capacity / 64 rounded up to a power of two: the kernel is instantiated per capacity class because the widest sort it must
+// be able to run sets its register count (EMAX 4: 123 VGPRs = 4 waves/SIMD, 8: 150 = 3, 16: 211 = 2).
+template <int EMAX>
 __global__ void __launch_bounds__(256)
 sort_composite_fwd(const TraceArgs A)
 {
@@ -1203,9 +1206,11 @@ sort_composite_fwd(const TraceArgs A)
         if (n > A.cap) continue;                            // overflow: the K-buffer kernel owns this ray
         if (n <= 64) sort_composite_ray<1>(A, r, n, lane, st_hits);
         else if (n <= 128) sort_composite_ray<2>(A, r, n, lane, st_hits);
-        else if (n <= 256) sort_composite_ray<4>(A, r, n, lane, st_hits);
-        else if (n <= 512) sort_composite_ray<8>(A, r, n, lane, st_hits);
-        else sort_composite_ray<16>(A, r, n, lane, st_hits);
+        else if (EMAX <= 4 || n <= 256) sort_composite_ray<4>(A, r, n, lane, st_hits);
+        else if constexpr (EMAX >= 8) {
+            if (EMAX == 8 || n <= 512) sort_composite_ray<8>(A, r, n, lane, st_hits);
+            else if constexpr (EMAX >= 16) sort_composite_ray<16>(A, r, n, lane, st_hits);
+        }
     }
     if (A.stats && lane == 0) atomicAdd(A.stats + 0, (unsigned long long)st_hits);
 }
@@ -1881,7 +1886,13 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
                     hipLaunchKernelGGL(collect_hits, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S);
             }
             ENVGS_CHECK_LAUNCH(dcfg, st);
-            { ProfScope p2(K_TRACE_SORT, st); hipLaunchKernelGGL(sort_composite_fwd, dim3(stride_grid(rays_seg, 4)), dim3(256), 0, st, S); }
+            {
+                ProfScope p2(K_TRACE_SORT, st);
+                const dim3 g(stride_grid(rays_seg, 4)), b(256);
+                if (S.cap <= 256) hipLaunchKernelGGL(sort_composite_fwd<4>, g, b, 0, st, S);
+                else if (S.cap <= 512) hipLaunchKernelGGL(sort_composite_fwd<8>, g, b, 0, st, S);
+                else hipLaunchKernelGGL(sort_composite_fwd<16>, g, b, 0, st, S);
+            }
             ENVGS_CHECK_LAUNCH(dcfg, st);
             { ProfScope p8(K_TRACE_REGISTER, st); hipLaunchKernelGGL(register_hits, dim3(stride_grid(rays_seg, 64)), dim3(64), 0, st, S); }
             ENVGS_CHECK_LAUNCH(dcfg, st);
