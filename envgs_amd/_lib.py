@@ -25,6 +25,11 @@ class AdamTensor(ctypes.Structure):
                 ("numel", ctypes.c_int64), ("lr", ctypes.c_float), ("step", ctypes.c_float)]
 
 
+class RowsTensor(ctypes.Structure):
+    """struct envgs_rows_tensor (include/envgs_densify.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("row_bytes", ctypes.c_int64)]
+
+
 class TraceLists(ctypes.Structure):
     """struct envgs_trace_lists (include/envgs_trace.h)."""
     _fields_ = [("hit_lists", ctypes.c_void_p), ("hit_cnt", ctypes.c_void_p), ("n_used", ctypes.c_void_p), ("cap", ctypes.c_int32),
@@ -64,6 +69,10 @@ SYMBOLS = {
     "envgs_reflect_forward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float] + [_P] * 8 + [_P]),
     "envgs_reflect_backward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float] + [_P] * 11 + [_P]),
     "envgs_fused_adam": (c_int, [ctypes.c_int32, ctypes.POINTER(AdamTensor), ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
+    "envgs_compact_temp_bytes": (ctypes.c_size_t, [ctypes.c_int64]),
+    "envgs_compact_scan": (c_int, [ctypes.c_int64, _P, _P, _P, _P, ctypes.c_size_t, _P]),
+    "envgs_compact_gather": (c_int, [ctypes.c_int32, ctypes.POINTER(RowsTensor), ctypes.c_int64, _P, _P, _P]),
+    "envgs_knn3_mean_dist2": (c_int, [ctypes.c_int32, _P, _P, _P]),
     "envgs_prof_enable": (None, [c_int]),
     "envgs_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     "envgs_prof_kernel_name": (ctypes.c_char_p, [c_int]),
