@@ -207,6 +207,29 @@ def main():
     # per-kernel HIP-event times (this rank)
     N_avg = n_acc["N"] / max(n_acc["steps"], 1)
     tcounts = tracing.last_trace_counts() if envgs else None
+
+    # the metric's second half, "render Mpix/s": forward only under no_grad (inference: no per-hit state, no entries), outside the timed region
+    def render(it):
+        vi = (it * world + rank) % 8
+        with torch.no_grad():
+            if envgs:
+                envgs_step.envgs_forward(pkg, tpkg, tracer, cams[vi], rays[vi], params, env_params, bg, env_bg, sh_degree)
+            else:
+                pkg.GaussianRasterizer(raster_settings=settings(cams[vi]))(
+                    means3D=params["means3D"], means2D=torch.zeros_like(params["means3D"]), shs=params["shs"], colors_precomp=None,
+                    opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"], cov3D_precomp=None)
+    n_render = max(2, min(args.steps, 10))
+    render(0); render(1)
+    sync_all()
+    tr0 = time.perf_counter()
+    for it in range(n_render):
+        render(it)
+    sync_all()
+    render_s = (time.perf_counter() - tr0) / n_render
+    if world > 1:
+        tt = torch.tensor([render_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        render_s = float(tt.item())
     kernels = {}
     for k in range(NK):
         t_, c_ = ctypes.c_double(0), ctypes.c_int(0)
@@ -269,6 +292,7 @@ def main():
                        "caller_glue": ("torch (reference expressions)" if (not envgs or args.torch_glue) else "fused HIP (envgs_amd.fused)"),
                        "allreduce_bytes_per_step": int(ar_bytes)},
             "train_mpix_per_s": round(value * HW / 1e6, 2),
+            "render_mpix_per_s": round(world * HW / render_s / 1e6, 2), "render_ms_per_view": round(render_s * 1e3, 4),
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "trace_counts": tcounts,
         }
         print(json.dumps(line))
