@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--torch-glue", action="store_true", help="keep the reference's torch expressions for the caller-side glue (default: fused HIP, SURVEY 8(f).1)")
     ap.add_argument("--optim", default="fused", choices=["fused", "torch", "none"],
                     help="optimizer step inside the timed iteration: sparse fused Adam (envgs_amd.optim, SURVEY 8(f).2), torch.optim.Adam, or none")
+    ap.add_argument("--no-overlap-allreduce", action="store_true", help="N > 1: one flat all-reduce after backward() instead of per-set buckets launched from backward hooks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the same view traced by the brute-force CPU oracle (bounded sample)")
@@ -90,7 +91,7 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count())     # (a functional test may run 2 gloo ranks on one GPU)
     torch.cuda.set_device(dev)
     lib = _lib.load()
     import torch.distributed as dist
@@ -151,6 +152,11 @@ def main():
     elif args.optim == "torch":
         opt = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
     last_grads = []
+    # N > 1: the gradient exchange starts inside backward() -- the environment bucket (final once the tracer's backward is done) is in
+    # flight over xGMI while the base pass is still differentiating; --no-overlap-allreduce = one flat bucket after backward()
+    reducer = None
+    if world > 1 and not args.no_overlap_allreduce:
+        reducer = edist.OverlappedGradReducer([list(env_params.values()), list(params.values())], average=True)
 
     def step(it):
         vi = (it * world + rank) % 8
@@ -168,7 +174,7 @@ def main():
             loss = (color * dcol).sum() + (allmap * dall).sum()
         n_acc["N"] += raster.LAST_STATS["N"]; n_acc["steps"] += 1
         loss.backward()
-        nbytes = edist.allreduce_grads(all_params, average=True) if world > 1 else 0
+        nbytes = (reducer.finish() if reducer is not None else edist.allreduce_grads(all_params, average=True)) if world > 1 else 0
         if opt is not None:
             opt.step()
         last_grads[:] = [p_.grad for p_ in all_params]
@@ -287,7 +293,7 @@ def main():
             "config": {"workload": ("Ref-Real sedan-like full EnvGS (ch05 raster + env LBVH trace)" if envgs else
                                     "Ref-NeRF toaster-like base 2DGS raster only (BASELINE configs[1]), SH deg 3 in-kernel"),
                        "gaussians": P, "env_gaussians": (args.env_gaussians if envgs else 0), "resolution": [H, W], "channels": C, "views": 8,
-                       "parallelism": "dp%d (camera batch sharded, flat grad all-reduce)" % world,
+                       "parallelism": "dp%d (camera batch sharded, %s)" % (world, "env / base grad buckets all-reduced from backward hooks" if reducer is not None else "flat grad all-reduce"),
                        "optimizer": {"fused": "sparse fused Adam, one launch (envgs_amd.optim)", "torch": "torch.optim.Adam", "none": "none"}[args.optim],
                        "caller_glue": ("torch (reference expressions)" if (not envgs or args.torch_glue) else "fused HIP (envgs_amd.fused)"),
                        "allreduce_bytes_per_step": int(ar_bytes)},

@@ -25,7 +25,7 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("ENVGS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)
@@ -62,6 +62,81 @@ def allreduce_grads(tensors, average=True, group=None):
             t.grad.copy_(new)
         off += n
     return flat.numel() * 4
+
+
+class OverlappedGradReducer:
+    """The gradient exchange of `allreduce_grads`, started from inside the backward pass.
+
+    `buckets` = lists of parameters in the order their gradients become final (for EnvGS: the environment set first -- the tracer's
+    backward runs before the base rasterizer's -- then the base set).  A post-accumulate-grad hook on every parameter launches the
+    bucket's ONE flat all-reduce (async) as soon as its last gradient has been accumulated, so the environment bucket travels over xGMI
+    while the base pass is still differentiating; `finish()` waits, averages and writes the results back into `.grad`.  Numerically
+    identical to `allreduce_grads` bucket by bucket.  With a single process (or no process group) it does nothing."""
+
+    def __init__(self, buckets, average=True, group=None):
+        self.buckets = [[t for t in b if t is not None] for b in buckets]
+        self.average, self.group = average, group
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self._handles = []
+        self._reset()
+        if self.enabled:
+            for bi, b in enumerate(self.buckets):
+                for t in b:
+                    self._handles.append(t.register_post_accumulate_grad_hook(self._hook(bi)))
+
+    def _reset(self):
+        self._pending = [len(b) for b in self.buckets]
+        self._inflight = [None] * len(self.buckets)
+
+    def _hook(self, bi):
+        def fn(param):
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0 and self._inflight[bi] is None:
+                self._launch(bi)
+        return fn
+
+    def _launch(self, bi):
+        b = self.buckets[bi]
+        if not b:
+            return
+        grads = [t.grad if t.grad is not None else torch.zeros_like(t) for t in b]
+        flat = torch.cat([g.reshape(-1).float() for g in grads])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._inflight[bi] = (flat, grads, work)
+
+    def finish(self):
+        """Call after backward(): completes every bucket (launching those whose hooks did not all fire -- a parameter without a
+        gradient this step) and returns the bytes exchanged."""
+        if not self.enabled:
+            return 0
+        nbytes = 0
+        world = dist.get_world_size(self.group)
+        for bi, b in enumerate(self.buckets):
+            if not b:
+                continue
+            if self._inflight[bi] is None:
+                self._launch(bi)
+            flat, grads, work = self._inflight[bi]
+            work.wait()
+            if self.average:
+                flat.div_(world)
+            off = 0
+            for t, g in zip(b, grads):
+                n = g.numel()
+                new = flat[off:off + n].view_as(g).to(g.dtype)
+                if t.grad is None:
+                    t.grad = new.clone()
+                else:
+                    t.grad.copy_(new)
+                off += n
+            nbytes += flat.numel() * 4
+        self._reset()
+        return nbytes
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
 
 
 def allreduce_densify_stats(grad_norm_accum, denom, weight_accum, max_radii, group=None):
