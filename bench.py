@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--optim", default="fused", choices=["fused", "torch", "none"],
                     help="optimizer step inside the timed iteration: sparse fused Adam (envgs_amd.optim, SURVEY 8(f).2), torch.optim.Adam, or none")
     ap.add_argument("--no-overlap-allreduce", action="store_true", help="N > 1: one flat all-reduce after backward() instead of per-set buckets launched from backward hooks")
+    ap.add_argument("--no-render", action="store_true", help="skip the forward-only render timing (profiling runs: keeps the kernel statistics to the training steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the same view traced by the brute-force CPU oracle (bounded sample)")
@@ -224,15 +225,17 @@ def main():
                 pkg.GaussianRasterizer(raster_settings=settings(cams[vi]))(
                     means3D=params["means3D"], means2D=torch.zeros_like(params["means3D"]), shs=params["shs"], colors_precomp=None,
                     opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"], cov3D_precomp=None)
-    n_render = max(2, min(args.steps, 10))
-    render(0); render(1)
-    sync_all()
-    tr0 = time.perf_counter()
-    for it in range(n_render):
-        render(it)
-    sync_all()
-    render_s = (time.perf_counter() - tr0) / n_render
-    if world > 1:
+    n_render = 0 if args.no_render else max(2, min(args.steps, 10))
+    render_s = float("nan")
+    if n_render:
+        render(0); render(1)
+        sync_all()
+        tr0 = time.perf_counter()
+        for it in range(n_render):
+            render(it)
+        sync_all()
+        render_s = (time.perf_counter() - tr0) / n_render
+    if world > 1 and n_render:
         tt = torch.tensor([render_s], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         render_s = float(tt.item())
@@ -298,7 +301,8 @@ def main():
                        "caller_glue": ("torch (reference expressions)" if (not envgs or args.torch_glue) else "fused HIP (envgs_amd.fused)"),
                        "allreduce_bytes_per_step": int(ar_bytes)},
             "train_mpix_per_s": round(value * HW / 1e6, 2),
-            "render_mpix_per_s": round(world * HW / render_s / 1e6, 2), "render_ms_per_view": round(render_s * 1e3, 4),
+            "render_mpix_per_s": (round(world * HW / render_s / 1e6, 2) if n_render else None),
+            "render_ms_per_view": (round(render_s * 1e3, 4) if n_render else None),
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "trace_counts": tcounts,
         }
         print(json.dumps(line))

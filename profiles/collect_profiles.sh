@@ -1,10 +1,10 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 rm -rf $O/p_envgs $O/p_raster $O/pmc_fetch $O/pmc_write $O/pmc_*
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_envgs -o envgs -- python $R/bench.py --steps 20 --warmup 4 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_raster -o raster -- python $R/bench.py --workload raster --steps 30 --warmup 4 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_envgs -o envgs -- python $R/bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-render > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_raster -o raster -- python $R/bench.py --workload raster --steps 30 --warmup 4 --no-cpu-baseline --no-render > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-render > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-render > /dev/null 2>&1
 cd $R
 python bench.py > $O/bench_envgs_final.json 2> $O/bench_envgs_final.err
 python bench.py --workload raster > $O/bench_raster_final.json 2> $O/bench_raster_final.err

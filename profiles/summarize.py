@@ -41,7 +41,7 @@ def pmc():
              'envgs::register_hits': 'trace.register_hits', 'envgs::batch_surfel_bwd': 'trace.batch_surfel_bwd',
              'envgs::reduce_surfel_records': 'trace.reduce_surfel_records'}
     out = {"_how": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / rocprofv3 --pmc WRITE_SIZE --kernel-trace (two separate passes, no other trace domains) -- "
-                   "python bench.py --steps 3 --warmup 1 --no-cpu-baseline on MI355X; per-launch averages. Units per MI355X_MICROARCH.md: counters are KB; on gfx950 "
+                   "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-render on MI355X; per-launch averages. Units per MI355X_MICROARCH.md: counters are KB; on gfx950 "
                    "FETCH_SIZE reports 1/2 of the bytes of 16 B/lane reads, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024. WRITE_SIZE is uncalibrated "
                    "(scattered 4-8 B stores are counted at 32 B granularity).", "kernels": {}}
     for k, v in names.items():
@@ -52,8 +52,8 @@ def pmc():
         json.dump(out, open(os.path.join(ROOT, 'profiles', '%s_pmc_envgs.json' % TAG), 'w'), indent=1)
 
 
-stats('envgs', 24, 'full EnvGS step: 300k base surfels ch05 raster + 163840 env surfels LBVH trace, 800x800; python bench.py --steps 20 --warmup 4 --no-cpu-baseline')
-stats('raster', 34, 'raster only: 300k surfels, SH deg 3 in-kernel, 800x800; python bench.py --workload raster --steps 30 --warmup 4 --no-cpu-baseline')
+stats('envgs', 24, 'full EnvGS step: 300k base surfels ch05 raster + 163840 env surfels LBVH trace, 800x800; python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-render (the tracer forward runs as two batch segments on two streams: 2 launches per step, overlapping, so the kernel times sum to more than the step)')
+stats('raster', 34, 'raster only: 300k surfels, SH deg 3 in-kernel, 800x800; python bench.py --workload raster --steps 30 --warmup 4 --no-cpu-baseline --no-render')
 pmc()
 for n in ('envgs', 'raster'):
     src = os.path.join(ROOT, 'gpurun_out', 'bench_%s_final.json' % n)
