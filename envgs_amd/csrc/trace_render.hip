@@ -903,7 +903,10 @@ collect_hits(const TraceArgs A)
 // that is pruned simply stops passing box tests.  Visit order (near child first by majority vote) only affects how early the bounds
 // tighten: the lists are sorted afterwards.
 constexpr int PSTACK = 64;
-__global__ void __launch_bounds__(64)
+// (8 waves per SIMD: with two segments in flight ~10 k wavefronts want a slot; the (n - o) * (1/d) slab form is kept on purpose -- the
+//  one-fma form n*(1/d) - o/d needs an error margin proportional to |o/d|, and in a packet ONE ray with a tiny direction component then
+//  drags the whole wavefront through nodes nobody hits: measured +0.6 ms)
+__global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(64)
 collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ srec)
 {
     __shared__ int stk[PSTACK];
