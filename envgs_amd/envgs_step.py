@@ -75,6 +75,18 @@ def base_pass(pkg, cam, base, bg, sh_degree, scale_modifier=1.0):
                 weight=weight, means2D=means2D, allmap=allmap)
 
 
+def visibility_filter(wet, means3D=None, K=None, R=None, T=None, H=None, W=None, start_from_first=False):
+    """Post-trace visibility of optix_utils.py:203-213: a surfel is visible if any ray blended it (`wet > 0`), or -- only when the trace
+    starts at the camera (`start_from_first`) -- if it projects inside the image at depth >= 0.2.  (P,) bool, detached."""
+    with torch.no_grad():
+        vis = wet[..., 0] > 0.0
+        if start_from_first:
+            uvd = (K @ (R @ means3D[..., None] + T))[..., 0]
+            uv = uvd[..., :2] / uvd[..., 2:]
+            vis = vis | ((uvd[..., 2] >= 0.2) & (uv[..., 0] >= 0.0) & (uv[..., 0] <= W) & (uv[..., 1] >= 0.0) & (uv[..., 1] <= H))
+        return vis.detach().clone()
+
+
 def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree):
     """HardwareRendering.render_gaussians of optix_utils.py with start_from_first=False, max_trace_depth=0."""
     ts = tpkg.SurfelTracingSettings(

@@ -39,3 +39,17 @@ for lo, hi in ((1, 1), (2, 2), (3, 4), (5, 8), (9, 16), (17, 32), (33, 48), (49,
     c = int(h[lo:hi + 1].sum()); hh = int((h[lo:hi + 1] * torch.arange(lo, hi + 1).numpy()).sum())
     print("cnt %2d-%2d: %5.1f%% of entries, %5.1f%% of hits" % (lo, hi, 100.0 * c / cnt.numel(), 100.0 * hh / int(cnt.sum())))
 print("entries per batch: mean %.0f max %d" % (float(D.float().mean()), int(D.max())))
+
+# dump a sample of batches for offline packing simulations
+import numpy as np
+sel = torch.arange(0, nb, 50, device=dev)
+cap = saved["cap"]
+out = dict(D=D[sel].cpu().numpy(), entries=[], pairs=[])
+for b in sel.tolist():
+    d = int(D[b])
+    out["entries"].append(ent[b, :d].cpu().numpy())
+    tot = int((((ent[b, :d] >> 24) & 63) + 1).sum())
+    out["pairs"].append(keep["pairs"][b, :tot].cpu().numpy())
+os.makedirs("gpurun_out", exist_ok=True)
+np.savez_compressed("gpurun_out/batches_sample.npz", D=out["D"], entries=np.concatenate(out["entries"]), pairs=np.concatenate(out["pairs"]))
+print("dumped", len(sel), "batches")

@@ -27,3 +27,20 @@ def test_config1_eager_vs_c_oracle():
     for ch in (0, 1, 2, 3, 4):
         assert_close_frac(allmap[ch].numpy(), ref["allmap"][ch], 1e-4, max_bad_frac=1e-3, flip_bound=0.05, what="allmap%d" % ch)
     assert_close_frac(weight.numpy(), ref["weight"], 1e-4, max_bad_frac=1e-3, flip_bound=0.05, what="weight")
+
+
+def test_visibility_filter_semantics():
+    """SURVEY 8 row a9 (optix_utils.py:203-213): wet > 0, OR-ed with the in-image / z >= 0.2 test only when tracing starts at the camera."""
+    import torch
+    from envgs_amd.envgs_step import visibility_filter
+    wet = torch.tensor([[0.0], [0.3], [0.0], [0.0], [0.0]])
+    K = torch.tensor([[100.0, 0, 50], [0, 100.0, 40], [0, 0, 1]])
+    R = torch.eye(3); T = torch.zeros(3, 1)
+    means = torch.tensor([[0.0, 0.0, 1.0],      # centre of the image, z = 1         -> visible by projection
+                          [9.0, 9.0, 1.0],      # off-image but blended by a ray     -> visible by wet
+                          [0.0, 0.0, 0.1],      # too close (z < 0.2)
+                          [0.6, 0.0, 1.0],      # u = 110 > W = 100                  -> outside
+                          [-0.5, -0.4, 1.0]])   # u = 0, v = 0: the inclusive border -> visible
+    assert visibility_filter(wet).tolist() == [False, True, False, False, False]
+    got = visibility_filter(wet, means, K, R, T, H=80, W=100, start_from_first=True)
+    assert got.tolist() == [True, True, False, False, True] and got.dtype == torch.bool
