@@ -73,6 +73,9 @@ SYMBOLS = {
     "envgs_compact_scan": (c_int, [ctypes.c_int64, _P, _P, _P, _P, ctypes.c_size_t, _P]),
     "envgs_compact_gather": (c_int, [ctypes.c_int32, ctypes.POINTER(RowsTensor), ctypes.c_int64, _P, _P, _P]),
     "envgs_knn3_mean_dist2": (c_int, [ctypes.c_int32, _P, _P, _P]),
+    "envgs_l1_ssim_partial_count": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "envgs_l1_ssim_forward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, _P]),
+    "envgs_l1_ssim_backward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _P, _P]),
     "envgs_prof_enable": (None, [c_int]),
     "envgs_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     "envgs_prof_kernel_name": (ctypes.c_char_p, [c_int]),

@@ -7,7 +7,7 @@ namespace envgs {
 enum KernelId {
     K_PROJECT = 0, K_SCAN, K_EMIT_KEYS, K_SORT, K_RANGES, K_COMPOSITE_FWD, K_COMPOSITE_BWD, K_PROJECT_BWD,
     K_BVH_BUILD, K_TRACE_FWD, K_TRACE_BWD, K_TRACE_COLLECT, K_TRACE_SORT, K_TRACE_COMPOSITE, K_TRACE_KBUF_FWD, K_TRACE_LIST_BWD,
-    K_TRACE_KBUF_BWD, K_TRACE_REDUCE, K_TRACE_REGISTER, K_FUSED_ADAM, K_COUNT
+    K_TRACE_KBUF_BWD, K_TRACE_REDUCE, K_TRACE_REGISTER, K_FUSED_ADAM, K_LOSS_FWD, K_LOSS_BWD, K_COUNT
 };
 void prof_begin(int id, hipStream_t stream);
 void prof_end(int id, hipStream_t stream);

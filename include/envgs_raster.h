@@ -130,7 +130,7 @@ ENVGS_API int envgs_raster_backward(const envgs_raster_cfg *cfg, uint32_t N,
  * kernel_id: 0 project_surfels, 1 scan, 2 emit_tile_keys, 3 radix_sort_pairs, 4 find_tile_ranges,
  *            5 composite_fwd, 6 composite_bwd, 7 project_surfels_bwd, 8 bvh_build, 9 trace_fwd (whole forward), 10 trace_bwd
  *            (whole backward), 11 collect_hits, 12 sort_composite_fwd, 13 (unused), 14 K-buffer forward, 15 batch_surfel_bwd,
- *            16 K-buffer backward, 17 reduce_surfel_records, 18 register_hits, 19 fused_adam_multi.  envgs_prof_kernel_name(id) returns "" past the last id.
+ *            16 K-buffer backward, 17 reduce_surfel_records, 18 register_hits, 19 fused_adam_multi, 20 l1_ssim_fwd, 21 l1_ssim_bwd.  envgs_prof_kernel_name(id) returns "" past the last id.
  * envgs_prof_read synchronises on the recorded events, returns the summed milliseconds and launch count
  * since the last read, and resets the counter.
  */
