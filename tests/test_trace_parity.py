@@ -288,3 +288,39 @@ def test_trace_batch_table_overflow_and_unsorted_rays(sort_rays):
     chk(L["others"].grad.cpu().numpy(), rb["dothers"], "dothers")
     chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
     chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
+
+
+def test_trace_two_segment_forward_pipeline_vs_oracle():
+    """Enough rays (>= 512 batches) for the forward to run as TWO batch segments on two streams (collect -> sort+composite -> register each):
+    the joined result -- images, per-surfel weights, every gradient through the per-batch entries of both segments -- against the oracle."""
+    from oracle import trace as otr
+    from envgs_amd import tracing
+    g, _, _ = trace_scene(P=1500, R=4, seed=17, camera=False)
+    g["scales"] = g["scales"] * 0.5
+    cam = synth.orbit_camera(3, H=192, W=192, fx=160.0, radius=1.0)                 # 36 864 coherent rays = 576 batches
+    ro, rd = synth.get_rays(cam)
+    ro, rd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous()
+    R = ro.shape[0]
+    assert (R + 63) // 64 >= 512
+    bg = torch.tensor([0.2, 0.3, 0.1])
+    gen = torch.Generator().manual_seed(4)
+    gr = [torch.randn(R, 3, generator=gen) / R, torch.randn(R, generator=gen) / R, torch.randn(R, generator=gen) / R, torch.randn(R, 3, generator=gen) / R,
+          torch.randn(R, 2, generator=gen) / R]
+    outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, 3, True, False, grads=gr)
+    table, singles = tracing.last_entry_counts()
+    assert table > 0
+    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
+    ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(), g["opacities"].numpy(),
+                            shs=g["shs"].numpy(), sh_degree=3, others=g["others"].numpy(), bg=bg.numpy(), start_from_first=False)
+    for a, b, nm in ((rgb, ref["rgb"], "rgb"), (dpt[:, 0], ref["dpt"], "dpt"), (acc[:, 0], ref["acc"], "acc"), (norm, ref["norm"], "norm"),
+                     (aux, ref["aux"], "aux"), (wet[:, 0], ref["wet"], "wet")):
+        assert_close_frac(a, b, 2e-4, max_bad_frac=2e-3, flip_bound=0.05, what=nm)
+    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
+    chk = lambda a, b, nm: assert_close_frac(a, b, 1e-3, max_bad_frac=5e-3, flip_bound=0.3, what=nm)
+    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
+    chk(L["scales"].grad.cpu().numpy(), rb["dscales"], "dscales")
+    chk(L["rotations"].grad.cpu().numpy(), rb["drots"], "drots")
+    chk(L["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"], "dopac")
+    chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
+    chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
+    chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
