@@ -1780,7 +1780,8 @@ size_t envgs_trace_ray_sort_temp_bytes(int32_t num_rays)
     return bytes;
 }
 
-size_t envgs_trace_stack_spill_ints(int32_t num_rays) { return (size_t)persistent_grid(num_rays, 24) * STACK * 64; }
+// one slab per persistent wavefront of the collection kernels, for each of the (at most two) batch segments that run concurrently
+size_t envgs_trace_stack_spill_ints(int32_t num_rays) { return (size_t)2 * persistent_grid(num_rays, 24) * STACK * 64; }
 
 int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const float *ray_o, const float *ray_d,
                         const float *means3D, const float *scales, const float *rotations, const float *opacities,
@@ -1851,7 +1852,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         const int nbatch_all = (cfg->num_rays + 63) / 64;
         int nseg = 2;                                         // measured: 1 -> 18.3 ms / step, 2 -> 17.5, 4 -> 19.4 (each collection launch lasts at least one batch)
         { const char *sv = getenv("ENVGS_SEGMENTS"); if (sv) nseg = atoi(sv); }
-        if (nseg > 8) nseg = 8;
+        if (nseg > 2) nseg = 2;                               // (the stack-spill slab and the fetch counters are sized for two)
         while (nseg > 1 && nbatch_all / nseg < 256) nseg >>= 1;
         if (nseg < 1) nseg = 1;
         hipStream_t aux = nullptr;
@@ -1877,7 +1878,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             hipStream_t st = (sg & 1) ? aux : stream;
             TraceArgs S = A;
             S.seg = sg;
-            S.spill_stride = persistent_grid(cfg->num_rays, 32);
+            S.spill_stride = persistent_grid(cfg->num_rays, 24);     // >= this segment's grid; matches envgs_trace_stack_spill_ints
             S.batch0 = (int)((long long)nbatch_all * sg / nseg);
             S.batch1 = (int)((long long)nbatch_all * (sg + 1) / nseg);
             const int rays_seg = (S.batch1 - S.batch0) * 64;
