@@ -120,6 +120,10 @@ __device__ __forceinline__ void sh_basis_grad(int D, float x, float y, float z, 
     }
 }
 
+// t_min of the first stage: camera rays skip the near 0.2 (the rasterizer's near plane), reflected rays start at 0, and the secondary rays of a
+// bounce traced as a call of their own start just off the surface they left (1e-3, what the in-kernel bounce stages use)
+__device__ __forceinline__ float first_tmin(int start_from_first) { return start_from_first == 1 ? NEAR_N : (start_from_first == 2 ? 1.0e-3f : 0.0f); }
+
 struct TraceArgs {
     int P, R, D, M, ND, start_from_first, has_others, bg_len;
     float spec_thr;
@@ -329,7 +333,7 @@ trace_fwd(const TraceArgs A, const int ray_h, const int ray_w)
         }
         float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
         float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
-        float tmin = A.start_from_first ? NEAR_N : 0.0f;
+        float tmin = first_tmin(A.start_from_first);
         float out_rgb[3] = {0.f, 0.f, 0.f};
         unsigned st_hits = 0, st_visits = 0, st_rounds = 0;
         float thr = 1.0f;                               // product of specular weights of the previous stages
@@ -660,7 +664,7 @@ trace_bwd(const TraceArgs A, const int ray_h, const int ray_w)
         bwd_load_ray(A, r, B);
         BwdAcc acc;
         bwd_init_acc(acc);
-        const float tmin = A.start_from_first ? NEAR_N : 0.0f;
+        const float tmin = first_tmin(A.start_from_first);
         float basis[16];
         sh_basis(A.D, B.ux, B.uy, B.uz, basis);
         __syncthreads();                                  // previous batch's flush reads are done
@@ -806,7 +810,7 @@ collect_hits(const TraceArgs A)
         const int rr = valid ? r : 0;
         const float ox = A.ray_o[3 * rr], oy = A.ray_o[3 * rr + 1], oz = A.ray_o[3 * rr + 2];
         const float dx = A.ray_d[3 * rr], dy = A.ray_d[3 * rr + 1], dz = A.ray_d[3 * rr + 2];
-        const float tmin = A.start_from_first ? NEAR_N : 0.0f;
+        const float tmin = first_tmin(A.start_from_first);
         const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
         // bins: LINEAR in t over the ray's chord through the scene box (a fog terminates after a roughly constant optical depth, i.e. at a
         // roughly constant fraction of the chord: 16 linear bins resolve that point to 1/15 of the chord, half-octave bins to +41 %)
@@ -931,7 +935,7 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
         const int rr = valid ? r : 0;
         const float ox = A.ray_o[3 * rr], oy = A.ray_o[3 * rr + 1], oz = A.ray_o[3 * rr + 2];
         const float dx = A.ray_d[3 * rr], dy = A.ray_d[3 * rr + 1], dz = A.ray_d[3 * rr + 2];
-        const float tmin = A.start_from_first ? NEAR_N : 0.0f;
+        const float tmin = first_tmin(A.start_from_first);
         const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
         // bins: LINEAR in t over the ray's chord through the scene box (a fog terminates after a roughly constant optical depth, i.e. at a
         // roughly constant fraction of the chord: 16 linear bins resolve that point to 1/15 of the chord, half-octave bins to +41 %)

@@ -50,7 +50,8 @@ typedef struct envgs_trace_cfg {
     int32_t sh_degree;         /* active degree 0..3 */
     int32_t sh_coeffs;         /* coefficients stored per surfel (shs is (P, sh_coeffs, 3)); 0 => colors_precomp (P,3) */
     int32_t max_trace_depth;   /* specular bounces after the primary stage */
-    int32_t start_from_first;  /* 1: rays are camera rays (t_min = 0.2); 0: rays are already-reflected rays (t > 0) */
+    int32_t start_from_first;  /* 1: rays are camera rays (t_min = 0.2); 0: rays are already-reflected rays (t > 0);
+                                  2: secondary rays of a bounce traced as a call of their own (t_min = 1e-3) */
     int32_t has_others;        /* others_precomp (P,2) present */
     int32_t bg_len;
     int32_t debug;
