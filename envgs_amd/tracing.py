@@ -232,7 +232,8 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
         keep["n_rec_event"] = torch.cuda.Event(); keep["n_rec_event"].record(torch.cuda.current_stream(dev))
     saved = dict(cfg=cfg, nodes=nodes, ro=ro, rd=rd, means3D=means3D, scales=scales, rotations=rotations, opacities=opacities,
                  shs=shs, colors_precomp=colors_precomp, others=others_precomp, bg=bg, srec=srec, counters=counters,
-                 rgb=rgb, dpt=dpt, acc=acc, norm=norm, aux=aux, final_T=final_T, lead=lead, lists=lists, keep=keep, cap=cap)
+                 rgb=(rgb if ND == 1 else mid[:, 13:16].contiguous()),      # the backward differentiates STAGE 0: its own colour, not the blend
+                 dpt=dpt, acc=acc, norm=norm, aux=aux, final_T=final_T, lead=lead, lists=lists, keep=keep, cap=cap)
     outs = (rgb.reshape(lead + (3,)), dpt.reshape(lead + (1,)), acc.reshape(lead + (1,)), norm.reshape(lead + (3,)),
             dist.reshape(lead + (1,)), aux.reshape(lead + (2,)), mid.reshape(lead + (16 * ND,)), wet)
     return outs, saved

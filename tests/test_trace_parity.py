@@ -83,18 +83,39 @@ def test_trace_forward_backward_vs_oracle(use_sh, camera, deg, P, R):
     chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
 
 
-def test_trace_bounces_and_image_shaped_rays():
+@pytest.mark.parametrize("stage_lists", [True, False])
+def test_trace_bounces_and_image_shaped_rays(stage_lists):
+    """Two specular bounces: as one list-path trace per stage (the default) and inside the K-buffer kernel -- same images, same per-stage
+    `mid` records, same (stage-0) gradients as the oracle; the per-surfel weight comes from stage 0 only."""
     from oracle import trace as otr
+    from envgs_amd import tracing
     g, ro, rd = trace_scene(P=150, R=400, seed=4, camera=True)       # 20x20 camera rays
+    R = ro.shape[0]
     bg = torch.tensor([0.0, 0.0, 0.0])
-    outs, *_ = _run_hip(g, ro, rd, bg, 1, True, True, depth=2, thr=0.1, shape=(20, 20))
+    gen = torch.Generator().manual_seed(12)
+    gr = [torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen), torch.randn(R, 3, generator=gen),
+          torch.randn(R, 2, generator=gen)]
+    old = tracing.BOUNCE_LISTS["on"]
+    try:
+        tracing.BOUNCE_LISTS["on"] = stage_lists
+        outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, 1, True, True, grads=gr, depth=2, thr=0.1, shape=(20, 20))
+    finally:
+        tracing.BOUNCE_LISTS["on"] = old
     rgb, dpt, acc, norm, dist, aux, mid, wet = outs
     assert rgb.shape == (20, 20, 3) and dpt.shape == (20, 20, 1) and mid.shape == (20, 20, 48) and wet.shape == (150, 1)
     ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(),
                             g["opacities"].numpy(), shs=g["shs"].numpy(), sh_degree=1, others=g["others"].numpy(), bg=bg.numpy(),
                             max_trace_depth=2, specular_threshold=0.1, start_from_first=True)
+    assert (ref["mid"][:, 16 + 7] != 0).any() and (ref["mid"][:, 32 + 7] != 0).any()          # both bounce stages really ran for some rays
     assert_close_frac(rgb.detach().reshape(-1, 3).cpu().numpy(), ref["rgb"], 2e-4, max_bad_frac=5e-3, flip_bound=0.1, what="rgb")
     assert_close_frac(mid.detach().reshape(-1, 48).cpu().numpy(), ref["mid"], 2e-4, max_bad_frac=5e-3, flip_bound=0.2, what="mid")
+    assert_close_frac(wet.detach().cpu().numpy()[:, 0], ref["wet"], 2e-4, max_bad_frac=5e-3, flip_bound=0.1, what="wet")
+    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
+    chk = lambda a, b, nm: assert_close_frac(a, b, 1e-3, max_bad_frac=5e-3, flip_bound=0.3, what=nm)
+    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
+    chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
+    chk(L["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"], "dopac")
+    chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
 
 
 def test_trace_edge_cases():
