@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--gaussians", type=int, default=300000)
     ap.add_argument("--env-gaussians", type=int, default=163840)
     ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--height", type=int, default=0, help="image height if not square (default: --res)")
+    ap.add_argument("--width", type=int, default=0, help="image width if not square (default: --res)")
+    ap.add_argument("--trace-depth", type=int, default=0, help="specular bounces of the env trace (EnvGS: 0; BASELINE configs[4]: 2); uses random 'others'")
     ap.add_argument("--torch-glue", action="store_true", help="keep the reference's torch expressions for the caller-side glue (default: fused HIP, SURVEY 8(f).1)")
     ap.add_argument("--optim", default="fused", choices=["fused", "torch", "none"],
                     help="optimizer step inside the timed iteration: sparse fused Adam (envgs_amd.optim, SURVEY 8(f).2), torch.optim.Adam, or none")
@@ -97,7 +100,7 @@ def main():
     lib = _lib.load()
     import torch.distributed as dist
 
-    P, H, W = args.gaussians, args.res, args.res
+    P, H, W = args.gaussians, (args.height or args.res), (args.width or args.res)
     HW = H * W
     envgs = args.workload == "envgs"
     C = 5 if envgs else 3
@@ -118,6 +121,10 @@ def main():
         params["roughness"] = g["roughness"].clone().requires_grad_(True)
         ge = synth.env_gaussians(args.env_gaussians, seed=1, device=dev)
         env_params = {k: ge[k].clone().requires_grad_(True) for k in names}
+        if args.trace_depth > 0:                   # bounces need a per-surfel specular value on the env set (others_precomp[:, 0]); half of the rays bounce
+            from envgs_amd import envgs_step as _es
+            _es.TRACE.update(depth=args.trace_depth, specular_threshold=0.5)
+            env_others = torch.rand(args.env_gaussians, 2, generator=torch.Generator().manual_seed(3)).to(dev)
 
     if envgs:
         import diff_surfel_rasterization_wet_ch05 as pkg
@@ -131,6 +138,10 @@ def main():
     else:
         import diff_surfel_rasterization_wet as pkg
     sh_degree = torch.tensor([3], device=dev)
+
+    env_in = dict(env_params)
+    if envgs and args.trace_depth > 0:
+        env_in["others"] = env_others
 
     def settings(cam):
         return pkg.GaussianRasterizationSettings(
@@ -163,7 +174,7 @@ def main():
         vi = (it * world + rank) % 8
         cam = cams[vi]
         if envgs:
-            out = envgs_step.envgs_forward(pkg, tpkg, tracer, cam, rays[vi], params, env_params, bg, env_bg, sh_degree)
+            out = envgs_step.envgs_forward(pkg, tpkg, tracer, cam, rays[vi], params, env_in, bg, env_bg, sh_degree)
             last_rays[0], last_rays[1] = out["ref_o"].detach(), out["ref_d"].detach()
             allmap = out["base"]["allmap"]
             loss = (out["rgb"] * dcol_hw3).sum() + (allmap * dall).sum()
@@ -220,7 +231,7 @@ def main():
         vi = (it * world + rank) % 8
         with torch.no_grad():
             if envgs:
-                envgs_step.envgs_forward(pkg, tpkg, tracer, cams[vi], rays[vi], params, env_params, bg, env_bg, sh_degree)
+                envgs_step.envgs_forward(pkg, tpkg, tracer, cams[vi], rays[vi], params, env_in, bg, env_bg, sh_degree)
             else:
                 pkg.GaussianRasterizer(raster_settings=settings(cams[vi]))(
                     means3D=params["means3D"], means2D=torch.zeros_like(params["means3D"]), shs=params["shs"], colors_precomp=None,
@@ -295,7 +306,7 @@ def main():
             "dtype": "f32", "data": "synthetic (seeded, BASELINE.md section 3; random-init Gaussians)",
             "config": {"workload": ("Ref-Real sedan-like full EnvGS (ch05 raster + env LBVH trace)" if envgs else
                                     "Ref-NeRF toaster-like base 2DGS raster only (BASELINE configs[1]), SH deg 3 in-kernel"),
-                       "gaussians": P, "env_gaussians": (args.env_gaussians if envgs else 0), "resolution": [H, W], "channels": C, "views": 8,
+                       "gaussians": P, "env_gaussians": (args.env_gaussians if envgs else 0), "resolution": [H, W], "trace_depth": (args.trace_depth if envgs else None), "channels": C, "views": 8,
                        "parallelism": "dp%d (camera batch sharded, %s)" % (world, "env / base grad buckets all-reduced from backward hooks" if reducer is not None else "flat grad all-reduce"),
                        "optimizer": {"fused": "sparse fused Adam, one launch (envgs_amd.optim)", "torch": "torch.optim.Adam", "none": "none"}[args.optim],
                        "caller_glue": ("torch (reference expressions)" if (not envgs or args.torch_glue) else "fused HIP (envgs_amd.fused)"),

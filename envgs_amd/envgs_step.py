@@ -87,18 +87,21 @@ def visibility_filter(wet, means3D=None, K=None, R=None, T=None, H=None, W=None,
         return vis.detach().clone()
 
 
+TRACE = {"depth": 0, "specular_threshold": 0.0}    # EnvGS hard-codes 0 bounces (envgs_sampler.py:510,548); bench.py --trace-depth overrides
+
+
 def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree):
     """HardwareRendering.render_gaussians of optix_utils.py with start_from_first=False, max_trace_depth=0."""
     ts = tpkg.SurfelTracingSettings(
         image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=env_bg,
         scale_modifier=1.0, viewmatrix=cam.world_view_transform.contiguous(), projmatrix=cam.full_proj_transform.contiguous(),
-        sh_degree=sh_degree, campos=cam.camera_center.contiguous(), prefiltered=False, debug=False, max_trace_depth=0,
-        specular_threshold=0.0)
+        sh_degree=sh_degree, campos=cam.camera_center.contiguous(), prefiltered=False, debug=False, max_trace_depth=int(TRACE["depth"]),
+        specular_threshold=float(TRACE["specular_threshold"]))
     v, f = synth.get_disks(env["means3D"], env["scales"], env["rotations"])
     tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
     grads3D = torch.zeros_like(env["means3D"], requires_grad=True) + 0
     return tracer(ref_o.contiguous(), ref_d.contiguous(), v, means3D=env["means3D"].contiguous(), grads3D=grads3D,
-                  shs=env["shs"].contiguous(), colors_precomp=None, others_precomp=None, opacities=env["opacities"].contiguous(),
+                  shs=env["shs"].contiguous(), colors_precomp=None, others_precomp=env.get("others"), opacities=env["opacities"].contiguous(),
                   scales=env["scales"].contiguous(), rotations=env["rotations"].contiguous(), cov3D_precomp=None,
                   tracer_settings=ts, start_from_first=False)
 
