@@ -1167,9 +1167,11 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
             if (state) {
                 // (the acc sum S[4] is not stored: sum_{j<=k} w_j = 1 - T_before * (1 - alpha), which the backward rebuilds)
                 float4 *o = state + (size_t)i * sstr;
-                o[0] = make_float4(Tb, S[0], S[1], S[2]);
-                o[1] = make_float4(S[3], S[5], S[6], S[7]);
-                if (A.has_others) o[2] = make_float4(S[8], S[9], 0.f, 0.f);
+                // streamed once, read once by the backward much later: non-temporal, so it does not evict the surfel records / SH blocks
+                typedef float nt4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store((nt4){Tb, S[0], S[1], S[2]}, reinterpret_cast<nt4 *>(o));
+                __builtin_nontemporal_store((nt4){S[3], S[5], S[6], S[7]}, reinterpret_cast<nt4 *>(o + 1));
+                if (A.has_others) __builtin_nontemporal_store((nt4){S[8], S[9], 0.f, 0.f}, reinterpret_cast<nt4 *>(o + 2));
             }
         }
         const int nu = f < 64 ? f : min(64, n - cb);                    // hits of this chunk that were blended
