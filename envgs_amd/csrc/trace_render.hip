@@ -1238,8 +1238,8 @@ __global__ void __launch_bounds__(64)
 register_hits(const TraceArgs A)
 {
     __shared__ int key[RH_TAB];
-    __shared__ unsigned cnt[RH_TAB];                 // hits of this surfel in the batch; after the flush: offset of its first pair
-    __shared__ unsigned long long wsum[RH_TAB];
+    __shared__ unsigned long long acc[RH_TAB];       // low 8 bits: hits of this surfel in the batch (<= 64), above: fixed-point weight sum -- ONE
+                                                     // returning ds_add_rtn_u64 per hit gives its rank; after the flush: offset of its first pair
     __shared__ unsigned nfail, ndense;
     __shared__ unsigned short hod[RH_TAB];           // table slot of the d-th distinct surfel, in order of first appearance
     const int lane = threadIdx.x;
@@ -1251,7 +1251,7 @@ register_hits(const TraceArgs A)
         unsigned long long *ent = A.entries ? A.entries + (size_t)batch * region : nullptr;
         unsigned *prs = A.pairs ? A.pairs + (size_t)batch * region : nullptr;
         __syncthreads();
-        for (int i = lane; i < RH_TAB; i += 64) { key[i] = -1; cnt[i] = 0u; wsum[i] = 0ull; }
+        for (int i = lane; i < RH_TAB; i += 64) { key[i] = -1; acc[i] = 0ull; }
         if (lane == 0) { nfail = 0u; ndense = 0u; }
         __syncthreads();
         const int r = ray_of(A, base + lane);
@@ -1277,8 +1277,7 @@ register_hits(const TraceArgs A)
                 }
                 unsigned x = 0xFFFFFFFFu;
                 if (ok) {
-                    const unsigned rank = atomicAdd(&cnt[h], 1u);
-                    atomicAdd(&wsum[h], wq);
+                    const unsigned rank = (unsigned)(atomicAdd(&acc[h], (wq << 8) | 1ull) & 0xFFull);
                     x = (h << 8) | rank;                                  // rank < 64: a ray meets a planar surfel once
                 } else {                                                  // table full around h: an entry of its own
                     const unsigned long long old = atomicAdd(A.surf_acc + (size_t)e[j].y * NCOPY + copy, (wq << 24) | 1ull);
@@ -1299,13 +1298,14 @@ register_hits(const TraceArgs A)
             const bool occ = d < D;
             const int h = occ ? (int)hod[d] : 0;
             const int sid = occ ? key[h] : 0;
-            const unsigned cn = occ ? cnt[h] : 0u;
+            const unsigned long long av = occ ? acc[h] : 0ull;
+            const unsigned cn = (unsigned)(av & 0xFFull);
             const float incl = wave_scan_add((float)cn);                 // exact: at most 64*cap < 2^24 hits per batch
             const unsigned offh = carry_off + (unsigned)incl - cn;
             if (occ) {
-                const unsigned long long old = atomicAdd(A.surf_acc + (size_t)sid * NCOPY + copy, (wsum[h] << 24) | 1ull);
+                const unsigned long long old = atomicAdd(A.surf_acc + (size_t)sid * NCOPY + copy, ((av >> 8) << 24) | 1ull);
                 if (ent) ent[d] = (unsigned long long)(unsigned)sid | ((unsigned long long)(cn - 1u) << 24) | ((old & 0xFFFFFFull) << 32);
-                cnt[h] = offh;
+                acc[h] = (unsigned long long)offh;
             }
             carry_off += (unsigned)wave_bcast(incl, 63);
         }
@@ -1315,7 +1315,7 @@ register_hits(const TraceArgs A)
         if (prs)
             for (int k = 0; k < n; k++) {
                 const unsigned x = list[k].x;
-                if (x != 0xFFFFFFFFu) prs[cnt[x >> 8] + (x & 255u)] = ((unsigned)lane << 16) | (unsigned)k;
+                if (x != 0xFFFFFFFFu) prs[(unsigned)acc[x >> 8] + (x & 255u)] = ((unsigned)lane << 16) | (unsigned)k;
             }
     }
 }
