@@ -1,4 +1,6 @@
-"""PLY point-cloud checkpoints in the reference's layout (the file-format half), without `plyfile`.
+"""Checkpoints in the reference's two formats (the file-format half): PLY point clouds without `plyfile`, and the trainer's
+`.pt` model files (`save_model_pt` / `load_model_pt` / `activate`, below; key layout PINNED by tests/golden/model_golden.pt, which was written from the
+reference's own GaussianModel instances).
 
 `save_ply` / `load_ply` follow `GaussianModel.save_ply` / `load_ply` (easyvolcap/utils/gaussian2d_utils.py:918-1000): one `vertex` element of float32
 properties  x y z nx ny nz f_dc_0..2 f_rest_0..(3K-4) opacity scale_0..1 rot_0..3  (K = (sh_degree + 1)^2), binary little-endian, features stored
@@ -96,3 +98,71 @@ def load_ply(path, max_sh_degree=3, device="cpu"):
     tt = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device)
     return dict(xyz=tt(xyz), features_dc=tt(dc).transpose(1, 2).contiguous(), features_rest=tt(rest).transpose(1, 2).contiguous(),
                 opacity=tt(col("opacity")[:, None]), scaling=tt(scales), rotation=tt(rots))
+
+
+# ---- `.pt` model checkpoints -----------------------------------------------------------------------------------------------------------------
+# The reference's trainer writes torch.save({'model': model.state_dict(), 'epoch': e, ['optimizer', 'scheduler', 'moderator']})
+# (easyvolcap/utils/net_utils.py:486-504).  The EnvGS sampler owns two GaussianModel modules, `sampler.pcd` (base set) and `sampler.env`
+# (environment set) (models/samplers/gaussian2d_sampler.py:148, envgs_sampler.py:165; the optimizer prefixes 'sampler.pcd.' / 'sampler.env.' of
+# envgs_sampler.py:231,344), each with the raw parameters of gaussian2d_utils.py:453-467 and the buffers of :294,309-312.
+PT_PARAMS = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity", "_specular", "_roughness")
+PT_BUFFERS = ("active_sh_degree", "max_radii2D", "xyz_gradient_accum", "denom", "xyz_weight_accum")
+PT_SETS = {"pcd": "sampler.pcd.", "env": "sampler.env."}
+
+
+def save_model_pt(path, sets, epoch=-1, extra=None):
+    """sets = {"pcd": {...}, "env": {...}}: raw (pre-activation) tensors keyed by PT_PARAMS / PT_BUFFERS names.  Missing buffers are written as
+    the zeros the reference's constructor registers; `active_sh_degree` defaults to the degree the feature count implies."""
+    model = {}
+    for name, d in sets.items():
+        prefix = PT_SETS[name]
+        P = d["_xyz"].shape[0]
+        for k in PT_PARAMS:
+            if k in d:
+                model[prefix + k] = d[k].detach().cpu().contiguous()
+        deg = int(round((d["_features_rest"].shape[1] + 1) ** 0.5)) - 1
+        defaults = {"active_sh_degree": torch.full((1,), deg, dtype=torch.long), "max_radii2D": torch.zeros(P),
+                    "xyz_gradient_accum": torch.zeros(P, 1), "denom": torch.zeros(P, 1), "xyz_weight_accum": torch.zeros(P, 1)}
+        for k in PT_BUFFERS:
+            model[prefix + k] = (d[k].detach().cpu() if k in d else defaults[k])
+    blob = {"model": model, "epoch": int(epoch)}
+    if extra:
+        blob.update(extra)
+    torch.save(blob, path)
+
+
+def load_model_pt(path, device="cpu"):
+    """-> ({"pcd": {...}, "env": {...}}, epoch).  Accepts the reference's file: keys outside the two Gaussian sets (networks, optimizer, moderator)
+    are ignored, a DDP 'module.' prefix is dropped (net_utils.py:493 notes the incorrect naming), a file without an environment set (a plain
+    2DGS run) returns only "pcd"."""
+    blob = torch.load(path, map_location="cpu", weights_only=True)
+    model = blob["model"] if "model" in blob else blob
+    sets = {}
+    for key, val in model.items():
+        if key.startswith("module."):
+            key = key[len("module."):]
+        for name, prefix in PT_SETS.items():
+            if key.startswith(prefix) and key[len(prefix):] in PT_PARAMS + PT_BUFFERS:
+                sets.setdefault(name, {})[key[len(prefix):]] = val.to(device)
+    for name, d in sets.items():
+        missing = [k for k in PT_PARAMS[:6] if k not in d]
+        if missing:
+            raise KeyError("checkpoint %s: set '%s' lacks %s" % (path, name, missing))
+        P = d["_xyz"].shape[0]
+        for k in PT_PARAMS:
+            if k in d and d[k].shape[0] != P:
+                raise ValueError("checkpoint %s: %s%s has %d rows, _xyz has %d" % (path, PT_SETS[name], k, d[k].shape[0], P))
+    return sets, int(blob.get("epoch", -1)) if isinstance(blob, dict) else -1
+
+
+def activate(raw):
+    """Raw parameters -> the renderer's inputs, with the reference's activations (gaussian2d_utils.py:330-352 setup_functions, :363-390 getters):
+    exp scaling, normalised rotation, sigmoid opacity / specular / roughness, features = cat(dc, rest)."""
+    out = dict(means3D=raw["_xyz"], shs=torch.cat([raw["_features_dc"], raw["_features_rest"]], dim=1).contiguous(),
+               scales=torch.exp(raw["_scaling"]), rotations=torch.nn.functional.normalize(raw["_rotation"], dim=-1),
+               opacities=torch.sigmoid(raw["_opacity"]))
+    if "_specular" in raw:
+        out["specular"] = torch.sigmoid(raw["_specular"])
+    if "_roughness" in raw:
+        out["roughness"] = torch.sigmoid(raw["_roughness"])
+    return out

@@ -66,3 +66,89 @@ def test_ply_reader_tolerates_order_extras_and_ascii(tmp_path):
     back = ckpt.load_ply(apath)
     for k, v in m.items():
         assert torch.allclose(back[k], v, rtol=0, atol=0), k
+
+
+def _raw_set(P, K, seed, reflective):
+    g = torch.Generator().manual_seed(seed)
+    d = {"_xyz": torch.randn(P, 3, generator=g), "_features_dc": torch.randn(P, 1, 3, generator=g), "_features_rest": torch.randn(P, K - 1, 3, generator=g),
+         "_scaling": torch.randn(P, 2, generator=g) - 4, "_rotation": torch.randn(P, 4, generator=g), "_opacity": torch.randn(P, 1, generator=g)}
+    if reflective:
+        d["_specular"] = torch.randn(P, 1, generator=g); d["_roughness"] = torch.zeros(P, 1)
+    return d
+
+
+def test_pt_checkpoint_round_trip_and_reference_key_layout(tmp_path):
+    pcd, env = _raw_set(50, 16, 0, True), _raw_set(30, 16, 1, False)
+    pcd["max_radii2D"] = torch.arange(50.0)
+    p = str(tmp_path / "latest.pt")
+    ckpt.save_model_pt(p, {"pcd": pcd, "env": env}, epoch=12)
+    blob = torch.load(p, weights_only=True)
+    assert blob["epoch"] == 12
+    keys = set(blob["model"])
+    # the names the reference's trainer would look up (net_utils.py:363-377 loads by state_dict key)
+    assert {"sampler.pcd._xyz", "sampler.pcd._features_dc", "sampler.pcd._specular", "sampler.env._scaling", "sampler.env.active_sh_degree",
+            "sampler.pcd.xyz_weight_accum", "sampler.pcd.denom"} <= keys and "sampler.env._specular" not in keys
+    assert blob["model"]["sampler.env.active_sh_degree"].dtype == torch.long and int(blob["model"]["sampler.env.active_sh_degree"]) == 3
+    sets, epoch = ckpt.load_model_pt(p)
+    assert epoch == 12 and set(sets) == {"pcd", "env"}
+    for name, src in (("pcd", pcd), ("env", env)):
+        for k, v in src.items():
+            assert torch.equal(sets[name][k], v), (name, k)
+    assert torch.equal(sets["pcd"]["max_radii2D"], torch.arange(50.0)) and float(sets["env"]["denom"].abs().sum()) == 0
+
+
+def test_pt_checkpoint_reads_a_trainer_style_file(tmp_path):
+    """Extra entries (networks, optimizer state), a DDP prefix and a base-only model are all accepted; a truncated set is refused."""
+    pcd = _raw_set(20, 16, 2, True)
+    model = {"module.sampler.pcd." + k: v for k, v in pcd.items()}
+    model["module.network.some_mlp.weight"] = torch.zeros(4, 4)
+    p = str(tmp_path / "ddp.pt")
+    torch.save({"model": model, "epoch": 3, "optimizer": {"state": {}, "param_groups": []}}, p)
+    sets, epoch = ckpt.load_model_pt(p)
+    assert epoch == 3 and set(sets) == {"pcd"} and torch.equal(sets["pcd"]["_rotation"], pcd["_rotation"])
+    del model["module.sampler.pcd._opacity"]
+    torch.save({"model": model, "epoch": 3}, p)
+    with pytest.raises(KeyError):
+        ckpt.load_model_pt(p)
+
+
+def test_activate_matches_the_reference_getters():
+    raw = _raw_set(40, 16, 5, True)
+    a = ckpt.activate(raw)
+    assert a["shs"].shape == (40, 16, 3) and torch.equal(a["shs"][:, :1], raw["_features_dc"])
+    assert torch.allclose(a["scales"], raw["_scaling"].exp()) and torch.allclose(a["rotations"].norm(dim=-1), torch.ones(40), atol=1e-6)
+    assert torch.allclose(a["opacities"], torch.sigmoid(raw["_opacity"])) and torch.allclose(a["roughness"], torch.full((40, 1), 0.5))
+    assert "specular" not in ckpt.activate(_raw_set(4, 16, 6, False))
+
+
+def test_pt_checkpoint_against_the_reference_models_own_state_dict(tmp_path):
+    """tests/golden/model_golden.pt was written from the reference's GaussianModel instances (tests/golden/make_ckpt_golden.py): its key names,
+    shapes and dtypes are what a reference checkpoint holds, its `activated` entries what the reference's getters return."""
+    import os
+    gold_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_golden.pt")
+    gold = torch.load(gold_path, weights_only=True)
+    sets, epoch = ckpt.load_model_pt(gold_path)
+    assert epoch == 7 and set(sets) == {"pcd", "env"}
+    for name in ("pcd", "env"):
+        assert set(sets[name]) == set(ckpt.PT_PARAMS + ckpt.PT_BUFFERS)                 # nothing of the reference's module is dropped
+        for k, v in sets[name].items():
+            assert torch.equal(v, gold["model"][ckpt.PT_SETS[name] + k])
+        a = ckpt.activate(sets[name])
+        assert set(a) == set(gold["activated"][name])
+        for k, v in gold["activated"][name].items():
+            assert a[k].shape == v.shape and torch.allclose(a[k], v, rtol=1e-6, atol=1e-7), (name, k)
+    # the writer reproduces the reference's layout: same keys, shapes, dtypes and values
+    p = str(tmp_path / "again.pt")
+    ckpt.save_model_pt(p, sets, epoch=7)
+    mine = torch.load(p, weights_only=True)["model"]
+    assert set(mine) == set(gold["model"])
+    for k, v in gold["model"].items():
+        assert mine[k].dtype == v.dtype and mine[k].shape == v.shape and torch.equal(mine[k], v), k
+    # and the defaults it invents for absent buffers are the reference constructor's
+    bare = {k: v for k, v in sets["env"].items() if k in ckpt.PT_PARAMS}
+    ckpt.save_model_pt(p, {"env": bare})
+    mine = torch.load(p, weights_only=True)["model"]
+    for k in ckpt.PT_BUFFERS:
+        g = gold["model"]["sampler.env." + k]
+        assert mine["sampler.env." + k].dtype == g.dtype and mine["sampler.env." + k].shape == g.shape, k
+    assert int(mine["sampler.env.active_sh_degree"]) == 3
