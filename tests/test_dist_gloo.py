@@ -27,7 +27,8 @@ def _worker(rank, world, port, q):
     nbytes = edist.allreduce_grads([a, b, None], average=True)
     st = [torch.full((4, 1), float(rank + 1)), torch.full((4, 1), 1.0), torch.full((4,), 0.5 * (rank + 1)), torch.tensor([1, 9, 3, 4]) if rank == 0 else torch.tensor([5, 2, 3, 8])]
     edist.allreduce_densify_stats(*st)
-    q.put((rank, views, a.grad.clone(), b.grad.clone(), nbytes, [t.clone() for t in st]))
+    # plain lists, not tensors: a tensor in a Queue travels as a shared-memory file that is gone if this process exits before the parent reads it
+    q.put((rank, views, a.grad.tolist(), b.grad.tolist(), nbytes, [t.tolist() for t in st]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -46,6 +47,7 @@ def test_flat_grad_allreduce_and_view_sharding_world2():
     v0, v1 = res[0][1], res[1][1]
     assert sorted(v0 + v1) == list(range(8)) and not set(v0) & set(v1)          # the 8-view batch is partitioned
     for rank, _, ga, gb, nbytes, st in res:
+        ga, gb, st = torch.tensor(ga), torch.tensor(gb), [torch.tensor(t) for t in st]
         assert torch.allclose(ga, torch.full((5, 3), 1.5))                      # mean of 1 and 2
         assert torch.allclose(gb, torch.arange(7.0) / 2)                        # rank 1 contributed zeros
         assert nbytes == (15 + 7) * 4                                           # ONE flat bucket
