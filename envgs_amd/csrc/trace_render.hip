@@ -1198,9 +1198,11 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
     }
 }
 
-// EMAX = list capacity / 64 rounded up to a power of two: the kernel is instantiated per capacity class because the widest sort it must
-// be able to run sets its register count (EMAX 4: 123 VGPRs = 4 waves/SIMD, 8: 150 = 3, 16: 211 = 2).
-template <int EMAX>
+// The widest sort a kernel must be able to run sets its register count (E <= 4: 123 VGPRs = 4 waves/SIMD, 8: 150 = 3, 16: 211 = 2), and
+// lists longer than 256 hits are rare, so the work is split by list length: the main pass (LONG = false) takes every ray with at most 256
+// hits at 4 waves/SIMD; when the capacity allows longer lists a second launch (LONG = true, EMAX = 8 or 16) picks up the few rays
+// beyond 256 -- it scans the hit counts 64 rays per wavefront step and only sorts what the ballot finds.
+template <int EMAX, bool LONG>
 __global__ void __launch_bounds__(256)
 sort_composite_fwd(const TraceArgs A)
 {
@@ -1209,19 +1211,31 @@ sort_composite_fwd(const TraceArgs A)
     const int lane = threadIdx.x & 63;
     unsigned st_hits = 0;
     const int slot_end = min(A.R, A.batch1 * 64);
-    for (int slot = A.batch0 * 64 + blockIdx.x * 4 + (threadIdx.x >> 6); slot < slot_end; slot += gridDim.x * 4) {
-        const int r = ray_of(A, slot);
-        const int n = A.hit_cnt[r];
-        if (n > A.cap) continue;                            // overflow: the K-buffer kernel owns this ray
-        if (n <= 64) sort_composite_ray<1>(A, r, n, lane, st_hits);
-        else if (n <= 128) sort_composite_ray<2>(A, r, n, lane, st_hits);
-        else if (EMAX <= 4 || n <= 256) sort_composite_ray<4>(A, r, n, lane, st_hits);
-        else if constexpr (EMAX >= 8) {
-            if (EMAX == 8 || n <= 512) sort_composite_ray<8>(A, r, n, lane, st_hits);
-            else if constexpr (EMAX >= 16) sort_composite_ray<16>(A, r, n, lane, st_hits);
+    if constexpr (!LONG) {
+        for (int slot = A.batch0 * 64 + blockIdx.x * 4 + (threadIdx.x >> 6); slot < slot_end; slot += gridDim.x * 4) {
+            const int r = ray_of(A, slot);
+            const int n = A.hit_cnt[r];
+            if (n > A.cap || n > 256) continue;                 // overflow: the K-buffer kernel owns this ray; long: the LONG pass does
+            if (n <= 64) sort_composite_ray<1>(A, r, n, lane, st_hits);
+            else if (n <= 128) sort_composite_ray<2>(A, r, n, lane, st_hits);
+            else sort_composite_ray<4>(A, r, n, lane, st_hits);
+        }
+    } else {
+        for (int base = A.batch0 * 64 + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; base < slot_end; base += gridDim.x * 256) {
+            const int slot = base + lane;
+            int r = 0, n = 0;
+            if (slot < slot_end) { r = ray_of(A, slot); n = A.hit_cnt[r]; }
+            unsigned long long todo = __ballot(n > 256 && n <= A.cap);
+            while (todo) {
+                const int l = (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int rr = __shfl(r, l), nn = __shfl(n, l);
+                if (EMAX == 8 || nn <= 512) sort_composite_ray<8>(A, rr, nn, lane, st_hits);
+                else if constexpr (EMAX >= 16) sort_composite_ray<16>(A, rr, nn, lane, st_hits);
+            }
         }
     }
-    if (A.stats && lane == 0) atomicAdd(A.stats + 0, (unsigned long long)st_hits);
+    if (A.stats && lane == 0 && st_hits) atomicAdd(A.stats + 0, (unsigned long long)st_hits);
 }
 
 // Register every composited hit with its surfel, per BATCH of 64 coherence-sorted rays.  The rays of a batch mostly composite the SAME
@@ -1899,9 +1913,12 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             {
                 ProfScope p2(K_TRACE_SORT, st);
                 const dim3 g(stride_grid(rays_seg, 4)), b(256);
-                if (S.cap <= 256) hipLaunchKernelGGL(sort_composite_fwd<4>, g, b, 0, st, S);
-                else if (S.cap <= 512) hipLaunchKernelGGL(sort_composite_fwd<8>, g, b, 0, st, S);
-                else hipLaunchKernelGGL(sort_composite_fwd<16>, g, b, 0, st, S);
+                hipLaunchKernelGGL((sort_composite_fwd<4, false>), g, b, 0, st, S);
+                if (S.cap > 256) {
+                    const dim3 gl(stride_grid(rays_seg, 256));
+                    if (S.cap <= 512) hipLaunchKernelGGL((sort_composite_fwd<8, true>), gl, b, 0, st, S);
+                    else hipLaunchKernelGGL((sort_composite_fwd<16, true>), gl, b, 0, st, S);
+                }
             }
             ENVGS_CHECK_LAUNCH(dcfg, st);
             { ProfScope p8(K_TRACE_REGISTER, st); hipLaunchKernelGGL(register_hits, dim3(stride_grid(rays_seg, 64)), dim3(64), 0, st, S); }

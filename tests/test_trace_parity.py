@@ -345,3 +345,46 @@ def test_trace_two_segment_forward_pipeline_vs_oracle():
     chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
     chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
     chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
+
+
+@pytest.mark.parametrize("force_cap", [1024, 512, 320])
+def test_trace_very_long_lists(force_cap):
+    """A stack of 900 faint sheets: most rays blend several hundred hits before they terminate, so the sort / composite pass for lists beyond
+    256 entries runs (8 and 16 keys per lane), and with the smaller capacities the longest rays overflow into the K-buffer path."""
+    from oracle import trace as otr
+    from envgs_amd import tracing
+    P, R = 900, 192
+    gen = torch.Generator().manual_seed(21)
+    means = torch.stack([torch.randn(P, generator=gen) * 0.15, torch.randn(P, generator=gen) * 0.15, 2.0 + torch.arange(P) * 0.01], dim=1)
+    q = torch.tensor([1.0, 0, 0, 0]).expand(P, 4) + torch.randn(P, 4, generator=gen) * 0.05
+    g = dict(means3D=means, scales=torch.full((P, 2), 0.3) + 0.3 * torch.rand(P, 2, generator=gen), rotations=q / q.norm(dim=-1, keepdim=True),
+             opacities=0.02 + 0.04 * torch.rand(P, 1, generator=gen), shs=torch.randn(P, 16, 3, generator=gen) * 0.3,
+             others=torch.rand(P, 2, generator=gen))
+    # rays through the middle of the stack terminate after a few hundred hits, rays near its rim see falloffs below 1/255: 14 .. 712 hits
+    ro = torch.cat([(torch.rand(R, 2, generator=gen) - 0.5) * 1.6, torch.zeros(R, 1)], dim=1)
+    rd = torch.cat([torch.randn(R, 2, generator=gen) * 0.03, torch.ones(R, 1)], dim=1)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    gr = [torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen),
+          torch.randn(R, 3, generator=gen), torch.randn(R, 2, generator=gen)]
+    old = dict(tracing.HIT_CAP)
+    try:
+        tracing.HIT_CAP["force"] = force_cap
+        outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, 2, True, False, grads=gr)
+    finally:
+        tracing.HIT_CAP.clear(); tracing.HIT_CAP.update(old)
+    cnt = tracing.last_trace_counts()
+    ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(), g["opacities"].numpy(),
+                            shs=g["shs"].numpy(), sh_degree=2, others=g["others"].numpy(), bg=bg.numpy(), start_from_first=False)
+    assert ref["nhits"].max() > 512 and ((ref["nhits"] > 256) & (ref["nhits"] <= 512)).sum() > 20 and (ref["nhits"] <= 256).sum() > 5 and cnt["max_list"] > 512
+    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
+    for a, b, nm in ((rgb, ref["rgb"], "rgb"), (dpt[:, 0], ref["dpt"], "dpt"), (acc[:, 0], ref["acc"], "acc"), (norm, ref["norm"], "norm"),
+                     (aux, ref["aux"], "aux"), (wet[:, 0], ref["wet"], "wet")):
+        assert_close_frac(a, b, 3e-4, max_bad_frac=5e-3, flip_bound=0.05, what=nm)
+    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
+    chk = lambda a, b, nm: assert_close_frac(a, b, 2e-3, max_bad_frac=5e-3, flip_bound=0.3, what=nm)
+    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
+    chk(L["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"], "dopac")
+    chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
+    chk(L["others"].grad.cpu().numpy(), rb["dothers"], "dothers")
+    chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
+    chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
