@@ -35,18 +35,25 @@ def pmc():
         return d
     f = load(os.path.join(ROOT, 'gpurun_out/pmc_fetch/f_counter_collection.csv'), 'FETCH_SIZE')
     w = load(os.path.join(ROOT, 'gpurun_out/pmc_write/w_counter_collection.csv'), 'WRITE_SIZE')
-    names = {'envgs::composite_fwd<5>': 'composite_fwd', 'envgs::composite_bwd<5>': 'composite_bwd', 'envgs::project_surfels': 'project_surfels',
+    names = {'envgs::composite_fwd': 'composite_fwd', 'envgs::composite_bwd': 'composite_bwd', 'envgs::project_surfels': 'project_surfels',
              'envgs::project_surfels_bwd': 'project_surfels_bwd', 'envgs::emit_tile_keys': 'emit_tile_keys', 'envgs::find_tile_ranges': 'find_tile_ranges',
-             'envgs::collect_hits_packet': 'trace.collect_hits', 'envgs::collect_hits': 'trace.collect_hits(per-ray)', 'envgs::sort_composite_fwd<8>': 'trace.sort_composite_fwd', 'envgs::sort_composite_fwd<4>': 'trace.sort_composite_fwd', 'envgs::sort_composite_fwd<16>': 'trace.sort_composite_fwd',
+             'envgs::collect_hits_packet': 'trace.collect_hits', 'envgs::collect_hits': 'trace.collect_hits(per-ray)', 'envgs::sort_composite_fwd<4, false>': 'trace.sort_composite_fwd',
              'envgs::register_hits': 'trace.register_hits', 'envgs::batch_surfel_bwd': 'trace.batch_surfel_bwd',
              'envgs::reduce_surfel_records': 'trace.reduce_surfel_records'}
     out = {"_how": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / rocprofv3 --pmc WRITE_SIZE --kernel-trace (two separate passes, no other trace domains) -- "
                    "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-render on MI355X; per-launch averages. Units per MI355X_MICROARCH.md: counters are KB; on gfx950 "
                    "FETCH_SIZE reports 1/2 of the bytes of 16 B/lane reads, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024. WRITE_SIZE is uncalibrated "
                    "(scattered 4-8 B stores are counted at 32 B granularity).", "kernels": {}}
+    def pick(d, k):                         # exact name, or any template instantiation of it (kernel<...>), launches pooled
+        vals = []
+        for name, v in d.items():
+            if name == k or name.startswith(k + '<'):
+                vals += v
+        return vals
     for k, v in names.items():
-        if k in f:
-            fv = sum(f[k]) / len(f[k]); wv = sum(w[k]) / len(w[k]) if k in w else 0
+        fv_, wv_ = pick(f, k), pick(w, k)
+        if fv_:
+            fv = sum(fv_) / len(fv_); wv = sum(wv_) / len(wv_) if wv_ else 0
             out["kernels"][v] = {"FETCH_SIZE_KB": round(fv, 1), "WRITE_SIZE_KB": round(wv, 1), "hbm_bytes": int((2 * fv + wv) * 1024)}
     if out["kernels"]:
         json.dump(out, open(os.path.join(ROOT, 'profiles', '%s_pmc_envgs.json' % TAG), 'w'), indent=1)
@@ -55,7 +62,7 @@ def pmc():
 stats('envgs', 24, 'full EnvGS step: 300k base surfels ch05 raster + 163840 env surfels LBVH trace, 800x800; python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-render (the tracer forward runs as two batch segments on two streams: 2 launches per step, overlapping, so the kernel times sum to more than the step)')
 stats('raster', 34, 'raster only: 300k surfels, SH deg 3 in-kernel, 800x800; python bench.py --workload raster --steps 30 --warmup 4 --no-cpu-baseline --no-render')
 pmc()
-for n in ('envgs', 'raster'):
+for n in ('envgs', 'raster', 'env700k', 'config5'):
     src = os.path.join(ROOT, 'gpurun_out', 'bench_%s_final.json' % n)
     if os.path.exists(src) and os.path.getsize(src) > 10:
         open(os.path.join(ROOT, 'profiles', '%s_bench_%s.json' % (TAG, n)), 'w').write(open(src).read())
