@@ -68,6 +68,8 @@ SYMBOLS = {
     "envgs_sh_colors_backward": (c_int, [ctypes.c_int32] * 4 + [_P] * 9 + [_P]),
     "envgs_reflect_forward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float] + [_P] * 8 + [_P]),
     "envgs_reflect_backward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float] + [_P] * 11 + [_P]),
+    "envgs_surface_normal_forward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float] + [_P] * 4 + [_P]),
+    "envgs_surface_normal_backward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float] + [_P] * 5 + [_P]),
     "envgs_fused_adam": (c_int, [ctypes.c_int32, ctypes.POINTER(AdamTensor), ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
     "envgs_compact_temp_bytes": (ctypes.c_size_t, [ctypes.c_int64]),
     "envgs_compact_scan": (c_int, [ctypes.c_int64, _P, _P, _P, _P, ctypes.c_size_t, _P]),

@@ -194,6 +194,132 @@ reflect_bwd(int HW, float ratio, const float *__restrict__ allmap, const float *
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ surface normal (dpt2norm)
+// Tail of render() (gaussian2d_utils.py:1125-1142): surface depth = expected depth mixed with the median depth, back-projected through
+// the pixel grid (u = x, v = y, no half-pixel offset: dpt2xyz :1158-1187), pseudo normal = normalize(cross(P[y+1] - P[y-1], P[x+1] - P[x-1]))
+// on interior pixels (dpt2norm :1190-1206, F.normalize eps 1e-12), zero on the border, times the DETACHED alpha.
+struct SurfCam { float fx, fy, cx, cy, r[9]; };       // r = camera-to-world rotation, row major
+
+__device__ __forceinline__ SurfCam surf_cam(int H, int W, float fx, float fy, const float *__restrict__ V)
+{
+    SurfCam c;
+    c.fx = fx; c.fy = fy; c.cx = 0.5f * (float)W; c.cy = 0.5f * (float)H;
+    // world_view_transform (row-vector convention) holds R^T in its upper 3x3: that IS the camera-to-world rotation
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) c.r[i * 3 + j] = V[i * 4 + j];
+    return c;
+}
+
+__device__ __forceinline__ float surface_depth_at(const float *__restrict__ allmap, int HW, int p, float ratio, bool *de_ok, bool *dm_ok)
+{
+    float de = allmap[p] / allmap[HW + p];
+    *de_ok = fabsf(de) <= 3.0e38f; if (!*de_ok) de = 0.f;               // nan_to_num(., 0, 0)
+    float dm = allmap[5 * HW + p];
+    *dm_ok = fabsf(dm) <= 3.0e38f; if (!*dm_ok) dm = 0.f;
+    return de * (1.0f - ratio) + dm * ratio;
+}
+
+__device__ __forceinline__ void pixel_dir(const SurfCam &c, int x, int y, float *d)
+{
+    const float a = ((float)x - c.cx) / c.fx, b = ((float)y - c.cy) / c.fy;
+    d[0] = c.r[0] * a + c.r[1] * b + c.r[2]; d[1] = c.r[3] * a + c.r[4] * b + c.r[5]; d[2] = c.r[6] * a + c.r[7] * b + c.r[8];
+}
+
+// normal at interior pixel (x, y) from the four neighbour depths; returns cross product length (0 -> zero normal)
+__device__ __forceinline__ float surf_normal_at(const SurfCam &c, int x, int y, float dU, float dD, float dL, float dR, float *n, float *ex, float *ey)
+{
+    float u[3], d[3], l[3], r[3];
+    pixel_dir(c, x, y - 1, u); pixel_dir(c, x, y + 1, d); pixel_dir(c, x - 1, y, l); pixel_dir(c, x + 1, y, r);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ex[k] = dD * d[k] - dU * u[k]; ey[k] = dR * r[k] - dL * l[k]; }
+    const float c0 = ex[1] * ey[2] - ex[2] * ey[1], c1 = ex[2] * ey[0] - ex[0] * ey[2], c2 = ex[0] * ey[1] - ex[1] * ey[0];
+    const float len = sqrtf(c0 * c0 + c1 * c1 + c2 * c2), il = 1.0f / fmaxf(len, 1e-12f);
+    n[0] = c0 * il; n[1] = c1 * il; n[2] = c2 * il;
+    return len;
+}
+
+__global__ void __launch_bounds__(256)
+surface_normal_fwd(int H, int W, float ratio, float fx, float fy, const float *__restrict__ V, const float *__restrict__ allmap,
+                   float *__restrict__ sdepth, float *__restrict__ snormal)
+{
+    const SurfCam cam = surf_cam(H, W, fx, fy, V);
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int HW = H * W;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    bool a, b;
+    sdepth[p] = surface_depth_at(allmap, HW, p, ratio, &a, &b);
+    float n[3] = {0.f, 0.f, 0.f};
+    if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {
+        float ex[3], ey[3];
+        surf_normal_at(cam, x, y, surface_depth_at(allmap, HW, p - W, ratio, &a, &b), surface_depth_at(allmap, HW, p + W, ratio, &a, &b),
+                       surface_depth_at(allmap, HW, p - 1, ratio, &a, &b), surface_depth_at(allmap, HW, p + 1, ratio, &a, &b), n, ex, ey);
+    }
+    const float al = allmap[HW + p];
+    snormal[p] = n[0] * al; snormal[HW + p] = n[1] * al; snormal[2 * HW + p] = n[2] * al;
+}
+
+// dL/d(depth of pixel q's neighbour) through the normal at q; which = 0 up (y-1), 1 down (y+1), 2 left, 3 right.  Gather form: every pixel
+// asks its four neighbours what they owe it, so nothing is accumulated atomically.
+__device__ __forceinline__ float normal_grad_to_neighbour(const SurfCam &c, const float *__restrict__ allmap, const float *__restrict__ gsn, int H, int W,
+                                                          float ratio, int qx, int qy, int which)
+{
+    if (!(qx > 0 && qx < W - 1 && qy > 0 && qy < H - 1)) return 0.f;
+    const int HW = H * W, q = qy * W + qx;
+    bool a, b;
+    float n[3], ex[3], ey[3];
+    const float len = surf_normal_at(c, qx, qy, surface_depth_at(allmap, HW, q - W, ratio, &a, &b), surface_depth_at(allmap, HW, q + W, ratio, &a, &b),
+                                     surface_depth_at(allmap, HW, q - 1, ratio, &a, &b), surface_depth_at(allmap, HW, q + 1, ratio, &a, &b), n, ex, ey);
+    const float al = allmap[HW + q];
+    const float g0 = gsn[q] * al, g1 = gsn[HW + q] * al, g2 = gsn[2 * HW + q] * al;
+    // n = c / max(|c|, eps): dL/dc = (g - n (n.g)) / |c|   (|c| > eps; below it n = c / eps and dL/dc = g / eps)
+    float gc0, gc1, gc2;
+    if (len > 1e-12f) {
+        const float ng = n[0] * g0 + n[1] * g1 + n[2] * g2, il = 1.0f / len;
+        gc0 = (g0 - n[0] * ng) * il; gc1 = (g1 - n[1] * ng) * il; gc2 = (g2 - n[2] * ng) * il;
+    } else { gc0 = g0 * 1e12f; gc1 = g1 * 1e12f; gc2 = g2 * 1e12f; }
+    // c = ex x ey:  dL/dex = ey x gc,  dL/dey = gc x ex
+    float ge[3];
+    if (which < 2) { ge[0] = ey[1] * gc2 - ey[2] * gc1; ge[1] = ey[2] * gc0 - ey[0] * gc2; ge[2] = ey[0] * gc1 - ey[1] * gc0; }
+    else { ge[0] = gc1 * ex[2] - gc2 * ex[1]; ge[1] = gc2 * ex[0] - gc0 * ex[2]; ge[2] = gc0 * ex[1] - gc1 * ex[0]; }
+    float d[3];
+    const int nx = which == 2 ? qx - 1 : which == 3 ? qx + 1 : qx, ny = which == 0 ? qy - 1 : which == 1 ? qy + 1 : qy;
+    pixel_dir(c, nx, ny, d);
+    const float s = (which == 0 || which == 2) ? -1.f : 1.f;             // ex = P[down] - P[up], ey = P[right] - P[left]
+    return s * (ge[0] * d[0] + ge[1] * d[1] + ge[2] * d[2]);
+}
+
+__global__ void __launch_bounds__(256)
+surface_normal_bwd(int H, int W, float ratio, float fx, float fy, const float *__restrict__ V, const float *__restrict__ allmap,
+                   const float *__restrict__ gsd, const float *__restrict__ gsn, float *__restrict__ dallmap)
+{
+    const SurfCam cam = surf_cam(H, W, fx, fy, V);
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int HW = H * W;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    float g = gsd ? gsd[p] : 0.f;
+    if (gsn) {
+        // this pixel is the UP neighbour of (x, y+1), the DOWN neighbour of (x, y-1), the LEFT neighbour of (x+1, y), the RIGHT one of (x-1, y)
+        g += normal_grad_to_neighbour(cam, allmap, gsn, H, W, ratio, x, y + 1, 0);
+        g += normal_grad_to_neighbour(cam, allmap, gsn, H, W, ratio, x, y - 1, 1);
+        g += normal_grad_to_neighbour(cam, allmap, gsn, H, W, ratio, x + 1, y, 2);
+        g += normal_grad_to_neighbour(cam, allmap, gsn, H, W, ratio, x - 1, y, 3);
+    }
+    bool de_ok, dm_ok;
+    surface_depth_at(allmap, HW, p, ratio, &de_ok, &dm_ok);
+    const float Dw = allmap[p], A = allmap[HW + p];
+    const float gde = de_ok ? g * (1.0f - ratio) : 0.f;
+    dallmap[p] = de_ok ? gde / A : 0.f;
+    dallmap[HW + p] = de_ok ? -gde * Dw / (A * A) : 0.f;             // (the alpha that scales the normal is detached)
+    dallmap[2 * HW + p] = 0.f; dallmap[3 * HW + p] = 0.f; dallmap[4 * HW + p] = 0.f;
+    dallmap[5 * HW + p] = dm_ok ? g * ratio : 0.f;
+    dallmap[6 * HW + p] = 0.f;
+}
+
 }  // namespace envgs
 
 using namespace envgs;
@@ -241,6 +367,26 @@ int envgs_reflect_backward(int32_t H, int32_t W, float depth_ratio, const float 
     const int HW = H * W;
     hipLaunchKernelGGL(reflect_bwd, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, HW, depth_ratio, allmap, ray_o, ray_d, viewmatrix,
                        dnormal_world, ddepth, dref_o, dref_d, dallmap, dray_o, dray_d);
+    return (int)hipGetLastError();
+}
+
+int envgs_surface_normal_forward(int32_t H, int32_t W, float depth_ratio, float fx, float fy, const float *allmap, const float *viewmatrix,
+                                 float *surf_depth, float *surf_normal, void *stream)
+{
+    if (H <= 0 || W <= 0 || !(fx > 0.f) || !(fy > 0.f) || !allmap || !viewmatrix || !surf_depth || !surf_normal) return ENVGS_ERR_BAD_ARG;
+    const int HW = H * W;
+    hipLaunchKernelGGL(surface_normal_fwd, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, H, W, depth_ratio, fx, fy, viewmatrix,
+                       allmap, surf_depth, surf_normal);
+    return (int)hipGetLastError();
+}
+
+int envgs_surface_normal_backward(int32_t H, int32_t W, float depth_ratio, float fx, float fy, const float *allmap, const float *viewmatrix,
+                                  const float *dsurf_depth, const float *dsurf_normal, float *dallmap, void *stream)
+{
+    if (H <= 0 || W <= 0 || !(fx > 0.f) || !(fy > 0.f) || !allmap || !viewmatrix || !dallmap) return ENVGS_ERR_BAD_ARG;
+    const int HW = H * W;
+    hipLaunchKernelGGL(surface_normal_bwd, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, H, W, depth_ratio, fx, fy, viewmatrix,
+                       allmap, dsurf_depth, dsurf_normal, dallmap);
     return (int)hipGetLastError();
 }
 

@@ -1221,6 +1221,8 @@ sort_composite_fwd(const TraceArgs A)
             else sort_composite_ray<4>(A, r, n, lane, st_hits);
         }
     } else {
+        // the longest list so far (this segment's collection has finished, so its own maximum is in): nothing to do in the usual case
+        if ((int)__hip_atomic_load(A.counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 256) return;
         for (int base = A.batch0 * 64 + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; base < slot_end; base += gridDim.x * 256) {
             const int slot = base + lane;
             int r = 0, n = 0;
@@ -1915,7 +1917,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
                 const dim3 g(stride_grid(rays_seg, 4)), b(256);
                 hipLaunchKernelGGL((sort_composite_fwd<4, false>), g, b, 0, st, S);
                 if (S.cap > 256) {
-                    const dim3 gl(stride_grid(rays_seg, 256));
+                    const dim3 gl(min(stride_grid(rays_seg, 256), 512));
                     if (S.cap <= 512) hipLaunchKernelGGL((sort_composite_fwd<8, true>), gl, b, 0, st, S);
                     else hipLaunchKernelGGL((sort_composite_fwd<16, true>), gl, b, 0, st, S);
                 }

@@ -9,6 +9,8 @@ Followed call sequence (all paths relative to /root/reference):
   easyvolcap/utils/optix_utils.py:71-85,87-267              build_bvh (get_disks + rebuild) and render_gaussians (env pass)
   easyvolcap/models/samplers/envgs_sampler.py:474           rgb = (1 - spec) * rgb_base + spec * rgb_env
 """
+import math
+
 import torch
 
 from . import synth
@@ -73,6 +75,35 @@ def base_pass(pkg, cam, base, bg, sh_degree, scale_modifier=1.0):
     depth = torch.nan_to_num(allmap[0:1] / alpha, 0, 0)
     return dict(rgb=img[:3], spec=img[3:4], rough=img[4:5], alpha=alpha, normal=normal, depth=depth, radii=radii,
                 weight=weight, means2D=means2D, allmap=allmap)
+
+
+def dpt2norm(cam, dpt):
+    """dpt2xyz + dpt2norm of gaussian2d_utils.py:1158-1206 (torch, any device): depth (1,H,W) -> pseudo surface normals (H,W,3), zero border."""
+    dev = dpt.device
+    c2w = torch.linalg.inv(cam.world_view_transform.T)
+    W, H = cam.image_width, cam.image_height
+    fx = W / (2 * math.tan(cam.FoVx / 2.)); fy = H / (2 * math.tan(cam.FoVy / 2.))
+    K = torch.tensor([[fx, 0., W / 2.], [0., fy, H / 2.], [0., 0., 1.0]], dtype=torch.float32, device=dev)
+    u, v = torch.meshgrid(torch.arange(W, dtype=torch.float32, device=dev), torch.arange(H, dtype=torch.float32, device=dev), indexing='xy')
+    pix = torch.stack([u, v, torch.ones_like(u)], dim=-1).reshape(-1, 3)
+    ray_d = pix @ torch.linalg.inv(K).mT @ c2w[:3, :3].mT
+    xyz = (dpt.reshape(-1, 1) * ray_d + c2w[:3, 3]).reshape(H, W, 3)
+    out = torch.zeros_like(xyz)
+    dx = xyz[2:, 1:-1] - xyz[:-2, 1:-1]
+    dy = xyz[1:-1, 2:] - xyz[1:-1, :-2]
+    out[1:-1, 1:-1, :] = torch.nn.functional.normalize(torch.cross(dx, dy, dim=-1), dim=-1)
+    return out
+
+
+def surface_maps(cam, allmap, depth_ratio=0.0):
+    """surf_depth (1,H,W), surf_normal (3,H,W): the regulariser maps of render()'s tail (gaussian2d_utils.py:1125-1142), torch expressions
+    (envgs_amd.fused.surface_normal is the one-kernel form)."""
+    alpha = allmap[1:2]
+    median = torch.nan_to_num(allmap[5:6], 0, 0)
+    expect = torch.nan_to_num(allmap[0:1] / alpha, 0, 0)
+    depth = expect * (1 - depth_ratio) + median * depth_ratio
+    normal = dpt2norm(cam, depth).permute(2, 0, 1) * alpha.detach()
+    return depth, normal
 
 
 def visibility_filter(wet, means3D=None, K=None, R=None, T=None, H=None, W=None, start_from_first=False):

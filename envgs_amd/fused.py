@@ -93,3 +93,44 @@ class _Reflect(torch.autograd.Function):
 
 def reflect(allmap, ray_o, ray_d, viewmatrix, depth_ratio=0.0):
     return _Reflect.apply(allmap, ray_o, ray_d, viewmatrix, depth_ratio)
+
+
+class _SurfaceNormal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, allmap, viewmatrix, fx, fy, depth_ratio):
+        lib = _lib.load()
+        if allmap.device.type != "cuda":
+            raise RuntimeError("envgs_amd.fused needs tensors on the GPU; there is no CPU path")
+        allmap, viewmatrix = _f32c(allmap), _f32c(viewmatrix)
+        _, H, W = allmap.shape
+        f32 = dict(dtype=torch.float32, device=allmap.device)
+        sd = torch.empty(1, H, W, **f32); sn = torch.empty(3, H, W, **f32)
+        p = _lib.ptr
+        _lib.check(lib.envgs_surface_normal_forward(H, W, float(depth_ratio), float(fx), float(fy), p(allmap), p(viewmatrix), p(sd), p(sn),
+                                                    _stream(allmap.device)), "envgs_surface_normal_forward")
+        ctx.save_for_backward(allmap, viewmatrix)
+        ctx.cfg = (float(depth_ratio), float(fx), float(fy))
+        return sd, sn
+
+    @staticmethod
+    def backward(ctx, g_sd, g_sn):
+        lib = _lib.load()
+        allmap, viewmatrix = ctx.saved_tensors
+        _, H, W = allmap.shape
+        ratio, fx, fy = ctx.cfg
+        c = lambda g: None if g is None else _f32c(g)
+        g_sd, g_sn = c(g_sd), c(g_sn)
+        dall = torch.empty_like(allmap)
+        p = _lib.ptr
+        _lib.check(lib.envgs_surface_normal_backward(H, W, ratio, fx, fy, p(allmap), p(viewmatrix), p(g_sd), p(g_sn), p(dall),
+                                                     _stream(allmap.device)), "envgs_surface_normal_backward")
+        return dall, None, None, None, None
+
+
+def surface_normal(allmap, cam, depth_ratio=0.0):
+    """surf_depth (1,H,W), surf_normal (3,H,W) of render()'s tail (gaussian2d_utils.py:1125-1142, dpt2norm :1190-1206) in one kernel each way;
+    cam: the prepare_gaussian_camera namespace (image size, FoVx / FoVy, world_view_transform)."""
+    import math
+    fx = cam.image_width / (2.0 * math.tan(cam.FoVx / 2.0))
+    fy = cam.image_height / (2.0 * math.tan(cam.FoVy / 2.0))
+    return _SurfaceNormal.apply(allmap, cam.world_view_transform, fx, fy, depth_ratio)

@@ -48,6 +48,19 @@ ENVGS_API int envgs_reflect_backward(int32_t H, int32_t W, float depth_ratio, co
                                      const float *dref_o, const float *dref_d, float *dallmap, float *dray_o, float *dray_d,
                                      void *stream);
 
+/*
+ * The regulariser maps of render()'s tail (gaussian2d_utils.py:1125-1142): surf_depth (1,H,W) = expected depth (allmap[0] / allmap[1],
+ * nan -> 0) mixed with the median depth (allmap[5]) by depth_ratio, and surf_normal (3,H,W) = dpt2norm(surf_depth) * alpha.detach()
+ * (dpt2xyz / dpt2norm, :1158-1206: back-projection through the integer pixel grid with fx = W / (2 tan(FoVx/2)), central differences on
+ * interior pixels, zero border).  viewmatrix: world_view_transform (4,4) on the device; its upper 3x3 is the camera-to-world rotation
+ * (the reference inverts the matrix; for a rigid camera that is the same).  The backward WRITES dallmap (7,H,W): channels 0, 1, 5; the rest zero.
+ */
+ENVGS_API int envgs_surface_normal_forward(int32_t H, int32_t W, float depth_ratio, float fx, float fy, const float *allmap,
+                                           const float *viewmatrix, float *surf_depth, float *surf_normal, void *stream);
+ENVGS_API int envgs_surface_normal_backward(int32_t H, int32_t W, float depth_ratio, float fx, float fy, const float *allmap,
+                                            const float *viewmatrix, const float *dsurf_depth, const float *dsurf_normal,
+                                            float *dallmap, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

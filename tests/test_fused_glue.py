@@ -70,3 +70,41 @@ def test_reflect_matches_torch(ratio):
     torch.testing.assert_close(o1.grad, o2.grad, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(d1.grad, d2.grad, rtol=1e-4, atol=1e-4)
     assert torch.isfinite(a1.grad).all()
+
+
+@pytest.mark.parametrize("ratio", [0.0, 0.4])
+def test_surface_normal_matches_torch(ratio):
+    """fused.surface_normal (depth select + dpt2norm + alpha scaling, one kernel each way) vs the torch expressions of render()'s tail
+    (envgs_step.surface_maps; its dpt2norm is pinned against the reference's by tests/test_golden.py)."""
+    from envgs_amd import fused
+    dev = torch.device("cuda:0")
+    H, W = 44, 60
+    cam = synth.orbit_camera(3, H=H, W=W, fx=1111.1 * W / 800.0, device=dev)
+    gen = torch.Generator().manual_seed(5)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    allmap = torch.randn(7, H, W, generator=gen)
+    allmap[1] = torch.rand(H, W, generator=gen) * 0.9 + 0.05
+    allmap[0] = allmap[1] * (3.0 + 0.01 * xx + 0.3 * torch.sin(yy / 5.0) + 0.05 * torch.rand(H, W, generator=gen))
+    allmap[5] = 3.2 + 0.02 * yy + 0.05 * torch.rand(H, W, generator=gen)
+    allmap[1, :3, :7] = 0; allmap[0, :3, :7] = 0          # empty pixels: depth 0/0 -> 0
+    allmap = allmap.to(dev)
+    a1 = allmap.clone().requires_grad_(True)
+    sd, sn = fused.surface_normal(a1, cam, ratio)
+    a2 = allmap.clone().requires_grad_(True)
+    sd2, sn2 = envgs_step.surface_maps(cam, a2, ratio)
+    assert sd.shape == (1, H, W) and sn.shape == (3, H, W)
+    torch.testing.assert_close(sd, sd2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(sn, sn2, rtol=2e-4, atol=2e-5)
+    snd = sn.detach()
+    assert float(snd[:, 0].abs().max()) == 0 and float(snd[:, :, -1].abs().max()) == 0 and float(snd[:, 5:-5, 10:-5].abs().min(dim=0).values.max()) > 0
+    wd, wn = torch.randn_like(sd2), torch.randn_like(sn2)
+    ((sd * wd).sum() + (sn * wn).sum()).backward()
+    ((sd2 * wd).sum() + (sn2 * wn).sum()).backward()
+    live = allmap[1] > 0
+    g1, g2 = a1.grad, a2.grad
+    assert torch.isfinite(g1).all()
+    scale = float(g2[:, live].abs().max())
+    for ch in (0, 1, 5):
+        err = (g1[ch][live] - g2[ch][live]).abs().max()
+        assert float(err) <= 2e-4 * scale + 1e-6, (ch, float(err), scale)
+    assert float(g1[[2, 3, 4, 6]].abs().max()) == 0 and float(g1[:2][:, ~live].abs().max()) == 0

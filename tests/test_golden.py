@@ -84,3 +84,13 @@ def test_get_rays(golden):
     # z_depth convention: camera-space z of every direction is exactly 1
     z = (rd.reshape(-1, 3) @ cam.R.T)[:, 2]
     assert torch.allclose(z, torch.ones_like(z), atol=1e-5)
+
+
+def test_dpt2norm_twin(golden):
+    """envgs_step.dpt2norm (the torch re-derivation the fused surface_normal kernel is tested against) vs the reference's own dpt2norm."""
+    from envgs_amd import envgs_step
+    cam = _cam(golden)
+    out = envgs_step.dpt2norm(cam, torch.tensor(golden["dpt"])[None])
+    ref = golden["dpt2norm"]
+    assert out.shape == ref.shape and float(np.abs(ref[1:-1, 1:-1]).sum()) > 0 and float(np.abs(ref[0]).sum()) == 0
+    np.testing.assert_allclose(out.numpy(), ref, rtol=1e-4, atol=2e-5)
