@@ -388,3 +388,31 @@ def test_trace_very_long_lists(force_cap):
     chk(L["others"].grad.cpu().numpy(), rb["dothers"], "dothers")
     chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
     chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
+
+
+@pytest.mark.parametrize("P,R", [(50, 0), (0, 64), (0, 0), (1, 64)])
+def test_trace_empty_inputs(P, R):
+    """No rays, no surfels, neither, and a single surfel: shapes follow the inputs, an empty scene renders the background, backward runs."""
+    import diff_surfel_tracing as mod
+    dev = torch.device("cuda:0")
+    g, ro, rd = trace_scene(P=50, R=64, seed=2, camera=False)
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    L = {k: g[k][:P].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+    v, f = synth.get_disks(L["means3D"].detach(), L["scales"].detach(), L["rotations"].detach())
+    tracer = mod.SurfelTracer()
+    tracer.build_acceleration_structure(v, f, rebuild=True)
+    o = ro[:R].to(dev).requires_grad_(True); d = rd[:R].to(dev).requires_grad_(True)
+    outs = tracer(o, d, v, means3D=L["means3D"], grads3D=None, shs=L["shs"], colors_precomp=None, others_precomp=None, opacities=L["opacities"],
+                  scales=L["scales"], rotations=L["rotations"], cov3D_precomp=None, tracer_settings=_settings(mod, bg, 1, dev), start_from_first=False)
+    rgb, dpt, acc, norm, dist, aux, mid, wet = outs
+    assert [tuple(x.shape) for x in outs] == [(R, 3), (R, 1), (R, 1), (R, 3), (R, 1), (R, 2), (R, 16), (P, 1)]
+    (rgb.sum() + acc.sum()).backward()
+    torch.cuda.synchronize()
+    assert o.grad is not None and o.grad.shape == (R, 3) and torch.isfinite(o.grad).all()
+    if P == 0 and R:
+        assert torch.allclose(rgb.detach(), bg.to(dev).expand(R, 3)) and float(acc.detach().abs().max()) == 0 and float(o.grad.abs().max()) == 0
+    if P == 1:
+        from oracle import trace as otr
+        ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"][:1].numpy(), g["scales"][:1].numpy(), g["rotations"][:1].numpy(),
+                                g["opacities"][:1].numpy(), shs=g["shs"][:1].numpy(), sh_degree=1, bg=bg.numpy(), start_from_first=False)
+        assert_close_frac(rgb.detach().cpu().numpy(), ref["rgb"], 2e-4, max_bad_frac=0.02, flip_bound=0.1, what="rgb")
