@@ -1781,6 +1781,14 @@ static int stride_grid(int R, int per_block)
     return (g + 7) & ~7;                 // multiple of 8: xcd_block() needs it
 }
 
+// The list path packs surfel ids, ray slots and per-surfel entry counts into 24-bit fields: beyond 2^24 surfels or rays both directions take
+// the K-buffer kernels (correct at any size, slower).
+static bool lists_usable(const envgs_trace_cfg *cfg, const envgs_trace_lists *L)
+{
+    return L && L->cap > 0 && cfg->max_trace_depth == 0 && cfg->P > 0 && cfg->P < (1 << 24) && cfg->num_rays < (1 << 24) && L->hit_lists &&
+           L->hit_cnt && L->n_used && L->stack_spill && L->surf_cnt && L->surf_off && L->surf_acc && L->scan_temp;
+}
+
 }  // namespace envgs
 
 using namespace envgs;
@@ -1842,8 +1850,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     A.mod = cfg->scale_modifier;
     { const char *ev = getenv("ENVGS_TRACE_EXP"); A.exp = ev ? atoi(ev) : 0; }
     int rh, rw; ray_layout(cfg, &rh, &rw);
-    const bool lists = L && L->cap > 0 && cfg->max_trace_depth == 0 && cfg->P > 0 && L->hit_lists && L->hit_cnt && L->n_used &&
-                       L->stack_spill && L->surf_cnt && L->surf_off && L->surf_acc && L->scan_temp && cfg->num_rays < (1 << 24);
+    const bool lists = lists_usable(cfg, L);
     if (L && L->cap > SORT_MAX) return ENVGS_ERR_BAD_ARG;
     ProfScope prof_(K_TRACE_FWD, stream);
     if (lists) {
@@ -1985,7 +1992,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     int rh, rw; ray_layout(cfg, &rh, &rw);
     {
         ProfScope prof_(K_TRACE_BWD, stream);
-        if (L && L->cap > 0 && cfg->max_trace_depth == 0 && L->hit_lists && L->hit_cnt && L->n_used) {
+        if (lists_usable(cfg, L)) {                    // the same test as the forward: the lists exist exactly when it filled them
             A.hits = (uint2 *)L->hit_lists; A.hit_cnt = L->hit_cnt; A.n_used = L->n_used; A.cap = L->cap;
             if (L->ray_keys && L->ray_order && L->ray_sort_temp && !(A.exp & 64)) A.order = L->ray_order + cfg->num_rays;
             if (L->records && L->num_records > 0 && L->surf_cnt && L->surf_off && L->hit_state && L->entries && L->pairs && L->n_entries && !(A.exp & 8)) {

@@ -64,6 +64,9 @@ typedef struct envgs_trace_cfg {
  * Scratch of the list path (bounce-free tracing; all DEVICE pointers, caller-allocated).  HBM is used deliberately here
  * (288 GB per MI355X): per-ray hit lists make the backward traversal-free, per-(batch, surfel) gradient records grouped by surfel make
  * it atomic-free (the L2 atomic units retire ~0.15 T dword-atomics/s, which is what bounded a scatter-add backward).
+ * Pass the SAME struct to envgs_trace_forward and envgs_trace_backward.  The list path serves max_trace_depth == 0 with fewer than 2^24
+ * surfels and 2^24 rays (ids, ray slots and entry counts are packed into 24-bit fields); anything else -- or a NULL struct, or cap == 0 --
+ * takes the K-buffer kernels in both directions, which have no such limits.
  */
 typedef struct envgs_trace_lists {
     uint32_t *hit_lists;     /* (R, cap, 2): after the forward the first n_used entries are sorted by (t, id); word 1 = surfel id */
