@@ -1275,10 +1275,17 @@ register_hits(const TraceArgs A)
         uint2 *list = A.hits;
         if (r < A.R && A.hit_cnt[r] <= A.cap) { n = A.n_used[r]; list = A.hits + (size_t)r * A.cap; }
         constexpr int U = 4;
+        // (each lane walks its own list row: the loads of one step are 64 different cache lines, so the next step's entries are requested
+        //  before this step's chain of LDS atomics starts)
+        uint2 nxt[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) nxt[j] = (j < n) ? list[j] : make_uint2(0u, 0u);
         for (int kb = 0; kb < n; kb += U) {
             uint2 e[U];
 #pragma unroll
-            for (int j = 0; j < U; j++) e[j] = (kb + j < n) ? list[kb + j] : make_uint2(0u, 0u);
+            for (int j = 0; j < U; j++) e[j] = nxt[j];
+#pragma unroll
+            for (int j = 0; j < U; j++) nxt[j] = (kb + U + j < n) ? list[kb + U + j] : make_uint2(0u, 0u);
 #pragma unroll
             for (int j = 0; j < U; j++) {
                 if (kb + j >= n) break;
@@ -1328,11 +1335,17 @@ register_hits(const TraceArgs A)
         const unsigned carry_d = D;
         __syncthreads();
         if (A.n_entries && lane == 0) { A.n_entries[2 * batch] = (int)carry_d; A.n_entries[2 * batch + 1] = (int)nfail; }
-        if (prs)
-            for (int k = 0; k < n; k++) {
-                const unsigned x = list[k].x;
-                if (x != 0xFFFFFFFFu) prs[(unsigned)acc[x >> 8] + (x & 255u)] = ((unsigned)lane << 16) | (unsigned)k;
+        if (prs) {
+            constexpr int U2 = 8;                               // independent loads first: one memory round trip per 8 hits, not per hit
+            for (int kb = 0; kb < n; kb += U2) {
+                unsigned x[U2];
+#pragma unroll
+                for (int j = 0; j < U2; j++) x[j] = (kb + j < n) ? list[kb + j].x : 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < U2; j++)
+                    if (x[j] != 0xFFFFFFFFu) prs[(unsigned)acc[x[j] >> 8] + (x[j] & 255u)] = ((unsigned)lane << 16) | (unsigned)(kb + j);
             }
+        }
     }
 }
 
