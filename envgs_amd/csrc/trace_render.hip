@@ -1250,7 +1250,8 @@ sort_composite_fwd(const TraceArgs A)
 //                  the table are filed from the TOP of the region downwards (n_entries[2b] = D, n_entries[2b+1] = singles)
 //   pairs[b][...]  (lane << 16 | k) of every hit, grouped by entry in entry order (singles again from the top)
 constexpr int RH_TAB = 1024;
-__global__ void __launch_bounds__(64)
+constexpr int RH_W = 8;                                  // wavefronts per batch: wave q takes list positions q, q + RH_W, ... of every ray
+__global__ void __launch_bounds__(64 * RH_W)
 register_hits(const TraceArgs A)
 {
     __shared__ int key[RH_TAB];
@@ -1258,7 +1259,7 @@ register_hits(const TraceArgs A)
                                                      // returning ds_add_rtn_u64 per hit gives its rank; after the flush: offset of its first pair
     __shared__ unsigned nfail, ndense;
     __shared__ unsigned short hod[RH_TAB];           // table slot of the d-th distinct surfel, in order of first appearance
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const float wscale = __builtin_ldexpf(1.0f, A.wfrac);
     const size_t region = (size_t)64 * A.cap;
     for (int base = (A.batch0 + (int)blockIdx.x) * 64; base < min(A.R, A.batch1 * 64); base += gridDim.x * 64) {
@@ -1267,8 +1268,8 @@ register_hits(const TraceArgs A)
         unsigned long long *ent = A.entries ? A.entries + (size_t)batch * region : nullptr;
         unsigned *prs = A.pairs ? A.pairs + (size_t)batch * region : nullptr;
         __syncthreads();
-        for (int i = lane; i < RH_TAB; i += 64) { key[i] = -1; acc[i] = 0ull; }
-        if (lane == 0) { nfail = 0u; ndense = 0u; }
+        for (int i = threadIdx.x; i < RH_TAB; i += 64 * RH_W) { key[i] = -1; acc[i] = 0ull; }
+        if (threadIdx.x == 0) { nfail = 0u; ndense = 0u; }
         __syncthreads();
         const int r = ray_of(A, base + lane);
         int n = 0;
@@ -1279,16 +1280,17 @@ register_hits(const TraceArgs A)
         //  before this step's chain of LDS atomics starts)
         uint2 nxt[U];
 #pragma unroll
-        for (int j = 0; j < U; j++) nxt[j] = (j < n) ? list[j] : make_uint2(0u, 0u);
-        for (int kb = 0; kb < n; kb += U) {
+        for (int j = 0; j < U; j++) { const int k = part + j * RH_W; nxt[j] = (k < n) ? list[k] : make_uint2(0u, 0u); }
+        for (int kb = part; kb < n; kb += U * RH_W) {
             uint2 e[U];
 #pragma unroll
             for (int j = 0; j < U; j++) e[j] = nxt[j];
 #pragma unroll
-            for (int j = 0; j < U; j++) nxt[j] = (kb + U + j < n) ? list[kb + U + j] : make_uint2(0u, 0u);
+            for (int j = 0; j < U; j++) { const int k = kb + (U + j) * RH_W; nxt[j] = (k < n) ? list[k] : make_uint2(0u, 0u); }
 #pragma unroll
             for (int j = 0; j < U; j++) {
-                if (kb + j >= n) break;
+                const int k = kb + j * RH_W;
+                if (k >= n) break;
                 const unsigned long long wq = (unsigned long long)ceilf(__uint_as_float(e[j].x) * wscale);
                 unsigned h = (e[j].y * 2654435761u) >> 22;
                 bool ok = false;
@@ -1306,44 +1308,45 @@ register_hits(const TraceArgs A)
                     const unsigned long long old = atomicAdd(A.surf_acc + (size_t)e[j].y * NCOPY + copy, (wq << 24) | 1ull);
                     const unsigned f = atomicAdd(&nfail, 1u);
                     if (ent) ent[region - 1 - f] = (unsigned long long)e[j].y | ((old & 0xFFFFFFull) << 32);
-                    if (prs) prs[region - 1 - f] = ((unsigned)lane << 16) | (unsigned)(kb + j);
+                    if (prs) prs[region - 1 - f] = ((unsigned)lane << 16) | (unsigned)k;
                 }
-                list[kb + j].x = x;
+                list[k].x = x;
             }
         }
         __syncthreads();
         // Flush in order of FIRST APPEARANCE along the rays (~ front to back): the backward then meets each ray's hits in roughly ascending
         // list position, so the per-hit state it gathers is consumed cache line by cache line instead of at random.
         const unsigned D = ndense;
-        unsigned carry_off = 0u;
-        for (unsigned c = 0; c < D; c += 64) {
-            const unsigned d = c + lane;
-            const bool occ = d < D;
-            const int h = occ ? (int)hod[d] : 0;
-            const int sid = occ ? key[h] : 0;
-            const unsigned long long av = occ ? acc[h] : 0ull;
-            const unsigned cn = (unsigned)(av & 0xFFull);
-            const float incl = wave_scan_add((float)cn);                 // exact: at most 64*cap < 2^24 hits per batch
-            const unsigned offh = carry_off + (unsigned)incl - cn;
-            if (occ) {
-                const unsigned long long old = atomicAdd(A.surf_acc + (size_t)sid * NCOPY + copy, ((av >> 8) << 24) | 1ull);
-                if (ent) ent[d] = (unsigned long long)(unsigned)sid | ((unsigned long long)(cn - 1u) << 24) | ((old & 0xFFFFFFull) << 32);
-                acc[h] = (unsigned long long)offh;
+        if (part == 0) {
+            unsigned carry_off = 0u;
+            for (unsigned c = 0; c < D; c += 64) {
+                const unsigned d = c + lane;
+                const bool occ = d < D;
+                const int h = occ ? (int)hod[d] : 0;
+                const int sid = occ ? key[h] : 0;
+                const unsigned long long av = occ ? acc[h] : 0ull;
+                const unsigned cn = (unsigned)(av & 0xFFull);
+                const float incl = wave_scan_add((float)cn);                 // exact: at most 64*cap < 2^24 hits per batch
+                const unsigned offh = carry_off + (unsigned)incl - cn;
+                if (occ) {
+                    const unsigned long long old = atomicAdd(A.surf_acc + (size_t)sid * NCOPY + copy, ((av >> 8) << 24) | 1ull);
+                    if (ent) ent[d] = (unsigned long long)(unsigned)sid | ((unsigned long long)(cn - 1u) << 24) | ((old & 0xFFFFFFull) << 32);
+                    acc[h] = (unsigned long long)offh;
+                }
+                carry_off += (unsigned)wave_bcast(incl, 63);
             }
-            carry_off += (unsigned)wave_bcast(incl, 63);
+            if (A.n_entries && lane == 0) { A.n_entries[2 * batch] = (int)D; A.n_entries[2 * batch + 1] = (int)nfail; }
         }
-        const unsigned carry_d = D;
         __syncthreads();
-        if (A.n_entries && lane == 0) { A.n_entries[2 * batch] = (int)carry_d; A.n_entries[2 * batch + 1] = (int)nfail; }
         if (prs) {
-            constexpr int U2 = 8;                               // independent loads first: one memory round trip per 8 hits, not per hit
-            for (int kb = 0; kb < n; kb += U2) {
+            constexpr int U2 = 4;                               // independent loads first: one memory round trip per 4 hits, not per hit
+            for (int kb = part; kb < n; kb += U2 * RH_W) {
                 unsigned x[U2];
 #pragma unroll
-                for (int j = 0; j < U2; j++) x[j] = (kb + j < n) ? list[kb + j].x : 0xFFFFFFFFu;
+                for (int j = 0; j < U2; j++) { const int k = kb + j * RH_W; x[j] = (k < n) ? list[k].x : 0xFFFFFFFFu; }
 #pragma unroll
                 for (int j = 0; j < U2; j++)
-                    if (x[j] != 0xFFFFFFFFu) prs[(unsigned)acc[x[j] >> 8] + (x[j] & 255u)] = ((unsigned)lane << 16) | (unsigned)(kb + j);
+                    if (x[j] != 0xFFFFFFFFu) prs[(unsigned)acc[x[j] >> 8] + (x[j] & 255u)] = ((unsigned)lane << 16) | (unsigned)(kb + j * RH_W);
             }
         }
     }
@@ -1943,7 +1946,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
                 }
             }
             ENVGS_CHECK_LAUNCH(dcfg, st);
-            { ProfScope p8(K_TRACE_REGISTER, st); hipLaunchKernelGGL(register_hits, dim3(stride_grid(rays_seg, 64)), dim3(64), 0, st, S); }
+            { ProfScope p8(K_TRACE_REGISTER, st); hipLaunchKernelGGL(register_hits, dim3(stride_grid(rays_seg, 64)), dim3(64 * RH_W), 0, st, S); }
             ENVGS_CHECK_LAUNCH(dcfg, st);
         }
         if (nseg > 1) {
