@@ -1250,6 +1250,7 @@ sort_composite_fwd(const TraceArgs A)
 //                  the table are filed from the TOP of the region downwards (n_entries[2b] = D, n_entries[2b+1] = singles)
 //   pairs[b][...]  (lane << 16 | k) of every hit, grouped by entry in entry order (singles again from the top)
 constexpr int RH_TAB = 1024;
+constexpr int RH_STAGE = 8192;                           // pairs staged in LDS per batch (32 KB); the rest, if any, is stored directly
 constexpr int RH_W = 8;                                  // wavefronts per batch: wave q takes list positions q, q + RH_W, ... of every ray
 __global__ void __launch_bounds__(64 * RH_W)
 register_hits(const TraceArgs A)
@@ -1259,6 +1260,9 @@ register_hits(const TraceArgs A)
                                                      // returning ds_add_rtn_u64 per hit gives its rank; after the flush: offset of its first pair
     __shared__ unsigned nfail, ndense;
     __shared__ unsigned short hod[RH_TAB];           // table slot of the d-th distinct surfel, in order of first appearance
+    __shared__ unsigned pstage[RH_STAGE];            // the batch's pairs, assembled here and written out as one contiguous run (a scattered 4 B
+                                                     // store costs a whole 32 B sector of write traffic)
+    __shared__ unsigned ptotal;
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const float wscale = __builtin_ldexpf(1.0f, A.wfrac);
     const size_t region = (size_t)64 * A.cap;
@@ -1336,6 +1340,7 @@ register_hits(const TraceArgs A)
                 carry_off += (unsigned)wave_bcast(incl, 63);
             }
             if (A.n_entries && lane == 0) { A.n_entries[2 * batch] = (int)D; A.n_entries[2 * batch + 1] = (int)nfail; }
+            if (lane == 0) ptotal = carry_off;
         }
         __syncthreads();
         if (prs) {
@@ -1346,8 +1351,14 @@ register_hits(const TraceArgs A)
                 for (int j = 0; j < U2; j++) { const int k = kb + j * RH_W; x[j] = (k < n) ? list[k].x : 0xFFFFFFFFu; }
 #pragma unroll
                 for (int j = 0; j < U2; j++)
-                    if (x[j] != 0xFFFFFFFFu) prs[(unsigned)acc[x[j] >> 8] + (x[j] & 255u)] = ((unsigned)lane << 16) | (unsigned)(kb + j * RH_W);
+                    if (x[j] != 0xFFFFFFFFu) {
+                        const unsigned idx = (unsigned)acc[x[j] >> 8] + (x[j] & 255u), v = ((unsigned)lane << 16) | (unsigned)(kb + j * RH_W);
+                        if (idx < (unsigned)RH_STAGE) pstage[idx] = v; else prs[idx] = v;
+                    }
             }
+            __syncthreads();
+            const unsigned T = min(ptotal, (unsigned)RH_STAGE);
+            for (unsigned i = threadIdx.x; i < T; i += 64 * RH_W) prs[i] = pstage[i];
         }
     }
 }
