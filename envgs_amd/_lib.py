@@ -59,6 +59,7 @@ SYMBOLS = {
     "envgs_raster_bin_and_render": (c_int, [ctypes.POINTER(RasterCfg), c_uint32] + [_P] * 9 + [_P, c_size_t] + [_P] * 6 + [_P]),
     "envgs_raster_backward": (c_int, [ctypes.POINTER(RasterCfg), c_uint32] + [_P] * 28 + [_P]),
     "envgs_bvh_temp_bytes": (c_size_t, [ctypes.c_int32]),
+    "envgs_bvh_node_floats": (c_size_t, [ctypes.c_int32]),
     "envgs_bvh_build": (c_int, [ctypes.c_int32, _P, _P, _P, _P, c_size_t, ctypes.c_int32, _P]),
     "envgs_trace_stack_spill_ints": (c_size_t, [ctypes.c_int32]),
     "envgs_trace_ray_sort_temp_bytes": (c_size_t, [ctypes.c_int32]),

@@ -276,6 +276,42 @@ __global__ void single_leaf_node(const float *__restrict__ leaf_box, float *__re
     }
 }
 
+// 4-wide nodes for the packet traversal: node4[i] holds the GRANDCHILDREN of binary node i (a child that is a leaf stays as it is), boxes as
+// structure-of-arrays quads [lo.x | lo.y | lo.z | hi.x | hi.y | hi.z | refs | -] x 4 slots = 128 B.  Every binary node gets one (the traversal
+// only ever follows every other level; the rest is 128 B per surfel of unused memory) so the kernel is a plain map, no compaction.  Empty slots
+// are far-away points that no ray's slab test passes.
+__global__ void __launch_bounds__(256)
+build_wide_nodes(int n_internal, const float *__restrict__ nodes, float *__restrict__ nodes4)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_internal) return;
+    float lo[4][3], hi[4][3];
+    int ref[4];
+    int k = 0;
+    const float *nd = nodes + (size_t)i * NODE;
+    for (int side = 0; side < 2; side++) {
+        const int c = __float_as_int(nd[12 + side]);
+        if (c < 0) {
+            for (int a = 0; a < 3; a++) { lo[k][a] = nd[side * 6 + a]; hi[k][a] = nd[side * 6 + 3 + a]; }
+            ref[k++] = c;
+        } else {
+            const float *cd = nodes + (size_t)c * NODE;
+            for (int s2 = 0; s2 < 2; s2++) {
+                for (int a = 0; a < 3; a++) { lo[k][a] = cd[s2 * 6 + a]; hi[k][a] = cd[s2 * 6 + 3 + a]; }
+                ref[k++] = __float_as_int(cd[12 + s2]);
+            }
+        }
+    }
+    for (; k < 4; k++) {
+        for (int a = 0; a < 3; a++) { lo[k][a] = 1.0e30f; hi[k][a] = 1.0e30f; }
+        ref[k] = ~0;
+    }
+    float *o = nodes4 + (size_t)i * 32;
+    for (int a = 0; a < 3; a++)
+        for (int q = 0; q < 4; q++) { o[a * 4 + q] = lo[q][a]; o[12 + a * 4 + q] = hi[q][a]; }
+    for (int q = 0; q < 4; q++) { o[24 + q] = __int_as_float(ref[q]); o[28 + q] = 0.f; }
+}
+
 }  // namespace envgs
 
 using namespace envgs;
@@ -283,6 +319,8 @@ using namespace envgs;
 extern "C" {
 
 size_t envgs_bvh_temp_bytes(int32_t P) { return carve(P, nullptr).total; }
+
+size_t envgs_bvh_node_floats(int32_t P) { return (size_t)(NODE + 32) * (size_t)(P > 1 ? P - 1 : 1); }
 
 int envgs_bvh_build(int32_t P, const float *vertices, const float *opacities, float *nodes, void *temp, size_t temp_bytes, int32_t debug,
                     void *stream_)
@@ -302,6 +340,8 @@ int envgs_bvh_build(int32_t P, const float *vertices, const float *opacities, fl
     if (P == 1) {
         hipLaunchKernelGGL(single_leaf_node, dim3(1), dim3(64), 0, stream, t.leaf_box, nodes);
         ENVGS_CHECK_LAUNCH(cfg, stream);
+        hipLaunchKernelGGL(build_wide_nodes, dim3(1), dim3(256), 0, stream, 1, nodes, nodes + NODE);
+        ENVGS_CHECK_LAUNCH(cfg, stream);
         return 0;
     }
     hipLaunchKernelGGL(bounds_final, dim3(1), dim3(256), 0, stream, nblocks, t.partial, t.bounds);
@@ -318,6 +358,8 @@ int envgs_bvh_build(int32_t P, const float *vertices, const float *opacities, fl
         ENVGS_CHECK_LAUNCH(cfg, stream);
     }
     hipLaunchKernelGGL(build_hierarchy, dim3((P - 1 + 255) / 256), dim3(256), 0, stream, P, t.keys_out, t.st, nodes);
+    ENVGS_CHECK_LAUNCH(cfg, stream);
+    hipLaunchKernelGGL(build_wide_nodes, dim3((P - 1 + 255) / 256), dim3(256), 0, stream, P - 1, nodes, nodes + (size_t)(P - 1) * NODE);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;
 }

@@ -153,6 +153,7 @@ struct TraceArgs {
     unsigned long long num_records;
     const unsigned *order;    // (R) ray permutation (coherence sort) or NULL
     int exp;            // diagnostic switches (ENVGS_TRACE_EXP env var; 0 in production): 8 = atomic-flush backward instead of records,
+                        // 16 = binary packet traversal instead of the 4-wide one,
                         // 64 = no coherence sort of the rays, 512 = per-ray collection kernel even when the rays are sorted
     int *stack_spill;   // collect_hits: (grid, STACK, 64) ints of stack overflow space
     int only_overflow;  // K-buffer kernels: process only rays whose hit_cnt exceeds cap
@@ -1025,6 +1026,140 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
             else if (goL) cur = lc;
             else if (goR) cur = rc;
             else cur = -1;
+        }
+        if (valid) { A.hit_cnt[r] = n; found_tot += (unsigned)n; }
+        int mx = n;
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        if (lane == 0) atomicMax((int *)(A.counter + 1), mx);
+    }
+    if (A.stats) {
+        const float ff = wave_sum((float)found_tot);
+        if (lane == 0) { atomicAdd(A.stats + 1, (unsigned long long)visits); atomicAdd(A.stats + 3, (unsigned long long)ff); }
+    }
+}
+
+// The same traversal over the 4-wide nodes (trace_bvh.hip: node4[i] = the grandchildren of binary node i): half the steps, and each step is
+// one scalar-load round trip plus the stack / mask bookkeeping of the scalar unit, which is what the binary walk spends most of its time on.
+// Children that any ray hits are entered nearest first, ordered by the entry distance of each child's first hitting lane (the rays of a
+// batch are coherent; the order only affects how early the termination bounds tighten).  `visits` counts 64 B units (two per wide node).
+__global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(64)
+collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec)
+{
+    __shared__ int stk[PSTACK];
+    int *spill = A.stack_spill + ((size_t)A.seg * A.spill_stride + blockIdx.x) * (STACK * 64);
+    const int lane = threadIdx.x;
+    unsigned visits = 0, found_tot = 0;
+    float rlx, rly, rlz, rhx, rhy, rhz;                   // the scene box = union of the root's two child boxes
+    {
+        const float4 n0 = nodes[0], n1 = nodes[1], n2 = nodes[2];
+        rlx = fminf(n0.x, n1.z); rly = fminf(n0.y, n1.w); rlz = fminf(n0.z, n2.x);
+        rhx = fmaxf(n0.w, n2.y); rhy = fmaxf(n1.x, n2.z); rhz = fmaxf(n1.y, n2.w);
+    }
+    const int home = xcc_id();
+    const int nbatch = A.batch1 - A.batch0;
+    while (true) {
+        const int fb = fetch_batch(A.counter + 32 + 8 * A.seg, nbatch, home, lane);
+        if (fb < 0) break;
+        const int batch = A.batch0 + fb;
+        const int base = batch << 6;
+        const int r = ray_of(A, base + lane);
+        const bool valid = r < A.R;
+        const int rr = valid ? r : 0;
+        const float ox = A.ray_o[3 * rr], oy = A.ray_o[3 * rr + 1], oz = A.ray_o[3 * rr + 2];
+        const float dx = A.ray_d[3 * rr], dy = A.ray_d[3 * rr + 1], dz = A.ray_d[3 * rr + 2];
+        const float tmin = first_tmin(A.start_from_first);
+        const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+        float tA, bin_w, inv_bin_w;
+        {
+            const float a0 = (rlx - ox) * ix, a1 = (rhx - ox) * ix, b0 = (rly - oy) * iy, b1 = (rhy - oy) * iy, c0 = (rlz - oz) * iz, c1 = (rhz - oz) * iz;
+            const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1)), tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+            tA = fmaxf(tn, tmin);
+            float span = tf - tA;
+            if (!(span > 0.0f) || !(span < 1.0e30f)) span = 1.0f;
+            bin_w = span * (1.00001f / (float)(NBIN - 1));
+            inv_bin_w = 1.0f / bin_w;
+        }
+        float od[NBIN];
+#pragma unroll
+        for (int b = 0; b < NBIN; b++) od[b] = 0.f;
+        float tkill = 3.0e38f, odtot = 0.f;
+        int pend = 0;
+        uint2 *list = A.hits + (size_t)rr * A.cap;
+        int n = 0;
+        int sp = 0;
+        int cur = 0;
+        while (true) {
+            if (cur < 0) {
+                if (sp == 0) break;
+                --sp;
+                int top;
+                if (sp < PSTACK) top = stk[sp]; else top = __builtin_nontemporal_load(spill + (sp - PSTACK));
+                cur = __builtin_amdgcn_readfirstlane(top);
+            }
+            const float4 *nd = nodes4 + (size_t)cur * 8;
+            const float4 qlx = nd[0], qly = nd[1], qlz = nd[2], qhx = nd[3], qhy = nd[4], qhz = nd[5], qrf = nd[6];
+            const float lxs[4] = {qlx.x, qlx.y, qlx.z, qlx.w}, lys[4] = {qly.x, qly.y, qly.z, qly.w}, lzs[4] = {qlz.x, qlz.y, qlz.z, qlz.w};
+            const float hxs[4] = {qhx.x, qhx.y, qhx.z, qhx.w}, hys[4] = {qhy.x, qhy.y, qhy.z, qhy.w}, hzs[4] = {qhz.x, qhz.y, qhz.z, qhz.w};
+            const float rfs[4] = {qrf.x, qrf.y, qrf.z, qrf.w};
+            int key[4], ref[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int ch = __builtin_amdgcn_readfirstlane(__float_as_int(rfs[c]));
+                const float a0 = (lxs[c] - ox) * ix, a1 = (hxs[c] - ox) * ix, b0 = (lys[c] - oy) * iy, b1 = (hys[c] - oy) * iy,
+                            c0 = (lzs[c] - oz) * iz, c1 = (hzs[c] - oz) * iz;
+                const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
+                const float tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+                const bool hit = valid && (tn <= tf) && (tf >= tmin) && (tn <= tkill);
+                const unsigned long long m = __ballot(hit);
+                key[c] = 0x7fffffff; ref[c] = -1;
+                if (m != 0ull) {
+                    if (ch < 0) {
+                        const int sid = ~ch;
+                        const float4 *sr = srec + (size_t)sid * 4;
+                        const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], sr[3], ox, oy, oz, dx, dy, dz);
+                        if (hit && h.ok && h.t > tmin && h.t <= tkill) {
+                            if (n < A.cap) list[n] = make_uint2(__float_as_uint(h.t), (unsigned)sid);
+                            n++;
+                            const float x = (h.t - tA) * inv_bin_w;
+                            int b = x <= 0.0f ? 0 : (int)ceilf(x + 1e-3f);
+                            b = b > NBIN - 1 ? NBIN - 1 : b;
+                            const float dep = -__logf(1.0f - h.alpha);
+#pragma unroll
+                            for (int q = 0; q < NBIN; q++) od[q] += (q == b) ? dep : 0.f;
+                            odtot += dep;
+                        }
+                        pend++;
+                    } else {
+                        // entry distance of the first hitting lane, clamped at 0 so that the float bits order like integers
+                        const int fl = (int)__builtin_ctzll(m);
+                        key[c] = __builtin_amdgcn_readlane(__float_as_int(fmaxf(tn, 0.0f)), fl);
+                        ref[c] = ch;
+                        visits += 2u * (unsigned)__popcll(m);
+                    }
+                }
+            }
+            if (pend >= 3) {               // refresh the bound every third leaf test (a stale bound only collects a little more)
+                pend = 0;
+                if (__ballot(odtot >= KILL_OD) != 0ull) {
+                    float cum = 0.f; int kb = NBIN - 1;
+#pragma unroll
+                    for (int q = 0; q < NBIN - 1; q++) { cum += od[q]; kb = (cum >= KILL_OD && kb == NBIN - 1) ? q : kb; }
+                    tkill = kb < NBIN - 1 ? tA + (float)kb * bin_w : 3.0e38f;
+                }
+            }
+            // sort the (at most four) internal children by key: 5 scalar compare-exchanges; unused slots carry INT_MAX and end up last
+#define ENVGS_CSWAP(a, b) { const bool sw = key[a] > key[b]; const int ka = sw ? key[b] : key[a], kb2 = sw ? key[a] : key[b], \
+                                       ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b]; key[a] = ka; key[b] = kb2; ref[a] = ra; ref[b] = rb; }
+            ENVGS_CSWAP(0, 1) ENVGS_CSWAP(2, 3) ENVGS_CSWAP(0, 2) ENVGS_CSWAP(1, 3) ENVGS_CSWAP(1, 2)
+#undef ENVGS_CSWAP
+            // nearest next; the others go on the stack far to near
+#pragma unroll
+            for (int c = 3; c >= 1; c--)
+                if (ref[c] >= 0) {
+                    if (sp < PSTACK) stk[sp] = ref[c]; else if (sp < PSTACK + STACK * 64) spill[sp - PSTACK] = ref[c];
+                    sp++;
+                }
+            cur = ref[0];
         }
         if (valid) { A.hit_cnt[r] = n; found_tot += (unsigned)n; }
         int mx = n;
@@ -1940,7 +2075,10 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             const int rays_seg = (S.batch1 - S.batch0) * 64;
             {
                 ProfScope p1(K_TRACE_COLLECT, st);
-                if (S.order && !(S.exp & 512))
+                if (S.order && !(S.exp & 512) && !(S.exp & 16))
+                    hipLaunchKernelGGL(collect_hits_packet4, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S, S.nodes,
+                                       S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4, S.srec);
+                else if (S.order && !(S.exp & 512))
                     hipLaunchKernelGGL(collect_hits_packet, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S, S.nodes, S.srec);
                 else
                     hipLaunchKernelGGL(collect_hits, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S);

@@ -59,7 +59,7 @@ def _stream(dev):
 
 
 def build_bvh(vertices, opacities=None, debug=False):
-    """LBVH over the (4P,3) quad vertices (leaf boxes tightened by `opacities` when given).  Returns ((max(P-1,1),16) nodes, P)."""
+    """LBVH over the (4P,3) quad vertices (leaf boxes tightened by `opacities` when given).  Returns (nodes: envgs_bvh_node_floats(P) floats, P)."""
     lib = _lib.load()
     v = _f32c(vertices.detach())
     if v.device.type != "cuda":
@@ -68,7 +68,7 @@ def build_bvh(vertices, opacities=None, debug=False):
         raise RuntimeError("vertices must be (4P,3) in the get_disks layout, got %s" % (tuple(v.shape),))
     P = v.shape[0] // 4
     dev = v.device
-    nodes = torch.empty(max(P - 1, 1), 16, dtype=torch.float32, device=dev)
+    nodes = torch.empty(lib.envgs_bvh_node_floats(P), dtype=torch.float32, device=dev)    # binary nodes, then the 4-wide nodes
     tb = lib.envgs_bvh_temp_bytes(P)
     temp = torch.empty(max(tb, 1), dtype=torch.uint8, device=dev)
     op = None if opacities is None else _f32c(opacities.detach()).reshape(-1)

@@ -96,13 +96,16 @@ typedef struct envgs_trace_lists {
 
 /* Scratch bytes for the Morton sort + build of P surfels. */
 ENVGS_API size_t envgs_bvh_temp_bytes(int32_t P);
+/* Floats of the `nodes` buffer for P surfels: max(P-1,1) binary nodes of 16 floats, followed by as many 4-wide nodes of 32 floats (the
+ * grandchildren of each binary node, boxes as structure-of-arrays; what the packet traversal of coherence-sorted rays walks). */
+ENVGS_API size_t envgs_bvh_node_floats(int32_t P);
 
 /*
  * SurfelTracer.build_acceleration_structure(vertices, faces, rebuild) (optix_utils.py:78).
  * Builds the LBVH over the P quads (faces are implied by the get_disks layout: 2 triangles per 4 vertices).
  * opacities (P) is optional (NULL = plain quad boxes): when given, each leaf box is tightened to the part of the quad where the
  * surfel can still reach alpha >= 1/255 (disc of radius sqrt(2 ln(255 o)) sigma), and surfels with o <= 1/255 shrink to a point -- exact for every ray, and the reason the drop-in module defers the build to the first trace after a rebuild request
- * (only then are the opacities known).  nodes: (max(P-1,1),16) floats out.  temp: envgs_bvh_temp_bytes(P).
+ * (only then are the opacities known).  nodes: envgs_bvh_node_floats(P) floats out.  temp: envgs_bvh_temp_bytes(P).
  */
 ENVGS_API int envgs_bvh_build(int32_t P, const float *vertices, const float *opacities, float *nodes, void *temp, size_t temp_bytes,
                               int32_t debug, void *stream);
