@@ -1042,7 +1042,7 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
 // one scalar-load round trip plus the stack / mask bookkeeping of the scalar unit, which is what the binary walk spends most of its time on.
 // Children that any ray hits are entered nearest first, ordered by the entry distance of each child's first hitting lane (the rays of a
 // batch are coherent; the order only affects how early the termination bounds tighten).  `visits` counts 64 B units (two per wide node).
-__global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(64)
+__global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(64)
 collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec)
 {
     __shared__ int stk[PSTACK];
