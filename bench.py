@@ -12,7 +12,7 @@ the flat per-Gaussian gradient buffer is all-reduced once per step over RCCL/xGM
 Inputs are synthetic and resident in HBM before the timed region starts.
 
 Besides the driver's contract fields the line carries
-  roofline     : dominant kernel (composite_bwd, R7), algorithmic bytes / HIP-event launch time vs the 8 TB/s HBM peak
+  roofline     : dominant kernel (most time per step), algorithmic bytes / HIP-event launch time vs the 8 TB/s HBM peak
   cpu_baseline : the CPU oracle (oracle/, OpenMP over the host cores) on the same scene, rank 0, N=1 only
   kernels      : per-kernel ms/launch and achieved GB/s from HIP events on the launch stream
 """
@@ -273,7 +273,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = args.steps * world / elapsed
         leaf = {k: v for k, v in kernels.items() if k not in ("trace_fwd", "trace_bwd") and v["GBps"]}
-        dom = max(leaf, key=lambda k: leaf[k]["ms"]) if leaf else None
+        dom = max(leaf, key=lambda k: leaf[k]["ms"] * leaf[k]["launches"]) if leaf else None      # most time per step (launches included)
         roof = None
         if dom:
             A = kernels[dom]["GBps"]
@@ -288,8 +288,9 @@ def main():
                     "frac": round(A / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "alg_bytes_per_launch": int(kernels[dom]["alg_MB"] * 1e6), "ms_per_launch": kernels[dom]["ms"],
                     "tile_instances_N": int(N_avg),
-                    "note": "dominant kernel by HIP-event time; algorithmic bytes per DESIGN.md (raster: SURVEY.md 8d formulas; tracer: "
-                            "byte model over the kernel's own hit / node-visit counters).  Gather-heavy and VALU/latency bound rather "
+                    "note": "dominant kernel = most HIP-event time per step (duration x launches); algorithmic bytes per DESIGN.md (raster: SURVEY.md 8d formulas; tracer: "
+                            "the per-ray byte model of SURVEY.md 8d over the kernel's own hit / node-visit counters -- a 64-ray packet or a (batch, surfel) entry fetches "
+                            "a record once for all its rays, so a kernel can exceed the model's bytes per second without moving them).  Gather-heavy and VALU/latency bound rather "
                             "than streaming: the HBM fraction is reported as mandated; traffic = (2*FETCH_SIZE + WRITE_SIZE) per launch from "
                             "profiles/r01_pmc_envgs.json (separate --pmc passes), null if that profile has no row for this kernel"}
             rb = kernels.get("composite_bwd")
