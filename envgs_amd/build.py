@@ -16,9 +16,11 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fvisibility=hidden",
           "-Wall", "-Wno-unused-function"]
 # per-file extra flags; raster_project.hip feeds bit-exact integer keys -> no FMA contraction there
-# trace_render.hip: the SLP vectoriser pairs scalar fp32 ops into v_pk_* and then spends two v_mov per packed op assembling register pairs
+# tracer kernels: the SLP vectoriser pairs scalar fp32 ops into v_pk_* and then spends two v_mov per packed op assembling register pairs
 # (batch_surfel_bwd: 89 v_mov per entry, 255 VGPRs; without it 17 and 221)
-EXTRA = {"raster_project.hip": ["-ffp-contract=off"], "trace_render.hip": ["-fno-slp-vectorize"]}
+_NO_SLP = ["-fno-slp-vectorize"]
+EXTRA = {"raster_project.hip": ["-ffp-contract=off"], "trace_kbuffer.hip": _NO_SLP, "trace_collect.hip": _NO_SLP, "trace_lists.hip": _NO_SLP,
+         "trace_surfel_bwd.hip": _NO_SLP, "trace_api.hip": _NO_SLP}
 
 
 def _sources():

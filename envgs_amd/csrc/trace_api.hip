@@ -1,0 +1,270 @@
+// trace_api.hip -- the C-ABI of the tracer (include/envgs_trace.h): argument checks, scratch carving, the launch sequences of the forward
+// (two batch segments on two streams) and the backward.
+#include "trace_common.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace envgs {
+
+static int persistent_grid(int R, int per_cu = 8)
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int want = (R + 63) / 64;
+    const int cap = cus * per_cu;
+    return want < cap ? (want > 0 ? want : 1) : cap;
+}
+
+// grid for a grid-stride kernel that handles `per_block` rays per block iteration
+static int stride_grid(int R, int per_block)
+{
+    const int want = (R + per_block - 1) / per_block;
+    const int cap = 256 * 32;
+    const int g = want < cap ? (want > 0 ? want : 1) : cap;
+    return (g + 7) & ~7;                 // multiple of 8: xcd_block() needs it
+}
+
+// The list path packs surfel ids, ray slots and per-surfel entry counts into 24-bit fields: beyond 2^24 surfels or rays both directions take
+// the K-buffer kernels (correct at any size, slower).
+static bool lists_usable(const envgs_trace_cfg *cfg, const envgs_trace_lists *L)
+{
+    return L && L->cap > 0 && cfg->max_trace_depth == 0 && cfg->P > 0 && cfg->P < (1 << 24) && cfg->num_rays < (1 << 24) && L->hit_lists &&
+           L->hit_cnt && L->n_used && L->stack_spill && L->surf_cnt && L->surf_off && L->surf_acc && L->scan_temp;
+}
+
+
+}  // namespace envgs
+
+using namespace envgs;
+
+static void ray_layout(const envgs_trace_cfg *cfg, int *rh, int *rw)
+{
+    const bool ok = cfg->ray_h > 0 && cfg->ray_w > 0 && (long long)cfg->ray_h * cfg->ray_w == cfg->num_rays;
+    *rh = ok ? cfg->ray_h : 0;
+    *rw = ok ? cfg->ray_w : 0;
+}
+
+extern "C" {
+
+size_t envgs_trace_ray_sort_temp_bytes(int32_t num_rays)
+{
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned *)nullptr, (unsigned *)nullptr, (const unsigned *)nullptr, (unsigned *)nullptr,
+                                    (size_t)(num_rays > 0 ? num_rays : 1), 0u, 31u);
+    return bytes;
+}
+
+// one slab per persistent wavefront of the collection kernels, for each of the (at most two) batch segments that run concurrently
+size_t envgs_trace_stack_spill_ints(int32_t num_rays) { return (size_t)2 * persistent_grid(num_rays, 24) * STACK * 64; }
+
+int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const float *ray_o, const float *ray_d,
+                        const float *means3D, const float *scales, const float *rotations, const float *opacities,
+                        const float *shs, const float *colors_precomp, const float *others_precomp, const float *bg,
+                        float *srec, uint32_t *counters, float *rgb, float *dpt, float *acc, float *norm, float *dist,
+                        float *aux, float *mid, float *wet, float *final_T, const envgs_trace_lists *L, void *stream_)
+{
+    if (!cfg || cfg->P < 0 || cfg->num_rays < 0 || cfg->sh_degree < 0 || cfg->sh_degree > 3 || cfg->max_trace_depth < 0 || cfg->max_trace_depth > 7)
+        return ENVGS_ERR_BAD_ARG;
+    if (cfg->num_rays == 0) return 0;
+    if (!ray_o || !ray_d || !bg || !counters || !rgb || !dpt || !acc || !norm || !dist || !aux || !mid || !final_T) return ENVGS_ERR_BAD_ARG;
+    if (cfg->P > 0 && (!nodes || !means3D || !scales || !rotations || !opacities || !srec || !wet)) return ENVGS_ERR_BAD_ARG;
+    if (cfg->P > 0 && (cfg->sh_coeffs > 0 ? (!shs || cfg->sh_coeffs < (cfg->sh_degree + 1) * (cfg->sh_degree + 1)) : !colors_precomp)) return ENVGS_ERR_BAD_ARG;
+    if (cfg->has_others && cfg->P > 0 && !others_precomp) return ENVGS_ERR_BAD_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    envgs_raster_cfg dbg; dbg.debug = cfg->debug;
+    const envgs_raster_cfg *dcfg = &dbg;
+    hipError_t e = hipMemsetAsync(counters, 0, 96 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return (int)e;
+    if (cfg->P > 0) {
+        e = hipMemsetAsync(wet, 0, sizeof(float) * (size_t)cfg->P, stream);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(make_surfel_records, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, cfg->scale_modifier,
+                           means3D, scales, rotations, opacities, srec);
+        ENVGS_CHECK_LAUNCH(dcfg, stream);
+    }
+    e = hipMemsetAsync(mid, 0, sizeof(float) * (size_t)cfg->num_rays * MID * (cfg->max_trace_depth + 1), stream);
+    if (e != hipSuccess) return (int)e;
+    TraceArgs A;
+    A = TraceArgs{};
+    A.P = cfg->P; A.R = cfg->num_rays; A.D = cfg->sh_degree; A.M = cfg->sh_coeffs; A.ND = cfg->max_trace_depth + 1;
+    A.start_from_first = cfg->start_from_first; A.has_others = cfg->has_others; A.bg_len = cfg->bg_len; A.spec_thr = cfg->specular_threshold;
+    A.nodes = (const float4 *)nodes; A.srec = (const float4 *)srec; A.shs = shs; A.colors = colors_precomp; A.others = others_precomp;
+    A.bg = bg; A.ray_o = ray_o; A.ray_d = ray_d; A.counter = counters; A.stats = (unsigned long long *)(counters + 2);
+    A.rgb = rgb; A.dpt = dpt; A.acc = acc; A.norm = norm; A.dist = dist; A.aux = aux; A.mid = mid; A.wet = wet; A.final_T = final_T;
+    A.mod = cfg->scale_modifier;
+    { const char *ev = getenv("ENVGS_TRACE_EXP"); A.exp = ev ? atoi(ev) : 0; }
+    int rh, rw; ray_layout(cfg, &rh, &rw);
+    const bool lists = lists_usable(cfg, L);
+    if (L && L->cap > SORT_MAX) return ENVGS_ERR_BAD_ARG;
+    ProfScope prof_(K_TRACE_FWD, stream);
+    if (lists) {
+        if (L->scan_temp_bytes < scan_temp_bytes(cfg->P * NCOPY)) return ENVGS_ERR_TEMP_TOO_SMALL;
+        A.hits = (uint2 *)L->hit_lists; A.hit_cnt = L->hit_cnt; A.n_used = L->n_used; A.cap = L->cap; A.stack_spill = L->stack_spill;
+        A.surf_cnt = L->surf_cnt; A.surf_off = L->surf_off; A.surf_acc = (unsigned long long *)L->surf_acc;
+        if (L->ray_keys && L->ray_order && L->ray_sort_temp && !(A.exp & 64)) {
+            // coherence sort of the rays (keys / values double-buffered in ray_keys / ray_order: 2R words each)
+            const int R = cfg->num_rays;
+            hipLaunchKernelGGL(make_ray_keys, dim3((R + 255) / 256), dim3(256), 0, stream, R, ray_o, ray_d, A.nodes, cfg->P, L->ray_keys, L->ray_order);
+            ENVGS_CHECK_LAUNCH(dcfg, stream);
+            size_t tb = L->ray_sort_temp_bytes;
+            e = rocprim::radix_sort_pairs(L->ray_sort_temp, tb, L->ray_keys, L->ray_keys + R, L->ray_order, L->ray_order + R, (size_t)R, 0u, 31u, stream);
+            if (e != hipSuccess) return (int)e;
+            A.order = L->ray_order + R;
+        }
+        {   // 40-bit fixed-point weight: enough integer bits that even a surfel seen with w = 1 by every ray cannot overflow
+            int ib = 1;
+            while ((1ll << ib) <= (long long)cfg->num_rays) ib++;
+            A.wfrac = 40 - ib > 30 ? 30 : 40 - ib;
+        }
+        e = hipMemsetAsync(L->surf_acc, 0, sizeof(unsigned long long) * (size_t)cfg->P * NCOPY, stream);
+        if (e != hipSuccess) return (int)e;
+        A.state = (float4 *)L->hit_state; A.entries = (unsigned long long *)L->entries; A.pairs = L->pairs; A.n_entries = L->n_entries;
+        // The ray batches are split into two segments that run collect -> sort+composite -> register on two streams: the collection
+        // kernel is a persistent grid whose wavefronts drain over the time of one whole batch, and the second segment's wavefronts
+        // (and the first segment's next kernel) move into the CUs it leaves idle.
+        const int nbatch_all = (cfg->num_rays + 63) / 64;
+        int nseg = 2;                                         // measured: 1 -> 18.3 ms / step, 2 -> 17.5, 4 -> 19.4 (each collection launch lasts at least one batch)
+        { const char *sv = getenv("ENVGS_SEGMENTS"); if (sv) nseg = atoi(sv); }
+        if (nseg > 2) nseg = 2;                               // (the stack-spill slab and the fetch counters are sized for two)
+        while (nseg > 1 && nbatch_all / nseg < 256) nseg >>= 1;
+        if (nseg < 1) nseg = 1;
+        hipStream_t aux = nullptr;
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+        if (nseg > 1) {
+            // one auxiliary stream + fork / join events per device, created on first use (one process drives one GPU in this design,
+            // but nothing here assumes it)
+            static hipStream_t s_aux[16] = {};
+            static hipEvent_t s_fork[16] = {}, s_join[16] = {};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) nseg = 1;
+            else if (!s_aux[dev]) {
+                if (hipStreamCreateWithFlags(&s_aux[dev], hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&s_fork[dev], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&s_join[dev], hipEventDisableTiming) != hipSuccess) { s_aux[dev] = nullptr; nseg = 1; }
+            }
+            if (nseg > 1) {
+                aux = s_aux[dev]; ev_fork = s_fork[dev]; ev_join = s_join[dev];
+                if (hipEventRecord(ev_fork, stream) != hipSuccess || hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+            }
+        }
+        for (int sg = 0; sg < nseg; sg++) {                   // even segments on the caller's stream, odd ones on the auxiliary stream
+            hipStream_t st = (sg & 1) ? aux : stream;
+            TraceArgs S = A;
+            S.seg = sg;
+            S.spill_stride = persistent_grid(cfg->num_rays, 24);     // >= this segment's grid; matches envgs_trace_stack_spill_ints
+            S.batch0 = (int)((long long)nbatch_all * sg / nseg);
+            S.batch1 = (int)((long long)nbatch_all * (sg + 1) / nseg);
+            const int rays_seg = (S.batch1 - S.batch0) * 64;
+            {
+                ProfScope p1(K_TRACE_COLLECT, st);
+                if (S.order && !(S.exp & 512) && !(S.exp & 16))
+                    hipLaunchKernelGGL(collect_hits_packet4, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S, S.nodes,
+                                       S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4, S.srec);
+                else if (S.order && !(S.exp & 512))
+                    hipLaunchKernelGGL(collect_hits_packet, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S, S.nodes, S.srec);
+                else
+                    hipLaunchKernelGGL(collect_hits, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S);
+            }
+            ENVGS_CHECK_LAUNCH(dcfg, st);
+            {
+                ProfScope p2(K_TRACE_SORT, st);
+                const dim3 g(stride_grid(rays_seg, 4)), b(256);
+                hipLaunchKernelGGL((sort_composite_fwd<4, false>), g, b, 0, st, S);
+                if (S.cap > 256) {
+                    const dim3 gl(min(stride_grid(rays_seg, 256), 512));
+                    if (S.cap <= 512) hipLaunchKernelGGL((sort_composite_fwd<8, true>), gl, b, 0, st, S);
+                    else hipLaunchKernelGGL((sort_composite_fwd<16, true>), gl, b, 0, st, S);
+                }
+            }
+            ENVGS_CHECK_LAUNCH(dcfg, st);
+            { ProfScope p8(K_TRACE_REGISTER, st); hipLaunchKernelGGL(register_hits, dim3(stride_grid(rays_seg, 64)), dim3(64 * RH_W), 0, st, S); }
+            ENVGS_CHECK_LAUNCH(dcfg, st);
+        }
+        if (nseg > 1) {
+            if (hipEventRecord(ev_join, aux) != hipSuccess || hipStreamWaitEvent(stream, ev_join, 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+        }
+        hipLaunchKernelGGL(unpack_surfel_acc, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, A.wfrac, A.surf_acc, L->surf_cnt, wet);
+        ENVGS_CHECK_LAUNCH(dcfg, stream);
+        {   // records of the backward are addressed through the inclusive scan of the per-surfel hit counts
+            const int rc = launch_scan(L->surf_cnt, L->surf_off, cfg->P * NCOPY, L->scan_temp, L->scan_temp_bytes, stream);
+            if (rc) return rc;
+        }
+        e = hipMemsetAsync(counters, 0, sizeof(uint32_t), stream);          // ray-fetch counter for the overflow pass
+        if (e != hipSuccess) return (int)e;
+        A.only_overflow = 1;
+    }
+    { ProfScope p4(K_TRACE_KBUF_FWD, stream); hipLaunchKernelGGL(trace_fwd, dim3(persistent_grid(cfg->num_rays)), dim3(64), 0, stream, A, rh, rw); }
+    ENVGS_CHECK_LAUNCH(dcfg, stream);
+    return 0;
+}
+
+int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const float *ray_o, const float *ray_d,
+                         const float *means3D, const float *scales, const float *rotations, const float *opacities,
+                         const float *shs, const float *colors_precomp, const float *others_precomp, const float *bg,
+                         const float *srec, uint32_t *counters, const float *rgb, const float *dpt, const float *acc,
+                         const float *norm, const float *aux, const float *final_T, const float *dL_drgb, const float *dL_ddpt,
+                         const float *dL_dacc, const float *dL_dnorm, const float *dL_daux, float *geo_rec, float *dmeans3D,
+                         float *dgrads3D, float *dscales, float *drots, float *dopacities, float *dshs, float *dcolors,
+                         float *dothers, float *dray_o, float *dray_d, const envgs_trace_lists *L, void *stream_)
+{
+    if (!cfg || cfg->P < 0 || cfg->num_rays < 0) return ENVGS_ERR_BAD_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    envgs_raster_cfg dbg; dbg.debug = cfg->debug;
+    const envgs_raster_cfg *dcfg = &dbg;
+    const size_t P = (size_t)cfg->P, R = (size_t)cfg->num_rays;
+    hipError_t e;
+#define ZERO(ptr, n) do { if ((ptr) && (n) > 0) { e = hipMemsetAsync((ptr), 0, sizeof(float) * (n), stream); if (e != hipSuccess) return (int)e; } } while (0)
+    ZERO(geo_rec, P * ENVGS_GEOREC_STRIDE); ZERO(dmeans3D, P * 3); ZERO(dgrads3D, P * 3); ZERO(dscales, P * 2); ZERO(drots, P * 4);
+    ZERO(dopacities, P); ZERO(dothers, P * 2); ZERO(dray_o, R * 3); ZERO(dray_d, R * 3);
+    if (cfg->sh_coeffs > 0) ZERO(dshs, P * cfg->sh_coeffs * 3); else ZERO(dcolors, P * 3);
+#undef ZERO
+    if (cfg->num_rays == 0 || cfg->P == 0) return 0;
+    if (!nodes || !ray_o || !ray_d || !srec || !counters || !rgb || !dpt || !acc || !norm || !aux || !final_T || !dL_drgb || !dL_ddpt ||
+        !dL_dacc || !dL_dnorm || !dL_daux || !geo_rec || !dmeans3D || !dscales || !drots || !dopacities || !dray_o || !dray_d || !rotations || !bg)
+        return ENVGS_ERR_BAD_ARG;
+    if (cfg->sh_coeffs > 0 ? (!shs || !dshs) : (!colors_precomp || !dcolors)) return ENVGS_ERR_BAD_ARG;
+    e = hipMemsetAsync(counters, 0, sizeof(uint32_t), stream);      // only the ray-fetch counter: [1] (largest list) and the stats stay readable
+    if (e != hipSuccess) return (int)e;
+    TraceArgs A;
+    A = TraceArgs{};
+    A.P = cfg->P; A.R = cfg->num_rays; A.D = cfg->sh_degree; A.M = cfg->sh_coeffs; A.ND = 1;
+    A.start_from_first = cfg->start_from_first; A.has_others = cfg->has_others; A.bg_len = cfg->bg_len; A.spec_thr = cfg->specular_threshold;
+    A.nodes = (const float4 *)nodes; A.srec = (const float4 *)srec; A.shs = shs; A.colors = colors_precomp; A.others = others_precomp;
+    A.bg = bg; A.ray_o = ray_o; A.ray_d = ray_d; A.counter = counters;
+    A.f_rgb = rgb; A.f_dpt = dpt; A.f_acc = acc; A.f_norm = norm; A.f_aux = aux; A.f_T = final_T;
+    A.g_rgb = dL_drgb; A.g_dpt = dL_ddpt; A.g_acc = dL_dacc; A.g_norm = dL_dnorm; A.g_aux = dL_daux;
+    A.geo_rec = geo_rec; A.dshs = dshs; A.dcolors = dcolors;
+    { const char *ev = getenv("ENVGS_TRACE_EXP"); A.exp = ev ? atoi(ev) : 0; }
+    A.dothers = dothers; A.dray_o = dray_o; A.dray_d = dray_d; A.mod = cfg->scale_modifier;
+    int rh, rw; ray_layout(cfg, &rh, &rw);
+    {
+        ProfScope prof_(K_TRACE_BWD, stream);
+        if (lists_usable(cfg, L)) {                    // the same test as the forward: the lists exist exactly when it filled them
+            A.hits = (uint2 *)L->hit_lists; A.hit_cnt = L->hit_cnt; A.n_used = L->n_used; A.cap = L->cap;
+            if (L->ray_keys && L->ray_order && L->ray_sort_temp && !(A.exp & 64)) A.order = L->ray_order + cfg->num_rays;
+            if (L->records && L->num_records > 0 && L->surf_cnt && L->surf_off && L->hit_state && L->entries && L->pairs && L->n_entries && !(A.exp & 8)) {
+                // atomic-free: one record per (batch, surfel) entry, grouped by surfel; then each surfel's records are summed
+                A.surf_cnt = L->surf_cnt; A.surf_off = L->surf_off; A.records = L->records; A.num_records = L->num_records;
+                A.state = (float4 *)L->hit_state; A.entries = (unsigned long long *)L->entries; A.pairs = L->pairs; A.n_entries = L->n_entries;
+                { ProfScope p5(K_TRACE_LIST_BWD, stream); hipLaunchKernelGGL(batch_surfel_bwd, dim3(stride_grid((cfg->num_rays + 63) / 64, 1)), dim3(64), 0, stream, A); }
+                { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, stream, A); }
+            } else {
+                ProfScope p5(K_TRACE_LIST_BWD, stream);
+                hipLaunchKernelGGL(composite_lists_bwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A);
+            }
+            A.only_overflow = 1;
+        }
+        { ProfScope p6(K_TRACE_KBUF_BWD, stream); hipLaunchKernelGGL(trace_bwd, dim3(persistent_grid(cfg->num_rays)), dim3(64), 0, stream, A, rh, rw); }
+    }
+    ENVGS_CHECK_LAUNCH(dcfg, stream);
+    hipLaunchKernelGGL(finish_surfel_grads, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, rotations, geo_rec, dmeans3D, dscales,
+                       dopacities, drots, dgrads3D);
+    ENVGS_CHECK_LAUNCH(dcfg, stream);
+    return 0;
+}
+
+}  // extern "C"
+

@@ -1,0 +1,429 @@
+// trace_collect.hip -- list path, step 1: the coherence sort key of a ray and the unordered hit collection (per-ray kernel, packet kernel over the
+// binary nodes, packet kernel over the 4-wide nodes).
+#include "trace_common.h"
+
+namespace envgs {
+
+// Sort key of a ray: octahedral direction (2 x 8 bits, Morton-interleaved) in the high bits, origin cell (3 x 5 bits) below.
+__global__ void __launch_bounds__(256)
+make_ray_keys(int R, const float *__restrict__ ray_o, const float *__restrict__ ray_d, const float4 *__restrict__ nodes, int P,
+              unsigned *__restrict__ keys, unsigned *__restrict__ vals)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float lo[3] = {-1.f, -1.f, -1.f}, ext[3] = {2.f, 2.f, 2.f};
+    if (P > 0) {
+        const float4 n0 = nodes[0], n1 = nodes[1], n2 = nodes[2];
+        lo[0] = fminf(n0.x, n1.z); lo[1] = fminf(n0.y, n1.w); lo[2] = fminf(n0.z, n2.x);
+        ext[0] = fmaxf(n0.w, n2.y) - lo[0]; ext[1] = fmaxf(n1.x, n2.z) - lo[1]; ext[2] = fmaxf(n1.y, n2.w) - lo[2];
+    }
+    const float dx = ray_d[3 * r], dy = ray_d[3 * r + 1], dz = ray_d[3 * r + 2];
+    const float inv = 1.0f / (fabsf(dx) + fabsf(dy) + fabsf(dz) + 1e-30f);
+    float u = dx * inv, v = dy * inv;
+    if (dz < 0.f) { const float uu = (1.f - fabsf(v)) * (u >= 0.f ? 1.f : -1.f), vv = (1.f - fabsf(u)) * (v >= 0.f ? 1.f : -1.f); u = uu; v = vv; }
+    const unsigned qu = (unsigned)fminf(fmaxf((u * 0.5f + 0.5f) * 256.f, 0.f), 255.f), qv = (unsigned)fminf(fmaxf((v * 0.5f + 0.5f) * 256.f, 0.f), 255.f);
+    unsigned dkey = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) dkey |= ((qu >> b) & 1u) << (2 * b) | ((qv >> b) & 1u) << (2 * b + 1);
+    unsigned okey = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float t = ext[c] > 0.f ? (ray_o[3 * r + c] - lo[c]) / ext[c] : 0.f;
+        const unsigned q = (unsigned)fminf(fmaxf(t * 32.f, 0.f), 31.f);
+#pragma unroll
+        for (int b = 0; b < 5; b++) okey |= ((q >> b) & 1u) << (3 * b + c);
+    }
+    keys[r] = (dkey << 15) | okey;
+    vals[r] = (unsigned)r;
+}
+
+__global__ void __launch_bounds__(64)
+collect_hits(const TraceArgs A)
+{
+    // Shallow LDS stack (6 KB per wavefront -> ~26 wavefronts per CU instead of 10); the rare deeper pushes spill to a
+    // per-wavefront slab in HBM.  Hits are sorted afterwards, so the visiting order only matters for how early the bound tightens.
+    __shared__ int stk[LDS_STACK][64];
+    int *spill = A.stack_spill + ((size_t)A.seg * A.spill_stride + blockIdx.x) * (STACK * 64);
+    const int lane = threadIdx.x;
+    unsigned visits = 0, rays_done = 0, found_tot = 0;
+    // the scene box = union of the root's two child boxes (uniform loads)
+    float rlx = 0.f, rly = 0.f, rlz = 0.f, rhx = 0.f, rhy = 0.f, rhz = 0.f;
+    if (A.P > 0) {
+        const float4 n0 = A.nodes[0], n1 = A.nodes[1], n2 = A.nodes[2];
+        rlx = fminf(n0.x, n1.z); rly = fminf(n0.y, n1.w); rlz = fminf(n0.z, n2.x);
+        rhx = fmaxf(n0.w, n2.y); rhy = fmaxf(n1.x, n2.z); rhz = fmaxf(n1.y, n2.w);
+    }
+    const int home = xcc_id();
+    const int nbatch = A.batch1 - A.batch0;
+    while (true) {
+        const int fb = fetch_batch(A.counter + 32 + 8 * A.seg, nbatch, home, lane);
+        if (fb < 0) break;
+        const int batch = A.batch0 + fb;
+        const int base = batch << 6;
+        const int r = ray_of(A, base + lane);
+        const bool valid = r < A.R;
+        const int rr = valid ? r : 0;
+        const float ox = A.ray_o[3 * rr], oy = A.ray_o[3 * rr + 1], oz = A.ray_o[3 * rr + 2];
+        const float dx = A.ray_d[3 * rr], dy = A.ray_d[3 * rr + 1], dz = A.ray_d[3 * rr + 2];
+        const float tmin = first_tmin(A.start_from_first);
+        const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+        // bins: LINEAR in t over the ray's chord through the scene box (a fog terminates after a roughly constant optical depth, i.e. at a
+        // roughly constant fraction of the chord: 16 linear bins resolve that point to 1/15 of the chord, half-octave bins to +41 %)
+        float tA, bin_w, inv_bin_w;
+        {
+            const float a0 = (rlx - ox) * ix, a1 = (rhx - ox) * ix, b0 = (rly - oy) * iy, b1 = (rhy - oy) * iy, c0 = (rlz - oz) * iz, c1 = (rhz - oz) * iz;
+            const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1)), tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+            tA = fmaxf(tn, tmin);
+            float span = tf - tA;
+            if (!(span > 0.0f) || !(span < 1.0e30f)) span = 1.0f;               // the ray misses the scene (or a degenerate box): nothing to bin
+            bin_w = span * (1.00001f / (float)(NBIN - 1));
+            inv_bin_w = 1.0f / bin_w;
+        }
+        float od[NBIN];
+#pragma unroll
+        for (int b = 0; b < NBIN; b++) od[b] = 0.f;
+        float tkill = 3.0e38f;
+        uint2 *list = A.hits + (size_t)rr * A.cap;
+        int n = 0;
+        int sp = 0;
+        int cur = (valid && A.P > 0) ? 0 : -1;
+        while (true) {
+            if (cur < 0) {
+                if (sp == 0) break;
+                --sp;
+                cur = sp < LDS_STACK ? stk[sp][lane] : spill[(sp - LDS_STACK) * 64 + lane];
+            }
+            const float4 *nd = A.nodes + (size_t)cur * 4;
+            visits++;
+            const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+            const int lc = __float_as_int(n3.x), rc = __float_as_int(n3.y);
+            float a0 = (n0.x - ox) * ix, a1 = (n0.w - ox) * ix, b0 = (n0.y - oy) * iy, b1 = (n1.x - oy) * iy, c0 = (n0.z - oz) * iz, c1 = (n1.y - oz) * iz;
+            const float tnL = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
+            const float tfL = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+            a0 = (n1.z - ox) * ix; a1 = (n2.y - ox) * ix; b0 = (n1.w - oy) * iy; b1 = (n2.z - oy) * iy; c0 = (n2.x - oz) * iz; c1 = (n2.w - oz) * iz;
+            const float tnR = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
+            const float tfR = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+            bool hitL = (tnL <= tfL) && (tfL >= tmin) && (tnL <= tkill);
+            bool hitR = (tnR <= tfR) && (tfR >= tmin) && (tnR <= tkill);
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const bool hit = side == 0 ? hitL : hitR;
+                const int ch = side == 0 ? lc : rc;
+                if (hit && ch < 0) {
+                    const int sid = ~ch;
+                    const float4 *sr = A.srec + (size_t)sid * 4;
+                    const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], sr[3], ox, oy, oz, dx, dy, dz);
+                    if (h.ok && h.t > tmin && h.t <= tkill) {
+                        if (n < A.cap) list[n] = make_uint2(__float_as_uint(h.t), (unsigned)sid);
+                        n++;
+                        // bin (biased upwards: a hit may only ever be filed FARTHER than it is, which keeps the bound conservative)
+                        const float x = (h.t - tA) * inv_bin_w;
+                        int b = x <= 0.0f ? 0 : (int)ceilf(x + 1e-3f);
+                        b = b > NBIN - 1 ? NBIN - 1 : b;
+                        const float dep = -__logf(1.0f - h.alpha);
+#pragma unroll
+                        for (int q = 0; q < NBIN; q++) od[q] += (q == b) ? dep : 0.f;
+                        float cum = 0.f; int kb = NBIN - 1;
+#pragma unroll
+                        for (int q = 0; q < NBIN - 1; q++) { cum += od[q]; kb = (cum >= KILL_OD && kb == NBIN - 1) ? q : kb; }
+                        tkill = kb < NBIN - 1 ? tA + (float)kb * bin_w : 3.0e38f;
+                    }
+                }
+            }
+            hitL = hitL && lc >= 0;
+            hitR = hitR && rc >= 0;
+            if (hitL && hitR) {
+                const bool leftFirst = tnL <= tnR;
+                const int farc = leftFirst ? rc : lc;
+                if (sp < LDS_STACK) stk[sp][lane] = farc; else if (sp < LDS_STACK + STACK) spill[(sp - LDS_STACK) * 64 + lane] = farc;
+                sp++;
+                cur = leftFirst ? lc : rc;
+            }
+            else if (hitL) cur = lc;
+            else if (hitR) cur = rc;
+            else cur = -1;
+        }
+        if (valid) { A.hit_cnt[r] = n; rays_done++; found_tot += (unsigned)n; }
+        // wave max of n -> global max (adaptive cap of the next call)
+        int mx = n;
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        if (lane == 0) atomicMax((int *)(A.counter + 1), mx);
+    }
+    if (A.stats) {
+        const float fv = wave_sum((float)visits), ff = wave_sum((float)found_tot);
+        if (lane == 0) { atomicAdd(A.stats + 1, (unsigned long long)fv); atomicAdd(A.stats + 3, (unsigned long long)ff); }
+    }
+}
+
+// Packet form of collect_hits for coherence-sorted rays.  The 64 rays of a batch mostly walk the SAME nodes (measured on the bench
+// scene: the union of the surfels a batch finds is 2.4x what one of its rays finds), so the wavefront walks the tree ONCE with a single,
+// wave-uniform stack: node and surfel records come in through the scalar unit (s_load: one 64 B fetch per wavefront instead of up to
+// 64 gathers), every lane tests its own ray against them with its own termination bound, and control flow never diverges.  A lane
+// that is pruned simply stops passing box tests.  Visit order (near child first by majority vote) only affects how early the bounds
+// tighten: the lists are sorted afterwards.
+// (8 waves per SIMD: with two segments in flight ~10 k wavefronts want a slot; the (n - o) * (1/d) slab form is kept on purpose -- the
+//  one-fma form n*(1/d) - o/d needs an error margin proportional to |o/d|, and in a packet ONE ray with a tiny direction component then
+//  drags the whole wavefront through nodes nobody hits: measured +0.6 ms)
+__global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(64)
+collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ srec)
+{
+    __shared__ int stk[PSTACK];
+    int *spill = A.stack_spill + ((size_t)A.seg * A.spill_stride + blockIdx.x) * (STACK * 64);
+    const int lane = threadIdx.x;
+    unsigned visits = 0, found_tot = 0;
+    float rlx, rly, rlz, rhx, rhy, rhz;                   // the scene box = union of the root's two child boxes
+    {
+        const float4 n0 = nodes[0], n1 = nodes[1], n2 = nodes[2];
+        rlx = fminf(n0.x, n1.z); rly = fminf(n0.y, n1.w); rlz = fminf(n0.z, n2.x);
+        rhx = fmaxf(n0.w, n2.y); rhy = fmaxf(n1.x, n2.z); rhz = fmaxf(n1.y, n2.w);
+    }
+    const int home = xcc_id();
+    const int nbatch = A.batch1 - A.batch0;
+    while (true) {
+        const int fb = fetch_batch(A.counter + 32 + 8 * A.seg, nbatch, home, lane);
+        if (fb < 0) break;
+        const int batch = A.batch0 + fb;
+        const int base = batch << 6;
+        const int r = ray_of(A, base + lane);
+        const bool valid = r < A.R;
+        const int rr = valid ? r : 0;
+        const float ox = A.ray_o[3 * rr], oy = A.ray_o[3 * rr + 1], oz = A.ray_o[3 * rr + 2];
+        const float dx = A.ray_d[3 * rr], dy = A.ray_d[3 * rr + 1], dz = A.ray_d[3 * rr + 2];
+        const float tmin = first_tmin(A.start_from_first);
+        const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+        // bins: LINEAR in t over the ray's chord through the scene box (a fog terminates after a roughly constant optical depth, i.e. at a
+        // roughly constant fraction of the chord: 16 linear bins resolve that point to 1/15 of the chord, half-octave bins to +41 %)
+        float tA, bin_w, inv_bin_w;
+        {
+            const float a0 = (rlx - ox) * ix, a1 = (rhx - ox) * ix, b0 = (rly - oy) * iy, b1 = (rhy - oy) * iy, c0 = (rlz - oz) * iz, c1 = (rhz - oz) * iz;
+            const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1)), tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+            tA = fmaxf(tn, tmin);
+            float span = tf - tA;
+            if (!(span > 0.0f) || !(span < 1.0e30f)) span = 1.0f;               // the ray misses the scene (or a degenerate box): nothing to bin
+            bin_w = span * (1.00001f / (float)(NBIN - 1));
+            inv_bin_w = 1.0f / bin_w;
+        }
+        float od[NBIN];
+#pragma unroll
+        for (int b = 0; b < NBIN; b++) od[b] = 0.f;
+        float tkill = 3.0e38f, odtot = 0.f;
+        int pend = 0;
+        uint2 *list = A.hits + (size_t)rr * A.cap;
+        int n = 0;
+        int sp = 0;
+        int cur = 0;
+        visits += (unsigned)__popcll(__ballot(valid));
+        while (true) {
+            if (cur < 0) {
+                if (sp == 0) break;
+                --sp;
+                int top;
+                if (sp < PSTACK) top = stk[sp]; else top = __builtin_nontemporal_load(spill + (sp - PSTACK));
+                cur = __builtin_amdgcn_readfirstlane(top);
+            }
+            const float4 *nd = nodes + (size_t)cur * 4;
+            const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+            const int lc = __builtin_amdgcn_readfirstlane(__float_as_int(n3.x)), rc = __builtin_amdgcn_readfirstlane(__float_as_int(n3.y));
+            float a0 = (n0.x - ox) * ix, a1 = (n0.w - ox) * ix, b0 = (n0.y - oy) * iy, b1 = (n1.x - oy) * iy, c0 = (n0.z - oz) * iz, c1 = (n1.y - oz) * iz;
+            const float tnL = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
+            const float tfL = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+            a0 = (n1.z - ox) * ix; a1 = (n2.y - ox) * ix; b0 = (n1.w - oy) * iy; b1 = (n2.z - oy) * iy; c0 = (n2.x - oz) * iz; c1 = (n2.w - oz) * iz;
+            const float tnR = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
+            const float tfR = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+            const bool hitL = valid && (tnL <= tfL) && (tfL >= tmin) && (tnL <= tkill);
+            const bool hitR = valid && (tnR <= tfR) && (tfR >= tmin) && (tnR <= tkill);
+            const unsigned long long mL = __ballot(hitL), mR = __ballot(hitR);
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const bool hit = side == 0 ? hitL : hitR;
+                const int ch = side == 0 ? lc : rc;
+                const unsigned long long m = side == 0 ? mL : mR;
+                if (ch < 0 && m != 0ull) {
+                    const int sid = ~ch;
+                    const float4 *sr = srec + (size_t)sid * 4;
+                    const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], sr[3], ox, oy, oz, dx, dy, dz);
+                    if (hit && h.ok && h.t > tmin && h.t <= tkill) {
+                        if (n < A.cap) list[n] = make_uint2(__float_as_uint(h.t), (unsigned)sid);
+                        n++;
+                        const float x = (h.t - tA) * inv_bin_w;
+                        int b = x <= 0.0f ? 0 : (int)ceilf(x + 1e-3f);
+                        b = b > NBIN - 1 ? NBIN - 1 : b;
+                        const float dep = -__logf(1.0f - h.alpha);
+#pragma unroll
+                        for (int q = 0; q < NBIN; q++) od[q] += (q == b) ? dep : 0.f;
+                        odtot += dep;
+                    }
+                    pend++;
+                }
+            }
+            if (pend >= 3) {               // refresh the bound every third leaf test (a stale bound only collects a little more)
+                pend = 0;
+                if (__ballot(odtot >= KILL_OD) != 0ull) {
+                    float cum = 0.f; int kb = NBIN - 1;
+#pragma unroll
+                    for (int q = 0; q < NBIN - 1; q++) { cum += od[q]; kb = (cum >= KILL_OD && kb == NBIN - 1) ? q : kb; }
+                    tkill = kb < NBIN - 1 ? tA + (float)kb * bin_w : 3.0e38f;
+                }
+            }
+            const bool goL = lc >= 0 && mL != 0ull, goR = rc >= 0 && mR != 0ull;
+            if (goL) visits += (unsigned)__popcll(mL);
+            if (goR) visits += (unsigned)__popcll(mR);
+            if (goL && goR) {
+                const unsigned long long both = mL & mR, lf = __ballot(hitL && hitR && tnL <= tnR);
+                const bool leftFirst = both ? (2 * __popcll(lf) >= __popcll(both)) : (__popcll(mL) >= __popcll(mR));
+                const int farc = leftFirst ? rc : lc;
+                if (sp < PSTACK) stk[sp] = farc; else if (sp < PSTACK + STACK * 64) spill[sp - PSTACK] = farc;
+                sp++;
+                cur = leftFirst ? lc : rc;
+            }
+            else if (goL) cur = lc;
+            else if (goR) cur = rc;
+            else cur = -1;
+        }
+        if (valid) { A.hit_cnt[r] = n; found_tot += (unsigned)n; }
+        int mx = n;
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        if (lane == 0) atomicMax((int *)(A.counter + 1), mx);
+    }
+    if (A.stats) {
+        const float ff = wave_sum((float)found_tot);
+        if (lane == 0) { atomicAdd(A.stats + 1, (unsigned long long)visits); atomicAdd(A.stats + 3, (unsigned long long)ff); }
+    }
+}
+
+// The same traversal over the 4-wide nodes (trace_bvh.hip: node4[i] = the grandchildren of binary node i): half the steps, and each step is
+// one scalar-load round trip plus the stack / mask bookkeeping of the scalar unit, which is what the binary walk spends most of its time on.
+// Children that any ray hits are entered nearest first, ordered by the entry distance of each child's first hitting lane (the rays of a
+// batch are coherent; the order only affects how early the termination bounds tighten).  `visits` counts 64 B units (two per wide node).
+__global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(64)
+collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec)
+{
+    __shared__ int stk[PSTACK];
+    int *spill = A.stack_spill + ((size_t)A.seg * A.spill_stride + blockIdx.x) * (STACK * 64);
+    const int lane = threadIdx.x;
+    unsigned visits = 0, found_tot = 0;
+    float rlx, rly, rlz, rhx, rhy, rhz;                   // the scene box = union of the root's two child boxes
+    {
+        const float4 n0 = nodes[0], n1 = nodes[1], n2 = nodes[2];
+        rlx = fminf(n0.x, n1.z); rly = fminf(n0.y, n1.w); rlz = fminf(n0.z, n2.x);
+        rhx = fmaxf(n0.w, n2.y); rhy = fmaxf(n1.x, n2.z); rhz = fmaxf(n1.y, n2.w);
+    }
+    const int home = xcc_id();
+    const int nbatch = A.batch1 - A.batch0;
+    while (true) {
+        const int fb = fetch_batch(A.counter + 32 + 8 * A.seg, nbatch, home, lane);
+        if (fb < 0) break;
+        const int batch = A.batch0 + fb;
+        const int base = batch << 6;
+        const int r = ray_of(A, base + lane);
+        const bool valid = r < A.R;
+        const int rr = valid ? r : 0;
+        const float ox = A.ray_o[3 * rr], oy = A.ray_o[3 * rr + 1], oz = A.ray_o[3 * rr + 2];
+        const float dx = A.ray_d[3 * rr], dy = A.ray_d[3 * rr + 1], dz = A.ray_d[3 * rr + 2];
+        const float tmin = first_tmin(A.start_from_first);
+        const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+        float tA, bin_w, inv_bin_w;
+        {
+            const float a0 = (rlx - ox) * ix, a1 = (rhx - ox) * ix, b0 = (rly - oy) * iy, b1 = (rhy - oy) * iy, c0 = (rlz - oz) * iz, c1 = (rhz - oz) * iz;
+            const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1)), tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+            tA = fmaxf(tn, tmin);
+            float span = tf - tA;
+            if (!(span > 0.0f) || !(span < 1.0e30f)) span = 1.0f;
+            bin_w = span * (1.00001f / (float)(NBIN - 1));
+            inv_bin_w = 1.0f / bin_w;
+        }
+        float od[NBIN];
+#pragma unroll
+        for (int b = 0; b < NBIN; b++) od[b] = 0.f;
+        float tkill = 3.0e38f, odtot = 0.f;
+        int pend = 0;
+        uint2 *list = A.hits + (size_t)rr * A.cap;
+        int n = 0;
+        int sp = 0;
+        int cur = 0;
+        while (true) {
+            if (cur < 0) {
+                if (sp == 0) break;
+                --sp;
+                int top;
+                if (sp < PSTACK) top = stk[sp]; else top = __builtin_nontemporal_load(spill + (sp - PSTACK));
+                cur = __builtin_amdgcn_readfirstlane(top);
+            }
+            const float4 *nd = nodes4 + (size_t)cur * 8;
+            const float4 qlx = nd[0], qly = nd[1], qlz = nd[2], qhx = nd[3], qhy = nd[4], qhz = nd[5], qrf = nd[6];
+            const float lxs[4] = {qlx.x, qlx.y, qlx.z, qlx.w}, lys[4] = {qly.x, qly.y, qly.z, qly.w}, lzs[4] = {qlz.x, qlz.y, qlz.z, qlz.w};
+            const float hxs[4] = {qhx.x, qhx.y, qhx.z, qhx.w}, hys[4] = {qhy.x, qhy.y, qhy.z, qhy.w}, hzs[4] = {qhz.x, qhz.y, qhz.z, qhz.w};
+            const float rfs[4] = {qrf.x, qrf.y, qrf.z, qrf.w};
+            int key[4], ref[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int ch = __builtin_amdgcn_readfirstlane(__float_as_int(rfs[c]));
+                const float a0 = (lxs[c] - ox) * ix, a1 = (hxs[c] - ox) * ix, b0 = (lys[c] - oy) * iy, b1 = (hys[c] - oy) * iy,
+                            c0 = (lzs[c] - oz) * iz, c1 = (hzs[c] - oz) * iz;
+                const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
+                const float tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+                const bool hit = valid && (tn <= tf) && (tf >= tmin) && (tn <= tkill);
+                const unsigned long long m = __ballot(hit);
+                key[c] = 0x7fffffff; ref[c] = -1;
+                if (m != 0ull) {
+                    if (ch < 0) {
+                        const int sid = ~ch;
+                        const float4 *sr = srec + (size_t)sid * 4;
+                        const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], sr[3], ox, oy, oz, dx, dy, dz);
+                        if (hit && h.ok && h.t > tmin && h.t <= tkill) {
+                            if (n < A.cap) list[n] = make_uint2(__float_as_uint(h.t), (unsigned)sid);
+                            n++;
+                            const float x = (h.t - tA) * inv_bin_w;
+                            int b = x <= 0.0f ? 0 : (int)ceilf(x + 1e-3f);
+                            b = b > NBIN - 1 ? NBIN - 1 : b;
+                            const float dep = -__logf(1.0f - h.alpha);
+#pragma unroll
+                            for (int q = 0; q < NBIN; q++) od[q] += (q == b) ? dep : 0.f;
+                            odtot += dep;
+                        }
+                        pend++;
+                    } else {
+                        // entry distance of the first hitting lane, clamped at 0 so that the float bits order like integers
+                        const int fl = (int)__builtin_ctzll(m);
+                        key[c] = __builtin_amdgcn_readlane(__float_as_int(fmaxf(tn, 0.0f)), fl);
+                        ref[c] = ch;
+                        visits += 2u * (unsigned)__popcll(m);
+                    }
+                }
+            }
+            if (pend >= 3) {               // refresh the bound every third leaf test (a stale bound only collects a little more)
+                pend = 0;
+                if (__ballot(odtot >= KILL_OD) != 0ull) {
+                    float cum = 0.f; int kb = NBIN - 1;
+#pragma unroll
+                    for (int q = 0; q < NBIN - 1; q++) { cum += od[q]; kb = (cum >= KILL_OD && kb == NBIN - 1) ? q : kb; }
+                    tkill = kb < NBIN - 1 ? tA + (float)kb * bin_w : 3.0e38f;
+                }
+            }
+            // sort the (at most four) internal children by key: 5 scalar compare-exchanges; unused slots carry INT_MAX and end up last
+#define ENVGS_CSWAP(a, b) { const bool sw = key[a] > key[b]; const int ka = sw ? key[b] : key[a], kb2 = sw ? key[a] : key[b], \
+                                       ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b]; key[a] = ka; key[b] = kb2; ref[a] = ra; ref[b] = rb; }
+            ENVGS_CSWAP(0, 1) ENVGS_CSWAP(2, 3) ENVGS_CSWAP(0, 2) ENVGS_CSWAP(1, 3) ENVGS_CSWAP(1, 2)
+#undef ENVGS_CSWAP
+            // nearest next; the others go on the stack far to near
+#pragma unroll
+            for (int c = 3; c >= 1; c--)
+                if (ref[c] >= 0) {
+                    if (sp < PSTACK) stk[sp] = ref[c]; else if (sp < PSTACK + STACK * 64) spill[sp - PSTACK] = ref[c];
+                    sp++;
+                }
+            cur = ref[0];
+        }
+        if (valid) { A.hit_cnt[r] = n; found_tot += (unsigned)n; }
+        int mx = n;
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        if (lane == 0) atomicMax((int *)(A.counter + 1), mx);
+    }
+    if (A.stats) {
+        const float ff = wave_sum((float)found_tot);
+        if (lane == 0) { atomicAdd(A.stats + 1, (unsigned long long)visits); atomicAdd(A.stats + 3, (unsigned long long)ff); }
+    }
+}
+
+
+}  // namespace envgs

@@ -1,0 +1,354 @@
+// trace_lists.hip -- list path, steps 2 and 3: register-resident bitonic sort + lane-per-hit compositing of every ray's list, then the per-batch
+// registration of the composited hits with their surfels (entries, pairs, per-surfel weights).
+#include "trace_common.h"
+
+namespace envgs {
+
+// Cross-lane fetch of a 32-bit value from lane ^ S (S < 64): DPP quad permutes for 1 and 2, ds_swizzle (crossbar only, no LDS memory)
+// for 4, 8, 16, v_permlane32_swap for 32.
+template <int S>
+__device__ __forceinline__ unsigned xlane(unsigned v)
+{
+    if constexpr (S == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);
+    else if constexpr (S == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);
+    else if constexpr (S == 32) {
+        const envgs_u2 r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (threadIdx.x & 32) ? r.x : r.y;
+    } else return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (S << 10));
+}
+
+// One compare-exchange layer of the bitonic network over E*64 keys held as E registers per lane (element e*64 + lane).
+template <int E, int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_layer(unsigned long long (&k)[E], const int lane)
+{
+    if constexpr (STRIDE >= 64) {
+        constexpr int SE = STRIDE / 64;
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            if ((e & SE) == 0) {
+                const bool up = ((e * 64) & SIZE) == 0;                   // SIZE >= 128 here: decided by the register index alone
+                const unsigned long long a = k[e], b = k[e | SE];
+                const bool sw = (a > b) == up;
+                k[e] = sw ? b : a; k[e | SE] = sw ? a : b;
+            }
+    } else {
+        const bool lower = (lane & STRIDE) == 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const bool up = SIZE < 64 ? ((lane & SIZE) == 0) : (((e * 64) & SIZE) == 0);
+            const unsigned long long mine = k[e];
+            const unsigned long long p = ((unsigned long long)xlane<STRIDE>((unsigned)(mine >> 32)) << 32) | xlane<STRIDE>((unsigned)mine);
+            const bool keepmin = lower == up;
+            k[e] = ((p < mine) == keepmin) ? p : mine;
+        }
+    }
+}
+template <int E, int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_merge(unsigned long long (&k)[E], const int lane)
+{
+    bitonic_layer<E, SIZE, STRIDE>(k, lane);
+    if constexpr (STRIDE > 1) bitonic_merge<E, SIZE, STRIDE / 2>(k, lane);
+}
+template <int E, int SIZE>
+__device__ __forceinline__ void bitonic_sort(unsigned long long (&k)[E], const int lane)
+{
+    if constexpr (SIZE > 2) bitonic_sort<E, SIZE / 2>(k, lane);
+    bitonic_merge<E, SIZE, SIZE / 2>(k, lane);
+}
+
+// Sort AND composite, one wavefront per ray, one LANE per hit.  A lane-per-ray walk is a chain of dependent
+// gathers -- list entry -> surfel record + SH block -> blend -> next entry -- whose length is the ray's hit count; here the 64 hits of
+// a chunk fetch their records independently (all gathers in flight at once) and the front-to-back recurrences (transmittance product,
+// the two distortion moments, the ten blended sums) become wavefront scans.  The (t, id) keys are sorted IN REGISTERS -- E keys per
+// lane, a bitonic network whose cross-lane layers use DPP / ds_swizzle / permlane32 and whose long strides are register-to-register --
+// so the sorted chunk c is simply register c: no LDS, no barriers, no bank conflicts.  The sorted list is written back only up to the
+// terminating hit.
+template <int E>
+__device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int r, const int n, const int lane, unsigned &st_hits)
+{
+    uint2 *list = A.hits + (size_t)r * A.cap;
+    unsigned long long kreg[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int i = e * 64 + lane;
+        unsigned long long kk = ~0ull;
+        if (i < n) { const uint2 q = list[i]; kk = ((unsigned long long)q.x << 32) | q.y; }
+        kreg[e] = kk;
+    }
+    bitonic_sort<E, E * 64>(kreg, lane);
+    const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
+    const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
+    float basis[16];
+    {
+        const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        sh_basis(A.D, dx * il, dy * il, dz * il, basis);
+    }
+    // carried across chunks (wave-uniform): transmittance, the two distortion moments, and the ten blended sums
+    // [rgb 3, depth, acc, normal 3, aux 2] -- kept as running PREFIX sums because the backward needs them per hit
+    float T = 1.0f, M1 = 0.f, M2 = 0.f, C[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) C[j] = 0.f;
+    float dist = 0.f;                                   // per-lane partial sum
+    int used = 0;
+    const int sstr = A.has_others ? 3 : 2;              // per-hit state row: 32 B, or 48 B when the two `others` sums are needed too
+    float4 *state = A.state ? A.state + (size_t)r * A.cap * sstr : nullptr;
+#pragma unroll
+    for (int ce = 0; ce < E; ce++) {
+        const int cb = ce * 64;
+        if (cb >= n) break;
+        const int i = cb + lane;
+        const bool has = i < n;
+        int sid = 0;
+        float alpha = 0.f, t = 0.f, sg = 0.f;
+        float4 s3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has) {
+            sid = (int)(unsigned)kreg[ce];
+            const float4 *sr = A.srec + (size_t)sid * 4;
+            s3 = sr[3];
+            const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], s3, ox, oy, oz, dx, dy, dz);
+            alpha = h.alpha; t = h.t; sg = h.denom < 0.0f ? 1.f : -1.f;
+        }
+        const float P = wave_scan_mul(1.0f - alpha);                    // prod_{j<=i} (1 - alpha_j) within the chunk
+        const float Pex = dpp_fill<0x138>(P, 1.f);                      // wave_shr:1
+        const float test_T = T * P, Tb = T * Pex;                       // transmittance after / before this hit
+        const unsigned long long stop = __ballot(has && test_T < T_EPS);
+        const int f = stop ? (int)__builtin_ctzll(stop) : 64;           // first terminating lane: it and everything behind is dropped
+        const bool use = has && lane < f;
+        const float w = use ? alpha * Tb : 0.f;
+        float col[3] = {0.f, 0.f, 0.f}; bool cl[3];
+        if (use) surfel_color(A, sid, basis, col, cl);
+        const float tt = t > NEAR_N ? t : NEAR_N;
+        const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / tt);
+        const float mw = m * w, mmw = m * m * w;
+        const float S1 = wave_scan_add(mw), S2 = wave_scan_add(mmw);
+        const float M1b = M1 + (S1 - mw), M2b = M2 + (S2 - mmw);        // moments before this hit
+        dist += (m * m * (1.0f - Tb) + M2b - 2.0f * m * M1b) * w;
+        float x0 = 0.f, x1 = 0.f;
+        if (A.has_others && use) { x0 = A.others[2 * sid]; x1 = A.others[2 * sid + 1]; }
+        float S[10] = {w * col[0], w * col[1], w * col[2], w * t, w, sg * w * s3.x, sg * w * s3.y, sg * w * s3.z, w * x0, w * x1};
+#pragma unroll
+        for (int j = 0; j < 10; j++) S[j] = C[j] + wave_scan_add(S[j]);               // inclusive: this hit already added
+        if (use) {
+            list[i] = make_uint2(__float_as_uint(w), (unsigned)sid);
+            if (state) {
+                // (the acc sum S[4] is not stored: sum_{j<=k} w_j = 1 - T_before * (1 - alpha), which the backward rebuilds)
+                float4 *o = state + (size_t)i * sstr;
+                // streamed once, read once by the backward much later: non-temporal, so it does not evict the surfel records / SH blocks
+                typedef float nt4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store((nt4){Tb, S[0], S[1], S[2]}, reinterpret_cast<nt4 *>(o));
+                __builtin_nontemporal_store((nt4){S[3], S[5], S[6], S[7]}, reinterpret_cast<nt4 *>(o + 1));
+                if (A.has_others) __builtin_nontemporal_store((nt4){S[8], S[9], 0.f, 0.f}, reinterpret_cast<nt4 *>(o + 2));
+            }
+        }
+        const int nu = f < 64 ? f : min(64, n - cb);                    // hits of this chunk that were blended
+        used += nu;
+        M1 += wave_bcast(S1, 63); M2 += wave_bcast(S2, 63);
+#pragma unroll
+        for (int j = 0; j < 10; j++) C[j] = wave_bcast(S[j], 63);
+        if (nu > 0) T = T * wave_bcast(P, nu - 1);
+        if (f < 64) break;
+    }
+    st_hits += (unsigned)used;
+    dist = wave_sum(dist);
+    if (lane == 0) {
+        A.n_used[r] = used;
+        const float c0 = C[0] + T * (0 < A.bg_len ? A.bg[0] : 0.f), c1 = C[1] + T * (1 < A.bg_len ? A.bg[1] : 0.f), c2 = C[2] + T * (2 < A.bg_len ? A.bg[2] : 0.f);
+        A.rgb[3 * r] = c0; A.rgb[3 * r + 1] = c1; A.rgb[3 * r + 2] = c2;
+        A.dpt[r] = C[3]; A.acc[r] = C[4]; A.dist[r] = dist;
+        A.norm[3 * r] = C[5]; A.norm[3 * r + 1] = C[6]; A.norm[3 * r + 2] = C[7];
+        A.aux[2 * r] = C[8]; A.aux[2 * r + 1] = C[9];
+        A.final_T[r] = T;
+        float *mm = A.mid + (size_t)r * MID;
+        mm[0] = ox; mm[1] = oy; mm[2] = oz; mm[3] = dx; mm[4] = dy; mm[5] = dz; mm[6] = C[3]; mm[7] = C[4];
+        mm[8] = C[5]; mm[9] = C[6]; mm[10] = C[7]; mm[11] = C[8]; mm[12] = C[9]; mm[13] = c0; mm[14] = c1; mm[15] = c2;
+    }
+}
+
+// The widest sort a kernel must be able to run sets its register count (E <= 4: 123 VGPRs = 4 waves/SIMD, 8: 150 = 3, 16: 211 = 2), and
+// lists longer than 256 hits are rare, so the work is split by list length: the main pass (LONG = false) takes every ray with at most 256
+// hits at 4 waves/SIMD; when the capacity allows longer lists a second launch (LONG = true, EMAX = 8 or 16) picks up the few rays
+// beyond 256 -- it scans the hit counts 64 rays per wavefront step and only sorts what the ballot finds.
+template <int EMAX, bool LONG>
+__global__ void __launch_bounds__(256)
+sort_composite_fwd(const TraceArgs A)
+{
+    // 4 wavefronts per workgroup take 4 CONSECUTIVE rays of the coherence-sorted order: they blend mostly the same surfels at the same
+    // time, so the records / SH blocks one of them pulls into this CU's L1 serve the others
+    const int lane = threadIdx.x & 63;
+    unsigned st_hits = 0;
+    const int slot_end = min(A.R, A.batch1 * 64);
+    if constexpr (!LONG) {
+        for (int slot = A.batch0 * 64 + blockIdx.x * 4 + (threadIdx.x >> 6); slot < slot_end; slot += gridDim.x * 4) {
+            const int r = ray_of(A, slot);
+            const int n = A.hit_cnt[r];
+            if (n > A.cap || n > 256) continue;                 // overflow: the K-buffer kernel owns this ray; long: the LONG pass does
+            if (n <= 64) sort_composite_ray<1>(A, r, n, lane, st_hits);
+            else if (n <= 128) sort_composite_ray<2>(A, r, n, lane, st_hits);
+            else sort_composite_ray<4>(A, r, n, lane, st_hits);
+        }
+    } else {
+        // the longest list so far (this segment's collection has finished, so its own maximum is in): nothing to do in the usual case
+        if ((int)__hip_atomic_load(A.counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 256) return;
+        for (int base = A.batch0 * 64 + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; base < slot_end; base += gridDim.x * 256) {
+            const int slot = base + lane;
+            int r = 0, n = 0;
+            if (slot < slot_end) { r = ray_of(A, slot); n = A.hit_cnt[r]; }
+            unsigned long long todo = __ballot(n > 256 && n <= A.cap);
+            while (todo) {
+                const int l = (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int rr = __shfl(r, l), nn = __shfl(n, l);
+                if (EMAX == 8 || nn <= 512) sort_composite_ray<8>(A, rr, nn, lane, st_hits);
+                else if constexpr (EMAX >= 16) sort_composite_ray<16>(A, rr, nn, lane, st_hits);
+            }
+        }
+    }
+    if (A.stats && lane == 0 && st_hits) atomicAdd(A.stats + 0, (unsigned long long)st_hits);
+}
+
+// Register every composited hit with its surfel, per BATCH of 64 coherence-sorted rays.  The rays of a batch mostly composite the SAME
+// surfels (measured: 27 hits per distinct surfel per batch), and device-scope atomics run at ~10 G/s on this chip whatever their width
+// or scope, so a wavefront first merges its batch in an LDS hash table (ds_cmpst / ds_add: hit count, weight sum in 40-bit fixed point)
+// and then spends ONE global 64-bit atomic per DISTINCT surfel: weight += sum (rounded up, so any contribution keeps the surfel
+// "visible") and entry count += 1, whose old value is the slot of this (batch, surfel) ENTRY among the surfel's entries -- where the
+// backward will put the entry's gradient record.  Outputs for the backward, per batch b (region = 64*cap slots):
+//   entries[b][e]  e < D: the distinct surfels of the table, packed  sid | (hits-1) << 24 | slot << 32 ; singles that found no room in
+//                  the table are filed from the TOP of the region downwards (n_entries[2b] = D, n_entries[2b+1] = singles)
+//   pairs[b][...]  (lane << 16 | k) of every hit, grouped by entry in entry order (singles again from the top)
+constexpr int RH_TAB = 1024;
+constexpr int RH_STAGE = 8192;                           // pairs staged in LDS per batch (32 KB); the rest, if any, is stored directly
+__global__ void __launch_bounds__(64 * RH_W)
+register_hits(const TraceArgs A)
+{
+    __shared__ int key[RH_TAB];
+    __shared__ unsigned long long acc[RH_TAB];       // low 8 bits: hits of this surfel in the batch (<= 64), above: fixed-point weight sum -- ONE
+                                                     // returning ds_add_rtn_u64 per hit gives its rank; after the flush: offset of its first pair
+    __shared__ unsigned nfail, ndense;
+    __shared__ unsigned short hod[RH_TAB];           // table slot of the d-th distinct surfel, in order of first appearance
+    __shared__ unsigned pstage[RH_STAGE];            // the batch's pairs, assembled here and written out as one contiguous run (a scattered 4 B
+                                                     // store costs a whole 32 B sector of write traffic)
+    __shared__ unsigned ptotal;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const float wscale = __builtin_ldexpf(1.0f, A.wfrac);
+    const size_t region = (size_t)64 * A.cap;
+    for (int base = (A.batch0 + (int)blockIdx.x) * 64; base < min(A.R, A.batch1 * 64); base += gridDim.x * 64) {
+        const int batch = base >> 6;
+        const int copy = batch & (NCOPY - 1);
+        unsigned long long *ent = A.entries ? A.entries + (size_t)batch * region : nullptr;
+        unsigned *prs = A.pairs ? A.pairs + (size_t)batch * region : nullptr;
+        __syncthreads();
+        for (int i = threadIdx.x; i < RH_TAB; i += 64 * RH_W) { key[i] = -1; acc[i] = 0ull; }
+        if (threadIdx.x == 0) { nfail = 0u; ndense = 0u; }
+        __syncthreads();
+        const int r = ray_of(A, base + lane);
+        int n = 0;
+        uint2 *list = A.hits;
+        if (r < A.R && A.hit_cnt[r] <= A.cap) { n = A.n_used[r]; list = A.hits + (size_t)r * A.cap; }
+        constexpr int U = 4;
+        // (each lane walks its own list row: the loads of one step are 64 different cache lines, so the next step's entries are requested
+        //  before this step's chain of LDS atomics starts)
+        uint2 nxt[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) { const int k = part + j * RH_W; nxt[j] = (k < n) ? list[k] : make_uint2(0u, 0u); }
+        for (int kb = part; kb < n; kb += U * RH_W) {
+            uint2 e[U];
+#pragma unroll
+            for (int j = 0; j < U; j++) e[j] = nxt[j];
+#pragma unroll
+            for (int j = 0; j < U; j++) { const int k = kb + (U + j) * RH_W; nxt[j] = (k < n) ? list[k] : make_uint2(0u, 0u); }
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const int k = kb + j * RH_W;
+                if (k >= n) break;
+                const unsigned long long wq = (unsigned long long)ceilf(__uint_as_float(e[j].x) * wscale);
+                unsigned h = (e[j].y * 2654435761u) >> 22;
+                bool ok = false;
+                for (int t = 0; t < 24; t++) {
+                    const int old = atomicCAS(&key[h], -1, (int)e[j].y);
+                    if (old == -1) hod[atomicAdd(&ndense, 1u)] = (unsigned short)h;      // first to see this surfel: entries keep this order
+                    if (old == -1 || old == (int)e[j].y) { ok = true; break; }
+                    h = (h + 1) & (RH_TAB - 1);
+                }
+                unsigned x = 0xFFFFFFFFu;
+                if (ok) {
+                    const unsigned rank = (unsigned)(atomicAdd(&acc[h], (wq << 8) | 1ull) & 0xFFull);
+                    x = (h << 8) | rank;                                  // rank < 64: a ray meets a planar surfel once
+                } else {                                                  // table full around h: an entry of its own
+                    const unsigned long long old = atomicAdd(A.surf_acc + (size_t)e[j].y * NCOPY + copy, (wq << 24) | 1ull);
+                    const unsigned f = atomicAdd(&nfail, 1u);
+                    if (ent) ent[region - 1 - f] = (unsigned long long)e[j].y | ((old & 0xFFFFFFull) << 32);
+                    if (prs) prs[region - 1 - f] = ((unsigned)lane << 16) | (unsigned)k;
+                }
+                list[k].x = x;
+            }
+        }
+        __syncthreads();
+        // Flush in order of FIRST APPEARANCE along the rays (~ front to back): the backward then meets each ray's hits in roughly ascending
+        // list position, so the per-hit state it gathers is consumed cache line by cache line instead of at random.
+        const unsigned D = ndense;
+        if (part == 0) {
+            unsigned carry_off = 0u;
+            for (unsigned c = 0; c < D; c += 64) {
+                const unsigned d = c + lane;
+                const bool occ = d < D;
+                const int h = occ ? (int)hod[d] : 0;
+                const int sid = occ ? key[h] : 0;
+                const unsigned long long av = occ ? acc[h] : 0ull;
+                const unsigned cn = (unsigned)(av & 0xFFull);
+                const float incl = wave_scan_add((float)cn);                 // exact: at most 64*cap < 2^24 hits per batch
+                const unsigned offh = carry_off + (unsigned)incl - cn;
+                if (occ) {
+                    const unsigned long long old = atomicAdd(A.surf_acc + (size_t)sid * NCOPY + copy, ((av >> 8) << 24) | 1ull);
+                    if (ent) ent[d] = (unsigned long long)(unsigned)sid | ((unsigned long long)(cn - 1u) << 24) | ((old & 0xFFFFFFull) << 32);
+                    acc[h] = (unsigned long long)offh;
+                }
+                carry_off += (unsigned)wave_bcast(incl, 63);
+            }
+            if (A.n_entries && lane == 0) { A.n_entries[2 * batch] = (int)D; A.n_entries[2 * batch + 1] = (int)nfail; }
+            if (lane == 0) ptotal = carry_off;
+        }
+        __syncthreads();
+        if (prs) {
+            constexpr int U2 = 4;                               // independent loads first: one memory round trip per 4 hits, not per hit
+            for (int kb = part; kb < n; kb += U2 * RH_W) {
+                unsigned x[U2];
+#pragma unroll
+                for (int j = 0; j < U2; j++) { const int k = kb + j * RH_W; x[j] = (k < n) ? list[k].x : 0xFFFFFFFFu; }
+#pragma unroll
+                for (int j = 0; j < U2; j++)
+                    if (x[j] != 0xFFFFFFFFu) {
+                        const unsigned idx = (unsigned)acc[x[j] >> 8] + (x[j] & 255u), v = ((unsigned)lane << 16) | (unsigned)(kb + j * RH_W);
+                        if (idx < (unsigned)RH_STAGE) pstage[idx] = v; else prs[idx] = v;
+                    }
+            }
+            __syncthreads();
+            const unsigned T = min(ptotal, (unsigned)RH_STAGE);
+            for (unsigned i = threadIdx.x; i < T; i += 64 * RH_W) prs[i] = pstage[i];
+        }
+    }
+}
+
+// Split the packed per-surfel accumulators of composite_lists_fwd into hit counts (for the scan) and weights (added to `wet`,
+// which the K-buffer path may already have contributed to in float).
+__global__ void __launch_bounds__(256)
+unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, unsigned *__restrict__ cnt, float *__restrict__ wet)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    unsigned long long wsum = 0;
+#pragma unroll
+    for (int c = 0; c < NCOPY; c++) {
+        const unsigned long long a = acc[(size_t)i * NCOPY + c];
+        cnt[(size_t)i * NCOPY + c] = (unsigned)(a & 0xFFFFFFull);
+        wsum += a >> 24;
+    }
+    const float w = (float)((double)wsum / (double)(1ull << wfrac));
+    if (w != 0.0f) wet[i] += w;
+}
+
+
+template __global__ void sort_composite_fwd<4, false>(const TraceArgs A);
+template __global__ void sort_composite_fwd<8, true>(const TraceArgs A);
+template __global__ void sort_composite_fwd<16, true>(const TraceArgs A);
+
+}  // namespace envgs

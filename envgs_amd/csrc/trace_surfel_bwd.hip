@@ -1,0 +1,414 @@
+// trace_surfel_bwd.hip -- list path backward: the surfel-major batch kernel (lane = ray, MFMA reduction), the per-surfel record reduction, the
+// parameter-gradient finish, and the per-ray atomic-flush fallback (composite_lists_bwd).
+#include "trace_common.h"
+
+namespace envgs {
+
+__global__ void __launch_bounds__(64)
+composite_lists_bwd(const TraceArgs A)
+{
+    __shared__ float fld[NFLD][65];
+    const int lane = threadIdx.x;
+    const FlushRole role = flush_role(A, lane);
+    const int nb = (A.D + 1) * (A.D + 1);
+    for (int base = blockIdx.x * 64; base < A.R; base += gridDim.x * 64) {
+        const int r = ray_of(A, base + lane);
+        const bool valid = r < A.R && A.hit_cnt[r < A.R ? r : 0] <= A.cap;
+        const int rr = r < A.R ? r : 0;
+        BwdRay B;
+        bwd_load_ray(A, rr, B);
+        BwdAcc acc;
+        bwd_init_acc(acc);
+        float basis[16];
+        sh_basis(A.D, B.ux, B.uy, B.uz, basis);
+        __syncthreads();
+        fld[19][lane] = B.ux; fld[20][lane] = B.uy; fld[21][lane] = B.uz;
+        const int n = valid ? A.n_used[rr] : 0;
+        const uint2 *list = A.hits + (size_t)rr * A.cap;
+        int nmax = n;
+        for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+        for (int k = 0; k < nmax; k++) {
+            bool has = false;
+            int sid = 0;
+            float dc0 = 0.f, dc1 = 0.f, dc2 = 0.f, gv[15];
+#pragma unroll
+            for (int q = 0; q < 15; q++) gv[q] = 0.f;
+            if (k < n) {
+                sid = (int)list[k].y;
+                has = bwd_hit(A, B, acc, basis, nb, sid, dc0, dc1, dc2, gv);
+            }
+            flush_hits(A, fld, lane, role, has, sid, dc0, dc1, dc2, gv);
+        }
+        if (valid) bwd_store_ray(A, r, B, acc);
+    }
+}
+
+// Backward of the list path, SURFEL-MAJOR per batch (the tracer's counterpart of the rasterizer's tile backward): one wavefront owns a
+// batch of 64 coherence-sorted rays, LANE = RAY.  It walks the batch's entries (distinct surfels); the surfel's record and SH block are
+// staged through LDS 16 entries ahead (coalesced, off the critical path) and read back as broadcasts, each ray that composited the surfel
+// fetches the per-hit state the forward stored (transmittance before the hit, the ten prefix sums after it), evaluates its gradient
+// independently of every other hit, and the 63 gradient words (48 SH + 15 geometry) are transpose-reduced over the wavefront into ONE
+// 256 B record per (batch, surfel) written by the 64 lanes as one coalesced line pair.  ~27x fewer records than one per hit, no
+// per-hit gathers of surfel data, no dependent chain along the ray, no atomics.
+constexpr int BS_GROUP = 16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int RECW = 64;      // floats per (batch, surfel) gradient record: 48 SH (or 3 colour) + 15 geometry + pad
+__global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64)
+batch_surfel_bwd(const TraceArgs A)
+{
+    __shared__ float4 sdat[2][BS_GROUP][16];               // per entry: surfel record (4 x 16 B) + SH block (12 x 16 B)
+    __shared__ unsigned long long sdesc[2][BS_GROUP];      // sid | (hits-1) << 24 ; record index << 32
+    __shared__ unsigned short kmat[2][BS_GROUP][64];       // per entry and ray: list position of the hit + 1, 0 = the ray did not blend it
+    __shared__ unsigned spb[2][BS_GROUP];                  // per entry: index of its first pair
+    __shared__ unsigned scn[2][BS_GROUP];                  // per entry: hits
+    __shared__ float btile[16][64];                        // B operand of the reduction MFMAs: 16 words per ray, swizzled (see below)
+    const int lane = threadIdx.x;
+    const int nb = (A.D + 1) * (A.D + 1);
+    const size_t region = (size_t)64 * A.cap;
+    const int nbatch = (A.R + 63) >> 6;
+    for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+        const int base = batch << 6;
+        const int copy = batch & (NCOPY - 1);
+        const int r = ray_of(A, base + lane);
+        const bool valid = r < A.R && A.hit_cnt[r < A.R ? r : 0] <= A.cap;
+        const int rr = r < A.R ? r : 0;
+        // Per-ray constants.  The suffix terms of dL/dalpha only ever appear as  sum_j g_j (final_j - prefix_j)  (+ the background term), so
+        // the twelve final sums fold into ONE scalar F = sum_j g_j final_j + T_final (bg . g_rgb): 17 live registers instead of 33.
+        float basis[16], Box, Boy, Boz, Bdx, Bdy, Bdz, gR0, gR1, gR2, gD, gA, gN0, gN1, gN2, gX0, gX1, Fsum;
+        {
+            BwdRay B;
+            bwd_load_ray(A, rr, B);
+#pragma unroll
+            for (int k = 0; k < 16; k++) basis[k] = 0.f;
+            sh_basis(A.D, B.ux, B.uy, B.uz, basis);
+            if (A.M == 0) basis[0] = kC0;
+            Box = B.ox; Boy = B.oy; Boz = B.oz; Bdx = B.dx; Bdy = B.dy; Bdz = B.dz;
+            gR0 = B.gR0; gR1 = B.gR1; gR2 = B.gR2; gD = B.gD; gA = B.gA; gN0 = B.gN0; gN1 = B.gN1; gN2 = B.gN2; gX0 = B.gX0; gX1 = B.gX1;
+            Fsum = B.gR0 * B.fr0 + B.gR1 * B.fr1 + B.gR2 * B.fr2 + B.gD * B.fD + B.gA * B.fA + B.gN0 * B.fN0 + B.gN1 * B.fN1 + B.gN2 * B.fN2 +
+                   B.gX0 * B.fX0 + B.gX1 * B.fX1 + B.fT * B.bgdot;
+        }
+        // A operand of the reduction MFMAs, constant for the batch: lane l holds basis_{l & 15} of ray 4s + (l >> 4)
+        float Areg[16];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) btile[k][(lane + 2 * k) & 63] = (valid && k < nb) ? basis[k] : (k == 0 ? kC0 : 0.f);
+        __syncthreads();
+#pragma unroll
+        for (int sI = 0; sI < 16; sI++) Areg[sI] = btile[lane & 15][(4 * sI + (lane >> 4) + 2 * (lane & 15)) & 63];
+        __syncthreads();
+        float Sk[16], dO0 = 0.f, dO1 = 0.f, dO2 = 0.f, dD0 = 0.f, dD1 = 0.f, dD2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) Sk[k] = 0.f;
+        const int sstr = A.has_others ? 3 : 2;
+        const float4 *state = A.state + (size_t)rr * A.cap * sstr;
+        const unsigned long long *ent = A.entries + (size_t)batch * region;
+        const unsigned *prs = A.pairs + (size_t)batch * region;
+        const int D = A.n_entries[2 * batch], NE = D + A.n_entries[2 * batch + 1];
+        unsigned poff = 0u;                                  // pairs of the table entries staged so far
+        // Stage one group of entries, a whole group ahead of its use: 4 lanes per entry fetch the surfel record and SH block, then the
+        // group's (lane, k) pairs (one contiguous run) are scattered into kmat -- so the main loop touches no global memory except
+        // each ray's per-hit state.
+        auto stage = [&](int g, int buf) {
+            const int el = lane >> 2, part = lane & 3;
+            const int e = g * BS_GROUP + el;
+            unsigned long long d = 0ull;
+            if (e < NE) {
+                d = e < D ? ent[e] : ent[region - 1 - (size_t)(e - D)];
+                const int sid = (int)(d & 0xFFFFFFull);
+                sdat[buf][el][part] = A.srec[(size_t)sid * 4 + part];
+                if (A.M == 16) {
+                    const float4 *s4 = reinterpret_cast<const float4 *>(A.shs + (size_t)sid * 48);
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        float4 x = s4[part * 3 + q];
+                        const int i0 = (part * 3 + q) * 4;             // words beyond the active degree are staged as zeros: the entry
+                        if (i0 + 0 >= nb * 3) x.x = 0.f;               // loop then needs no degree checks
+                        if (i0 + 1 >= nb * 3) x.y = 0.f;
+                        if (i0 + 2 >= nb * 3) x.z = 0.f;
+                        if (i0 + 3 >= nb * 3) x.w = 0.f;
+                        sdat[buf][el][4 + part * 3 + q] = x;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        float v[4];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const int idx = (part * 3 + q) * 4 + c;
+                            v[c] = A.M > 0 ? (idx < nb * 3 ? A.shs[(size_t)sid * A.M * 3 + idx] : 0.f) : (idx < 3 ? A.colors[(size_t)sid * 3 + idx] : 0.f);
+                        }
+                        sdat[buf][el][4 + part * 3 + q] = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+                if (part == 0) {
+                    const size_t ci = (size_t)sid * NCOPY + copy;
+                    const unsigned rec = A.surf_off[ci] - A.surf_cnt[ci] + (unsigned)(d >> 32);
+                    sdesc[buf][el] = (d & 0x3FFFFFFFull) | ((unsigned long long)rec << 32);
+                }
+            }
+            if (part == 0) scn[buf][el] = e < NE ? (unsigned)((d >> 24) & 63ull) + 1u : 0u;
+            {   // clear kmat[buf]: 2 KB = 32 B per lane
+                uint4 *km = reinterpret_cast<uint4 *>(&kmat[buf][0][0]);
+                km[lane * 2] = make_uint4(0u, 0u, 0u, 0u); km[lane * 2 + 1] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            __syncthreads();
+            // prefix of the hit counts (every lane reads the 16 counts as broadcasts) and each entry's first pair
+            unsigned pref[BS_GROUP + 1];
+            pref[0] = 0u;
+#pragma unroll
+            for (int q = 0; q < BS_GROUP; q++) pref[q + 1] = pref[q] + scn[buf][q];
+            unsigned tab_before = 0u;                        // hits of the group's TABLE entries before entry q (singles live elsewhere)
+#pragma unroll
+            for (int q = 0; q < BS_GROUP; q++) {
+                const int eq = g * BS_GROUP + q;
+                if (lane == q) spb[buf][q] = eq < D ? poff + tab_before : (unsigned)(region - 1 - (size_t)(eq - D));
+                if (eq < D) tab_before += scn[buf][q];
+            }
+            __syncthreads();
+            const unsigned total = pref[BS_GROUP];
+            for (unsigned q = lane; q < total; q += 64) {
+                int eli = 0;
+#pragma unroll
+                for (int t = 1; t < BS_GROUP; t++) eli += q >= pref[t] ? 1 : 0;
+                const unsigned pr = prs[spb[buf][eli] + (q - pref[eli])];
+                kmat[buf][eli][pr >> 16] = (unsigned short)((pr & 0xFFFFu) + 1u);
+            }
+            poff += tab_before;
+        };
+        __syncthreads();
+        stage(0, 0);
+        for (int g = 0; g * BS_GROUP < NE; g++) {
+            const int buf = g & 1;
+            __syncthreads();                                   // group g staged; group g-1 fully consumed
+            if ((g + 1) * BS_GROUP < NE) stage(g + 1, buf ^ 1);
+            const int ne = min(BS_GROUP, NE - g * BS_GROUP);
+            // software pipeline over the entries: the per-hit state of entry el+1 is in flight while entry el is evaluated
+            int k1 = valid ? (int)kmat[buf][0][lane] : 0;
+            float4 st0, st1, st2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            { const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) * sstr : A.state; st0 = sp[0]; st1 = sp[1]; if (A.has_others) st2 = sp[2]; }      // unconditional (idle lanes share one address): no branch, no wait
+            for (int el = 0; el < ne; el++) {
+                const unsigned long long d = sdesc[buf][el];
+                const int sid = (int)(d & 0xFFFFFFull);
+                const unsigned long long rec = d >> 32;
+                const bool act = k1 > 0;
+                // this ray's 16 B-matrix words -- dL/dcolour (3) and the first 13 geometry words -- go straight to the LDS tile (zeros from
+                // rays that did not blend this surfel); the last two geometry words are summed with DPP.  Tile layout: word n of ray j at
+                // n*64 + ((j + 2n) & 63): conflict-free both for these writes (fixed n, 64 rays) and for the MFMA operand reads (16 words
+                // x 4 rays).  One wavefront per workgroup: its LDS operations execute in program order, so no barrier is needed -- and a
+                // barrier's vmcnt(0) would drain the state prefetch that is in flight.
+                float g13 = 0.f, g14 = 0.f;
+#define BT(n) btile[(n)][(lane + 2 * (n)) & 63]
+                if (act) {
+                    const float4 s0 = sdat[buf][el][0], s1 = sdat[buf][el][1], s2 = sdat[buf][el][2], s3 = sdat[buf][el][3];
+                    const SurfHit h = hit_surfel(s0, s1, s2, s3, Box, Boy, Boz, Bdx, Bdy, Bdz);
+                    float col[3]; bool cl[3] = {false, false, false};
+                    if (A.M > 0) {
+                        float rc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int q4 = 0; q4 < 12; q4++) {
+                            const float4 x = sdat[buf][el][4 + q4];
+                            const float xe[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                            for (int e = 0; e < 4; e++) { const int idx = 4 * q4 + e; rc[idx % 3] += basis[idx / 3] * xe[e]; }
+                        }
+#pragma unroll
+                        for (int c = 0; c < 3; c++) { const float v = rc[c] + 0.5f; cl[c] = v < 0.f; col[c] = cl[c] ? 0.f : v; }
+                    } else { const float4 x = sdat[buf][el][4]; col[0] = x.x; col[1] = x.y; col[2] = x.z; }
+                    const float x0 = A.has_others ? A.others[2 * sid] : 0.f, x1 = A.has_others ? A.others[2 * sid + 1] : 0.f;
+                    const float alpha = h.alpha, Tb = st0.x;
+                    const float w = alpha * Tb;
+                    const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
+                    const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
+                    const float inv1m = __builtin_amdgcn_rcpf(1.0f - alpha);          // v_rcp_f32 (1 ulp): gradient-only terms need no IEEE division
+                    const float gv_ = gR0 * col[0] + gR1 * col[1] + gR2 * col[2] + gD * h.t + gA + gN0 * nf0 + gN1 * nf1 + gN2 * nf2 + gX0 * x0 + gX1 * x1;
+                    const float gS = gR0 * st0.y + gR1 * st0.z + gR2 * st0.w + gD * st1.x + gA * (1.0f - Tb * (1.0f - alpha)) + gN0 * st1.y + gN1 * st1.z +
+                                     gN2 * st1.w + gX0 * st2.x + gX1 * st2.y;
+                    const float dLa = Tb * gv_ - (Fsum - gS) * inv1m;
+                    const float dc[3] = {cl[0] ? 0.f : w * gR0, cl[1] ? 0.f : w * gR1, cl[2] ? 0.f : w * gR2};
+                    if (A.M > 0) {
+#pragma unroll
+                        for (int q4 = 0; q4 < 12; q4++) {
+                            const float4 x = sdat[buf][el][4 + q4];
+                            const float xe[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                            for (int e = 0; e < 4; e++) { const int idx = 4 * q4 + e; Sk[idx / 3] += xe[e] * dc[idx % 3]; }
+                        }
+                    }
+                    if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * gX1); }
+                    const float dLG = s0.w * dLa;
+                    const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
+                    const float isu = __builtin_amdgcn_rcpf(s1.w), isv = __builtin_amdgcn_rcpf(s2.w);
+                    const float qx = Box + h.t * Bdx - s0.x, qy = Boy + h.t * Bdy - s0.y, qz = Boz + h.t * Bdz - s0.z;
+                    const float dq0 = dLu * s1.x + dLv * s2.x, dq1 = dLu * s1.y + dLv * s2.y, dq2 = dLu * s1.z + dLv * s2.z;
+                    const float cu = dLu * isu, cv = dLv * isv;
+                    const float dLt_tot = w * gD + dq0 * Bdx + dq1 * Bdy + dq2 * Bdz;
+                    const float kt = dLt_tot * __builtin_amdgcn_rcpf(h.denom);
+                    BT(0) = dc[0]; BT(1) = dc[1]; BT(2) = dc[2];
+                    const float e0 = dq0 - kt * s3.x, e1 = dq1 - kt * s3.y, e2 = dq2 - kt * s3.z;
+                    BT(3) = -e0; BT(4) = -e1; BT(5) = -e2;
+                    BT(6) = cu * qx; BT(7) = cu * qy; BT(8) = cu * qz;
+                    BT(9) = cv * qx; BT(10) = cv * qy; BT(11) = cv * qz;
+                    const float ws = w * sgn;
+                    BT(12) = ws * gN0 - kt * qx; BT(13) = ws * gN1 - kt * qy; BT(14) = ws * gN2 - kt * qz;
+                    BT(15) = -cu * h.u * A.mod;
+                    g13 = -cv * h.v * A.mod;
+                    g14 = h.G * dLa;
+                    dO0 += e0; dO1 += e1; dO2 += e2;
+                    dD0 += h.t * e0; dD1 += h.t * e1; dD2 += h.t * e2;
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 16; n++) BT(n) = 0.f;
+                }
+#undef BT
+                if (el + 1 < ne) {                           // next entry's state: in flight during the reduction below
+                    k1 = valid ? (int)kmat[buf][el + 1][lane] : 0;
+                    const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) * sstr : A.state;
+                    st0 = sp[0]; st1 = sp[1]; if (A.has_others) st2 = sp[2];
+                }
+                // Sum over the 64 rays on the matrix cores: D[16 x 16] = basis^T[16 x 64 rays] . B[64 rays x 16], K = 64 in 16 exact-f32
+                // MFMAs (four independent chains: the dependent latency is 40 cycles).  Columns 0-2 are the (16,3) SH gradient block;
+                // basis_0 is the constant C0 for every ray, so row 0 of the other 13 columns is C0 x (the plain sum of a geometry word).
+                f32x4 acc4 = {0.f, 0.f, 0.f, 0.f}, accB = acc4, accC = acc4, accD = acc4;
+                {
+                    const int n = lane & 15, j = lane >> 4;
+                    const float *brow = &btile[n][0];
+                    const int rot = 2 * n + j;
+#pragma unroll
+                    for (int sI = 0; sI < 16; sI += 4) {
+                        acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI], brow[(4 * sI + rot) & 63], acc4, 0, 0, 0);
+                        accB = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 1], brow[(4 * sI + 4 + rot) & 63], accB, 0, 0, 0);
+                        accC = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 2], brow[(4 * sI + 8 + rot) & 63], accC, 0, 0, 0);
+                        accD = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 3], brow[(4 * sI + 12 + rot) & 63], accD, 0, 0, 0);
+                    }
+                }
+                acc4 = (acc4 + accB) + (accC + accD);
+                const float s13 = wave_sum(g13), s14 = wave_sum(g14);
+                if (rec < A.num_records) {
+                    float *ro = A.records + rec * RECW;
+                    const int n = lane & 15, mrow = (lane >> 4) * 4;
+                    if (A.M > 0) {
+                        if (n < 3) { ro[(mrow + 0) * 3 + n] = acc4[0]; ro[(mrow + 1) * 3 + n] = acc4[1]; ro[(mrow + 2) * 3 + n] = acc4[2]; ro[(mrow + 3) * 3 + n] = acc4[3]; }
+                    } else if (lane < 3) ro[lane] = acc4[0] * (1.0f / kC0);
+                    if (lane >= 3 && lane < 16) ro[48 + lane - 3] = acc4[0] * (1.0f / kC0);
+                    if (lane == 0) { ro[61] = s13; ro[62] = s14; }
+                }
+            }
+        }
+        if (valid) {
+            BwdRay B;
+            bwd_load_ray(A, r, B);
+            BwdAcc acc;
+            bwd_init_acc(acc);
+            acc.dO0 = dO0; acc.dO1 = dO1; acc.dO2 = dO2; acc.dD0 = dD0; acc.dD1 = dD1; acc.dD2 = dD2;
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc.Sk[k] = Sk[k];
+            bwd_store_ray(A, r, B, acc);
+        }
+    }
+}
+
+// Stage 2: sum each surfel's (batch, surfel) records into the (zeroed) gradient buffers -- plain stores, every word has one owner; the
+// K-buffer pass for overflowed rays runs afterwards and adds to the same buffers atomically.  16 lanes per surfel, 16 B per lane = one
+// 256 B record per load instruction; the typical surfel has ~15 records, but a few are seen by thousands of batches: those are deferred
+// and summed by the whole workgroup (16 records per instruction) so that no lane group walks a megabyte on its own.
+constexpr int RED_LONG = 96;
+__device__ __forceinline__ void reduce_store(const TraceArgs &A, const int sid, const int q, const int nb, const float *v)
+{
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int wd = 4 * q + e;
+        if (wd < 48) {
+            if (A.M > 0) { if (wd / 3 < nb) A.dshs[(size_t)sid * A.M * 3 + wd] = v[e]; }
+            else if (wd < 3) A.dcolors[(size_t)sid * 3 + wd] = v[e];
+        } else if (wd < 63) A.geo_rec[(size_t)sid * GEO + (wd - 48)] = v[e];
+    }
+}
+__global__ void __launch_bounds__(256)
+reduce_surfel_records(const TraceArgs A)
+{
+    __shared__ int longs[64];
+    __shared__ int nlong;
+    __shared__ float4 part[16][16];
+    const int sub = threadIdx.x >> 4, q = threadIdx.x & 15;               // 16 surfels per workgroup
+    const int nb = (A.D + 1) * (A.D + 1);
+    const float4 *rp = reinterpret_cast<const float4 *>(A.records) + q;
+    if (threadIdx.x == 0) nlong = 0;
+    __syncthreads();
+    for (int sid0 = blockIdx.x * 16; sid0 < A.P; sid0 += gridDim.x * 16) {
+        const int sid = sid0 + sub;
+        if (sid >= A.P) continue;
+        const unsigned end = A.surf_off[(size_t)sid * NCOPY + NCOPY - 1];
+        const unsigned begin = A.surf_off[(size_t)sid * NCOPY] - A.surf_cnt[(size_t)sid * NCOPY];     // the NCOPY sub-segments are adjacent
+        if (end <= begin) continue;
+        if (end - begin > (unsigned)RED_LONG) {
+            int k = 0;
+            if (q == 0) k = atomicAdd(&nlong, 1);
+            k = __shfl(k, 0, 16);
+            if (k < 64) { if (q == 0) longs[k] = sid; continue; }          // (list full: fall through and do it the slow way)
+        }
+        const unsigned long long hi = end < A.num_records ? end : A.num_records;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        unsigned long long i = begin;
+        for (; i + 4 <= hi; i += 4) {
+            const float4 x0 = rp[i * 16], x1 = rp[(i + 1) * 16], x2 = rp[(i + 2) * 16], x3 = rp[(i + 3) * 16];
+            a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w; a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+            a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w; a3.x += x3.x; a3.y += x3.y; a3.z += x3.z; a3.w += x3.w;
+        }
+        for (; i < hi; i++) { const float4 x0 = rp[i * 16]; a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w; }
+        const float v[4] = {(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w)};
+        reduce_store(A, sid, q, nb, v);
+    }
+    __syncthreads();
+    const int nl = nlong < 64 ? nlong : 64;
+    for (int k = 0; k < nl; k++) {
+        const int sid = longs[k];
+        const unsigned end = A.surf_off[(size_t)sid * NCOPY + NCOPY - 1];
+        const unsigned begin = A.surf_off[(size_t)sid * NCOPY] - A.surf_cnt[(size_t)sid * NCOPY];
+        const unsigned long long hi = end < A.num_records ? end : A.num_records;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        unsigned long long i = (unsigned long long)begin + sub;
+        for (; i + 16 < hi; i += 32) {
+            const float4 x0 = rp[i * 16], x1 = rp[(i + 16) * 16];
+            a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w; a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+        }
+        if (i < hi) { const float4 x0 = rp[i * 16]; a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w; }
+        __syncthreads();
+        part[sub][q] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+        __syncthreads();
+        if (sub == 0) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 16; g++) { const float4 x = part[g][q]; v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w; }
+            reduce_store(A, sid, q, nb, v);
+        }
+    }
+}
+
+// per-surfel geometry record [dmu 3, da 3, db 3, dn 3, dsu, dsv, dopacity] -> parameter gradients; the rotation columns
+// (a,b,n) chain to the unit quaternion; dmeans is also copied into the densification sink.
+__global__ void __launch_bounds__(256)
+finish_surfel_grads(int P, const float *__restrict__ rots, const float *__restrict__ geo_rec, float *__restrict__ dmeans,
+                    float *__restrict__ dscales, float *__restrict__ dopac, float *__restrict__ drots, float *__restrict__ dgrads3D)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float q0 = rots[4 * i], q1 = rots[4 * i + 1], q2 = rots[4 * i + 2], q3 = rots[4 * i + 3];
+    const float inv = 1.0f / sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    const float r = q0 * inv, x = q1 * inv, y = q2 * inv, z = q3 * inv;
+    const float *g = geo_rec + (size_t)i * GEO;
+    const float *rr = g + 3;
+    // V[row][col]: col 0 = dL/da, col 1 = dL/db, col 2 = dL/dn
+#define VR(a, b) rr[(b) * 3 + (a)]
+    drots[4 * i + 0] = 2.f * (x * (VR(2, 1) - VR(1, 2)) + y * (VR(0, 2) - VR(2, 0)) + z * (VR(1, 0) - VR(0, 1)));
+    drots[4 * i + 1] = 2.f * (-2.f * x * (VR(1, 1) + VR(2, 2)) + y * (VR(1, 0) + VR(0, 1)) + z * (VR(2, 0) + VR(0, 2)) + r * (VR(2, 1) - VR(1, 2)));
+    drots[4 * i + 2] = 2.f * (x * (VR(1, 0) + VR(0, 1)) - 2.f * y * (VR(0, 0) + VR(2, 2)) + z * (VR(2, 1) + VR(1, 2)) + r * (VR(0, 2) - VR(2, 0)));
+    drots[4 * i + 3] = 2.f * (x * (VR(2, 0) + VR(0, 2)) + y * (VR(2, 1) + VR(1, 2)) - 2.f * z * (VR(0, 0) + VR(1, 1)) + r * (VR(1, 0) - VR(0, 1)));
+#undef VR
+    dmeans[3 * i] = g[0]; dmeans[3 * i + 1] = g[1]; dmeans[3 * i + 2] = g[2];
+    dscales[2 * i] = g[12]; dscales[2 * i + 1] = g[13];
+    dopac[i] = g[14];
+    if (dgrads3D) { dgrads3D[3 * i] = g[0]; dgrads3D[3 * i + 1] = g[1]; dgrads3D[3 * i + 2] = g[2]; }
+}
+
+
+}  // namespace envgs

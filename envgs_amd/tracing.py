@@ -89,7 +89,7 @@ def _cfg(settings, P, R, shs, others, start_from_first, ray_shape):
                          rh, rw, float(settings.scale_modifier), float(settings.specular_threshold))
 
 
-NCOPY = 8                    # must equal NCOPY in csrc/trace_render.hip
+NCOPY = 8                    # must equal NCOPY in csrc/trace_common.h
 HIT_CAP = {"cap": 512}
 SORT_RAYS = {"on": True}     # coherence-sort the rays (direction, origin) before tracing
 USE_RECORDS = {"on": True}   # atomic-free backward (one record per (batch, surfel) entry, grouped by surfel); False = cooperative atomic flush
