@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--height", type=int, default=0, help="image height if not square (default: --res)")
     ap.add_argument("--width", type=int, default=0, help="image width if not square (default: --res)")
+    ap.add_argument("--channels", type=int, default=5, choices=[5, 7], help="envgs workload: -ch05 (1 specular channel, EnvGS) or -ch07 (3, BASELINE configs[4])")
     ap.add_argument("--trace-depth", type=int, default=0, help="specular bounces of the env trace (EnvGS: 0; BASELINE configs[4]: 2); uses random 'others'")
     ap.add_argument("--torch-glue", action="store_true", help="keep the reference's torch expressions for the caller-side glue (default: fused HIP, SURVEY 8(f).1)")
     ap.add_argument("--optim", default="fused", choices=["fused", "torch", "none"],
@@ -103,7 +104,7 @@ def main():
     P, H, W = args.gaussians, (args.height or args.res), (args.width or args.res)
     HW = H * W
     envgs = args.workload == "envgs"
-    C = 5 if envgs else 3
+    C = args.channels if envgs else 3
     g = synth.base_gaussians(P, seed=0, device=dev)
     cams = [synth.orbit_camera(v, n_views=8, H=H, W=W, fx=1111.1 * W / 800.0, device=dev) for v in range(8)]
     bg = torch.ones(3, device=dev) if not envgs else torch.zeros(3, device=dev)
@@ -117,7 +118,7 @@ def main():
     env_params = {}
     ge = None
     if envgs:
-        params["specular"] = g["specular"].clone().requires_grad_(True)
+        params["specular"] = g["specular"].repeat(1, C - 4).contiguous().clone().requires_grad_(True)      # (P,1) for -ch05, (P,3) for -ch07
         params["roughness"] = g["roughness"].clone().requires_grad_(True)
         ge = synth.env_gaussians(args.env_gaussians, seed=1, device=dev)
         env_params = {k: ge[k].clone().requires_grad_(True) for k in names}
@@ -127,7 +128,8 @@ def main():
             env_others = torch.rand(args.env_gaussians, 2, generator=torch.Generator().manual_seed(3)).to(dev)
 
     if envgs:
-        import diff_surfel_rasterization_wet_ch05 as pkg
+        import importlib
+        pkg = importlib.import_module("diff_surfel_rasterization_wet_ch0%d" % C)
         import diff_surfel_tracing as tpkg
         from envgs_amd import envgs_step
         envgs_step.FUSED["on"] = not args.torch_glue
@@ -301,11 +303,11 @@ def main():
             cpu = cpu_baseline(g, cams[0], bg, dcol, dall, H, W, args.cpu_reps, C,
                                (ge, last_rays, args.cpu_rays) if envgs else None)
         line = {
-            "metric": "train iters/s (fwd+bwd of the render hot path + Adam step, one 800x800 view per GPU per iter) + render Mpix/s",
+            "metric": "train iters/s (fwd+bwd of the render hot path + Adam step, one %dx%d view per GPU per iter) + render Mpix/s" % (W, H),
             "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (seeded, BASELINE.md section 3; random-init Gaussians)",
-            "config": {"workload": ("Ref-Real sedan-like full EnvGS (ch05 raster + env LBVH trace)" if envgs else
+            "config": {"workload": (("Ref-Real sedan-like full EnvGS (ch0%d raster + env LBVH trace)" % C) if envgs else
                                     "Ref-NeRF toaster-like base 2DGS raster only (BASELINE configs[1]), SH deg 3 in-kernel"),
                        "gaussians": P, "env_gaussians": (args.env_gaussians if envgs else 0), "resolution": [H, W], "trace_depth": (args.trace_depth if envgs else None), "channels": C, "views": 8,
                        "parallelism": "dp%d (camera batch sharded, %s)" % (world, "env / base grad buckets all-reduced from backward hooks" if reducer is not None else "flat grad all-reduce"),
@@ -335,9 +337,9 @@ def cpu_baseline(g, cam, bg, dcol, dall, H, W, reps, C, env=None):
         dc, da = dcol.cpu().numpy(), dall.cpu().numpy()
         if C == 3:
             ckw = dict(shs=a["shs"], sh_degree=3)
-        else:                                     # ch05: colours precomputed (the python SH of the reference is not timed here)
+        else:                                     # ch05 / ch07: colours precomputed (the python SH of the reference is not timed here)
             rng = np.random.default_rng(0)
-            ckw = dict(colors_precomp=np.concatenate([rng.random((a["means3D"].shape[0], 3), dtype=np.float32), a["specular"], a["roughness"]], 1))
+            ckw = dict(colors_precomp=np.concatenate([rng.random((a["means3D"].shape[0], 3), dtype=np.float32), np.repeat(a["specular"], C - 4, axis=1), a["roughness"]], 1))
         t0 = time.perf_counter()
         for _ in range(reps):
             fwd = orc.raster_forward(a["means3D"], a["opacities"], view, proj, campos, W, H, scales=a["scales"],

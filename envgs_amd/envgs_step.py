@@ -63,8 +63,9 @@ def base_pass(pkg, cam, base, bg, sh_degree, scale_modifier=1.0):
     img, radii, allmap, weight = pkg.GaussianRasterizer(raster_settings=st)(
         means3D=base["means3D"], means2D=means2D, shs=None, colors_precomp=colors, opacities=base["opacities"],
         scales=base["scales"], rotations=base["rotations"], cov3D_precomp=None)
+    S = img.shape[0] - 4                         # specular channels: 1 (-ch05) or 3 (-ch07)
     if FUSED["on"]:
-        return dict(rgb=img[:3], spec=img[3:4], rough=img[4:5], alpha=allmap[1:2], radii=radii, weight=weight, means2D=means2D,
+        return dict(rgb=img[:3], spec=img[3:3 + S], rough=img[3 + S:4 + S], alpha=allmap[1:2], radii=radii, weight=weight, means2D=means2D,
                     allmap=allmap)
     alpha = allmap[1:2]
     # view -> world: the reference writes this as a (HW,3)@(3,3) matmul (gaussian2d_utils.py:1123); hipBLASLt picks a 4 ms GEMM for
@@ -73,7 +74,7 @@ def base_pass(pkg, cam, base, bg, sh_degree, scale_modifier=1.0):
     nv = allmap[2:5]
     normal = torch.stack([nv[0] * Rv[c, 0] + nv[1] * Rv[c, 1] + nv[2] * Rv[c, 2] for c in range(3)], dim=0)
     depth = torch.nan_to_num(allmap[0:1] / alpha, 0, 0)
-    return dict(rgb=img[:3], spec=img[3:4], rough=img[4:5], alpha=alpha, normal=normal, depth=depth, radii=radii,
+    return dict(rgb=img[:3], spec=img[3:3 + S], rough=img[3 + S:4 + S], alpha=alpha, normal=normal, depth=depth, radii=radii,
                 weight=weight, means2D=means2D, allmap=allmap)
 
 
