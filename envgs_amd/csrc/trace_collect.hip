@@ -168,7 +168,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(64)
 collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ srec)
 {
     __shared__ int stk[PSTACK];
-    int *spill = A.stack_spill + ((size_t)A.seg * A.spill_stride + blockIdx.x) * (STACK * 64);
     const int lane = threadIdx.x;
     unsigned visits = 0, found_tot = 0;
     float rlx, rly, rlz, rhx, rhy, rhz;                   // the scene box = union of the root's two child boxes
@@ -217,9 +216,9 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
             if (cur < 0) {
                 if (sp == 0) break;
                 --sp;
-                int top;
-                if (sp < PSTACK) top = stk[sp]; else top = __builtin_nontemporal_load(spill + (sp - PSTACK));
-                cur = __builtin_amdgcn_readfirstlane(top);
+                // LDS only (see PSTACK): with an HBM overflow area behind it the compiler merges the two reads into ONE flat load of a selected
+                // address, whose s_waitcnt vmcnt(0) also waits for every list store still in flight -- on every pop
+                cur = __builtin_amdgcn_readfirstlane(stk[sp]);
             }
             const float4 *nd = nodes + (size_t)cur * 4;
             const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
@@ -272,8 +271,7 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
                 const unsigned long long both = mL & mR, lf = __ballot(hitL && hitR && tnL <= tnR);
                 const bool leftFirst = both ? (2 * __popcll(lf) >= __popcll(both)) : (__popcll(mL) >= __popcll(mR));
                 const int farc = leftFirst ? rc : lc;
-                if (sp < PSTACK) stk[sp] = farc; else if (sp < PSTACK + STACK * 64) spill[sp - PSTACK] = farc;
-                sp++;
+                if (sp < PSTACK) stk[sp++] = farc;
                 cur = leftFirst ? lc : rc;
             }
             else if (goL) cur = lc;
@@ -299,7 +297,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(64)
 collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec)
 {
     __shared__ int stk[PSTACK];
-    int *spill = A.stack_spill + ((size_t)A.seg * A.spill_stride + blockIdx.x) * (STACK * 64);
     const int lane = threadIdx.x;
     unsigned visits = 0, found_tot = 0;
     float rlx, rly, rlz, rhx, rhy, rhz;                   // the scene box = union of the root's two child boxes
@@ -345,9 +342,9 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
             if (cur < 0) {
                 if (sp == 0) break;
                 --sp;
-                int top;
-                if (sp < PSTACK) top = stk[sp]; else top = __builtin_nontemporal_load(spill + (sp - PSTACK));
-                cur = __builtin_amdgcn_readfirstlane(top);
+                // LDS only (see PSTACK): with an HBM overflow area behind it the compiler merges the two reads into ONE flat load of a selected
+                // address, whose s_waitcnt vmcnt(0) also waits for every list store still in flight -- on every pop
+                cur = __builtin_amdgcn_readfirstlane(stk[sp]);
             }
             const float4 *nd = nodes4 + (size_t)cur * 8;
             const float4 qlx = nd[0], qly = nd[1], qlz = nd[2], qhx = nd[3], qhy = nd[4], qhz = nd[5], qrf = nd[6];
@@ -408,10 +405,7 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
             // nearest next; the others go on the stack far to near
 #pragma unroll
             for (int c = 3; c >= 1; c--)
-                if (ref[c] >= 0) {
-                    if (sp < PSTACK) stk[sp] = ref[c]; else if (sp < PSTACK + STACK * 64) spill[sp - PSTACK] = ref[c];
-                    sp++;
-                }
+                if (ref[c] >= 0 && sp < PSTACK) stk[sp++] = ref[c];
             cur = ref[0];
         }
         if (valid) { A.hit_cnt[r] = n; found_tot += (unsigned)n; }

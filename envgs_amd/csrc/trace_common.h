@@ -548,7 +548,9 @@ __device__ __forceinline__ int fetch_batch(unsigned *ctr /*8 counters*/, int nba
 constexpr int NBIN = 16;
 constexpr float KILL_OD = 9.2104f * 1.03f + 0.05f;       // -ln(1e-4) with margin for fp32 product vs sum-of-logs
 
-constexpr int PSTACK = 64;      // wave-uniform stack entries of the packet kernels kept in LDS
+// Wave-uniform stack of the packet kernels, in LDS.  It cannot overflow: the LBVH is at most 63 levels deep (62-bit unique Morton keys), the binary walk
+// holds one postponed child per level and the 4-wide walk at most three per TWO levels.
+constexpr int PSTACK = 128;
 constexpr int SORT_MAX = 1024;  // longest list the sort / composite pass takes (16 keys per lane)
 constexpr int RH_W = 8;         // register_hits: wavefronts per batch -- wave q takes list positions q, q + RH_W, ... of every ray
 
