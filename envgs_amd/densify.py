@@ -130,11 +130,14 @@ class SurfelSet:
 
     STATS = ("xyz_gradient_accum", "denom", "max_radii2D", "xyz_weight_accum")
 
-    def __init__(self, raw, optimizer=None, prefix="", spatial_scale=1.0, max_gs=None, max_gs_threshold=1.0, row_ops=None):
+    def __init__(self, raw, optimizer=None, prefix="", spatial_scale=1.0, max_gs=None, max_gs_threshold=1.0, row_ops=None, generator=None):
         self.names = [k for k in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity", "_specular", "_roughness") if k in raw]
         self.optimizer, self.prefix, self.spatial_scale = optimizer, prefix, float(spatial_scale)
         self.max_gs, self.max_gs_threshold = max_gs, max_gs_threshold
         self.rows = row_ops or prune_rows
+        # split offsets are random: with data parallelism every rank must draw the SAME ones, i.e. pass generators seeded
+        # identically on all ranks (or seed the global generator identically before every densification)
+        self.generator = generator
         self.p = {}
         groups = {g.get("name"): g for g in optimizer.param_groups} if optimizer is not None else {}
         for k in self.names:
@@ -267,7 +270,7 @@ class SurfelSet:
         scal = torch.exp(sel["_scaling"])
         stds = scal.repeat(N, 1)
         stds = torch.cat([stds, torch.zeros_like(stds[:, :1])], dim=-1)
-        samples = torch.normal(torch.zeros_like(stds), stds)
+        samples = torch.normal(torch.zeros_like(stds), stds, generator=self.generator)
         rots = build_rotation(sel["_rotation"]).repeat(N, 1, 1)
         new = {k: v.repeat(*([N] + [1] * (v.dim() - 1))) for k, v in sel.items()}
         new["_xyz"] = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + sel["_xyz"].repeat(N, 1)
