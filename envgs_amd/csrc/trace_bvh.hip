@@ -276,8 +276,8 @@ __global__ void single_leaf_node(const float *__restrict__ leaf_box, float *__re
     }
 }
 
-// 4-wide nodes for the packet traversal: node4[i] holds the GRANDCHILDREN of binary node i (a child that is a leaf stays as it is), boxes as
-// structure-of-arrays quads [lo.x | lo.y | lo.z | hi.x | hi.y | hi.z | refs | -] x 4 slots = 128 B.  Every binary node gets one (the traversal
+// 4-wide nodes for the packet traversal: node4[i] holds the GRANDCHILDREN of binary node i (a child that is a leaf stays as it is), 4 slots of
+// 32 B = 128 B.  Every binary node gets one (the traversal
 // only ever follows every other level; the rest is 128 B per surfel of unused memory) so the kernel is a plain map, no compaction.  Empty slots
 // are far-away points that no ray's slab test passes.
 __global__ void __launch_bounds__(256)
@@ -306,10 +306,13 @@ build_wide_nodes(int n_internal, const float *__restrict__ nodes, float *__restr
         for (int a = 0; a < 3; a++) { lo[k][a] = 1.0e30f; hi[k][a] = 1.0e30f; }
         ref[k] = ~0;
     }
+    // per slot 8 floats: [lo.x hi.x lo.y hi.y | lo.z hi.z ref 0] -- (lo, hi) of an axis adjacent, so that they arrive as an aligned scalar
+    // register PAIR and the slab test's subtract and multiply run as packed fp32 (v_pk_add_f32 / v_pk_mul_f32: both planes in one instruction)
     float *o = nodes4 + (size_t)i * 32;
-    for (int a = 0; a < 3; a++)
-        for (int q = 0; q < 4; q++) { o[a * 4 + q] = lo[q][a]; o[12 + a * 4 + q] = hi[q][a]; }
-    for (int q = 0; q < 4; q++) { o[24 + q] = __int_as_float(ref[q]); o[28 + q] = 0.f; }
+    for (int q = 0; q < 4; q++) {
+        o[q * 8 + 0] = lo[q][0]; o[q * 8 + 1] = hi[q][0]; o[q * 8 + 2] = lo[q][1]; o[q * 8 + 3] = hi[q][1];
+        o[q * 8 + 4] = lo[q][2]; o[q * 8 + 5] = hi[q][2]; o[q * 8 + 6] = __int_as_float(ref[q]); o[q * 8 + 7] = 0.f;
+    }
 }
 
 }  // namespace envgs

@@ -293,6 +293,7 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
 // one scalar-load round trip plus the stack / mask bookkeeping of the scalar unit, which is what the binary walk spends most of its time on.
 // Children that any ray hits are entered nearest first, ordered by the entry distance of each child's first hitting lane (the rays of a
 // batch are coherent; the order only affects how early the termination bounds tighten).  `visits` counts 64 B units (two per wide node).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(64)
 collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec)
 {
@@ -338,6 +339,7 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
         int n = 0;
         int sp = 0;
         int cur = 0;
+        const f32x2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz}, i2x = {ix, ix}, i2y = {iy, iy}, i2z = {iz, iz};
         while (true) {
             if (cur < 0) {
                 if (sp == 0) break;
@@ -347,18 +349,18 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
                 cur = __builtin_amdgcn_readfirstlane(stk[sp]);
             }
             const float4 *nd = nodes4 + (size_t)cur * 8;
-            const float4 qlx = nd[0], qly = nd[1], qlz = nd[2], qhx = nd[3], qhy = nd[4], qhz = nd[5], qrf = nd[6];
-            const float lxs[4] = {qlx.x, qlx.y, qlx.z, qlx.w}, lys[4] = {qly.x, qly.y, qly.z, qly.w}, lzs[4] = {qlz.x, qlz.y, qlz.z, qlz.w};
-            const float hxs[4] = {qhx.x, qhx.y, qhx.z, qhx.w}, hys[4] = {qhy.x, qhy.y, qhy.z, qhy.w}, hzs[4] = {qhz.x, qhz.y, qhz.z, qhz.w};
-            const float rfs[4] = {qrf.x, qrf.y, qrf.z, qrf.w};
+            float4 qa[4], qb[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) { qa[c] = nd[2 * c]; qb[c] = nd[2 * c + 1]; }
             int key[4], ref[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const int ch = __builtin_amdgcn_readfirstlane(__float_as_int(rfs[c]));
-                const float a0 = (lxs[c] - ox) * ix, a1 = (hxs[c] - ox) * ix, b0 = (lys[c] - oy) * iy, b1 = (hys[c] - oy) * iy,
-                            c0 = (lzs[c] - oz) * iz, c1 = (hzs[c] - oz) * iz;
-                const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1));
-                const float tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+                const int ch = __builtin_amdgcn_readfirstlane(__float_as_int(qb[c].z));
+                // both planes of an axis in one packed instruction: (lo, hi) - o, then * 1/d
+                const f32x2 sx = (f32x2{qa[c].x, qa[c].y} - o2x) * i2x, sy = (f32x2{qa[c].z, qa[c].w} - o2y) * i2y,
+                            sz = (f32x2{qb[c].x, qb[c].y} - o2z) * i2z;
+                const float tn = fmaxf(fmaxf(fminf(sx.x, sx.y), fminf(sy.x, sy.y)), fminf(sz.x, sz.y));
+                const float tf = fminf(fminf(fmaxf(sx.x, sx.y), fmaxf(sy.x, sy.y)), fmaxf(sz.x, sz.y));
                 const bool hit = valid && (tn <= tf) && (tf >= tmin) && (tn <= tkill);
                 const unsigned long long m = __ballot(hit);
                 key[c] = 0x7fffffff; ref[c] = -1;

@@ -97,7 +97,8 @@ typedef struct envgs_trace_lists {
 /* Scratch bytes for the Morton sort + build of P surfels. */
 ENVGS_API size_t envgs_bvh_temp_bytes(int32_t P);
 /* Floats of the `nodes` buffer for P surfels: max(P-1,1) binary nodes of 16 floats, followed by as many 4-wide nodes of 32 floats (the
- * grandchildren of each binary node, boxes as structure-of-arrays; what the packet traversal of coherence-sorted rays walks). */
+ * grandchildren of each binary node, 8 floats per slot: lo.x hi.x lo.y hi.y lo.z hi.z ref 0; what the packet traversal of coherence-sorted
+ * rays walks). */
 ENVGS_API size_t envgs_bvh_node_floats(int32_t P);
 
 /*

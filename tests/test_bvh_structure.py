@@ -70,7 +70,11 @@ def test_binary_and_wide_nodes(P, clustered):
     walk(0)
     assert (seen_leaf == 1).all() and (seen_node == 1).all()
     # --- wide nodes: slot boxes / refs are the grandchildren (a leaf child stays), unused slots are far-away points
-    wl = wide[:, :12].reshape(ni, 3, 4); wh = wide[:, 12:24].reshape(ni, 3, 4); wr = wide[:, 24:28].copy().view(np.int32)
+    w8 = wide.reshape(ni, 4, 8)                                     # per slot: lo.x hi.x lo.y hi.y lo.z hi.z ref 0
+    wl = np.stack([w8[:, :, 0], w8[:, :, 2], w8[:, :, 4]], axis=1)   # (node, axis, slot)
+    wh = np.stack([w8[:, :, 1], w8[:, :, 3], w8[:, :, 5]], axis=1)
+    wr = np.ascontiguousarray(w8[:, :, 6]).view(np.int32)
+    assert (w8[:, :, 7] == 0).all()
     for i in range(ni):
         exp = []
         for side in range(2):
