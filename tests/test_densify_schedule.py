@@ -114,3 +114,17 @@ def test_schedule_over_hip_compaction_equals_torch_indexing(name):
         assert torch.equal(sa[k], sb[k])
     # same decisions as the CPU reference run (the split offsets come from a different generator on the GPU, so only the counts are comparable)
     assert a["params"]["_xyz"].shape[0] == sc["after"]["params"]["_xyz"].shape[0] or name == "all_branches"
+
+
+def test_split_draws_follow_the_generator():
+    """Data parallelism: ranks that build their SurfelSet with identically seeded generators draw identical split offsets,
+    whatever happened to the global RNG in between."""
+    sc = torch.load(GOLD, weights_only=True)["clone_split_prune"]
+    outs = []
+    for junk in (0, 5):
+        s, opt = _build(sc["before"], sc["config"], "cpu", densify.torch_rows)
+        s.generator = torch.Generator().manual_seed(1234)
+        torch.manual_seed(junk); torch.rand(junk + 1)                 # the global generator differs between the two "ranks"
+        s.densify_and_prune(**sc["args"])
+        outs.append(s.p["_xyz"].detach().clone())
+    assert outs[0].shape == outs[1].shape and torch.equal(outs[0], outs[1])
