@@ -82,7 +82,9 @@ def main():
     ap.add_argument("--torch-glue", action="store_true", help="keep the reference's torch expressions for the caller-side glue (default: fused HIP, SURVEY 8(f).1)")
     ap.add_argument("--optim", default="fused", choices=["fused", "torch", "none"],
                     help="optimizer step inside the timed iteration: sparse fused Adam (envgs_amd.optim, SURVEY 8(f).2), torch.optim.Adam, or none")
-    ap.add_argument("--no-overlap-allreduce", action="store_true", help="N > 1: one flat all-reduce after backward() instead of per-set buckets launched from backward hooks")
+    ap.add_argument("--no-overlap-allreduce", action="store_true", help="N > 1: exchange the gradient buckets after backward() instead of launching them from backward hooks")
+    ap.add_argument("--exchange", default="direct", choices=["direct", "allreduce"],
+                    help="N > 1: direct reduce-scatter + all-gather over the xGMI mesh (all_to_all + local sum + all_gather), or one all_reduce per bucket")
     ap.add_argument("--no-render", action="store_true", help="skip the forward-only render timing (profiling runs: keeps the kernel statistics to the training steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=2)
@@ -169,12 +171,15 @@ def main():
     # N > 1: the gradient exchange starts inside backward() -- the environment bucket (final once the tracer's backward is done) is in
     # flight over xGMI while the base pass is still differentiating; --no-overlap-allreduce = one flat bucket after backward()
     reducer = None
-    if world > 1 and not args.no_overlap_allreduce:
-        reducer = edist.OverlappedGradReducer([list(env_params.values()), list(params.values())], average=True)
+    if world > 1:
+        reducer = edist.GradExchange(lambda: [list(env_params.values()), list(params.values())], average=True, algo=args.exchange,
+                                     overlap=not args.no_overlap_allreduce)
 
     def step(it):
         vi = (it * world + rank) % 8
         cam = cams[vi]
+        if reducer is not None:
+            reducer.begin_step()                   # .grad = zeroed views of the persistent flat buffers (the message itself)
         if envgs:
             out = envgs_step.envgs_forward(pkg, tpkg, tracer, cam, rays[vi], params, env_in, bg, env_bg, sh_degree)
             last_rays[0], last_rays[1] = out["ref_o"].detach(), out["ref_d"].detach()
@@ -188,12 +193,13 @@ def main():
             loss = (color * dcol).sum() + (allmap * dall).sum()
         n_acc["N"] += raster.LAST_STATS["N"]; n_acc["steps"] += 1
         loss.backward()
-        nbytes = (reducer.finish() if reducer is not None else edist.allreduce_grads(all_params, average=True)) if world > 1 else 0
+        nbytes = reducer.finish() if reducer is not None else 0
         if opt is not None:
             opt.step()
         last_grads[:] = [p_.grad for p_ in all_params]
-        for p_ in all_params:
-            p_.grad = None
+        if reducer is None:
+            for p_ in all_params:
+                p_.grad = None
         return nbytes
 
     def sync_all():
@@ -310,7 +316,7 @@ def main():
             "config": {"workload": (("Ref-Real sedan-like full EnvGS (ch0%d raster + env LBVH trace)" % C) if envgs else
                                     "Ref-NeRF toaster-like base 2DGS raster only (BASELINE configs[1]), SH deg 3 in-kernel"),
                        "gaussians": P, "env_gaussians": (args.env_gaussians if envgs else 0), "resolution": [H, W], "trace_depth": (args.trace_depth if envgs else None), "channels": C, "views": 8,
-                       "parallelism": "dp%d (camera batch sharded, %s)" % (world, "env / base grad buckets all-reduced from backward hooks" if reducer is not None else "flat grad all-reduce"),
+                       "parallelism": "dp%d (camera batch sharded, %s)" % (world, ("env / base flat grad buffers, %s, %s" % (args.exchange, "launched from backward hooks" if not args.no_overlap_allreduce else "after backward")) if reducer is not None else "single GPU"),
                        "optimizer": {"fused": "sparse fused Adam, one launch (envgs_amd.optim)", "torch": "torch.optim.Adam", "none": "none"}[args.optim],
                        "caller_glue": ("torch (reference expressions)" if (not envgs or args.torch_glue) else "fused HIP (envgs_amd.fused)"),
                        "allreduce_bytes_per_step": int(ar_bytes)},

@@ -79,6 +79,8 @@ SYMBOLS = {
     "envgs_l1_ssim_partial_count": (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "envgs_l1_ssim_forward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, _P]),
     "envgs_l1_ssim_backward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _P, _P]),
+    "envgs_debug_set": (None, [ctypes.c_int32, ctypes.c_int32]),
+    "envgs_debug_get": (ctypes.c_int32, [ctypes.c_int32]),
     "envgs_prof_enable": (None, [c_int]),
     "envgs_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     "envgs_prof_kernel_name": (ctypes.c_char_p, [c_int]),

@@ -16,4 +16,6 @@ struct ProfScope {
     ProfScope(int id_, hipStream_t s_) : id(id_), s(s_) { prof_begin(id, s); }
     ~ProfScope() { prof_end(id, s); }
 };
+// Process-global diagnostic switches (envgs_debug_set, include/envgs_raster.h); 0 = production.  The library never reads the environment.
+int debug_switch(int which);
 }  // namespace envgs

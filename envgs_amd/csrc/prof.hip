@@ -1,6 +1,7 @@
 // prof.hip -- HIP-event kernel timers behind envgs_prof_* (include/envgs_raster.h).
 #include "prof.h"
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -25,6 +26,9 @@ Pair get_pair()
     return p;
 }
 }  // namespace
+
+namespace { std::atomic<int> g_dbg[ENVGS_DBG_COUNT]; }
+int debug_switch(int which) { return (which >= 0 && which < ENVGS_DBG_COUNT) ? g_dbg[which].load(std::memory_order_relaxed) : 0; }
 
 void prof_begin(int id, hipStream_t stream)
 {
@@ -73,6 +77,13 @@ int envgs_prof_read(int kernel_id, double *total_ms, int *launches)
     *launches = n;
     return 0;
 }
+
+void envgs_debug_set(int32_t which, int32_t value)
+{
+    if (which >= 0 && which < ENVGS_DBG_COUNT) g_dbg[which].store(value, std::memory_order_relaxed);
+}
+
+int32_t envgs_debug_get(int32_t which) { return debug_switch(which); }
 
 const char *envgs_prof_kernel_name(int kernel_id)
 {

@@ -14,8 +14,6 @@
 // in oracle/surfel_raster_oracle.c ("parity unpinned" there).
 #include "common.h"
 
-#include <cstdlib>
-
 namespace envgs {
 
 struct Hit {
@@ -204,7 +202,7 @@ __global__ void __launch_bounds__(256)
 composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list,
               const float *__restrict__ geom, const float *__restrict__ colors, const float *__restrict__ bg,
               const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
-              const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap, float *__restrict__ grad_rec, const int exp)
+              const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap, float *__restrict__ grad_rec)
 {
     constexpr int V = 15 + C;          // gradient words per surfel
     constexpr int N4 = (V + 3) / 4;    // registers left after the transpose-reduce (4 words each)
@@ -350,7 +348,6 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
                 gv[12] = G * dL_dalpha;
             }
             // wavefront transpose-reduce (permlane swaps + DPP): lane r*16+k ends up owning the sum of word k + r*N4, then one LDS atomic instruction
-            if (exp & 1) { float mine = 0.f; for (int v = 0; v < V; v++) mine += gv[v]; if (mine == 123.456f) gacc[j][0] = mine; continue; }
             const float mine = wave_transpose_reduce<N4>(gv, lane);
             const int vi = (lane & 15) + (lane >> 4) * N4;
             if ((lane & 15) < N4 && vi < V) atomic_add_f32(&gacc[j][vi], mine);
@@ -366,8 +363,6 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
 }
 
 // ------------------------------------------------------------------------------------ launchers ---
-static int raster_exp() { const char *e = getenv("ENVGS_RASTER_EXP"); return e ? atoi(e) : 0; }   // experiment switches, 0 in production
-
 template <int C>
 static int run_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                    const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
@@ -405,7 +400,7 @@ static int run_bwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const ui
     const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
     ProfScope prof_(K_COMPOSITE_BWD, stream);
     hipLaunchKernelGGL(composite_bwd<C>, dim3(8 * ((gx * gy + 7) / 8)), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
-                       point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, raster_exp());
+                       point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;
 }

@@ -2,6 +2,8 @@
 // (two batch segments on two streams) and the backward.
 #include "trace_common.h"
 
+#include <mutex>
+
 #include <rocprim/device/device_radix_sort.hpp>
 
 namespace envgs {
@@ -95,7 +97,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     A.bg = bg; A.ray_o = ray_o; A.ray_d = ray_d; A.counter = counters; A.stats = (unsigned long long *)(counters + 2);
     A.rgb = rgb; A.dpt = dpt; A.acc = acc; A.norm = norm; A.dist = dist; A.aux = aux; A.mid = mid; A.wet = wet; A.final_T = final_T;
     A.mod = cfg->scale_modifier;
-    { const char *ev = getenv("ENVGS_TRACE_EXP"); A.exp = ev ? atoi(ev) : 0; }
+    A.exp = debug_switch(ENVGS_DBG_TRACE);
     int rh, rw; ray_layout(cfg, &rh, &rw);
     const bool lists = lists_usable(cfg, L);
     if (L && L->cap > SORT_MAX) return ENVGS_ERR_BAD_ARG;
@@ -127,7 +129,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         // (and the first segment's next kernel) move into the CUs it leaves idle.
         const int nbatch_all = (cfg->num_rays + 63) / 64;
         int nseg = 2;                                         // measured: 1 -> 18.3 ms / step, 2 -> 17.5, 4 -> 19.4 (each collection launch lasts at least one batch)
-        { const char *sv = getenv("ENVGS_SEGMENTS"); if (sv) nseg = atoi(sv); }
+        if (debug_switch(ENVGS_DBG_SEGMENTS) > 0) nseg = debug_switch(ENVGS_DBG_SEGMENTS);
         if (nseg > 2) nseg = 2;                               // (the stack-spill slab and the fetch counters are sized for two)
         while (nseg > 1 && nbatch_all / nseg < 256) nseg >>= 1;
         if (nseg < 1) nseg = 1;
@@ -138,12 +140,16 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             // but nothing here assumes it)
             static hipStream_t s_aux[16] = {};
             static hipEvent_t s_fork[16] = {}, s_join[16] = {};
+            static std::mutex s_mu;                               // the per-device stream / events are created once, under a lock
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) nseg = 1;
-            else if (!s_aux[dev]) {
-                if (hipStreamCreateWithFlags(&s_aux[dev], hipStreamNonBlocking) != hipSuccess ||
-                    hipEventCreateWithFlags(&s_fork[dev], hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&s_join[dev], hipEventDisableTiming) != hipSuccess) { s_aux[dev] = nullptr; nseg = 1; }
+            else {
+                std::lock_guard<std::mutex> lk(s_mu);
+                if (!s_aux[dev]) {
+                    if (hipStreamCreateWithFlags(&s_aux[dev], hipStreamNonBlocking) != hipSuccess ||
+                        hipEventCreateWithFlags(&s_fork[dev], hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&s_join[dev], hipEventDisableTiming) != hipSuccess) { s_aux[dev] = nullptr; nseg = 1; }
+                }
             }
             if (nseg > 1) {
                 aux = s_aux[dev]; ev_fork = s_fork[dev]; ev_join = s_join[dev];
@@ -237,7 +243,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     A.f_rgb = rgb; A.f_dpt = dpt; A.f_acc = acc; A.f_norm = norm; A.f_aux = aux; A.f_T = final_T;
     A.g_rgb = dL_drgb; A.g_dpt = dL_ddpt; A.g_acc = dL_dacc; A.g_norm = dL_dnorm; A.g_aux = dL_daux;
     A.geo_rec = geo_rec; A.dshs = dshs; A.dcolors = dcolors;
-    { const char *ev = getenv("ENVGS_TRACE_EXP"); A.exp = ev ? atoi(ev) : 0; }
+    A.exp = debug_switch(ENVGS_DBG_TRACE);
     A.dothers = dothers; A.dray_o = dray_o; A.dray_d = dray_d; A.mod = cfg->scale_modifier;
     int rh, rw; ray_layout(cfg, &rh, &rw);
     {

@@ -169,6 +169,7 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
 {
     __shared__ int stk[PSTACK];
     const int lane = threadIdx.x;
+    const int slimit = (A.exp & 1024) ? 2 : PSTACK;       // (test switch: forces the overflow hand-off)
     unsigned visits = 0, found_tot = 0;
     float rlx, rly, rlz, rhx, rhy, rhz;                   // the scene box = union of the root's two child boxes
     {
@@ -211,6 +212,7 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
         int n = 0;
         int sp = 0;
         int cur = 0;
+        bool ovf = false;                                  // wave-uniform: a child did not fit on the packet stack
         visits += (unsigned)__popcll(__ballot(valid));
         while (true) {
             if (cur < 0) {
@@ -271,12 +273,18 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
                 const unsigned long long both = mL & mR, lf = __ballot(hitL && hitR && tnL <= tnR);
                 const bool leftFirst = both ? (2 * __popcll(lf) >= __popcll(both)) : (__popcll(mL) >= __popcll(mR));
                 const int farc = leftFirst ? rc : lc;
-                if (sp < PSTACK) stk[sp++] = farc;
+                if (sp < slimit) stk[sp++] = farc; else ovf = true;
                 cur = leftFirst ? lc : rc;
             }
             else if (goL) cur = lc;
             else if (goR) cur = rc;
             else cur = -1;
+        }
+        if (ovf) {
+            // a postponed child was dropped: this batch's lists are incomplete.  Mark every ray as overflowed (hit_cnt > cap) so that it is
+            // traced by the K-buffer kernels instead (per-lane stacks, no packet stack), and count the event (counters[10]).
+            n = A.cap + 1;
+            if (lane == 0) atomicAdd(A.counter + 10, 1u);
         }
         if (valid) { A.hit_cnt[r] = n; found_tot += (unsigned)n; }
         int mx = n;
@@ -299,6 +307,7 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
 {
     __shared__ int stk[PSTACK];
     const int lane = threadIdx.x;
+    const int slimit = (A.exp & 1024) ? 2 : PSTACK;       // (test switch: forces the overflow hand-off)
     unsigned visits = 0, found_tot = 0;
     float rlx, rly, rlz, rhx, rhy, rhz;                   // the scene box = union of the root's two child boxes
     {
@@ -339,6 +348,7 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
         int n = 0;
         int sp = 0;
         int cur = 0;
+        bool ovf = false;                                  // wave-uniform: a child did not fit on the packet stack
         const f32x2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz}, i2x = {ix, ix}, i2y = {iy, iy}, i2z = {iz, iz};
         while (true) {
             if (cur < 0) {
@@ -407,8 +417,14 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
             // nearest next; the others go on the stack far to near
 #pragma unroll
             for (int c = 3; c >= 1; c--)
-                if (ref[c] >= 0 && sp < PSTACK) stk[sp++] = ref[c];
+                if (ref[c] >= 0) { if (sp < slimit) stk[sp++] = ref[c]; else ovf = true; }
             cur = ref[0];
+        }
+        if (ovf) {
+            // a postponed child was dropped: this batch's lists are incomplete.  Mark every ray as overflowed (hit_cnt > cap) so that it is
+            // traced by the K-buffer kernels instead (per-lane stacks, no packet stack), and count the event (counters[10]).
+            n = A.cap + 1;
+            if (lane == 0) atomicAdd(A.counter + 10, 1u);
         }
         if (valid) { A.hit_cnt[r] = n; found_tot += (unsigned)n; }
         int mx = n;

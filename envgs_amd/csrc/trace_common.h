@@ -138,9 +138,10 @@ struct TraceArgs {
     float *records;           // (num_records, 24) per-hit gradient records grouped by surfel
     unsigned long long num_records;
     const unsigned *order;    // (R) ray permutation (coherence sort) or NULL
-    int exp;            // diagnostic switches (ENVGS_TRACE_EXP env var; 0 in production): 8 = atomic-flush backward instead of records,
+    int exp;            // diagnostic switches (envgs_debug_set(ENVGS_DBG_TRACE, ...); 0 in production): 8 = atomic-flush backward instead of records,
                         // 16 = binary packet traversal instead of the 4-wide one,
-                        // 64 = no coherence sort of the rays, 512 = per-ray collection kernel even when the rays are sorted
+                        // 64 = no coherence sort of the rays, 512 = per-ray collection kernel even when the rays are sorted,
+                        // 1024 = packet stack limited to 2 entries (tests the overflow hand-off)
     int *stack_spill;   // collect_hits: (grid, STACK, 64) ints of stack overflow space
     int only_overflow;  // K-buffer kernels: process only rays whose hit_cnt exceeds cap
     int batch0, batch1; // list-path forward kernels: the range of 64-ray batches this launch owns (segments run on two streams)
@@ -548,8 +549,9 @@ __device__ __forceinline__ int fetch_batch(unsigned *ctr /*8 counters*/, int nba
 constexpr int NBIN = 16;
 constexpr float KILL_OD = 9.2104f * 1.03f + 0.05f;       // -ln(1e-4) with margin for fp32 product vs sum-of-logs
 
-// Wave-uniform stack of the packet kernels, in LDS.  It cannot overflow: the LBVH is at most 63 levels deep (62-bit unique Morton keys), the binary walk
-// holds one postponed child per level and the 4-wide walk at most three per TWO levels.
+// Wave-uniform stack of the packet kernels, in LDS.  Sized so that it does not overflow: the LBVH is at most 63 levels deep (62-bit unique Morton keys),
+// the binary walk holds one postponed child per level and the 4-wide walk at most three per TWO levels.  Should a child ever not fit, the batch is
+// flagged: its rays are handed to the K-buffer kernels (per-lane stacks) and counters[10] counts the event -- never a silently dropped subtree.
 constexpr int PSTACK = 128;
 constexpr int SORT_MAX = 1024;  // longest list the sort / composite pass takes (16 keys per lane)
 constexpr int RH_W = 8;         // register_hits: wavefronts per batch -- wave q takes list positions q, q + RH_W, ... of every ray

@@ -1,5 +1,5 @@
 """Multi-GPU data parallelism for the render-and-trace path: one process per GPU, camera batch sharded over
-ranks, ONE all-reduce of the flat per-Gaussian gradient buffer per step (RCCL over xGMI; `nccl` backend on ROCm).
+ranks, one exchange of the flat per-Gaussian gradient buffer per step (RCCL over xGMI; `nccl` backend on ROCm).
 
 The reference's only parallelism is DDP (easyvolcap/scripts/main.py:240-275), which cannot follow the
 nn.Parameter replacement done by densification (gaussian2d_utils.py:526-621), so the
@@ -7,8 +7,12 @@ exchange step is explicit here: every rank holds a full replica of the Gaussian 
 the view batch, and the summed gradients + densification statistics are made identical on all ranks so that
 every rank takes the same densify / prune decisions (gaussian2d_utils.py:901-909).
 
-Message size: 60 floats (240 B) per base Gaussian, 58 per env Gaussian -> 72 MB at P = 300 k: one flat bucket,
-one collective (xGMI is point-to-point; fewer, larger messages are the cheap ones).
+Message size: 60 floats (240 B) per base Gaussian, 58 per env Gaussian -> 72 MB at P = 300 k.  xGMI is a full mesh of
+point-to-point links (7 x ~153 GB/s per GPU), so the exchange is written as what the topology is good at
+(SURVEY.md section 8e): a DIRECT reduce-scatter (every rank sends chunk j straight to rank j: 7 transfers on 7 different
+links, one local sum) followed by a direct all-gather -- 2 x S/8 bytes per link instead of a ring's 2 x 7/8 x S through one.
+`GradExchange` keeps ONE persistent flat fp32 buffer per bucket that the parameters' `.grad` are views of: autograd
+accumulates straight into the message, nothing is packed or unpacked.
 """
 import os
 
@@ -34,115 +38,236 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def _active(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
 def shard_views(num_views, rank, world):
     """Views of an `num_views`-camera batch owned by `rank` (round-robin, so any world size divides the work)."""
     return list(range(rank, num_views, world))
 
 
-def allreduce_grads(tensors, average=True, group=None):
-    """Sum (or average) the .grad of every tensor in `tensors` across ranks with ONE collective on a flat bucket.
-    Tensors whose grad is None contribute zeros (a rank whose views saw nothing of a Gaussian)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+# ------------------------------------------------------------------------------------------------------------------
+# the collective itself
+
+def exchange_flat(flat, average=True, group=None, algo="direct", async_op=False):
+    """Sum (or average) the flat fp32 buffer `flat` over the ranks, in place.  len(flat) must be a multiple of the world size.
+
+    algo = "direct": reduce-scatter + all-gather, each ONE step over the full xGMI mesh:
+        all_to_all_single (chunk j of every rank -> rank j; 7 concurrent point-to-point transfers per GPU) -> local sum of the world
+        received chunks (one torch kernel over S/world floats x world) -> all_gather_into_tensor of the owned chunk back into `flat`.
+    algo = "allreduce": one `all_reduce` (the library picks the algorithm; a ring is per-link bound on xGMI).
+    Returns a callable that completes the exchange (waits, finishes the arithmetic); with async_op=False it has already been called."""
+    world = dist.get_world_size(group)
+    n = flat.numel()
+    assert flat.dtype == torch.float32 and flat.is_contiguous()
+    if algo == "direct" and n % world != 0:
+        raise ValueError("exchange_flat('direct') needs a buffer length that is a multiple of the world size (%d %% %d != 0)" % (n, world))
+    scale = (1.0 / world) if average else 1.0
+    if algo == "allreduce":
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+        def done():
+            work.wait()
+            if scale != 1.0:
+                flat.mul_(scale)
+    elif algo == "direct":
+        recv = torch.empty_like(flat)
+        w1 = dist.all_to_all_single(recv, flat, group=group, async_op=True)
+        state = {}
+
+        def done():
+            w1.wait()
+            mine = recv.view(world, n // world).sum(0)             # chunk `rank` of every peer, summed: this rank's share of the result
+            if scale != 1.0:
+                mine.mul_(scale)
+            state["mine"] = mine
+            dist.all_gather_into_tensor(flat, mine, group=group)
+    else:
+        raise ValueError("algo must be 'direct' or 'allreduce', got %r" % (algo,))
+    if not async_op:
+        done()
+        return lambda: None
+    return done
+
+
+class _Bucket:
+    __slots__ = ("params", "ids", "flat", "numel", "offsets", "pending", "done", "launched")
+
+
+class GradExchange:
+    """Persistent flat gradient buffers + the (optionally overlapped) exchange.
+
+    `get_buckets` is a CALLABLE returning the current buckets (lists of parameters) in the order their gradients become final (for
+    EnvGS: the environment set first -- the tracer's backward runs before the base rasterizer's -- then the base set).  It is called
+    again at every `begin_step()`, so parameters replaced by densification / pruning (gaussian2d_utils.py:526-621 makes a fresh
+    nn.Parameter for every tensor) are picked up: the layout is rebuilt whenever the identity or size of any parameter changed.
+
+    Per step:
+        ex.begin_step()              # (re)binds: p.grad = zeroed view of the bucket's flat buffer; arms the hooks
+        loss.backward() [x n]        # autograd accumulates in place into the views; with `overlap`, the LAST backward of the step
+                                     # (ex.arm_last() before it if there are several; default: the first) launches bucket i's exchange
+                                     # from a post-accumulate hook as soon as its last gradient is final -- always in bucket order
+        ex.finish()                  # launches what is left (in order), waits, averages; returns the bytes exchanged
+    Every rank issues the collectives in the same order (bucket 0, 1, ...) regardless of which parameters received a gradient, so ranks
+    whose views saw nothing of a set cannot dead-lock or mismatch sizes; a parameter without a gradient contributes the zeros of its view.
+    With one process (or no process group) only the flat-buffer views are maintained (`p.grad` is still zeroed / valid)."""
+
+    def __init__(self, get_buckets, average=True, group=None, algo="direct", overlap=True):
+        self.get_buckets = get_buckets if callable(get_buckets) else (lambda b=get_buckets: b)
+        self.average, self.group, self.algo, self.overlap = average, group, algo, overlap
+        self.enabled = _active(group)
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.buckets = []
+        self._hooks = []
+        self._armed = False
+        self._in_step = False
+
+    # -- layout ------------------------------------------------------------------------------------------------------
+    def _signature(self, lists):
+        return [[(id(p), tuple(p.shape), p.device) for p in b if p is not None] for b in lists]
+
+    def _rebuild(self, lists):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self.buckets = []
+        for bi, plist in enumerate(lists):
+            plist = [p for p in plist if p is not None]
+            B = _Bucket()
+            B.params, B.ids = plist, [id(p) for p in plist]
+            n = sum(p.numel() for p in plist)
+            B.numel = n
+            pad = (-n) % self.world
+            dev = plist[0].device if plist else torch.device("cpu")
+            B.flat = torch.zeros(n + pad, dtype=torch.float32, device=dev)
+            B.offsets, off = [], 0
+            for p in plist:
+                if p.dtype != torch.float32:
+                    raise RuntimeError("GradExchange: fp32 parameters only (got %s)" % p.dtype)
+                B.offsets.append(off)
+                off += p.numel()
+            self.buckets.append(B)
+            if self.enabled and self.overlap:
+                for p in plist:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._hook(bi)))
+        self._sig = self._signature(lists)
+
+    def begin_step(self):
+        """Call before the first backward of a step (replaces `p.grad = None` / optimizer.zero_grad())."""
+        lists = self.get_buckets()
+        if not self.buckets or self._signature(lists) != self._sig:
+            self._rebuild(lists)
+        for B in self.buckets:
+            B.flat.zero_()
+            for p, off in zip(B.params, B.offsets):
+                v = B.flat[off:off + p.numel()].view(p.shape)
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr() or p.grad.shape != v.shape:
+                    p.grad = v                                       # autograd accumulates IN PLACE into an existing .grad
+            B.pending, B.done, B.launched = len(B.params), None, False
+        self._armed = True
+        self._in_step = True
+
+    def arm_last(self):
+        """Several backward() calls per step (several views per rank): call this right before the LAST one.  Until then the hooks
+        only count nothing and launch nothing."""
+        for B in self.buckets:
+            B.pending = len(B.params)
+        self._armed = True
+
+    def hold(self):
+        """Disarm the hooks for the backward passes that are not the last one of the step."""
+        self._armed = False
+
+    # -- launching ---------------------------------------------------------------------------------------------------
+    def _hook(self, bi):
+        def fn(param):
+            if not (self._armed and self._in_step):
+                return
+            B = self.buckets[bi]
+            if B.launched:
+                raise RuntimeError("GradExchange: a gradient of bucket %d arrived after its exchange was launched -- more than one "
+                                   "backward() in this step?  Call hold() before the early ones and arm_last() before the last." % bi)
+            g = param.grad
+            if g is None or g.data_ptr() < B.flat.data_ptr() or g.data_ptr() >= B.flat.data_ptr() + B.flat.numel() * 4:
+                raise RuntimeError("GradExchange: a parameter's .grad no longer views the flat buffer (was .grad replaced or set to None "
+                                   "after begin_step()?)")
+            B.pending -= 1
+            self._launch_ready()
+        return fn
+
+    def _launch_ready(self):
+        # fixed order on every rank: bucket i only after bucket i-1
+        for B in self.buckets:
+            if B.launched:
+                continue
+            if B.pending > 0:
+                break
+            self._launch(B)
+
+    def _launch(self, B):
+        B.launched = True
+        if B.flat.numel():
+            B.done = exchange_flat(B.flat, average=self.average, group=self.group, algo=self.algo, async_op=True)
+
+    def finish(self):
+        """Call after the last backward(): launches the remaining buckets in order, completes all of them, returns the bytes exchanged."""
+        self._in_step = False
+        if not self.enabled:
+            return 0
+        nbytes = 0
+        for B in self.buckets:
+            if not B.launched:
+                self._launch(B)
+        for B in self.buckets:
+            if B.done is not None:
+                B.done()
+                B.done = None
+            nbytes += B.flat.numel() * 4
+        return nbytes
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# one-shot helpers (no persistent state)
+
+def allreduce_grads(tensors, average=True, group=None, algo="allreduce"):
+    """Sum (or average) the .grad of every tensor in `tensors` across ranks with ONE exchange of a flat bucket (packed here: the
+    stateless form, for callers that do not keep a `GradExchange`).  Tensors whose grad is None contribute zeros (a rank whose views
+    saw nothing of a Gaussian).  Returns the bytes exchanged."""
+    if not _active(group):
         return 0
     tensors = [t for t in tensors if t is not None]
     if not tensors:
         return 0
-    grads = [t.grad if t.grad is not None else torch.zeros_like(t) for t in tensors]
-    flat = torch.cat([g.reshape(-1).float() for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    if average:
-        flat.div_(dist.get_world_size(group))
+    world = dist.get_world_size(group)
+    n = sum(t.numel() for t in tensors)
+    flat = torch.zeros(n + (((-n) % world) if algo == "direct" else 0), dtype=torch.float32, device=tensors[0].device)
     off = 0
-    for t, g in zip(tensors, grads):
-        n = g.numel()
-        new = flat[off:off + n].view_as(g).to(g.dtype)
+    for t in tensors:
+        if t.grad is not None:
+            flat[off:off + t.numel()].copy_(t.grad.reshape(-1))
+        off += t.numel()
+    exchange_flat(flat, average=average, group=group, algo=algo)
+    off = 0
+    for t in tensors:
+        new = flat[off:off + t.numel()].view(t.shape)
         if t.grad is None:
-            t.grad = new.clone()
+            t.grad = new.to(t.dtype).clone()
         else:
             t.grad.copy_(new)
-        off += n
+        off += t.numel()
     return flat.numel() * 4
-
-
-class OverlappedGradReducer:
-    """The gradient exchange of `allreduce_grads`, started from inside the backward pass.
-
-    `buckets` = lists of parameters in the order their gradients become final (for EnvGS: the environment set first -- the tracer's
-    backward runs before the base rasterizer's -- then the base set).  A post-accumulate-grad hook on every parameter launches the
-    bucket's ONE flat all-reduce (async) as soon as its last gradient has been accumulated, so the environment bucket travels over xGMI
-    while the base pass is still differentiating; `finish()` waits, averages and writes the results back into `.grad`.  Numerically
-    identical to `allreduce_grads` bucket by bucket.  With a single process (or no process group) it does nothing."""
-
-    def __init__(self, buckets, average=True, group=None):
-        self.buckets = [[t for t in b if t is not None] for b in buckets]
-        self.average, self.group = average, group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-        self._handles = []
-        self._reset()
-        if self.enabled:
-            for bi, b in enumerate(self.buckets):
-                for t in b:
-                    self._handles.append(t.register_post_accumulate_grad_hook(self._hook(bi)))
-
-    def _reset(self):
-        self._pending = [len(b) for b in self.buckets]
-        self._inflight = [None] * len(self.buckets)
-
-    def _hook(self, bi):
-        def fn(param):
-            self._pending[bi] -= 1
-            if self._pending[bi] == 0 and self._inflight[bi] is None:
-                self._launch(bi)
-        return fn
-
-    def _launch(self, bi):
-        b = self.buckets[bi]
-        if not b:
-            return
-        grads = [t.grad if t.grad is not None else torch.zeros_like(t) for t in b]
-        flat = torch.cat([g.reshape(-1).float() for g in grads])
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._inflight[bi] = (flat, grads, work)
-
-    def finish(self):
-        """Call after backward(): completes every bucket (launching those whose hooks did not all fire -- a parameter without a
-        gradient this step) and returns the bytes exchanged."""
-        if not self.enabled:
-            return 0
-        nbytes = 0
-        world = dist.get_world_size(self.group)
-        for bi, b in enumerate(self.buckets):
-            if not b:
-                continue
-            if self._inflight[bi] is None:
-                self._launch(bi)
-            flat, grads, work = self._inflight[bi]
-            work.wait()
-            if self.average:
-                flat.div_(world)
-            off = 0
-            for t, g in zip(b, grads):
-                n = g.numel()
-                new = flat[off:off + n].view_as(g).to(g.dtype)
-                if t.grad is None:
-                    t.grad = new.clone()
-                else:
-                    t.grad.copy_(new)
-                off += n
-            nbytes += flat.numel() * 4
-        self._reset()
-        return nbytes
-
-    def remove(self):
-        for h in self._handles:
-            h.remove()
-        self._handles = []
 
 
 def allreduce_densify_stats(grad_norm_accum, denom, weight_accum, max_radii, group=None):
     """Make the densification statistics identical on every rank: sums for the accumulators
     (gaussian2d_utils.py:901-909), max for the screen radii (gaussian2d_sampler.py:330-332)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _active(group):
         return
     flat = torch.cat([grad_norm_accum.reshape(-1).float(), denom.reshape(-1).float(), weight_accum.reshape(-1).float()])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

@@ -53,20 +53,25 @@ def _stream(dev):
 
 import weakref
 
-_DEG_CACHE = weakref.WeakKeyDictionary()
+_DEG_CACHE = {}      # id(tensor) -> (weakref to the tensor, in-place version, value)
 
 
 def sh_degree_of(deg):
     """settings.sh_degree is a 1-element tensor in the reference (a registered buffer on the GPU, gaussian2d_utils.py:294) and
     reading it is a host sync.  The value is cached per tensor OBJECT and in-place version (the reference passes the same buffer
-    every iteration and bumps it in place once every 1000 iterations); a fresh tensor is always read."""
+    every iteration and bumps it in place once every 1000 iterations); a fresh tensor is always read.  The cache is keyed by id()
+    and validated through a weak reference -- no Tensor.__eq__ (a kernel launch + sync on a GPU buffer) is ever evaluated."""
     if not torch.is_tensor(deg):
         return int(deg)
-    hit = _DEG_CACHE.get(deg)
-    if hit is not None and hit[0] == deg._version:
-        return hit[1]
-    v = int(deg.item())
-    _DEG_CACHE[deg] = (deg._version, v)
+    key = id(deg)
+    hit = _DEG_CACHE.get(key)
+    if hit is not None and hit[0]() is deg and hit[1] == deg._version:
+        return hit[2]
+    v = int(deg.reshape(-1)[0].item())
+    if len(_DEG_CACHE) > 64:                                  # drop entries whose tensor died (ids are recycled)
+        for k in [k for k, h in _DEG_CACHE.items() if h[0]() is None]:
+            del _DEG_CACHE[k]
+    _DEG_CACHE[key] = (weakref.ref(deg), deg._version, v)
     return v
 
 

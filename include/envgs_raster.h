@@ -138,6 +138,20 @@ ENVGS_API void envgs_prof_enable(int on);
 ENVGS_API int envgs_prof_read(int kernel_id, double *total_ms, int *launches);
 ENVGS_API const char *envgs_prof_kernel_name(int kernel_id);
 
+/*
+ * Diagnostic switches for experiments and tests (scratch/, tests/, bench.py --debug-*): process-global, all 0 in production.
+ * The library never reads the environment; whoever sets a switch is responsible for reporting it (bench.py prints them).
+ *   ENVGS_DBG_TRACE  bit mask: 8 = atomic-flush tracer backward instead of records, 16 = binary packet traversal instead of the 4-wide one,
+ *                    64 = no coherence sort of the rays, 512 = per-ray collection kernel even when the rays are sorted,
+ *                    1024 = packet stack limited to 2 entries (forces the stack-overflow hand-off to the K-buffer path; tests only)
+ *   ENVGS_DBG_SEGMENTS  forward batch segments of the tracer (0 = default 2; 1 = single launch)
+ */
+#define ENVGS_DBG_TRACE 0
+#define ENVGS_DBG_SEGMENTS 1
+#define ENVGS_DBG_COUNT 2
+ENVGS_API void envgs_debug_set(int32_t which, int32_t value);
+ENVGS_API int32_t envgs_debug_get(int32_t which);
+
 #ifdef __cplusplus
 }
 #endif

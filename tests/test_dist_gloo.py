@@ -55,50 +55,76 @@ def test_flat_grad_allreduce_and_view_sharding_world2():
         assert torch.allclose(st[2], torch.full((4,), 1.5)) and st[3].tolist() == [5, 9, 3, 8]
 
 
-def _worker_overlap(rank, world, port, q):
+def _worker_exchange(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from envgs_amd import dist as edist
     edist.init_from_env(backend="gloo")
     torch.manual_seed(1)
-    env = [torch.randn(6, 3, requires_grad=True), torch.randn(6, requires_grad=True)]
-    base = [torch.randn(4, 2, requires_grad=True), torch.randn(4, requires_grad=True), torch.randn(3, requires_grad=True)]   # the last one stays unused
-    red = edist.OverlappedGradReducer([env, base], average=True)
+    sets = dict(env=[torch.nn.Parameter(torch.randn(6, 3)), torch.nn.Parameter(torch.randn(6))],
+                base=[torch.nn.Parameter(torch.randn(4, 2)), torch.nn.Parameter(torch.randn(4)), torch.nn.Parameter(torch.randn(3))])   # base[2] stays unused
+    ex = edist.GradExchange(lambda: [sets["env"], sets["base"]], average=True, algo="direct", overlap=True)
     out = []
-    for step in range(2):                                            # hooks must re-arm every step
-        for t in env + base:
-            t.grad = None
+    for step in range(4):
+        if step == 2:
+            # "densification": every tensor of the base set is replaced by a fresh, LONGER nn.Parameter (gaussian2d_utils.py:526-621)
+            sets["base"] = [torch.nn.Parameter(torch.cat([p.detach(), p.detach()[:1]])) for p in sets["base"]]
+        env, base = sets["env"], sets["base"]
+        ex.begin_step()
         x = float(rank + 1 + step)
-        loss = (env[0] * x).sum() + (env[1] * env[1] * x).sum() + (base[0] * 2 * x).sum() + (base[1] * x).sum() + (env[0] * base[0].sum()).sum()
-        loss.backward()
-        nbytes = red.finish()
-        out.append((nbytes, [None if t.grad is None else t.grad.tolist() for t in env + base]))     # plain lists: no shared-memory handles
-    red.remove()
-    q.put((rank, out, [t.detach().tolist() for t in env + base]))
+        if step == 3:
+            # two backward passes in one step (two views on this rank); on rank 1 the env set gets NO gradient from the last one, so its
+            # bucket can only be launched by finish() -- the launch order must still be env, base on both ranks
+            ex.hold()
+            ((env[0] * x).sum() + (env[1] * env[1] * x).sum()).backward()
+            ex.arm_last()
+            l2 = (base[0] * 2 * x).sum() + (base[1] * x).sum()
+            if rank == 0:
+                l2 = l2 + (env[0] * base[0].sum()).sum()
+            l2.backward()
+        else:
+            loss = (env[0] * x).sum() + (env[1] * env[1] * x).sum() + (base[0] * 2 * x).sum() + (base[1] * x).sum() + (env[0] * base[0].sum()).sum()
+            loss.backward()
+        nbytes = ex.finish()
+        assert all(p.grad is not None and p.grad.data_ptr() >= B.flat.data_ptr() for B in ex.buckets for p in B.params)    # still views
+        out.append((nbytes, [t.grad.tolist() for t in env + base], [t.detach().tolist() for t in env + base]))
+    # the stateless helper with the direct algorithm equals the plain all-reduce
+    a = torch.zeros(5, 3, requires_grad=True); a.grad = torch.full((5, 3), float(rank + 1))
+    edist.allreduce_grads([a], average=False, algo="direct")
+    ex.remove()
+    q.put((rank, out, a.grad.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(120)
-def test_overlapped_reducer_matches_plain_average_world2():
+def test_grad_exchange_flat_views_overlap_densify_and_multi_backward_world2():
+    """GradExchange: persistent flat buffers the .grad tensors view, direct reduce-scatter + all-gather, hooks that launch in a fixed
+    bucket order, parameters replaced by densification, several backward passes per step, grad-presence that differs between ranks."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_overlap, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_exchange, args=(r, world, port, q)) for r in range(world)]
     for p in procs: p.start()
     res = sorted([q.get(timeout=90) for _ in range(world)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
-    vals = [torch.tensor(v) for v in res[0][2]]                      # same seed: identical parameters on both ranks
-    for step in range(2):
+    for step in range(4):
+        vals = [torch.tensor(v) for v in res[0][1][step][2]]             # same seed: identical parameters on both ranks
+        assert all(torch.equal(torch.tensor(a), torch.tensor(b)) for a, b in zip(res[0][1][step][2], res[1][1][step][2]))
         xs = [1.0 + step, 2.0 + step]
         xm = sum(xs) / 2
-        exp = [torch.full((6, 3), xm) + vals[2].sum(), 2 * vals[1] * xm, torch.full((4, 2), 2 * xm) + vals[0].sum(), torch.full((4,), xm), torch.zeros(3)]
+        nb = vals[2].shape[0]
+        cross_env = vals[2].sum() * (0.5 if step == 3 else 1.0)           # step 3: only rank 0 has the coupling term
+        cross_base = vals[0].sum() * (0.5 if step == 3 else 1.0)
+        exp = [torch.full((6, 3), xm) + cross_env, 2 * vals[1] * xm, torch.full((nb, 2), 2 * xm) + cross_base, torch.full((nb,), xm), torch.zeros(nb - 1)]
         for rank, out, _ in res:
-            nbytes, grads = out[step]
-            assert nbytes == (18 + 6 + 8 + 4 + 3) * 4                # two flat buckets
+            nbytes, grads, _ = out[step]
+            assert nbytes == (18 + 6 + (4 * nb - 1) + ((4 * nb - 1) % 2)) * 4        # two flat buckets (padded to the world size)
             for g, e in zip(grads, exp):
-                assert g is not None and torch.allclose(torch.tensor(g), e, atol=1e-6), (step, rank, g, e)
+                assert torch.allclose(torch.tensor(g), e, atol=1e-5), (step, rank, g, e)
+    for rank, _, ga in res:
+        assert torch.allclose(torch.tensor(ga), torch.full((5, 3), 3.0))
 
 
 def test_single_process_is_a_noop():
