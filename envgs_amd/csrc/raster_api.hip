@@ -68,6 +68,20 @@ int envgs_raster_bin_and_render(const envgs_raster_cfg *cfg, uint32_t N, const f
     return launch_render_fwd(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream);
 }
 
+int envgs_raster_render_audit(const envgs_raster_cfg *cfg, const float *geom, const float *colors, const float *bg,
+                              const uint32_t *point_list, const uint32_t *ranges, float *out_color, float *allmap, float *final_T,
+                              int32_t *n_contrib, float *weight, uint8_t *contrib, int32_t lmax, void *stream_)
+{
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!ranges || !out_color || !allmap || !final_T || !n_contrib || !bg || !contrib || lmax <= 0) return ENVGS_ERR_BAD_ARG;
+    if (cfg->P > 0 && (!geom || !colors || !weight || !point_list)) return ENVGS_ERR_BAD_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    hipError_t e = hipMemsetAsync(contrib, 0, (size_t)cfg->width * cfg->height * (size_t)lmax, stream);
+    if (e != hipSuccess) return (int)e;
+    return launch_render_fwd(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream, contrib, lmax);
+}
+
 int envgs_raster_backward(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const float *colors, const float *bg,
                           const uint32_t *point_list, const uint32_t *ranges, const float *final_T,
                           const int32_t *n_contrib, const float *dL_dcolor, const float *dL_dallmap, const float *means3D,

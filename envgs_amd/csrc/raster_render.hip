@@ -102,12 +102,14 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float4 r0, const float4 
 }
 
 // ------------------------------------------------------------------------------------------ R6 ---
-template <int C>
+// AUDIT = true is the parity-audit instantiation of the SAME kernel (envgs_raster_render_audit): it additionally records, per pixel and
+// list entry, whether the entry was blended (contrib[pid][entry] = 1), so that tests can compare contributor SETS with the oracle.
+template <int C, bool AUDIT>
 __global__ void __launch_bounds__(256)
 composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list,
               const float *__restrict__ geom, const float *__restrict__ colors, const float *__restrict__ bg,
               float *__restrict__ out_color, float *__restrict__ allmap, float *__restrict__ final_T,
-              int32_t *__restrict__ n_contrib, float *__restrict__ weight)
+              int32_t *__restrict__ n_contrib, float *__restrict__ weight, uint8_t *__restrict__ audit_contrib, int audit_lmax)
 {
     __shared__ TileLds<C> lds;
     __shared__ float wacc[256];            // per-splat weight summed over the 4 wavefronts before it leaves the CU
@@ -163,6 +165,7 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
                 M1 += m * w;
                 M2 += m * m * w;
                 const int32_t contributor = (int32_t)(base - r0) + j + 1;
+                if (AUDIT) { if (contributor <= audit_lmax) audit_contrib[((size_t)pyi * W + pxi) * (size_t)audit_lmax + (contributor - 1)] = 1; }
                 if (T > 0.5f) { med = h.depth; medc = contributor; }
                 N0 += r2.w * w; N1 += r3.x * w; N2 += r3.y * w;
 #pragma unroll
@@ -366,28 +369,33 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
 template <int C>
 static int run_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                    const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
-                   int32_t *n_contrib, float *weight, hipStream_t stream)
+                   int32_t *n_contrib, float *weight, uint8_t *audit_contrib, int audit_lmax, hipStream_t stream)
 {
     const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
     ProfScope prof_(K_COMPOSITE_FWD, stream);
-    hipLaunchKernelGGL(composite_fwd<C>, dim3(8 * ((gx * gy + 7) / 8)), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
-                       point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight);
+    const dim3 grid(8 * ((gx * gy + 7) / 8)), block(256);
+    if (audit_contrib)
+        hipLaunchKernelGGL((composite_fwd<C, true>), grid, block, 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
+                           point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax);
+    else
+        hipLaunchKernelGGL((composite_fwd<C, false>), grid, block, 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
+                           point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, (uint8_t *)nullptr, 0);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;
 }
 
 int launch_render_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                       const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
-                      int32_t *n_contrib, float *weight, hipStream_t stream)
+                      int32_t *n_contrib, float *weight, hipStream_t stream, uint8_t *audit_contrib, int audit_lmax)
 {
     if (cfg->P > 0) {
         hipError_t e = hipMemsetAsync(weight, 0, sizeof(float) * (size_t)cfg->P, stream);
         if (e != hipSuccess) return (int)e;
     }
     switch (cfg->channels) {
-    case 3: return run_fwd<3>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream);
-    case 5: return run_fwd<5>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream);
-    case 7: return run_fwd<7>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream);
+    case 3: return run_fwd<3>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream);
+    case 5: return run_fwd<5>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream);
+    case 7: return run_fwd<7>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream);
     default: return ENVGS_ERR_BAD_ARG;
     }
 }

@@ -50,9 +50,14 @@ __device__ __forceinline__ SurfHit hit_surfel(const float4 s0, const float4 s1, 
                                               const float dy, const float dz)
 {
     SurfHit h;
-    h.denom = s3.x * dx + s3.y * dy + s3.z * dz;
-    const float num = s3.x * (s0.x - ox) + s3.y * (s0.y - oy) + s3.z * (s0.z - oz);
-    h.t = num / h.denom;
+    {
+        // t is the SORT KEY of the per-ray hit lists (index work: bit-exact against the oracle, like the rasterizer's depth keys): fixed
+        // evaluation order, no FMA contraction, IEEE division.  The normal in the surfel record is built the same way (make_surfel_records).
+#pragma clang fp contract(off)
+        h.denom = s3.x * dx + s3.y * dy + s3.z * dz;
+        const float num = s3.x * (s0.x - ox) + s3.y * (s0.y - oy) + s3.z * (s0.z - oz);
+        h.t = num / h.denom;
+    }
     const float qx = ox + h.t * dx - s0.x, qy = oy + h.t * dy - s0.y, qz = oz + h.t * dz - s0.z;
     h.u = s1.x * qx + s1.y * qy + s1.z * qz;
     h.v = s2.x * qx + s2.y * qy + s2.z * qz;

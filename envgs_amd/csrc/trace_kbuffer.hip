@@ -9,6 +9,7 @@ __global__ void __launch_bounds__(256)
 make_surfel_records(int P, float mod, const float *__restrict__ means, const float *__restrict__ scales,
                     const float *__restrict__ rots, const float *__restrict__ opac, float *__restrict__ srec)
 {
+#pragma clang fp contract(off)      // the frame feeds the hit distance t, a sort key that is bit-exact against the oracle (see hit_surfel)
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const float q0 = rots[4 * i], q1 = rots[4 * i + 1], q2 = rots[4 * i + 2], q3 = rots[4 * i + 3];

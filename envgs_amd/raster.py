@@ -149,6 +149,24 @@ def rasterize_forward(C, means3D, shs, colors_precomp, opacities, scales, rotati
     return (out_color, radii, allmap, weight), saved
 
 
+def render_audit(saved, lmax):
+    """Parity audit (tests): re-runs the compositing kernel in its AUDIT instantiation on the saved binning state and returns
+    (contrib (H*W, lmax) uint8, n_contrib (2,H,W), out_color) -- see envgs_raster_render_audit."""
+    lib = _lib.load()
+    cfg = saved["cfg"]
+    dev = saved["geom"].device
+    H, W, C, P = cfg.height, cfg.width, cfg.channels, cfg.P
+    f32 = dict(dtype=torch.float32, device=dev)
+    out_color = torch.empty(C, H, W, **f32); allmap = torch.empty(7, H, W, **f32); final_T = torch.empty(3, H, W, **f32)
+    n_contrib = torch.empty(2, H, W, dtype=torch.int32, device=dev); weight = torch.empty(max(P, 1), **f32)
+    contrib = torch.empty(H * W, int(lmax), dtype=torch.uint8, device=dev)
+    p = _lib.ptr
+    _lib.check(lib.envgs_raster_render_audit(cfg, p(saved["geom"]), p(saved["colors"]), p(saved["bg"]), p(saved["point_list"]),
+                                             p(saved["ranges"]), p(out_color), p(allmap), p(final_T), p(n_contrib), p(weight),
+                                             p(contrib), int(lmax), _stream(dev)), "envgs_raster_render_audit")
+    return contrib, n_contrib, out_color
+
+
 def rasterize_backward(saved, dL_dcolor, dL_dallmap):
     """R7+R8 through the C-ABI.  Returns dict of parameter gradients (None where not applicable)."""
     lib = _lib.load()

@@ -118,65 +118,11 @@ def _next_cap(dev):
     return HIT_CAP["cap"]
 
 
-BOUNCE_LISTS = {"on": True}  # specular bounces as one list-path trace per stage (False: all stages inside the K-buffer kernel)
-
-
-def _trace_forward_bounces(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_precomp, opacities, scales, rotations, settings,
-                           start_from_first, need_grad):
-    """max_trace_depth > 0 on the list path: stage 0 is the ordinary bounce-free trace (it alone is differentiated and it alone feeds
-    `wet`), every further stage is a forward-only list-path trace of the rays that bounce -- o + d * dpt / acc along d - 2 (d.n) n when
-    aux[0] > specular_threshold and acc > 0.5 -- and the stage colours are blended back to front, (1 - s_k) rgb_k + s_k rgb_{k+1}.
-    Same semantics as the in-kernel stages of the K-buffer path (and the oracle); ~20x faster on the bench scene."""
-    depth = int(settings.max_trace_depth)
-    s0 = settings._replace(max_trace_depth=0)
-    lead = tuple(ray_o.shape[:-1])
-    outs, saved = trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_precomp, opacities, scales, rotations, s0,
-                                start_from_first, need_grad=need_grad)
-    rgb0, dpt0, acc0, norm0, dist0, aux0, mid0, wet = outs
-    R = saved["ro"].shape[0]
-    dev = means3D.device
-    thr = float(settings.specular_threshold)
-    flat = lambda t, c: t.reshape(R, c)
-    stages = [dict(o=saved["ro"], d=saved["rd"], rgb=flat(rgb0, 3), dpt=flat(dpt0, 1), acc=flat(acc0, 1), norm=flat(norm0, 3), aux=flat(aux0, 2),
-                   idx=torch.arange(R, device=dev))]
-    for k in range(1, depth + 1):
-        p = stages[-1]
-        nl = p["norm"].norm(dim=-1, keepdim=True)
-        go = ((p["aux"][:, 0:1] > thr) & (p["acc"] > 0.5) & (nl > 0.0))[:, 0]
-        sel = go.nonzero(as_tuple=False)[:, 0]
-        if sel.numel() == 0:
-            break
-        o, d = p["o"][sel], p["d"][sel]
-        nh = p["norm"][sel] / nl[sel]
-        tdep = p["dpt"][sel] / p["acc"][sel]
-        dn = (d * nh).sum(-1, keepdim=True)
-        o2 = (o + d * tdep).contiguous()
-        d2 = (d - 2.0 * dn * nh).contiguous()
-        with torch.no_grad():
-            (r2, dp2, ac2, no2, _, au2, _, _), _ = trace_forward(nodes, o2, d2, means3D, shs, colors_precomp, others_precomp, opacities, scales, rotations,
-                                                                 s0, 2, need_grad=False)
-        stages.append(dict(o=o2, d=d2, rgb=r2, dpt=dp2, acc=ac2, norm=no2, aux=au2, idx=p["idx"][sel], sel=sel))
-    # blend back to front (each stage lives on the subset of its parent's rays that bounced)
-    col = stages[-1]["rgb"]
-    for k in range(len(stages) - 2, -1, -1):
-        p, c = stages[k], stages[k + 1]
-        out = p["rgb"].clone()
-        s = p["aux"][c["sel"], 0:1]
-        out[c["sel"]] = (1.0 - s) * p["rgb"][c["sel"]] + s * col
-        col = out
-    mid = torch.zeros(R, 16 * (depth + 1), dtype=torch.float32, device=dev)
-    for k, st in enumerate(stages):
-        mid[st["idx"], 16 * k:16 * k + 16] = torch.cat([st["o"], st["d"], st["dpt"], st["acc"], st["norm"], st["aux"], st["rgb"]], dim=1)
-    outs = (col.reshape(lead + (3,)), dpt0, acc0, norm0, dist0, aux0, mid.reshape(lead + (16 * (depth + 1),)), wet)
-    return outs, saved
+KEEP_LISTS = {"on": False}   # tests: keep the last forward's per-ray hit lists reachable through last_hit_lists()
 
 
 def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_precomp, opacities, scales, rotations, settings,
                   start_from_first, use_lists=True, need_grad=True):
-    if (int(settings.max_trace_depth) > 0 and use_lists and BOUNCE_LISTS["on"] and HIT_CAP.get("force", 1) != 0 and means3D.shape[0] > 0
-            and ray_o.numel() > 0):
-        return _trace_forward_bounces(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_precomp, opacities, scales, rotations, settings,
-                                      start_from_first, need_grad)
     lib = _lib.load()
     dev = means3D.device
     lead = tuple(ray_o.shape[:-1])
@@ -222,7 +168,8 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
                                        p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),
                                        p(norm), p(dist), p(aux), p(mid), p(wet), p(final_T), lists, _stream(dev)), "envgs_trace_forward")
-    LAST_STATS.update(P=P, R=R, counters=counters, n_entries=keep.get("n_entries"))
+    LAST_STATS.update(P=P, R=R, counters=counters, n_entries=keep.get("n_entries"), cap=cap,
+                      lists=((keep["hit_lists"], keep["n_used"], keep["hit_cnt"]) if (cap and KEEP_LISTS["on"]) else None))
     if cap:
         # asynchronous read-backs for later: the longest list (sizes the next call's cap) and the number of gradient records
         m = _mirror("max_list", dev)
@@ -232,7 +179,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
         keep["n_rec_event"] = torch.cuda.Event(); keep["n_rec_event"].record(torch.cuda.current_stream(dev))
     saved = dict(cfg=cfg, nodes=nodes, ro=ro, rd=rd, means3D=means3D, scales=scales, rotations=rotations, opacities=opacities,
                  shs=shs, colors_precomp=colors_precomp, others=others_precomp, bg=bg, srec=srec, counters=counters,
-                 rgb=(rgb if ND == 1 else mid[:, 13:16].contiguous()),      # the backward differentiates STAGE 0: its own colour, not the blend
+                 rgb=(rgb if ND == 1 else mid[:, 13:16].contiguous()),      # (C-ABI in-kernel bounces, forward use only: stage 0's own colour)
                  dpt=dpt, acc=acc, norm=norm, aux=aux, final_T=final_T, lead=lead, lists=lists, keep=keep, cap=cap)
     outs = (rgb.reshape(lead + (3,)), dpt.reshape(lead + (1,)), acc.reshape(lead + (1,)), norm.reshape(lead + (3,)),
             dist.reshape(lead + (1,)), aux.reshape(lead + (2,)), mid.reshape(lead + (16 * ND,)), wet)
@@ -277,6 +224,46 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
     lead = s["lead"]
     return dict(ray_o=dro.reshape(lead + (3,)), ray_d=drd.reshape(lead + (3,)), means3D=dmeans, grads3D=dgrads3D, shs=dshs,
                 colors_precomp=dcolors, others_precomp=dothers, opacities=dopac, scales=dscales, rotations=drots)
+
+
+def frame_from_transmat(cov3D_precomp, settings):
+    """Invert the python transMat of optix_utils.py:143-154 / gaussian2d_utils.py:1050-1061:
+
+        T = (splat2world[:, [0,1,3]] @ world2pix[:, [0,1,3]]).permute(0,2,1).reshape(-1,9),   world2pix = full_proj @ ndc2pix
+
+    Row r of splat2world[:, [0,1,3]] is (s_u a, 0), (s_v b, 0), (p, 1), so with PM = world2pix[:, [0,1,3]] (4x3) and PM3 = PM[:3]:
+    s_u a = M_u PM3^-1, s_v b = M_v PM3^-1 where M = T.reshape(3,3)^T.  Returns (scales (P,2) with scale_modifier divided out,
+    rotations (P,4) unit quaternions (r,x,y,z) of the frame [a, b, a x b]); plain torch expressions, so autograd carries the tracer's
+    gradients back to cov3D_precomp."""
+    T = cov3D_precomp
+    if T.dtype != torch.float32:
+        T = T.float()
+    dev = T.device
+    W, H = float(settings.image_width), float(settings.image_height)
+    fp = settings.projmatrix.to(dev).float()
+    PM = torch.stack([0.5 * W * fp[:, 0] + 0.5 * (W - 1.0) * fp[:, 3], 0.5 * H * fp[:, 1] + 0.5 * (H - 1.0) * fp[:, 3], fp[:, 3]], dim=1)   # (4,3)
+    inv = torch.linalg.inv(PM[:3].double()).float()                     # (3,3)
+    M = T.reshape(-1, 3, 3).transpose(1, 2)                              # rows: u, v, 1 ; columns: x*w, y*w, w
+    A = M[:, 0] @ inv; B = M[:, 1] @ inv                                # s_u a, s_v b   (P,3)
+    su = A.norm(dim=-1, keepdim=True); sv = B.norm(dim=-1, keepdim=True)
+    a = A / su; b = B / sv
+    n = torch.cross(a, b, dim=-1)
+    # rotation matrix with columns a, b, n -> quaternion; all four candidate forms, the numerically largest one selected
+    m00, m10, m20 = a[:, 0], a[:, 1], a[:, 2]
+    m01, m11, m21 = b[:, 0], b[:, 1], b[:, 2]
+    m02, m12, m22 = n[:, 0], n[:, 1], n[:, 2]
+    q_abs = torch.sqrt(torch.clamp_min(torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22, 1.0 - m00 - m11 + m22], dim=-1), 1e-12))
+    cand = torch.stack([
+        torch.stack([q_abs[:, 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
+        torch.stack([m21 - m12, q_abs[:, 1] ** 2, m10 + m01, m02 + m20], dim=-1),
+        torch.stack([m02 - m20, m10 + m01, q_abs[:, 2] ** 2, m12 + m21], dim=-1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[:, 3] ** 2], dim=-1)], dim=1)          # (P,4 candidates,4)
+    cand = cand / (2.0 * q_abs[..., None])
+    best = q_abs.detach().argmax(dim=-1)
+    q = cand[torch.arange(cand.shape[0], device=dev), best]
+    q = q / q.norm(dim=-1, keepdim=True)
+    mod = float(settings.scale_modifier)
+    return torch.cat([su, sv], dim=-1) / mod, q
 
 
 class _TraceSurfels(torch.autograd.Function):
@@ -329,11 +316,12 @@ class SurfelTracer(nn.Module):
                 opacities=None, scales=None, rotations=None, cov3D_precomp=None, tracer_settings=None, start_from_first=True):
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
-        if cov3D_precomp is not None:
-            raise Exception('The HIP surfel tracer intersects surfels analytically in world space and needs scales / rotations; '
-                            'a precomputed screen-space transMat (cov3D_precomp) cannot be traced.')
-        if scales is None or rotations is None:
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        if cov3D_precomp is not None:
+            # pipe.compute_cov3D_python (optix_utils.py:143-154): the caller hands over the screen-space transMat.  The tracer intersects
+            # surfels in WORLD space, so the tangent frame is recovered from it (differentiably: the gradient reaches cov3D_precomp)
+            scales, rotations = frame_from_transmat(cov3D_precomp, tracer_settings)
         if self.nodes is None and self._pending is None:
             if v is None:
                 raise RuntimeError("SurfelTracer: no acceleration structure; call build_acceleration_structure first")
@@ -349,9 +337,77 @@ class SurfelTracer(nn.Module):
         if grads3D is None:
             grads3D = torch.zeros_like(means3D)
         e = torch.Tensor([])
-        return _TraceSurfels.apply(ray_o, ray_d, v, means3D, grads3D, e if shs is None else shs,
-                                   e if colors_precomp is None else colors_precomp, e if others_precomp is None else others_precomp,
-                                   opacities, scales, rotations, None, tracer_settings, bool(start_from_first), self.nodes)
+        args = (v, means3D, grads3D, e if shs is None else shs, e if colors_precomp is None else colors_precomp,
+                e if others_precomp is None else others_precomp, opacities, scales, rotations, None)
+        depth = int(tracer_settings.max_trace_depth)
+        if depth == 0 or ray_o.numel() == 0 or means3D.shape[0] == 0:
+            return _TraceSurfels.apply(ray_o, ray_d, *args, tracer_settings._replace(max_trace_depth=0), bool(start_from_first), self.nodes)
+        return self._forward_bounces(ray_o, ray_d, args, tracer_settings, bool(start_from_first))
+
+    def _forward_bounces(self, ray_o, ray_d, args, settings, start_from_first):
+        """max_trace_depth > 0 (gaussian2d_sampler.py:413-426, optix_utils.py:117-118): every stage is one bounce-free traced call
+        (the differentiable `_TraceSurfels` node, list path), glued by ordinary torch expressions that autograd differentiates:
+
+            stage k bounces where aux_k[0] > specular_threshold, acc_k > 0.5 and |norm_k| > 0
+            o_{k+1} = o_k + d_k * dpt_k / acc_k          d_{k+1} = d_k - 2 (d_k . n) n,  n = norm_k / |norm_k|       (t_min = 1e-3)
+            rgb = (1 - s_0) rgb_0 + s_0 ((1 - s_1) rgb_1 + s_1 (...)),   s_k = aux_k[0]
+
+        so the backward IS the derivative of the returned `rgb`: through every stage's colour, through the blend weights s_k (into the
+        `others_precomp` channel and the opacities / geometry that composite it), and through the reflected-ray construction into the
+        previous stage's depth, accumulation and normal.  dpt / acc / norm / dist / aux / wet are stage 0's, as in the single-stage call;
+        `mid` holds the 16 channels of every stage (non-differentiable)."""
+        depth = int(settings.max_trace_depth)
+        thr = float(settings.specular_threshold)
+        s0 = settings._replace(max_trace_depth=0)
+        lead = tuple(ray_o.shape[:-1])
+        o = ray_o.reshape(-1, 3); d = ray_d.reshape(-1, 3)
+        R = o.shape[0]
+        dev = o.device
+        out0 = _TraceSurfels.apply(o, d, *args, s0, start_from_first, self.nodes)
+        stages = [dict(o=o, d=d, out=out0, idx=torch.arange(R, device=dev), sel=None)]
+        for k in range(1, depth + 1):
+            p = stages[-1]
+            rgb, dpt, acc, norm = p["out"][0], p["out"][1], p["out"][2], p["out"][3]
+            aux = p["out"][5]
+            with torch.no_grad():
+                nl = norm.norm(dim=-1, keepdim=True)
+                go = ((aux[:, 0:1] > thr) & (acc > 0.5) & (nl > 0.0))[:, 0]
+                sel = go.nonzero(as_tuple=False)[:, 0]
+            if sel.numel() == 0:
+                break
+            po, pd = p["o"][sel], p["d"][sel]
+            nsel = norm[sel]
+            nh = nsel / nsel.norm(dim=-1, keepdim=True)
+            tdep = dpt[sel] / acc[sel]
+            o2 = po + pd * tdep
+            d2 = pd - 2.0 * (pd * nh).sum(-1, keepdim=True) * nh
+            out = _TraceSurfels.apply(o2, d2, *args, s0, 2, self.nodes)
+            stages.append(dict(o=o2, d=d2, out=out, idx=p["idx"][sel], sel=sel))
+        col = stages[-1]["out"][0]
+        for k in range(len(stages) - 2, -1, -1):
+            p, c = stages[k], stages[k + 1]
+            prgb = p["out"][0]
+            s = p["out"][5][c["sel"], 0:1]
+            col = prgb.index_put((c["sel"],), (1.0 - s) * prgb[c["sel"]] + s * col)
+        with torch.no_grad():
+            mid = torch.zeros(R, 16 * (depth + 1), dtype=torch.float32, device=dev)
+            for k, st in enumerate(stages):
+                r_, dp_, ac_, no_, _, au_ = st["out"][:6]
+                mid[st["idx"], 16 * k:16 * k + 16] = torch.cat([st["o"], st["d"], dp_, ac_, no_, au_, r_], dim=1).float()
+        rgb0, dpt0, acc0, norm0, dist0, aux0, mid0, wet = out0
+        return (col.reshape(lead + (3,)), dpt0.reshape(lead + (1,)), acc0.reshape(lead + (1,)), norm0.reshape(lead + (3,)),
+                dist0.reshape(lead + (1,)), aux0.reshape(lead + (2,)), mid.reshape(lead + (16 * (depth + 1),)), wet)
+
+
+def last_hit_lists():
+    """Tests (KEEP_LISTS on): the sorted per-ray hit lists of the most recent list-path forward -- (ids (R,cap) int32 front to back,
+    tbits (R,cap) int32 = float bits of the hit distances, n_used (R,) hits composited before termination, hit_cnt (R,) hits found;
+    > cap = the ray took the K-buffer path)."""
+    L = LAST_STATS.get("lists")
+    if L is None:
+        return None
+    hl, n_used, hit_cnt = L
+    return hl[:, :, 1].contiguous(), hl[:, :, 0].contiguous(), n_used, hit_cnt
 
 
 def last_entry_counts():

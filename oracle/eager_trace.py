@@ -23,8 +23,9 @@ def _sh_basis(deg, d):
 
 
 def trace(ray_o, ray_d, means3D, scales, rotations, opacities, *, shs=None, colors_precomp=None, others=None, sh_degree=0,
-          bg=None, start_from_first=True, scale_modifier=1.0):
-    """Stage-0 tracing.  Returns rgb (R,3), dpt (R), acc (R), norm (R,3), aux (R,2), wet (P)."""
+          bg=None, start_from_first=True, scale_modifier=1.0, tmin=None):
+    """One stage of tracing.  Returns rgb (R,3), dpt (R), acc (R), norm (R,3), aux (R,2), wet (P).  tmin overrides the start_from_first rule
+    (bounce stages start at 1e-3)."""
     dt = means3D.dtype
     R_, P = ray_o.shape[0], means3D.shape[0]
     Rm = _rotmat(rotations)
@@ -34,7 +35,8 @@ def trace(ray_o, ray_d, means3D, scales, rotations, opacities, *, shs=None, colo
     num = (n * means3D).sum(-1)[None] - ray_o @ n.t()
     ok = denom != 0
     t = num / torch.where(ok, denom, torch.ones_like(denom))
-    tmin = NEAR_N if start_from_first else 0.0
+    if tmin is None:
+        tmin = NEAR_N if start_from_first else 0.0
     q = ray_o[:, None] + t[..., None] * ray_d[:, None] - means3D[None]  # (R,P,3)
     u = (q * a[None]).sum(-1) / su[None]; v = (q * b[None]).sum(-1) / sv[None]
     G = torch.exp(-0.5 * (u * u + v * v))
@@ -80,3 +82,32 @@ def trace(ray_o, ray_d, means3D, scales, rotations, opacities, *, shs=None, colo
         aux = torch.zeros(R_, 2, dtype=dt)
     wet = torch.zeros(P, dtype=dt).index_add(0, order.reshape(-1), w.detach().reshape(-1))
     return rgb, dpt, acc, norm, aux, wet
+
+
+def trace_bounces(ray_o, ray_d, means3D, scales, rotations, opacities, *, max_trace_depth, specular_threshold, **kw):
+    """max_trace_depth > 0 as ONE differentiable expression (float64 autograd gives the true derivative of the blended colour):
+    stage k+1 starts at o + d * dpt_k / acc_k along d - 2 (d.n) n (n = normalised accumulated normal) where aux_k[0] > threshold and
+    acc_k > 0.5, t_min = 1e-3; rgb = (1 - s_0) rgb_0 + s_0 ((1 - s_1) rgb_1 + ...), s_k = aux_k[0]  (surfel_trace_oracle.c header;
+    reference call sites gaussian2d_sampler.py:413-426, optix_utils.py:117-118).  Returns (rgb, dpt_0, acc_0, norm_0, aux_0, wet_0, n_stages)."""
+    first = trace(ray_o, ray_d, means3D, scales, rotations, opacities, **kw)
+    stages = [dict(o=ray_o, d=ray_d, out=first, sel=None)]
+    kw2 = dict(kw); kw2.pop("start_from_first", None)
+    for k in range(1, max_trace_depth + 1):
+        p = stages[-1]
+        rgb, dpt, acc, norm, aux, _ = p["out"]
+        nl = norm.detach().norm(dim=-1)
+        sel = ((aux.detach()[:, 0] > specular_threshold) & (acc.detach() > 0.5) & (nl > 0)).nonzero(as_tuple=False)[:, 0]
+        if sel.numel() == 0:
+            break
+        po, pd = p["o"][sel], p["d"][sel]
+        nh = norm[sel] / norm[sel].norm(dim=-1, keepdim=True)
+        o2 = po + pd * (dpt[sel] / acc[sel])[:, None]
+        d2 = pd - 2.0 * (pd * nh).sum(-1, keepdim=True) * nh
+        stages.append(dict(o=o2, d=d2, out=trace(o2, d2, means3D, scales, rotations, opacities, start_from_first=False, tmin=1e-3, **kw2), sel=sel))
+    col = stages[-1]["out"][0]
+    for k in range(len(stages) - 2, -1, -1):
+        p, c = stages[k], stages[k + 1]
+        s = p["out"][4][c["sel"], 0:1]
+        col = p["out"][0].index_put((c["sel"],), (1.0 - s) * p["out"][0][c["sel"]] + s * col)
+    rgb0, dpt0, acc0, norm0, aux0, wet0 = first
+    return col, dpt0, acc0, norm0, aux0, wet0, len(stages)

@@ -90,6 +90,21 @@ def raster_forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, *, 
     return out
 
 
+def raster_audit(fwd, want_contrib=False):
+    """Fragility audit of the forward `fwd` (orc_render_audit): returns dict(fragile (H,W) bool, tainted (P,) bool,
+    contrib (H*W, lmax) uint8 or None, lmax).  See the C comment for the definition."""
+    L = lib()
+    cfg = fwd["cfg"]; H, W, P = fwd["H"], fwd["W"], fwd["P"]
+    pl = fwd["point_list"] if fwd["N"] > 0 else np.zeros(1, np.uint32)
+    r = fwd["ranges"].astype(np.int64)
+    lmax = int((r[:, 1] - r[:, 0]).max()) if r.size else 0
+    fragile = np.zeros(H * W, np.uint8); tainted = np.zeros(max(P, 1), np.uint8)
+    contrib = np.zeros((H * W, max(lmax, 1)), np.uint8) if want_contrib else None
+    L.orc_render_audit(ctypes.byref(cfg), _p(fwd["ranges"]), _p(pl), _p(fwd["transmat"]), _p(fwd["xy"]), _p(fwd["normal_opacity"]),
+                       _p(fragile), _p(contrib), ctypes.c_int(max(lmax, 1)), _p(tainted))
+    return dict(fragile=fragile.reshape(H, W).astype(bool), tainted=tainted[:P].astype(bool), contrib=contrib, lmax=max(lmax, 1))
+
+
 def raster_backward(fwd, dL_dcolor, dL_dallmap):
     """Gradients for the forward `fwd` (dict from raster_forward).  Returns dict of float32 arrays + raw records."""
     L = lib()

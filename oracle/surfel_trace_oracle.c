@@ -279,6 +279,128 @@ void trc_forward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, con
 }
 
 /*
+ * Parity audit of one trace stage (test infrastructure for the 1e-4 contract; the counterpart of orc_render_audit).  Replays the
+ * stage per ray exactly as trace_stage does (same float code) next to a double-precision shadow computed from the RAW parameters
+ * (quaternion -> frame in double, so that frame rounding is part of the measured uncertainty), and flags a ray as FRAGILE when any
+ * decided quantity q lies within  K*|q_f32 - q_f64| + m0*|threshold|  of its threshold or when float and double decide differently.
+ * Decisions: |u| <= 3, |v| <= 3, alpha >= 1/255, T*(1-alpha) < 1e-4, and (bounce_thr >= 0) the bounce decisions aux0 > thr, acc > 0.5 of
+ * the composited stage.  The hit distance t is NOT among them: it is the sort key of the hit lists, i.e. index work, and the GPU evaluates
+ * it in this file's operation order without FMA contraction -- t (hence t > tmin and the (t, id) order) is bit-exact by construction, which
+ * the tests assert through `tbits`.
+ * Outputs: fragile (R) u8; ids / tbits (R, lcap) = surfel id and float bits of t of the composited hits front to back (first nhit[r]
+ * valid); nhit (R).  Non-fragile rays must match the GPU's sorted (t, id) list bit for bit and within 1e-4 in value.
+ */
+#define AUD_K 16.0
+#define AUD_M0 4e-6
+
+typedef struct { double a[3], b[3], n[3], mu[3], su, sv, opa; } surfel64_t;
+
+static void make_surfel64(const trc_cfg *cfg, int i, const float *means, const float *scales, const float *rots, const float *opac, surfel64_t *s)
+{
+    const float *q = rots + 4 * i;
+    double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    double inv = 1.0 / sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    double r = q0 * inv, x = q1 * inv, y = q2 * inv, z = q3 * inv;
+    s->a[0] = 1. - 2. * (y * y + z * z); s->a[1] = 2. * (x * y + r * z); s->a[2] = 2. * (x * z - r * y);
+    s->b[0] = 2. * (x * y - r * z); s->b[1] = 1. - 2. * (x * x + z * z); s->b[2] = 2. * (y * z + r * x);
+    s->n[0] = 2. * (x * z + r * y); s->n[1] = 2. * (y * z - r * x); s->n[2] = 1. - 2. * (x * x + y * y);
+    s->mu[0] = means[3 * i]; s->mu[1] = means[3 * i + 1]; s->mu[2] = means[3 * i + 2];
+    s->su = (double)scales[2 * i] * (double)cfg->scale_modifier; s->sv = (double)scales[2 * i + 1] * (double)cfg->scale_modifier;
+    s->opa = opac[i];
+}
+
+typedef struct { float t; int id; float alpha; double t64, alpha64; } aent_t;
+static int aent_cmp(const void *a, const void *b)
+{
+    const aent_t *x = (const aent_t *)a, *y = (const aent_t *)b;
+    if (x->t != y->t) return x->t < y->t ? -1 : 1;
+    return x->id < y->id ? -1 : (x->id > y->id);
+}
+
+static int near_thr(double q32, double q64, double thr) { return fabs(q64 - thr) <= AUD_K * fabs(q32 - q64) + AUD_M0 * fabs(thr); }
+
+void trc_audit(const trc_cfg *cfg, const float *ray_o, const float *ray_d, const float *means, const float *scales,
+               const float *rots, const float *opac, const float *others, float tmin_override, float bounce_thr,
+               uint8_t *fragile, int32_t *ids, uint32_t *tbits, int lcap, int32_t *nhit)
+{
+    const int P = cfg->P, R = cfg->R;
+    surfel_t *S = (surfel_t *)malloc(sizeof(surfel_t) * (P ? P : 1));
+    surfel64_t *S64 = (surfel64_t *)malloc(sizeof(surfel64_t) * (P ? P : 1));
+    for (int i = 0; i < P; i++) { make_surfel(cfg, i, means, scales, rots, opac, &S[i]); make_surfel64(cfg, i, means, scales, rots, opac, &S64[i]); }
+    const float tmin = tmin_override >= 0.0f ? tmin_override : (cfg->start_from_first ? NEAR_N : 0.0f);
+#pragma omp parallel
+    {
+        aent_t *ents = (aent_t *)malloc(sizeof(aent_t) * (P ? P : 1));
+#pragma omp for schedule(dynamic, 16)
+        for (int r = 0; r < R; r++) {
+            const float *o = ray_o + 3 * r, *d = ray_d + 3 * r;
+            const double o64[3] = {o[0], o[1], o[2]}, d64[3] = {d[0], d[1], d[2]};
+            int frag = 0, n = 0;
+            for (int i = 0; i < P; i++) {
+                rhit_t h;
+                const int ok = hit_surfel(&S[i], o, d, tmin, &h);
+                /* the float quantities without the early exits */
+                const surfel_t *f = &S[i];
+                const float denf = f->n[0] * d[0] + f->n[1] * d[1] + f->n[2] * d[2];
+                if (denf == 0.0f) continue;
+                const float tf = (f->n[0] * (f->mu[0] - o[0]) + f->n[1] * (f->mu[1] - o[1]) + f->n[2] * (f->mu[2] - o[2])) / denf;
+                if (!(tf > tmin)) continue;                 /* t is exact by construction in both implementations: not a fragile decision */
+                const float qxf = o[0] + tf * d[0] - f->mu[0], qyf = o[1] + tf * d[1] - f->mu[1], qzf = o[2] + tf * d[2] - f->mu[2];
+                const float uf = (f->a[0] * qxf + f->a[1] * qyf + f->a[2] * qzf) / f->su;
+                const float vf = (f->b[0] * qxf + f->b[1] * qyf + f->b[2] * qzf) / f->sv;
+                const float af0 = f->opa * expf(-0.5f * (uf * uf + vf * vf));
+                const float af = af0 < ALPHA_CAP ? af0 : ALPHA_CAP;
+                /* the double shadow, from the raw parameters */
+                const surfel64_t *s = &S64[i];
+                const double den = s->n[0] * d64[0] + s->n[1] * d64[1] + s->n[2] * d64[2];
+                double t64 = tf, u64 = uf, v64 = vf, a64 = af;
+                if (den != 0.0) {
+                    t64 = (s->n[0] * (s->mu[0] - o64[0]) + s->n[1] * (s->mu[1] - o64[1]) + s->n[2] * (s->mu[2] - o64[2])) / den;
+                    const double qx = o64[0] + t64 * d64[0] - s->mu[0], qy = o64[1] + t64 * d64[1] - s->mu[1], qz = o64[2] + t64 * d64[2] - s->mu[2];
+                    u64 = (s->a[0] * qx + s->a[1] * qy + s->a[2] * qz) / s->su;
+                    v64 = (s->b[0] * qx + s->b[1] * qy + s->b[2] * qz) / s->sv;
+                    const double a = s->opa * exp(-0.5 * (u64 * u64 + v64 * v64));
+                    a64 = a < (double)ALPHA_CAP ? a : (double)ALPHA_CAP;
+                }
+                const int ok64 = fabs(u64) <= (double)UV_MAX && fabs(v64) <= (double)UV_MAX && a64 >= (double)ALPHA_MIN;
+                if (ok != ok64) frag = 1;
+                /* only surfels that could make a difference: roughly inside the quad, roughly visible */
+                if (fabs(u64) <= UV_MAX + 0.5 && fabs(v64) <= UV_MAX + 0.5 && a64 >= 0.5 * (double)ALPHA_MIN) {
+                    if (near_thr(fabsf(uf), fabs(u64), (double)UV_MAX)) frag = 1;
+                    if (near_thr(fabsf(vf), fabs(v64), (double)UV_MAX)) frag = 1;
+                    if (near_thr(af, a64, (double)ALPHA_MIN)) frag = 1;
+                }
+                if (ok) { ents[n].t = h.t; ents[n].id = i; ents[n].alpha = h.alpha; ents[n].t64 = t64; ents[n].alpha64 = a64; n++; }
+            }
+            qsort(ents, n, sizeof(aent_t), aent_cmp);
+            float T = 1.0f, acc = 0.f, aux0 = 0.f;
+            double T64 = 1.0, acc64 = 0.0, aux064 = 0.0;
+            int nh = 0;
+            for (int k = 0; k < n; k++) {
+                const float test_T = T * (1.0f - ents[k].alpha);
+                const double test_T64 = T64 * (1.0 - ents[k].alpha64);
+                if (near_thr(test_T, test_T64, (double)T_EPS) || ((test_T < T_EPS) != (test_T64 < (double)T_EPS))) frag = 1;
+                if (test_T < T_EPS) break;
+                const float w = ents[k].alpha * T;
+                const double w64 = ents[k].alpha64 * T64;
+                acc += w; acc64 += w64;
+                if (others) { aux0 += w * others[2 * ents[k].id]; aux064 += w64 * (double)others[2 * ents[k].id]; }
+                if (nh < lcap) { ids[(size_t)r * lcap + nh] = ents[k].id; union { float f; uint32_t u; } cv; cv.f = ents[k].t; tbits[(size_t)r * lcap + nh] = cv.u; }
+                nh++;
+                T = test_T; T64 = test_T64;
+            }
+            if (bounce_thr >= 0.0f) {
+                if (near_thr(aux0, aux064, (double)bounce_thr) || near_thr(acc, acc64, 0.5)) frag = 1;
+            }
+            fragile[r] = (uint8_t)frag;
+            nhit[r] = nh;
+        }
+        free(ents);
+    }
+    free(S); free(S64);
+}
+
+/*
  * Backward of stage 0 (max_trace_depth == 0 semantics; secondary rays are detached).
  * Upstream: dL_drgb (R,3) dL_ddpt (R) dL_dacc (R) dL_dnorm (R,3) dL_daux (R,2).   (dist carries no gradient here.)
  * Outputs (double, zeroed here): dmeans (P,3) dscales (P,2) drots (P,4) dopac (P) dshs (P,M,3) | dcolors (P,3),

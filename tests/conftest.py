@@ -16,3 +16,31 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "boundary_golden.npz"))
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Measured parity errors of this run (tests/util.py:check_close), so that they are part of the test log the driver records."""
+    try:
+        from tests.util import ERROR_TABLE
+    except Exception:
+        return
+    if not ERROR_TABLE:
+        return
+    tr = terminalreporter
+    tr.write_sep("=", "measured parity errors (elementwise |a-b| / (|b| + mean|b|); fragile pixels / rays excluded and counted)")
+    worst = {}
+    for r in ERROR_TABLE:
+        key = (r["test"].split("[")[0], r["tensor"])
+        w = worst.get(key)
+        if w is None or r["max_err"] > w["max_err"]:
+            worst[key] = dict(r, cases=(w["cases"] + 1 if w else 1))
+        else:
+            w["cases"] += 1
+    for (test, tensor), r in sorted(worst.items()):
+        tol = "" if r["tol"] is None else " (tol %.0e)" % r["tol"]
+        tr.write_line("%-58s %-14s max %.2e%s  cases %d  n %d  excl %d %s" % (test[:58], tensor, r["max_err"], tol, r["cases"], r["n"], r["excluded"], r.get("note", "")))
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        import json
+        with open(os.path.join(out, "parity_errors.json"), "w") as f:
+            json.dump(ERROR_TABLE, f, indent=0)

@@ -1,10 +1,16 @@
 """GPU parity: the HIP rasterizer (through the C-ABI) against the CPU oracle, stage by stage.
-Bar (BASELINE.json north_star): bit-exact tile / sort indices; <=1e-4 rel on pixels and gradients."""
+Bar (BASELINE.json north_star): bit-exact tile / sort indices; <=1e-4 rel on pixels and gradients.
+
+How the bar is applied (tests/util.py:check_close): EVERY element must be within 1e-4 elementwise (relative, with an absolute floor at the
+tensor's mean magnitude).  Threshold flips are not absorbed by the tolerance: the oracle's audit (oracle/surfel_raster_oracle.c:
+orc_render_audit) marks the pixels whose contributor set is not determined beyond rounding noise; on all OTHER pixels the per-pixel
+contributor sets and n_contrib must be bit-exact (index work) and the values within 1e-4; gradients are compared with the upstream
+gradient zeroed at the fragile pixels (in both implementations), so they are flip-free as well.  Fragile pixels are counted and bounded."""
 import numpy as np
 import pytest
 import torch
 
-from tests.util import small_scene, cam_args, rel_err, assert_close_frac
+from tests.util import small_scene, cam_args, rel_err, check_close, record
 
 pytestmark = pytest.mark.gpu
 
@@ -38,16 +44,79 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_forward_stages_vs_oracle(case):
+
+def _mod_for(C):
+    import importlib
+    return importlib.import_module({3: "diff_surfel_rasterization_wet", 5: "diff_surfel_rasterization_wet_ch05", 7: "diff_surfel_rasterization_wet_ch07"}[C])
+
+
+def _compare_forward(test, outs, saved, ref, aud, sh, check_sets):
+    """Index work bit-exact; contributor sets / n_contrib bit-exact and values within 1e-4 on every non-fragile pixel."""
     from envgs_amd import raster
+    N = ref["N"]
+    assert saved["N"] == N and N > 0
+    frag = aud["fragile"]; ok = ~frag
+    nfr = int(frag.sum())
+    record(test, "fragile_px", frag.mean(), "(%d of %d pixels)" % (nfr, frag.size))
+    assert frag.mean() < 5e-3, "too many fragile pixels for the comparison to mean anything: %g" % frag.mean()
+
+    # R1: integer outputs bit-exact, geom bit-exact (same op order, no FMA)
+    np.testing.assert_array_equal(saved["radii"].cpu().numpy(), ref["radii"])
+    vis = ref["radii"] > 0
+    geom = saved["geom"].cpu().numpy()
+    np.testing.assert_array_equal(geom[vis, :9], ref["transmat"][vis])
+    np.testing.assert_array_equal(geom[vis, 9:11], ref["xy"][vis])
+    np.testing.assert_array_equal(geom[vis, 11:15], ref["normal_opacity"][vis])
+    np.testing.assert_array_equal(geom[vis, 15].view(np.uint32), ref["depth"][vis].view(np.uint32))
+    if sh:
+        check_close(test, "sh_rgb", saved["colors"].cpu().numpy()[vis], ref["rgb"][vis], tol=1e-5)
+        np.testing.assert_array_equal(saved["clamped"].cpu().numpy()[vis], ref["clamped"][vis])
+    # R2-R5: offsets, keys, sorted list, ranges bit-exact
+    if "offsets" in saved:
+        np.testing.assert_array_equal(saved["tiles_touched"].cpu().numpy().view(np.uint32), ref["tiles_touched"])
+        np.testing.assert_array_equal(saved["offsets"].cpu().numpy().view(np.uint32), ref["offsets"])
+        np.testing.assert_array_equal(saved["keys_unsorted"].cpu().numpy().view(np.uint64)[:N], ref["keys_unsorted"])
+        np.testing.assert_array_equal(saved["vals_unsorted"].cpu().numpy().view(np.uint32)[:N], ref["vals_unsorted"])
+        np.testing.assert_array_equal(saved["keys_sorted"].cpu().numpy().view(np.uint64)[:N], ref["keys_sorted"])
+    np.testing.assert_array_equal(saved["point_list"].cpu().numpy().view(np.uint32)[:N], ref["point_list"])
+    np.testing.assert_array_equal(saved["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
+
+    # R6 index work: last / median contributor bit-exact on every non-fragile pixel; contributor SETS too (small cases)
+    nc = saved["n_contrib"].cpu().numpy()
+    np.testing.assert_array_equal(nc[0][ok], ref["n_contrib"][0][ok])
+    np.testing.assert_array_equal(nc[1][ok], ref["n_contrib"][1][ok])
+    if check_sets:
+        contrib, nc_a, col_a = raster.render_audit(saved, aud["lmax"])
+        okf = ok.reshape(-1)
+        np.testing.assert_array_equal(contrib.cpu().numpy()[okf], aud["contrib"][okf])
+        assert torch.equal(nc_a, saved["n_contrib"]) and torch.equal(col_a, outs[0])      # the audit instantiation IS the product kernel
+    # R6 values
+    color, radii, allmap, weight = [o.cpu().numpy() for o in outs]
+    check_close(test, "color", color[:, ok], ref["out_color"][:, ok], excluded=nfr)
+    for ch, nm in ((0, "depth"), (1, "alpha"), (2, "normal.x"), (3, "normal.y"), (4, "normal.z"), (5, "median")):
+        check_close(test, "allmap." + nm, allmap[ch][ok], ref["allmap"][ch][ok], excluded=nfr)
+    # distortion: sum_i w_i (m_i^2 A + M2 - 2 m_i M1) cancels catastrophically in fp32 in BOTH implementations (tests/test_oracle_grad.py);
+    # its floor is the magnitude of what is summed (~ the alpha channel), not of the remainder
+    check_close(test, "allmap.dist", allmap[6][ok], ref["allmap"][6][ok], floor=float(np.abs(ref["allmap"][1][ok]).mean()), excluded=nfr)
+    check_close(test, "final_T", saved["final_T"].cpu().numpy()[:, ok], ref["final_T"][:, ok], excluded=nfr)
+    clean = ~aud["tainted"]
+    check_close(test, "weight", weight[clean, 0], ref["weight"][clean], excluded=int(aud["tainted"].sum()))
+    if aud["tainted"].any():        # surfels that touch a fragile pixel: one flipped splat there moves their weight by O(1) pixel
+        d = np.abs(weight[~clean, 0] - ref["weight"][~clean])
+        record(test, "weight.tainted", d.max(), "(absolute, %d surfels)" % int((~clean).sum()))
+        assert d.max() <= 1.0 * max(1, nfr)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_stages_vs_oracle(case, request):
+    from envgs_amd import raster
+    from oracle import raster as orc
     dev = torch.device("cuda:0")
     g, cam = small_scene(P=case["P"], H=case["H"], W=case["W"], seed=case["seed"], C=case["C"], sh=case["sh"],
                          scale_mul=case.get("scale_mul", 4.0))
     bg = torch.tensor([0.2, 0.5, 0.9])
     C = case["C"]
-    import importlib
-    mod = importlib.import_module({3: "diff_surfel_rasterization_wet", 5: "diff_surfel_rasterization_wet_ch05", 7: "diff_surfel_rasterization_wet_ch07"}[C])
+    mod = _mod_for(C)
     st = _settings(mod, cam, bg, case["deg"], dev)
     gd = {k: v.to(dev) for k, v in g.items()}
     outs, saved = raster.rasterize_forward(C, gd["means3D"], gd["shs"] if case["sh"] else None,
@@ -55,60 +124,35 @@ def test_forward_stages_vs_oracle(case):
                                            gd["rotations"], None, st, keep_binning=True)
     torch.cuda.synchronize()
     ref = _oracle(g, cam, bg, case["deg"], C, case["sh"])
-    N = ref["N"]
-    assert saved["N"] == N and N > 0
+    aud = orc.raster_audit(ref, want_contrib=True)
+    _compare_forward(request.node.name, outs, saved, ref, aud, case["sh"], check_sets=True)
 
-    # R1: integer outputs bit-exact, floats to 1e-5
-    np.testing.assert_array_equal(saved["radii"].cpu().numpy(), ref["radii"])
-    np.testing.assert_array_equal(saved["tiles_touched"].cpu().numpy().view(np.uint32), ref["tiles_touched"])
-    np.testing.assert_array_equal(saved["offsets"].cpu().numpy().view(np.uint32), ref["offsets"])
-    vis = ref["radii"] > 0
-    geom = saved["geom"].cpu().numpy()
-    np.testing.assert_array_equal(geom[vis, :9], ref["transmat"][vis])            # same op order, no FMA: exact
-    np.testing.assert_array_equal(geom[vis, 9:11], ref["xy"][vis])
-    np.testing.assert_array_equal(geom[vis, 11:15], ref["normal_opacity"][vis])
-    np.testing.assert_array_equal(geom[vis, 15].view(np.uint32), ref["depth"][vis].view(np.uint32))
-    if case["sh"]:
-        np.testing.assert_allclose(saved["colors"].cpu().numpy()[vis], ref["rgb"][vis], rtol=1e-5, atol=1e-6)
-        np.testing.assert_array_equal(saved["clamped"].cpu().numpy()[vis], ref["clamped"][vis])
 
-    # R3-R5: keys, sorted list, ranges bit-exact
-    np.testing.assert_array_equal(saved["keys_unsorted"].cpu().numpy().view(np.uint64)[:N], ref["keys_unsorted"])
-    np.testing.assert_array_equal(saved["vals_unsorted"].cpu().numpy().view(np.uint32)[:N], ref["vals_unsorted"])
-    np.testing.assert_array_equal(saved["keys_sorted"].cpu().numpy().view(np.uint64)[:N], ref["keys_sorted"])
-    np.testing.assert_array_equal(saved["point_list"].cpu().numpy().view(np.uint32)[:N], ref["point_list"])
-    np.testing.assert_array_equal(saved["ranges"].cpu().numpy().view(np.uint32), ref["ranges"])
+def _masked_upstream(C, H, W, seed, frag):
+    gen = torch.Generator().manual_seed(seed)
+    dcol = torch.randn(C, H, W, generator=gen) / (H * W)
+    dall = torch.randn(7, H, W, generator=gen) / (H * W)
+    m = torch.from_numpy(~frag)
+    return dcol * m, dall * m          # zero upstream gradient at fragile pixels, for BOTH implementations
 
-    # R6: pixels within 1e-4 relative; contributor counts equal except where a threshold sits inside fp noise
-    color, radii, allmap, weight = [o.cpu().numpy() for o in outs]
-    assert rel_err(color, ref["out_color"]) < PIX_TOL
-    for ch in (0, 1, 2, 3, 4):
-        assert rel_err(allmap[ch], ref["allmap"][ch]) < PIX_TOL, ch
-    assert rel_err(allmap[6], ref["allmap"][6]) < 5e-3            # fp32 cancellation in both (see test_oracle_grad)
-    nc = saved["n_contrib"].cpu().numpy()
-    assert (nc[0] != ref["n_contrib"][0]).mean() < 2e-3
-    assert (nc[1] != ref["n_contrib"][1]).mean() < 2e-3
-    same = (nc[1] == ref["n_contrib"][1])
-    assert rel_err(allmap[5][same], ref["allmap"][5][same]) < PIX_TOL
-    assert rel_err(saved["final_T"].cpu().numpy(), ref["final_T"]) < PIX_TOL
-    assert rel_err(weight[:, 0], ref["weight"]) < PIX_TOL
+
+GRAD_NAMES = (("means3D", "dmeans3D"), ("scales", "dscales"), ("rotations", "drots"), ("opacities", "dopacities"), ("means2D", "dmeans2D"))
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_backward_vs_oracle(case):
+def test_backward_vs_oracle(case, request):
     from oracle import raster as orc
-    import importlib
     dev = torch.device("cuda:0")
     C = case["C"]
     g, cam = small_scene(P=case["P"], H=case["H"], W=case["W"], seed=case["seed"], C=C, sh=case["sh"],
                          scale_mul=case.get("scale_mul", 4.0))
     bg = torch.tensor([0.2, 0.5, 0.9])
-    mod = importlib.import_module({3: "diff_surfel_rasterization_wet", 5: "diff_surfel_rasterization_wet_ch05", 7: "diff_surfel_rasterization_wet_ch07"}[C])
+    mod = _mod_for(C)
     st = _settings(mod, cam, bg, case["deg"], dev)
     H, W = case["H"], case["W"]
-    gen = torch.Generator().manual_seed(case["seed"] + 100)
-    dcol = torch.randn(C, H, W, generator=gen) / (H * W)
-    dall = torch.randn(7, H, W, generator=gen) / (H * W)
+    ref = _oracle(g, cam, bg, case["deg"], C, case["sh"])
+    aud = orc.raster_audit(ref)
+    dcol, dall = _masked_upstream(C, H, W, case["seed"] + 100, aud["fragile"])
 
     leaves = {k: g[k].to(dev).requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations")}
     if case["sh"]: leaves["shs"] = g["shs"].to(dev).requires_grad_(True)
@@ -123,17 +167,12 @@ def test_backward_vs_oracle(case):
     loss.backward()
     torch.cuda.synchronize()
 
-    ref = _oracle(g, cam, bg, case["deg"], C, case["sh"])
     rb = orc.raster_backward(ref, dcol.numpy(), dall.numpy())
-    tol = GRAD_TOL * 5      # atomics: summation order differs; a handful of threshold flips in fp noise
-    assert rel_err(leaves["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"]) < tol
-    assert rel_err(leaves["means3D"].grad.cpu().numpy(), rb["dmeans3D"]) < tol
-    assert rel_err(leaves["scales"].grad.cpu().numpy(), rb["dscales"]) < tol
-    assert rel_err(leaves["rotations"].grad.cpu().numpy(), rb["drots"]) < tol
-    assert rel_err(means2D.grad.cpu().numpy(), rb["dmeans2D"]) < tol
-    if case["sh"]: assert rel_err(leaves["shs"].grad.cpu().numpy(), rb["dshs"]) < tol
-    else: assert rel_err(leaves["colors_precomp"].grad.cpu().numpy(), rb["dcolors"]) < tol
-
+    test = request.node.name
+    nfr = int(aud["fragile"].sum())
+    grads = dict(leaves, means2D=means2D)
+    for k_hip, k_ref in GRAD_NAMES + ((("shs", "dshs"),) if case["sh"] else (("colors_precomp", "dcolors"),)):
+        check_close(test, k_ref, grads[k_hip].grad.cpu().numpy().reshape(rb[k_ref].shape), rb[k_ref], excluded=nfr)
 
 def test_precomputed_transmat_path():
     """cov3D_precomp (the python transMat of gaussian2d_utils.py:1050-1061) instead of scales/rotations."""
@@ -152,16 +191,16 @@ def test_precomputed_transmat_path():
     means2D = torch.zeros_like(m3, requires_grad=True) + 0
     color, radii, allmap, weight = mod.GaussianRasterizer(raster_settings=st)(
         means3D=m3, means2D=means2D, shs=shs, colors_precomp=None, opacities=op, scales=None, rotations=None, cov3D_precomp=tmd)
-    gen = torch.Generator().manual_seed(5)
-    dcol = torch.randn(3, 64, 64, generator=gen) / 4096
-    dall = torch.randn(7, 64, 64, generator=gen) / 4096
-    ((color * dcol.to(dev)).sum() + (allmap * dall.to(dev)).sum()).backward()
     ref = _oracle(g, cam, bg, 2, 3, True, precomp_T=tm)
+    aud = orc.raster_audit(ref)
+    dcol, dall = _masked_upstream(3, 64, 64, 5, aud["fragile"])
+    ((color * dcol.to(dev)).sum() + (allmap * dall.to(dev)).sum()).backward()
     rb = orc.raster_backward(ref, dcol.numpy(), dall.numpy())
-    assert rel_err(color.detach().cpu().numpy(), ref["out_color"]) < PIX_TOL
-    assert rel_err(tmd.grad.cpu().numpy(), rb["dtransmat_precomp"]) < 5e-4
-    assert rel_err(m3.grad.cpu().numpy(), rb["dmeans3D"]) < 5e-4          # SH view-direction term only
-    assert rel_err(shs.grad.cpu().numpy(), rb["dshs"]) < 5e-4
+    ok = ~aud["fragile"]
+    check_close("precomputed_transmat", "color", color.detach().cpu().numpy()[:, ok], ref["out_color"][:, ok], excluded=int((~ok).sum()))
+    check_close("precomputed_transmat", "dtransmat", tmd.grad.cpu().numpy(), rb["dtransmat_precomp"])
+    check_close("precomputed_transmat", "dmeans3D", m3.grad.cpu().numpy(), rb["dmeans3D"])          # SH view-direction term only
+    check_close("precomputed_transmat", "dshs", shs.grad.cpu().numpy(), rb["dshs"])
 
 
 def test_edge_cases():
@@ -211,10 +250,6 @@ def test_full_size_baseline_config_vs_oracle():
     gd = {k: v.to(dev) for k, v in g.items()}
     outs, saved = raster.rasterize_forward(3, gd["means3D"], gd["shs"], None, gd["opacities"], gd["scales"], gd["rotations"],
                                            None, st, keep_binning=True)
-    gen = torch.Generator().manual_seed(1)
-    dcol = torch.randn(3, H, W, generator=gen) / (H * W)
-    dall = torch.randn(7, H, W, generator=gen) / (H * W)
-    grads = raster.rasterize_backward(saved, dcol.to(dev), dall.to(dev))
     torch.cuda.synchronize()
     N = saved["N"]
     # properties that need no oracle: keys sorted, ranges partition [0,N), every list entry is a visible surfel
@@ -231,18 +266,13 @@ def test_full_size_baseline_config_vs_oracle():
     ref = orc.raster_forward(g["means3D"].numpy(), g["opacities"].numpy(), ca["viewmatrix"].numpy(), ca["projmatrix"].numpy(),
                              ca["campos"].numpy(), W, H, scales=g["scales"].numpy(), rotations=g["rotations"].numpy(),
                              shs=g["shs"].numpy(), sh_degree=3, bg=bg.numpy())
-    assert ref["N"] == N
-    np.testing.assert_array_equal(rad, ref["radii"])
-    np.testing.assert_array_equal(pl, ref["point_list"])
-    np.testing.assert_array_equal(r.astype(np.uint32), ref["ranges"])
-    color, _, allmap, weight = [o.cpu().numpy() for o in outs]
-    assert_close_frac(color, ref["out_color"], PIX_TOL, flip_bound=0.02, what="color")
-    for ch in (0, 1, 2, 3, 4):
-        assert_close_frac(allmap[ch], ref["allmap"][ch], PIX_TOL, flip_bound=0.02, what="allmap%d" % ch)
-    assert (saved["n_contrib"].cpu().numpy()[0] != ref["n_contrib"][0]).mean() < 1e-4
-    assert_close_frac(weight[:, 0], ref["weight"], PIX_TOL, flip_bound=0.02, what="weight")
+    aud = orc.raster_audit(ref)
+    test = "full_size_300k_800x800"
+    _compare_forward(test, outs, saved, ref, aud, True, check_sets=False)
+    # gradients: upstream zeroed at the fragile pixels for both implementations
+    dcol, dall = _masked_upstream(3, H, W, 1, aud["fragile"])
+    grads = raster.rasterize_backward(saved, dcol.to(dev), dall.to(dev))
+    torch.cuda.synchronize()
     rb = orc.raster_backward(ref, dcol.numpy(), dall.numpy())
-    for k_hip, k_ref in (("means3D", "dmeans3D"), ("scales", "dscales"), ("rotations", "drots"), ("opacities", "dopacities"),
-                         ("shs", "dshs"), ("means2D", "dmeans2D")):
-        a = grads[k_hip].cpu().numpy().reshape(rb[k_ref].shape)
-        assert_close_frac(a, rb[k_ref], 2e-4, max_bad_frac=1e-4, flip_bound=0.05, what=k_hip)
+    for k_hip, k_ref in GRAD_NAMES + (("shs", "dshs"),):
+        check_close(test, k_ref, grads[k_hip].cpu().numpy().reshape(rb[k_ref].shape), rb[k_ref], excluded=int(aud["fragile"].sum()))

@@ -1,12 +1,18 @@
-"""GPU parity: the HIP LBVH tracer (through the C-ABI and the drop-in SurfelTracer) against the brute-force
-CPU oracle.  Hit sets are validated implicitly: identical composited sums and per-surfel weights for every ray."""
+"""GPU parity: the HIP LBVH tracer (through the C-ABI and the drop-in SurfelTracer) against the brute-force CPU oracle.
+
+Bar (BASELINE.json north_star): bit-exact index work, <= 1e-4 on values and gradients -- applied per ELEMENT (tests/util.py:check_close).
+Threshold / ordering flips are separated from arithmetic error instead of being absorbed by a tolerance: the oracle's audit
+(oracle/surfel_trace_oracle.c:trc_audit) marks the rays whose hit set or hit ORDER is not determined beyond rounding noise; those rays are
+removed from the test input (a ray's result does not depend on the other rays), counted, and then on every remaining ray
+  * the sorted per-ray hit-id list the GPU composited must equal the brute-force list bit for bit (index parity),
+  * every output, the per-surfel weights and every gradient must be within 1e-4 elementwise."""
 import numpy as np
 import pytest
 import torch
 
 from envgs_amd import synth
 from tests.test_oracle_trace import trace_scene
-from tests.util import rel_err, assert_close_frac
+from tests.util import check_close, record
 
 pytestmark = pytest.mark.gpu
 
@@ -18,10 +24,11 @@ def _settings(mod, bg, deg, dev, depth=0, thr=0.0, H=1, W=1):
                                      prefiltered=False, debug=False, max_trace_depth=depth, specular_threshold=thr)
 
 
-def _run_hip(g, ro, rd, bg, deg, use_sh, sff, grads=None, depth=0, thr=0.0, shape=None):
+def _run_hip(g, ro, rd, bg, deg, use_sh, sff, grads=None, depth=0, thr=0.0, shape=None, others=True):
     import diff_surfel_tracing as mod
     dev = torch.device("cuda:0")
-    L = {k: g[k].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "others")}
+    L = {k: g[k].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities")}
+    if others: L["others"] = g["others"].to(dev).requires_grad_(True)
     if use_sh: L["shs"] = g["shs"].to(dev).requires_grad_(True)
     else: L["colors_precomp"] = g["colors_precomp"].to(dev).requires_grad_(True)
     o = ro.to(dev).requires_grad_(True); d = rd.to(dev).requires_grad_(True)
@@ -32,7 +39,7 @@ def _run_hip(g, ro, rd, bg, deg, use_sh, sff, grads=None, depth=0, thr=0.0, shap
     g3 = torch.zeros_like(L["means3D"], requires_grad=True) + 0
     g3.retain_grad()
     outs = tracer(oo, dd, v, means3D=L["means3D"], grads3D=g3, shs=L.get("shs"), colors_precomp=L.get("colors_precomp"),
-                  others_precomp=L["others"], opacities=L["opacities"], scales=L["scales"], rotations=L["rotations"],
+                  others_precomp=L.get("others"), opacities=L["opacities"], scales=L["scales"], rotations=L["rotations"],
                   cov3D_precomp=None, tracer_settings=_settings(mod, bg, deg, dev, depth, thr), start_from_first=sff)
     if grads is not None:
         rgb, dpt, acc, norm, dist, aux, mid, wet = outs
@@ -43,79 +50,254 @@ def _run_hip(g, ro, rd, bg, deg, use_sh, sff, grads=None, depth=0, thr=0.0, shap
     return outs, L, o, d, g3
 
 
+def _np(g, k):
+    return g[k].numpy()
+
+
+def _drop_fragile(test, g, ro, rd, sff, others=True, max_frac=0.03):
+    """The oracle's audit of the stage: returns the non-fragile rays and their brute-force sorted hit-id lists."""
+    from oracle import trace as otr
+    a = otr.trace_audit(ro.numpy(), rd.numpy(), _np(g, "means3D"), _np(g, "scales"), _np(g, "rotations"), _np(g, "opacities"),
+                        others=_np(g, "others") if others else None, start_from_first=sff)
+    keep = ~a["fragile"]
+    record(test, "fragile_rays", a["fragile"].mean(), "(%d of %d rays)" % (int(a["fragile"].sum()), keep.size))
+    assert a["fragile"].mean() <= max_frac, "too many fragile rays for the comparison to mean anything: %g" % a["fragile"].mean()
+    k = torch.from_numpy(keep)
+    return ro[k].contiguous(), rd[k].contiguous(), (a["ids"][keep], a["tbits"][keep]), a["nhit"][keep], int(a["fragile"].sum())
+
+
+def _check_index_parity(test, ids_ref, nhit_ref, require_lists=True):
+    """Index work is bit-exact: the GPU's sorted, composited hit-id list of every ray served by the list path == the brute-force list."""
+    from envgs_amd import tracing
+    L = tracing.last_hit_lists()
+    if L is None:
+        assert not require_lists, "the list path did not run"
+        return 0
+    ids, tb, n_used, hit_cnt = [x.cpu().numpy() for x in L]
+    ids_ref, tb_ref = ids_ref
+    cap = ids.shape[1]
+    listed = hit_cnt <= cap
+    np.testing.assert_array_equal(n_used[listed], nhit_ref[listed])
+    valid = (np.arange(cap)[None] < n_used[:, None])[listed]
+    w = min(cap, ids_ref.shape[1])
+    assert nhit_ref[listed].max(initial=0) <= w
+    np.testing.assert_array_equal(np.where(valid, ids[listed], -1)[:, :w], ids_ref[listed][:, :w])                    # the same surfels, in the same order
+    np.testing.assert_array_equal(np.where(valid, tb[listed].view(np.uint32), 0)[:, :w], tb_ref[listed][:, :w])       # at bit-identical distances
+    record(test, "hit_lists_bit_exact", 0.0, "(%d rays, %d composited (t, id) pairs compared)" % (int(listed.sum()), int(n_used[listed].sum())))
+    return int(listed.sum())
+
+
+GRADS_ALL = ("dmeans3D", "grads3D", "dscales", "drots", "dopacities", "dothers", "dcolor", "dray_o", "dray_d")
+
+
+def _parity(test, g, ro, rd, bg, deg, use_sh, sff, gr_scale=1.0, seed=9, which=GRADS_ALL, others=True, hip_ctx=None, require_lists=True,
+            zero_geo_grads=False, after_hip=None):
+    """Audit -> drop fragile rays -> HIP forward + backward -> oracle forward + backward -> index parity + the 1e-4 contract."""
+    from oracle import trace as otr
+    from envgs_amd import tracing
+    ro, rd, ids_ref, nhit_ref, nfr = _drop_fragile(test, g, ro, rd, sff, others=others)
+    R = ro.shape[0]
+    gen = torch.Generator().manual_seed(seed)
+    gr = [torch.randn(R, 3, generator=gen) * gr_scale, torch.randn(R, generator=gen) * gr_scale, torch.randn(R, generator=gen) * gr_scale,
+          torch.randn(R, 3, generator=gen) * gr_scale, torch.randn(R, 2, generator=gen) * gr_scale]
+    if zero_geo_grads:
+        gr[1:] = [torch.zeros(R), torch.zeros(R), torch.zeros(R, 3), torch.zeros(R, 2)]
+    old_keep = tracing.KEEP_LISTS["on"]
+    tracing.KEEP_LISTS["on"] = True
+    try:
+        if hip_ctx is not None: hip_ctx.__enter__()
+        try:
+            outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, deg, use_sh, sff, grads=gr, others=others)
+            cnt = tracing.last_trace_counts()
+            extra = after_hip() if after_hip is not None else None
+            n_listed = _check_index_parity(test, ids_ref, nhit_ref, require_lists=require_lists)
+        finally:
+            if hip_ctx is not None: hip_ctx.__exit__(None, None, None)
+    finally:
+        tracing.KEEP_LISTS["on"] = old_keep
+    assert cnt["stack_overflows"] == 0 or extra == "overflow-expected"
+    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
+    ckw = dict(shs=_np(g, "shs"), sh_degree=deg) if use_sh else dict(colors_precomp=_np(g, "colors_precomp"))
+    ref = otr.trace_forward(ro.numpy(), rd.numpy(), _np(g, "means3D"), _np(g, "scales"), _np(g, "rotations"), _np(g, "opacities"),
+                            others=_np(g, "others") if others else None, bg=bg.numpy(), start_from_first=sff, **ckw)
+    np.testing.assert_array_equal(ref["nhits"], nhit_ref)
+    for a, b, nm in ((rgb, ref["rgb"], "rgb"), (dpt[:, 0], ref["dpt"], "dpt"), (acc[:, 0], ref["acc"], "acc"), (norm, ref["norm"], "norm"),
+                     (aux, ref["aux"], "aux"), (wet[:, 0], ref["wet"], "wet")):
+        if nm == "aux" and not others: continue
+        check_close(test, nm, a, b, excluded=nfr)
+    # distortion cancels catastrophically in fp32 in both implementations: judged against the magnitude of what is summed (~ acc)
+    check_close(test, "dist", dist[:, 0], ref["dist"], floor=float(np.abs(ref["acc"]).mean()) + 1e-30, excluded=nfr)
+    np.testing.assert_array_equal(mid[:, 0:3], ro.numpy())
+    check_close(test, "mid.rgb", mid[:, 13:16], rgb, tol=1e-6)
+
+    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
+    got = dict(dmeans3D=L["means3D"].grad, grads3D=g3.grad, dscales=L["scales"].grad, drots=L["rotations"].grad, dopacities=L["opacities"].grad.reshape(-1),
+               dothers=L["others"].grad if others else None, dcolor=(L["shs"].grad if use_sh else L["colors_precomp"].grad), dray_o=o.grad, dray_d=d.grad)
+    want = dict(dmeans3D=rb["dmeans3D"], grads3D=rb["dmeans3D"], dscales=rb["dscales"], drots=rb["drots"], dopacities=rb["dopacities"],
+                dothers=rb["dothers"], dcolor=(rb["dshs"] if use_sh else rb["dcolors"]), dray_o=rb["dray_o"], dray_d=rb["dray_d"])
+    for k in which:
+        if got[k] is None or want[k] is None: continue
+        check_close(test, k, got[k].cpu().numpy(), want[k], excluded=nfr)
+    return dict(ref=ref, cnt=cnt, outs=outs, n_listed=n_listed, R=R, extra=extra)
+
+
 @pytest.mark.parametrize("use_sh,camera,deg,P,R", [(True, True, 3, 150, 400), (False, False, 0, 150, 400), (True, False, 2, 2000, 1024),
                                                    (True, False, 1, 1, 64), (False, True, 0, 40, 130)])
-def test_trace_forward_backward_vs_oracle(use_sh, camera, deg, P, R):
-    from oracle import trace as otr
+def test_trace_forward_backward_vs_oracle(use_sh, camera, deg, P, R, request):
     g, ro, rd = trace_scene(P=P, R=R, seed=7, camera=camera)
     if P > 500:
         g["scales"] = g["scales"] * 0.35                       # many small surfels: deep tree, > K hits per ray for some
-    R = ro.shape[0]
-    bg = torch.tensor([0.3, 0.1, 0.7])
-    gen = torch.Generator().manual_seed(9)
-    gr = [torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen),
-          torch.randn(R, 3, generator=gen), torch.randn(R, 2, generator=gen)]
-    outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, deg, use_sh, camera, grads=gr)
-    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
-    ckw = dict(shs=g["shs"].numpy(), sh_degree=deg) if use_sh else dict(colors_precomp=g["colors_precomp"].numpy())
-    ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(),
-                            g["opacities"].numpy(), others=g["others"].numpy(), bg=bg.numpy(), start_from_first=camera, **ckw)
-    if P > 1: assert ref["nhits"].mean() > 1
-    for a, b, nm in ((rgb, ref["rgb"], "rgb"), (dpt[:, 0], ref["dpt"], "dpt"), (acc[:, 0], ref["acc"], "acc"), (norm, ref["norm"], "norm"),
-                     (aux, ref["aux"], "aux"), (wet[:, 0], ref["wet"], "wet")):
-        assert_close_frac(a, b, 1e-4, max_bad_frac=2e-3, flip_bound=0.05, what=nm)
-    assert_close_frac(dist[:, 0], ref["dist"], 5e-3, max_bad_frac=2e-3, what="dist")
-    np.testing.assert_allclose(mid[:, 0:3], ro.numpy(), rtol=0, atol=0)
-    np.testing.assert_allclose(mid[:, 13:16], rgb, rtol=1e-6, atol=1e-7)
-
-    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
-    tol = 1e-3
-    chk = lambda a, b, nm: assert_close_frac(a, b, tol, max_bad_frac=5e-3, flip_bound=0.2, what=nm)
-    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
-    chk(g3.grad.cpu().numpy(), rb["dmeans3D"], "grads3D")
-    chk(L["scales"].grad.cpu().numpy(), rb["dscales"], "dscales")
-    chk(L["rotations"].grad.cpu().numpy(), rb["drots"], "drots")
-    chk(L["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"], "dopac")
-    chk(L["others"].grad.cpu().numpy(), rb["dothers"], "dothers")
-    if use_sh: chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
-    else: chk(L["colors_precomp"].grad.cpu().numpy(), rb["dcolors"], "dcolors")
-    chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
-    chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
+    res = _parity(request.node.name, g, ro, rd, torch.tensor([0.3, 0.1, 0.7]), deg, use_sh, camera)
+    if P > 1: assert res["ref"]["nhits"].mean() > 1
 
 
-@pytest.mark.parametrize("stage_lists", [True, False])
-def test_trace_bounces_and_image_shaped_rays(stage_lists):
-    """Two specular bounces: as one list-path trace per stage (the default) and inside the K-buffer kernel -- same images, same per-stage
-    `mid` records, same (stage-0) gradients as the oracle; the per-surfel weight comes from stage 0 only."""
-    from oracle import trace as otr
-    from envgs_amd import tracing
+class _Switch:
+    """Temporarily set entries of the tracing module's switch dicts / debug switches."""
+    def __init__(self, **kw): self.kw = kw
+    def __enter__(self):
+        from envgs_amd import tracing, _lib
+        self.old = {}
+        for k, v in self.kw.items():
+            if k == "force_cap":
+                self.old[k] = dict(tracing.HIT_CAP)
+                if v: tracing.HIT_CAP["force"] = v
+            elif k == "no_lists":
+                self.old[k] = tracing.trace_forward
+                orig = tracing.trace_forward
+                tracing.trace_forward = lambda *a, **kk: orig(*a, **{**kk, "use_lists": False})
+            elif k == "records": self.old[k] = tracing.USE_RECORDS["on"]; tracing.USE_RECORDS["on"] = v
+            elif k == "sort_rays": self.old[k] = tracing.SORT_RAYS["on"]; tracing.SORT_RAYS["on"] = v
+            elif k == "debug_trace":
+                lib = _lib.load(); self.old[k] = lib.envgs_debug_get(0); lib.envgs_debug_set(0, v)
+    def __exit__(self, *a):
+        from envgs_amd import tracing, _lib
+        for k, v in self.old.items():
+            if k == "force_cap": tracing.HIT_CAP.clear(); tracing.HIT_CAP.update(v)
+            elif k == "no_lists": tracing.trace_forward = v
+            elif k == "records": tracing.USE_RECORDS["on"] = v
+            elif k == "sort_rays": tracing.SORT_RAYS["on"] = v
+            elif k == "debug_trace": _lib.load().envgs_debug_set(0, v)
+
+
+def test_trace_bounces_true_derivative():
+    """max_trace_depth = 2 through the drop-in module: images, per-stage `mid` records and stage-0 weights against the C oracle's forward;
+    EVERY gradient against float64 autograd of the eager twin composed over the stages (oracle/eager_trace.py:trace_bounces) -- the
+    backward is the derivative of the returned blend: through each stage's colour, the blend weights and the reflected-ray construction."""
+    from oracle import trace as otr, eager_trace
+    test = "bounces_depth2"
     g, ro, rd = trace_scene(P=150, R=400, seed=4, camera=True)       # 20x20 camera rays
-    R = ro.shape[0]
     bg = torch.tensor([0.0, 0.0, 0.0])
+    thr, depth, deg = 0.1, 2, 1
+    P = 150
+    # image-shaped rays: shapes follow the ray tensor
+    outs, *_ = _run_hip(g, ro, rd, bg, deg, True, True, depth=depth, thr=thr, shape=(20, 20))
+    rgb, dpt, acc, norm, dist, aux, mid, wet = outs
+    assert rgb.shape == (20, 20, 3) and dpt.shape == (20, 20, 1) and mid.shape == (20, 20, 48) and wet.shape == (P, 1)
+    # audit every stage: stage-k rays come from the oracle's own `mid`
+    args = (_np(g, "means3D"), _np(g, "scales"), _np(g, "rotations"), _np(g, "opacities"))
+    ref = otr.trace_forward(ro.numpy(), rd.numpy(), *args, shs=_np(g, "shs"), sh_degree=deg, others=_np(g, "others"), bg=bg.numpy(),
+                            max_trace_depth=depth, specular_threshold=thr, start_from_first=True)
+    frag = otr.trace_audit(ro.numpy(), rd.numpy(), *args, others=_np(g, "others"), start_from_first=True, bounce_thr=thr)["fragile"]
+    for k in (1, 2):
+        ran = np.abs(ref["mid"][:, 16 * k + 3:16 * k + 6]).sum(-1) > 0
+        a = otr.trace_audit(ref["mid"][ran, 16 * k:16 * k + 3], ref["mid"][ran, 16 * k + 3:16 * k + 6], *args, others=_np(g, "others"),
+                            start_from_first=False, tmin=1e-3, bounce_thr=(thr if k < depth else None))
+        frag[np.nonzero(ran)[0][a["fragile"]]] = True
+    keep = torch.from_numpy(~frag)
+    record(test, "fragile_rays", frag.mean(), "(%d of %d rays, all stages)" % (int(frag.sum()), frag.size))
+    assert frag.mean() < 0.05
+    ro, rd = ro[keep].contiguous(), rd[keep].contiguous()
+    R = ro.shape[0]
     gen = torch.Generator().manual_seed(12)
     gr = [torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen), torch.randn(R, 3, generator=gen),
           torch.randn(R, 2, generator=gen)]
-    old = tracing.BOUNCE_LISTS["on"]
-    try:
-        tracing.BOUNCE_LISTS["on"] = stage_lists
-        outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, 1, True, True, grads=gr, depth=2, thr=0.1, shape=(20, 20))
-    finally:
-        tracing.BOUNCE_LISTS["on"] = old
-    rgb, dpt, acc, norm, dist, aux, mid, wet = outs
-    assert rgb.shape == (20, 20, 3) and dpt.shape == (20, 20, 1) and mid.shape == (20, 20, 48) and wet.shape == (150, 1)
-    ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(),
-                            g["opacities"].numpy(), shs=g["shs"].numpy(), sh_degree=1, others=g["others"].numpy(), bg=bg.numpy(),
-                            max_trace_depth=2, specular_threshold=0.1, start_from_first=True)
+    outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, deg, True, True, grads=gr, depth=depth, thr=thr)
+    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
+    ref = otr.trace_forward(ro.numpy(), rd.numpy(), *args, shs=_np(g, "shs"), sh_degree=deg, others=_np(g, "others"), bg=bg.numpy(),
+                            max_trace_depth=depth, specular_threshold=thr, start_from_first=True)
     assert (ref["mid"][:, 16 + 7] != 0).any() and (ref["mid"][:, 32 + 7] != 0).any()          # both bounce stages really ran for some rays
-    assert_close_frac(rgb.detach().reshape(-1, 3).cpu().numpy(), ref["rgb"], 2e-4, max_bad_frac=5e-3, flip_bound=0.1, what="rgb")
-    assert_close_frac(mid.detach().reshape(-1, 48).cpu().numpy(), ref["mid"], 2e-4, max_bad_frac=5e-3, flip_bound=0.2, what="mid")
-    assert_close_frac(wet.detach().cpu().numpy()[:, 0], ref["wet"], 2e-4, max_bad_frac=5e-3, flip_bound=0.1, what="wet")
-    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
-    chk = lambda a, b, nm: assert_close_frac(a, b, 1e-3, max_bad_frac=5e-3, flip_bound=0.3, what=nm)
-    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
-    chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
-    chk(L["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"], "dopac")
-    chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
+    nfr = int(frag.sum())
+    check_close(test, "rgb", rgb, ref["rgb"], excluded=nfr)
+    check_close(test, "mid", mid, ref["mid"], excluded=nfr)
+    check_close(test, "wet", wet[:, 0], ref["wet"], excluded=nfr)
+    # true derivative: float64 autograd through the composed stages
+    dd = torch.float64
+    E = {k: g[k].to(dd).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "others", "shs")}
+    o64 = ro.to(dd).requires_grad_(True); d64 = rd.to(dd).requires_grad_(True)
+    ergb, edpt, eacc, enorm, eaux, ewet, nst = eager_trace.trace_bounces(o64, d64, E["means3D"], E["scales"], E["rotations"], E["opacities"],
+                                                                          max_trace_depth=depth, specular_threshold=thr, shs=E["shs"], others=E["others"],
+                                                                          sh_degree=deg, bg=bg, start_from_first=True)
+    assert nst == 3
+    check_close(test, "rgb.vs_f64", rgb, ergb.detach().numpy(), excluded=nfr)
+    loss = sum((x.reshape(R, -1) * y.to(dd).reshape(R, -1)).sum() for x, y in zip((ergb, edpt, eacc, enorm, eaux), gr))
+    loss.backward()
+    q = g["rotations"].double()
+    proj = lambda v: v - (v * q).sum(-1, keepdim=True) * q                 # drots is defined on the unit sphere: compare tangent parts
+    for nm, a, b in (("dmeans3D", L["means3D"].grad, E["means3D"].grad), ("grads3D", g3.grad, E["means3D"].grad), ("dscales", L["scales"].grad, E["scales"].grad),
+                     ("dopacities", L["opacities"].grad, E["opacities"].grad), ("dothers", L["others"].grad, E["others"].grad), ("dshs", L["shs"].grad, E["shs"].grad),
+                     ("dray_o", o.grad, o64.grad), ("dray_d", d.grad, d64.grad)):
+        check_close(test, nm, a.cpu().numpy(), b.numpy(), excluded=nfr)
+    check_close(test, "drots", proj(L["rotations"].grad.cpu().double()).numpy(), proj(E["rotations"].grad).numpy(), excluded=nfr)
+
+
+def test_trace_kbuffer_in_kernel_bounces_forward():
+    """The C-ABI's in-kernel bounce stages (K-buffer kernels; forward use only -- the drop-in module composes stages instead)."""
+    from oracle import trace as otr
+    from envgs_amd import tracing
+    import diff_surfel_tracing as mod
+    dev = torch.device("cuda:0")
+    g, ro, rd = trace_scene(P=150, R=400, seed=4, camera=True)
+    bg = torch.zeros(3)
+    v, f = synth.get_disks(g["means3D"], g["scales"], g["rotations"])
+    nodes, P = tracing.build_bvh(v.to(dev), g["opacities"].to(dev))
+    gd = {k: x.to(dev) for k, x in g.items()}
+    outs, _ = tracing.trace_forward(nodes, ro.to(dev), rd.to(dev), gd["means3D"], gd["shs"], None, gd["others"], gd["opacities"], gd["scales"],
+                                    gd["rotations"], _settings(mod, bg, 1, dev, 2, 0.1), True, use_lists=False, need_grad=False)
+    ref = otr.trace_forward(ro.numpy(), rd.numpy(), _np(g, "means3D"), _np(g, "scales"), _np(g, "rotations"), _np(g, "opacities"), shs=_np(g, "shs"),
+                            sh_degree=1, others=_np(g, "others"), bg=bg.numpy(), max_trace_depth=2, specular_threshold=0.1, start_from_first=True)
+    a = otr.trace_audit(ro.numpy(), rd.numpy(), _np(g, "means3D"), _np(g, "scales"), _np(g, "rotations"), _np(g, "opacities"), others=_np(g, "others"),
+                        start_from_first=True, bounce_thr=0.1)
+    ok = ~a["fragile"]
+    same = np.all((ref["mid"] != 0) == (outs[6].cpu().numpy() != 0), axis=1) & ok            # rays whose stages agree (later stages are not audited here)
+    assert same.mean() > 0.9
+    check_close("kbuffer_in_kernel_bounces", "rgb", outs[0].cpu().numpy()[same], ref["rgb"][same], excluded=int((~same).sum()))
+    check_close("kbuffer_in_kernel_bounces", "mid", outs[6].cpu().numpy()[same], ref["mid"][same], excluded=int((~same).sum()))
+
+
+def test_trace_cov3D_precomp_matches_scales_rotations():
+    """pipe.compute_cov3D_python (optix_utils.py:143-154): the tracer accepts the screen-space transMat, recovers the world-space frame from
+    it and traces the same image; the gradient reaches the transMat (and, through the caller's own torch expressions, its parameters)."""
+    import diff_surfel_tracing as mod
+    dev = torch.device("cuda:0")
+    g, ro, rd = trace_scene(P=200, R=512, seed=5, camera=False)
+    cam = synth.orbit_camera(1, H=64, W=80, fx=100.0)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    st = mod.SurfelTracingSettings(image_height=64, image_width=80, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg.to(dev), scale_modifier=1.0,
+                                   viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev), sh_degree=torch.tensor([2], device=dev),
+                                   campos=cam.camera_center.to(dev), prefiltered=False, debug=False, max_trace_depth=0, specular_threshold=0.0)
+    res = {}
+    for mode in ("frame", "precomp"):
+        L = {k: g[k].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+        rn = L["rotations"] / L["rotations"].norm(dim=-1, keepdim=True)                     # what get_rotation does
+        v, f = synth.get_disks(L["means3D"].detach(), L["scales"].detach(), rn.detach())
+        tracer = mod.SurfelTracer(); tracer.build_acceleration_structure(v, f, rebuild=True)
+        kw = dict(means3D=L["means3D"], grads3D=None, shs=L["shs"], colors_precomp=None, others_precomp=None, opacities=L["opacities"],
+                  tracer_settings=st, start_from_first=False)
+        if mode == "frame":
+            outs = tracer(ro.to(dev), rd.to(dev), v, scales=L["scales"], rotations=rn, cov3D_precomp=None, **kw)
+        else:
+            class _C: pass
+            c = _C(); c.__dict__.update(cam.__dict__)
+            c.world_view_transform = cam.world_view_transform.to(dev); c.full_proj_transform = cam.full_proj_transform.to(dev)
+            tm = synth.transmat_python(c, L["means3D"], L["scales"], rn)                    # the caller's torch expression
+            outs = tracer(ro.to(dev), rd.to(dev), v, scales=None, rotations=None, cov3D_precomp=tm, **kw)
+        (outs[0] * torch.linspace(0.5, 1.5, 3, device=dev)).sum().backward()
+        torch.cuda.synchronize()
+        res[mode] = (outs[0].detach().cpu().numpy(), {k: x.grad.cpu().numpy() for k, x in L.items()})
+    assert np.abs(res["frame"][0] - bg.numpy()).max() > 0.05
+    check_close("cov3D_precomp", "rgb", res["precomp"][0], res["frame"][0], tol=2e-4)
+    for k in ("scales", "rotations", "opacities", "shs"):
+        check_close("cov3D_precomp", "d" + k, res["precomp"][1][k], res["frame"][1][k], tol=2e-3)
 
 
 def test_trace_edge_cases():
@@ -140,6 +322,8 @@ def test_trace_edge_cases():
         tracer(ro.to(dev), rd.to(dev), None, **{**kw, "colors_precomp": torch.rand(50, 3, device=dev)})
     with pytest.raises(Exception):
         tracer(ro.to(dev), rd.to(dev), None, **{**kw, "means3D": torch.rand(60, 3, device=dev)})
+    with pytest.raises(Exception):
+        tracer(ro.to(dev), rd.to(dev), None, **{**kw, "scales": None})
     # cached BVH (v=None at test time, optix_utils.py:83) under inference_mode, (1,S,3) rays
     with torch.inference_mode():
         rgb2, *_ = tracer(ro.to(dev)[None], rd.to(dev)[None], None, **kw)
@@ -147,55 +331,37 @@ def test_trace_edge_cases():
 
 
 @pytest.mark.parametrize("force_cap,records", [(12, True), (20, False), (0, True), (512, False)])
-def test_trace_list_path_overflow_handoff(force_cap, records):
+def test_trace_list_path_overflow_handoff(force_cap, records, request):
     """Per-ray hit lists with a tiny capacity: rays that overflow must be handed to the K-buffer kernels and give the same
     result as the oracle (forward and backward); force_cap=0 disables the list path entirely."""
-    from envgs_amd import tracing
-    from oracle import trace as otr
     g, ro, rd = trace_scene(P=600, R=512, seed=11, camera=False)
     g["scales"] = g["scales"] * 0.6
-    R = ro.shape[0]
-    bg = torch.tensor([0.1, 0.2, 0.3])
-    gen = torch.Generator().manual_seed(3)
-    gr = [torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen),
-          torch.randn(R, 3, generator=gen), torch.randn(R, 2, generator=gen)]
-    old = dict(tracing.HIT_CAP)
-    orig_fwd = tracing.trace_forward
-    old_rec = tracing.USE_RECORDS["on"]
-    try:
-        tracing.USE_RECORDS["on"] = records
-        if force_cap: tracing.HIT_CAP["force"] = force_cap
-        else: tracing.trace_forward = lambda *a, **k: orig_fwd(*a, **{**k, "use_lists": False})
-        outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, 3, True, False, grads=gr)
-        cnt = tracing.last_trace_counts()
-    finally:
-        tracing.HIT_CAP.clear(); tracing.HIT_CAP.update(old); tracing.trace_forward = orig_fwd; tracing.USE_RECORDS["on"] = old_rec
-    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
-    ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(),
-                            g["opacities"].numpy(), shs=g["shs"].numpy(), sh_degree=3, others=g["others"].numpy(), bg=bg.numpy(),
-                            start_from_first=False)
+    sw = _Switch(records=records, **({"force_cap": force_cap} if force_cap else {"no_lists": True}))
+    res = _parity(request.node.name, g, ro, rd, torch.tensor([0.1, 0.2, 0.3]), 3, True, False, seed=3, hip_ctx=sw, require_lists=bool(force_cap))
     if force_cap and force_cap < 100:
-        assert cnt["max_list"] > force_cap                 # the overflow path really ran
-        assert (ref["nhits"] <= force_cap).any()           # and so did the list path
-    assert_close_frac(rgb, ref["rgb"], 1e-4, max_bad_frac=2e-3, flip_bound=0.05, what="rgb")
-    assert_close_frac(wet[:, 0], ref["wet"], 1e-4, max_bad_frac=2e-3, flip_bound=0.05, what="wet")
-    assert_close_frac(mid[:, 13:16], ref["rgb"], 1e-4, max_bad_frac=2e-3, flip_bound=0.05, what="mid.rgb")
-    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
-    chk = lambda a, b, nm: assert_close_frac(a, b, 1e-3, max_bad_frac=5e-3, flip_bound=0.2, what=nm)
-    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
-    chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
-    chk(L["rotations"].grad.cpu().numpy(), rb["drots"], "drots")
-    chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
-    chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
+        assert res["cnt"]["max_list"] > force_cap                 # the overflow path really ran
+        assert (res["ref"]["nhits"] <= force_cap).any() and 0 < res["n_listed"] < res["R"]          # and so did the list path
+
+
+def test_trace_packet_stack_overflow_is_handed_off_not_dropped():
+    """The packet traversal's wave-uniform stack is limited to 2 entries (debug switch 1024): every batch that would have dropped a subtree
+    is flagged, counted, and traced by the K-buffer kernels instead -- identical results."""
+    from envgs_amd import tracing
+    g, ro, rd = trace_scene(P=2000, R=1024, seed=7, camera=False)
+    g["scales"] = g["scales"] * 0.35
+    state = {}
+    def after():
+        state["cnt"] = tracing.last_trace_counts()
+        return "overflow-expected"
+    res = _parity("packet_stack_overflow", g, ro, rd, torch.tensor([0.3, 0.1, 0.7]), 2, True, False, hip_ctx=_Switch(debug_trace=1024), after_hip=after)
+    assert state["cnt"]["stack_overflows"] > 0
+    record("packet_stack_overflow", "batches_handed_off", state["cnt"]["stack_overflows"])
 
 
 def test_trace_baseline_size_env_set_sample_vs_oracle():
     """BASELINE env set at full size (163 840 surfels over +-50, the reference's initial fog) traced by a 3 072-ray sample of
-    reflected-like rays: deep LBVH (stack spill path), long hit lists (termination bound, list sort), all gradients -- against the
+    reflected-like rays: deep LBVH, long hit lists (termination bound, list sort), all gradients -- against the
     brute-force oracle.  The whole 640 k-ray view is covered by bench.py; the oracle needs ~10 s for this sample."""
-    from oracle import trace as otr
-    from envgs_amd import tracing
-    dev = torch.device("cuda:0")
     P, R = 163840, 3072
     e = synth.env_gaussians(P, seed=1)
     gen = torch.Generator().manual_seed(5)
@@ -203,35 +369,16 @@ def test_trace_baseline_size_env_set_sample_vs_oracle():
     rd = torch.randn(R, 3, generator=gen); rd = rd / rd.norm(dim=-1, keepdim=True) * (0.8 + 0.4 * torch.rand(R, 1, generator=gen))
     g = dict(means3D=e["means3D"], scales=e["scales"], rotations=e["rotations"], opacities=e["opacities"], shs=e["shs"],
              others=torch.rand(P, 2, generator=gen), colors_precomp=torch.rand(P, 3, generator=gen))
-    bg = torch.tensor([0.0, 0.0, 0.0])
-    gr = [torch.randn(R, 3, generator=gen) / R, torch.zeros(R), torch.zeros(R), torch.zeros(R, 3), torch.zeros(R, 2)]
-    outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, 3, True, False, grads=gr)
-    cnt = tracing.last_trace_counts()
-    assert cnt["hits"] / R > 30 and cnt["max_list"] > 100            # a fog: long lists
-    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
-    ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(),
-                            g["opacities"].numpy(), shs=g["shs"].numpy(), sh_degree=3, others=g["others"].numpy(), bg=bg.numpy(),
-                            start_from_first=False)
-    assert abs(int(ref["nhits"].sum()) - cnt["hits"]) <= 1e-3 * cnt["hits"]      # same composited hits (threshold flips aside)
-    for a, b, nm in ((rgb, ref["rgb"], "rgb"), (dpt[:, 0], ref["dpt"], "dpt"), (acc[:, 0], ref["acc"], "acc"), (norm, ref["norm"], "norm"),
-                     (wet[:, 0], ref["wet"], "wet")):
-        assert_close_frac(a, b, 2e-4, max_bad_frac=2e-3, flip_bound=0.05, what=nm)
-    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
-    chk = lambda a, b, nm: assert_close_frac(a, b, 1e-3, max_bad_frac=2e-3, flip_bound=0.3, what=nm)
-    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
-    chk(L["scales"].grad.cpu().numpy(), rb["dscales"], "dscales")
-    chk(L["rotations"].grad.cpu().numpy(), rb["drots"], "drots")
-    chk(L["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"], "dopac")
-    chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
-    chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
-    chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
+    res = _parity("env_set_163840_sample", g, ro, rd, torch.zeros(3), 3, True, False, gr_scale=1.0 / R, seed=6, zero_geo_grads=True,
+                  which=("dmeans3D", "dscales", "drots", "dopacities", "dcolor", "dray_o", "dray_d"))
+    cnt = res["cnt"]
+    assert cnt["hits"] / res["R"] > 30 and cnt["max_list"] > 100            # a fog: long lists
+    assert int(res["ref"]["nhits"].sum()) == cnt["hits"]                     # the same composited hits, exactly
 
 
 def test_trace_clustered_surfels_deep_tree():
-    """Thousands of surfels packed into a tiny cluster (identical Morton prefixes -> a very deep LBVH: exercises the HBM stack-spill
-    path of the collection pass and the index tie-break of the Karras build) plus a sparse far set; also exact ties in t (coplanar
-    surfels) ordered by surfel id."""
-    from oracle import trace as otr
+    """Thousands of surfels packed into a tiny cluster (identical Morton prefixes -> a very deep LBVH: exercises the index tie-break of the
+    Karras build) plus a sparse far set; also exact ties in t (coplanar surfels) ordered by surfel id."""
     gen = torch.Generator().manual_seed(21)
     Pc, Pf = 3000, 200
     means = torch.cat([torch.tensor([0.0, 0.0, 5.0]) + 0.02 * torch.randn(Pc, 3, generator=gen), (torch.rand(Pf, 3, generator=gen) * 2 - 1) * 30])
@@ -247,29 +394,16 @@ def test_trace_clustered_surfels_deep_tree():
     ro = torch.randn(R, 3, generator=gen) * 0.2
     tgt = torch.tensor([0.0, 0.0, 5.0]) + 0.3 * torch.randn(R, 3, generator=gen)
     rd = tgt - ro; rd = rd / rd.norm(dim=-1, keepdim=True)
-    bg = torch.tensor([0.2, 0.2, 0.2])
-    gr = [torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen), torch.randn(R, 3, generator=gen), torch.zeros(R, 2)]
-    outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, 2, True, False, grads=gr)
-    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
-    ref = otr.trace_forward(ro.numpy(), rd.numpy(), means.numpy(), scales.numpy(), rots.numpy(), opac.numpy(), shs=g["shs"].numpy(), sh_degree=2,
-                            others=g["others"].numpy(), bg=bg.numpy(), start_from_first=False)
-    assert ref["nhits"].max() > 200
-    for a, b, nm in ((rgb, ref["rgb"], "rgb"), (dpt[:, 0], ref["dpt"], "dpt"), (acc[:, 0], ref["acc"], "acc"), (wet[:, 0], ref["wet"], "wet")):
-        assert_close_frac(a, b, 2e-4, max_bad_frac=5e-3, flip_bound=0.1, what=nm)
-    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
-    chk = lambda a, b, nm: assert_close_frac(a, b, 2e-3, max_bad_frac=5e-3, flip_bound=0.3, what=nm)
-    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
-    chk(L["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"], "dopac")
-    chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
-    chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
+    res = _parity("clustered_deep_tree", g, ro, rd, torch.tensor([0.2, 0.2, 0.2]), 2, True, False, seed=22,
+                  which=("dmeans3D", "dopacities", "dcolor", "dray_d"))
+    assert res["ref"]["nhits"].max() > 200
 
 
 @pytest.mark.parametrize("sort_rays", [True, False])
-def test_trace_batch_table_overflow_and_unsorted_rays(sort_rays):
+def test_trace_batch_table_overflow_and_unsorted_rays(sort_rays, request):
     """Incoherent rays through a dense set: a 64-ray batch blends far more distinct surfels than its 1024-slot merge table holds, so part
     of the hits become single entries (filed from the top of the batch's region) -- forward weights and every gradient must still match
     the oracle; with the coherence sort disabled the per-ray collection kernel feeds the same batch kernels."""
-    from oracle import trace as otr
     from envgs_amd import tracing
     gen = torch.Generator().manual_seed(33)
     P, R = 6000, 1000                                                   # R is not a multiple of 64: a ragged last batch
@@ -280,41 +414,16 @@ def test_trace_batch_table_overflow_and_unsorted_rays(sort_rays):
              shs=torch.randn(P, 16, 3, generator=gen) * 0.3, others=torch.rand(P, 2, generator=gen), colors_precomp=torch.rand(P, 3, generator=gen))
     ro = (torch.rand(R, 3, generator=gen) * 2 - 1) * 2.0
     rd = torch.randn(R, 3, generator=gen); rd = rd / rd.norm(dim=-1, keepdim=True)
-    bg = torch.tensor([0.1, 0.0, 0.2])
-    gr = [torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen), torch.randn(R, 3, generator=gen),
-          torch.randn(R, 2, generator=gen)]
-    old = tracing.SORT_RAYS["on"]
-    try:
-        tracing.SORT_RAYS["on"] = sort_rays
-        outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, 3, True, False, grads=gr)
-        table, singles = tracing.last_entry_counts()
-        cnt = tracing.last_trace_counts()
-    finally:
-        tracing.SORT_RAYS["on"] = old
+    res = _parity(request.node.name, g, ro, rd, torch.tensor([0.1, 0.0, 0.2]), 3, True, False, seed=34, hip_ctx=_Switch(sort_rays=sort_rays),
+                  after_hip=tracing.last_entry_counts)
+    table, singles = res["extra"]
     assert table > 0 and singles > 0, (table, singles)                 # both kinds of entries were produced
-    assert table + singles <= cnt["hits"]
-    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
-    ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(), g["opacities"].numpy(),
-                            shs=g["shs"].numpy(), sh_degree=3, others=g["others"].numpy(), bg=bg.numpy(), start_from_first=False)
-    for a, b, nm in ((rgb, ref["rgb"], "rgb"), (dpt[:, 0], ref["dpt"], "dpt"), (acc[:, 0], ref["acc"], "acc"), (aux, ref["aux"], "aux"),
-                     (wet[:, 0], ref["wet"], "wet")):
-        assert_close_frac(a, b, 2e-4, max_bad_frac=2e-3, flip_bound=0.05, what=nm)
-    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
-    chk = lambda a, b, nm: assert_close_frac(a, b, 1e-3, max_bad_frac=5e-3, flip_bound=0.3, what=nm)
-    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
-    chk(L["scales"].grad.cpu().numpy(), rb["dscales"], "dscales")
-    chk(L["rotations"].grad.cpu().numpy(), rb["drots"], "drots")
-    chk(L["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"], "dopac")
-    chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
-    chk(L["others"].grad.cpu().numpy(), rb["dothers"], "dothers")
-    chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
-    chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
+    assert table + singles <= res["cnt"]["hits"]
 
 
 def test_trace_two_segment_forward_pipeline_vs_oracle():
     """Enough rays (>= 512 batches) for the forward to run as TWO batch segments on two streams (collect -> sort+composite -> register each):
     the joined result -- images, per-surfel weights, every gradient through the per-batch entries of both segments -- against the oracle."""
-    from oracle import trace as otr
     from envgs_amd import tracing
     g, _, _ = trace_scene(P=1500, R=4, seed=17, camera=False)
     g["scales"] = g["scales"] * 0.5
@@ -322,37 +431,16 @@ def test_trace_two_segment_forward_pipeline_vs_oracle():
     ro, rd = synth.get_rays(cam)
     ro, rd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous()
     R = ro.shape[0]
-    assert (R + 63) // 64 >= 512
-    bg = torch.tensor([0.2, 0.3, 0.1])
-    gen = torch.Generator().manual_seed(4)
-    gr = [torch.randn(R, 3, generator=gen) / R, torch.randn(R, generator=gen) / R, torch.randn(R, generator=gen) / R, torch.randn(R, 3, generator=gen) / R,
-          torch.randn(R, 2, generator=gen) / R]
-    outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, 3, True, False, grads=gr)
-    table, singles = tracing.last_entry_counts()
-    assert table > 0
-    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
-    ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(), g["opacities"].numpy(),
-                            shs=g["shs"].numpy(), sh_degree=3, others=g["others"].numpy(), bg=bg.numpy(), start_from_first=False)
-    for a, b, nm in ((rgb, ref["rgb"], "rgb"), (dpt[:, 0], ref["dpt"], "dpt"), (acc[:, 0], ref["acc"], "acc"), (norm, ref["norm"], "norm"),
-                     (aux, ref["aux"], "aux"), (wet[:, 0], ref["wet"], "wet")):
-        assert_close_frac(a, b, 2e-4, max_bad_frac=2e-3, flip_bound=0.05, what=nm)
-    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
-    chk = lambda a, b, nm: assert_close_frac(a, b, 1e-3, max_bad_frac=5e-3, flip_bound=0.3, what=nm)
-    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
-    chk(L["scales"].grad.cpu().numpy(), rb["dscales"], "dscales")
-    chk(L["rotations"].grad.cpu().numpy(), rb["drots"], "drots")
-    chk(L["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"], "dopac")
-    chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
-    chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
-    chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
+    res = _parity("two_segment_pipeline", g, ro, rd, torch.tensor([0.2, 0.3, 0.1]), 3, True, False, gr_scale=1.0 / R, seed=4,
+                  after_hip=tracing.last_entry_counts)
+    assert (res["R"] + 63) // 64 >= 512
+    assert res["extra"][0] > 0
 
 
 @pytest.mark.parametrize("force_cap", [1024, 512, 320])
-def test_trace_very_long_lists(force_cap):
+def test_trace_very_long_lists(force_cap, request):
     """A stack of 900 faint sheets: most rays blend several hundred hits before they terminate, so the sort / composite pass for lists beyond
     256 entries runs (8 and 16 keys per lane), and with the smaller capacities the longest rays overflow into the K-buffer path."""
-    from oracle import trace as otr
-    from envgs_amd import tracing
     P, R = 900, 192
     gen = torch.Generator().manual_seed(21)
     means = torch.stack([torch.randn(P, generator=gen) * 0.15, torch.randn(P, generator=gen) * 0.15, 2.0 + torch.arange(P) * 0.01], dim=1)
@@ -363,31 +451,10 @@ def test_trace_very_long_lists(force_cap):
     # rays through the middle of the stack terminate after a few hundred hits, rays near its rim see falloffs below 1/255: 14 .. 712 hits
     ro = torch.cat([(torch.rand(R, 2, generator=gen) - 0.5) * 1.6, torch.zeros(R, 1)], dim=1)
     rd = torch.cat([torch.randn(R, 2, generator=gen) * 0.03, torch.ones(R, 1)], dim=1)
-    bg = torch.tensor([0.1, 0.2, 0.3])
-    gr = [torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen),
-          torch.randn(R, 3, generator=gen), torch.randn(R, 2, generator=gen)]
-    old = dict(tracing.HIT_CAP)
-    try:
-        tracing.HIT_CAP["force"] = force_cap
-        outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, 2, True, False, grads=gr)
-    finally:
-        tracing.HIT_CAP.clear(); tracing.HIT_CAP.update(old)
-    cnt = tracing.last_trace_counts()
-    ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"].numpy(), g["scales"].numpy(), g["rotations"].numpy(), g["opacities"].numpy(),
-                            shs=g["shs"].numpy(), sh_degree=2, others=g["others"].numpy(), bg=bg.numpy(), start_from_first=False)
-    assert ref["nhits"].max() > 512 and ((ref["nhits"] > 256) & (ref["nhits"] <= 512)).sum() > 20 and (ref["nhits"] <= 256).sum() > 5 and cnt["max_list"] > 512
-    rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
-    for a, b, nm in ((rgb, ref["rgb"], "rgb"), (dpt[:, 0], ref["dpt"], "dpt"), (acc[:, 0], ref["acc"], "acc"), (norm, ref["norm"], "norm"),
-                     (aux, ref["aux"], "aux"), (wet[:, 0], ref["wet"], "wet")):
-        assert_close_frac(a, b, 3e-4, max_bad_frac=5e-3, flip_bound=0.05, what=nm)
-    rb = otr.trace_backward(ref, *[x.numpy() for x in gr])
-    chk = lambda a, b, nm: assert_close_frac(a, b, 2e-3, max_bad_frac=5e-3, flip_bound=0.3, what=nm)
-    chk(L["means3D"].grad.cpu().numpy(), rb["dmeans3D"], "dmeans3D")
-    chk(L["opacities"].grad.cpu().numpy().reshape(-1), rb["dopacities"], "dopac")
-    chk(L["shs"].grad.cpu().numpy(), rb["dshs"], "dshs")
-    chk(L["others"].grad.cpu().numpy(), rb["dothers"], "dothers")
-    chk(o.grad.cpu().numpy(), rb["dray_o"], "dray_o")
-    chk(d.grad.cpu().numpy(), rb["dray_d"], "dray_d")
+    res = _parity(request.node.name, g, ro, rd, torch.tensor([0.1, 0.2, 0.3]), 2, True, False, seed=23, hip_ctx=_Switch(force_cap=force_cap),
+                  which=("dmeans3D", "dopacities", "dcolor", "dothers", "dray_o", "dray_d"), )
+    nh = res["ref"]["nhits"]
+    assert nh.max() > 512 and ((nh > 256) & (nh <= 512)).sum() > 10 and (nh <= 256).sum() > 5 and res["cnt"]["max_list"] > 512
 
 
 @pytest.mark.parametrize("P,R", [(50, 0), (0, 64), (0, 0), (1, 64)])
@@ -415,4 +482,7 @@ def test_trace_empty_inputs(P, R):
         from oracle import trace as otr
         ref = otr.trace_forward(ro.numpy(), rd.numpy(), g["means3D"][:1].numpy(), g["scales"][:1].numpy(), g["rotations"][:1].numpy(),
                                 g["opacities"][:1].numpy(), shs=g["shs"][:1].numpy(), sh_degree=1, bg=bg.numpy(), start_from_first=False)
-        assert_close_frac(rgb.detach().cpu().numpy(), ref["rgb"], 2e-4, max_bad_frac=0.02, flip_bound=0.1, what="rgb")
+        a = otr.trace_audit(ro.numpy(), rd.numpy(), g["means3D"][:1].numpy(), g["scales"][:1].numpy(), g["rotations"][:1].numpy(), g["opacities"][:1].numpy(),
+                            start_from_first=False)
+        ok = ~a["fragile"]
+        check_close("single_surfel", "rgb", rgb.detach().cpu().numpy()[ok], ref["rgb"][ok], excluded=int((~ok).sum()))
