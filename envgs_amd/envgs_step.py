@@ -68,11 +68,8 @@ def base_pass(pkg, cam, base, bg, sh_degree, scale_modifier=1.0):
         return dict(rgb=img[:3], spec=img[3:3 + S], rough=img[3 + S:4 + S], alpha=allmap[1:2], radii=radii, weight=weight, means2D=means2D,
                     allmap=allmap)
     alpha = allmap[1:2]
-    # view -> world: the reference writes this as a (HW,3)@(3,3) matmul (gaussian2d_utils.py:1123); hipBLASLt picks a 4 ms GEMM for
-    # that shape on this stack, so the same 9 multiply-adds are written elementwise here (the glue is next to fuse)
-    Rv = cam.world_view_transform[:3, :3]
-    nv = allmap[2:5]
-    normal = torch.stack([nv[0] * Rv[c, 0] + nv[1] * Rv[c, 1] + nv[2] * Rv[c, 2] for c in range(3)], dim=0)
+    # view -> world, the reference's own expression (gaussian2d_utils.py:1123)
+    normal = (allmap[2:5].permute(1, 2, 0) @ (cam.world_view_transform[:3, :3].T)).permute(2, 0, 1)
     depth = torch.nan_to_num(allmap[0:1] / alpha, 0, 0)
     return dict(rgb=img[:3], spec=img[3:3 + S], rough=img[3 + S:4 + S], alpha=alpha, normal=normal, depth=depth, radii=radii,
                 weight=weight, means2D=means2D, allmap=allmap)

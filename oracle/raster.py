@@ -91,8 +91,8 @@ def raster_forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, *, 
 
 
 def raster_audit(fwd, want_contrib=False):
-    """Fragility audit of the forward `fwd` (orc_render_audit): returns dict(fragile (H,W) bool, tainted (P,) bool,
-    contrib (H*W, lmax) uint8 or None, lmax).  See the C comment for the definition."""
+    """Fragility audit of the forward `fwd` (orc_render_audit): returns dict(fragile (H,W) bool = flips | illcond, tainted (P,) bool,
+    contrib (H*W, lmax) uint8 or None, lmax).  See the C comment for the definitions."""
     L = lib()
     cfg = fwd["cfg"]; H, W, P = fwd["H"], fwd["W"], fwd["P"]
     pl = fwd["point_list"] if fwd["N"] > 0 else np.zeros(1, np.uint32)
@@ -102,30 +102,66 @@ def raster_audit(fwd, want_contrib=False):
     contrib = np.zeros((H * W, max(lmax, 1)), np.uint8) if want_contrib else None
     L.orc_render_audit(ctypes.byref(cfg), _p(fwd["ranges"]), _p(pl), _p(fwd["transmat"]), _p(fwd["xy"]), _p(fwd["normal_opacity"]),
                        _p(fragile), _p(contrib), ctypes.c_int(max(lmax, 1)), _p(tainted))
-    return dict(fragile=fragile.reshape(H, W).astype(bool), tainted=tainted[:P].astype(bool), contrib=contrib, lmax=max(lmax, 1))
+    return dict(fragile=(fragile != 0).reshape(H, W), flips=((fragile & 1) != 0).reshape(H, W), illcond=((fragile & 2) != 0).reshape(H, W), relbad=((fragile & 4) != 0).reshape(H, W),
+                tainted=tainted[:P].astype(bool), contrib=contrib, lmax=max(lmax, 1))
 
 
-def raster_backward(fwd, dL_dcolor, dL_dallmap):
-    """Gradients for the forward `fwd` (dict from raster_forward).  Returns dict of float32 arrays + raw records."""
+def raster_backward(fwd, dL_dcolor, dL_dallmap, want_cond=False):
+    """Gradients for the forward `fwd` (dict from raster_forward).  Returns dict of float32 arrays + raw records.
+    want_cond: additionally `cond` = dict of sum |term| per gradient element (same keys): R7's records accumulated in absolute value and
+    pushed through R8 with the absolute value of its (linear) map -- the magnitude of what each element is a sum of."""
     L = lib()
     cfg = fwd["cfg"]; P, C, M = fwd["P"], fwd["C"], fwd["M"]
     inp = fwd["inputs"]
     dL_dcolor = _f32(dL_dcolor); dL_dallmap = _f32(dL_dallmap)
     pl = fwd["point_list"] if fwd["N"] > 0 else np.zeros(1, np.uint32)
     dT = np.zeros((P, 9)); dn = np.zeros((P, 3)); dop = np.zeros(P); dcol = np.zeros((P, C)); dm2 = np.zeros((P, 2))
+    ab = [np.zeros_like(x) for x in (dT, dn, dop, dcol, dm2)] if want_cond else [None] * 5
     L.orc_render_bwd(ctypes.byref(cfg), _p(fwd["ranges"]), _p(pl), _p(fwd["transmat"]), _p(fwd["xy"]),
                      _p(fwd["normal_opacity"]), _p(fwd["colors"]), _p(fwd["bg"]), ctypes.c_int(len(fwd["bg"])),
                      _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(dL_dcolor), _p(dL_dallmap), _p(dT), _p(dn), _p(dop),
-                     _p(dcol), _p(dm2))
-    dmeans3D = np.zeros((P, 3), np.float32); dmeans2D = np.zeros((P, 3), np.float32)
-    dscales = np.zeros((P, 2), np.float32); drots = np.zeros((P, 4), np.float32)
-    dshs = np.zeros((P, max(M, 1), 3), np.float32); dtm = np.zeros((P, 9), np.float32)
-    L.orc_preprocess_bwd(ctypes.byref(cfg), _p(inp["means3D"]), _p(inp["scales"]), _p(inp["rotations"]), _p(inp["shs"]),
-                         _p(fwd["clamped"]), _p(inp["transmat_precomp"]), _p(fwd["transmat"]), _p(fwd["radii"]),
-                         _p(inp["viewmatrix"]), _p(inp["projmatrix"]), _p(inp["campos"]), _p(dT), _p(dn), _p(dm2),
-                         _p(dcol), _p(dmeans3D), _p(dmeans2D), _p(dscales), _p(drots), _p(dshs), _p(dtm))
-    return dict(dmeans3D=dmeans3D, dmeans2D=dmeans2D, dscales=dscales, drots=drots,
-                dshs=dshs if inp["shs"] is not None else None,
-                dcolors=dcol.astype(np.float32) if inp["shs"] is None else None,
-                dopacities=dop.astype(np.float32), dtransmat_precomp=dtm if inp["transmat_precomp"] is not None else None,
-                rec_dT=dT, rec_dnormal=dn, rec_dcolor=dcol, rec_dmean2D=dm2, rec_dopacity=dop)
+                     _p(dcol), _p(dm2), *[_p(x) for x in ab])
+
+    def r8(dT_, dn_, dm2_, dcol_):
+        dmeans3D = np.zeros((P, 3), np.float32); dmeans2D = np.zeros((P, 3), np.float32)
+        dscales = np.zeros((P, 2), np.float32); drots = np.zeros((P, 4), np.float32)
+        dshs = np.zeros((P, max(M, 1), 3), np.float32); dtm = np.zeros((P, 9), np.float32)
+        L.orc_preprocess_bwd(ctypes.byref(cfg), _p(inp["means3D"]), _p(inp["scales"]), _p(inp["rotations"]), _p(inp["shs"]),
+                             _p(fwd["clamped"]), _p(inp["transmat_precomp"]), _p(fwd["transmat"]), _p(fwd["radii"]),
+                             _p(inp["viewmatrix"]), _p(inp["projmatrix"]), _p(inp["campos"]), _p(dT_), _p(dn_), _p(dm2_),
+                             _p(dcol_), _p(dmeans3D), _p(dmeans2D), _p(dscales), _p(drots), _p(dshs), _p(dtm))
+        return dict(dmeans3D=dmeans3D, dmeans2D=dmeans2D, dscales=dscales, drots=drots,
+                    dshs=dshs if inp["shs"] is not None else None,
+                    dtransmat_precomp=dtm if inp["transmat_precomp"] is not None else None)
+
+    out = r8(dT, dn, dm2, dcol)
+    out.update(dcolors=dcol.astype(np.float32) if inp["shs"] is None else None, dopacities=dop.astype(np.float32),
+               rec_dT=dT, rec_dnormal=dn, rec_dcolor=dcol, rec_dmean2D=dm2, rec_dopacity=dop)
+    def through_r8(aT, an, aop, acol, am2):
+        # R8 is linear in the records: sum_k |J_ik| * x_k = sum over the record words of |R8(e_k * x_k)|   (x >= 0)
+        z = lambda a: np.zeros_like(a)
+        res = None
+        probes = [(0, k) for k in range(9)] + [(1, k) for k in range(3)] + [(2, k) for k in range(2)] + [(3, k) for k in range(C)]
+        for which, k in probes:
+            args = [z(aT), z(an), z(am2), z(acol)]
+            src = (aT, an, am2, acol)[which]
+            args[which][:, k] = src[:, k]
+            o = r8(*args)
+            if res is None:
+                res = {kk: (np.abs(v).astype(np.float64) if v is not None else None) for kk, v in o.items()}
+            else:
+                for kk, v in o.items():
+                    if v is not None: res[kk] += np.abs(v)
+        res["dcolors"] = acol if inp["shs"] is None else None
+        res["dopacities"] = aop
+        return res
+
+    if want_cond:
+        out["cond"] = through_r8(*ab)
+        # the oracle's own fp32 uncertainty, term by term (orc_render_bwd_unc), pushed through |R8| the same way
+        un = [np.zeros_like(x) for x in (dT, dn, dop, dcol, dm2)]
+        L.orc_render_bwd_unc(ctypes.byref(cfg), _p(fwd["ranges"]), _p(pl), _p(fwd["transmat"]), _p(fwd["xy"]),
+                             _p(fwd["normal_opacity"]), _p(fwd["colors"]), _p(fwd["bg"]), ctypes.c_int(len(fwd["bg"])),
+                             _p(fwd["final_T"]), _p(fwd["n_contrib"]), _p(dL_dcolor), _p(dL_dallmap), *[_p(x) for x in un])
+        out["unc"] = through_r8(*un)
+    return out

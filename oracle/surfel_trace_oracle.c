@@ -411,8 +411,21 @@ void trc_backward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, co
                   const float *rots, const float *opac, const float *shs, const float *colors_precomp, const float *others,
                   const float *bg, const float *dL_drgb, const float *dL_ddpt, const float *dL_dacc, const float *dL_dnorm,
                   const float *dL_daux, double *dmeans, double *dscales, double *drots, double *dopac, double *dshs,
-                  double *dcolors, double *dothers, double *dray_o, double *dray_d)
+                  double *dcolors, double *dothers, double *dray_o, double *dray_d,
+                  double *c_means, double *c_scales, double *c_rots, double *c_opac, double *c_color, double *c_others,
+                  double *c_ray_o, double *c_ray_d,
+                  double *u_c_means, double *u_c_scales, double *u_c_rots, double *u_c_opac, double *u_c_color, double *u_c_others,
+                  double *u_c_ray_o, double *u_c_ray_d)
 {
+    /* u_* (optional, with c_*): the oracle's own fp32 UNCERTAINTY of every gradient element -- the same noise-scale accumulation with each
+     * hit weighted by rho = |w32 - w64| / w64 + |alpha32 - alpha64| / alpha64 + (|u32 - u64| + |v32 - v64|) / (|u| + |v| + 0.01), the relative
+     * distance between this file's float evaluation of the hit and a double evaluation from the raw parameters (the blend weight of the
+     * k-th hit carries the rounding of k transmittance factors: ~1e-4 after a hundred hits of a fog, in any fp32 implementation). */
+    /* c_* (optional, all or none; c_color is (P,M,3) or (P,3)): the NOISE SCALE of every gradient element -- the same accumulation with
+     * every hit's dL/dalpha replaced by the sum of the magnitudes it is a difference of (|g| * (T |value| + (|final| + |prefix|) / (1 - alpha)))
+     * and every coefficient by its absolute value.  An fp32 implementation that forms "suffix = final - prefix" carries an error of a few
+     * ulp of THOSE magnitudes into each hit's gradient, so this -- not the (possibly tiny) gradient itself -- is what its error is
+     * measured against (tests/util.py: condition-aware floor).  The oracle itself keeps all per-ray sums in double. */
     const int P = cfg->P, R = cfg->R, M = cfg->M;
     surfel_t *S = (surfel_t *)malloc(sizeof(surfel_t) * (P ? P : 1));
     for (int i = 0; i < P; i++) make_surfel(cfg, i, means, scales, rots, opac, &S[i]);
@@ -423,7 +436,30 @@ void trc_backward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, co
     if (M > 0) memset(dshs, 0, sizeof(double) * (size_t)P * M * 3); else memset(dcolors, 0, sizeof(double) * 3 * P);
     if (others) memset(dothers, 0, sizeof(double) * 2 * P);
     memset(dray_o, 0, sizeof(double) * 3 * R); memset(dray_d, 0, sizeof(double) * 3 * R);
+    double *cA_ = NULL, *cB_ = NULL, *cN_ = NULL;
+    if (c_means) {
+        memset(c_means, 0, sizeof(double) * 3 * P); memset(c_scales, 0, sizeof(double) * 2 * P); memset(c_rots, 0, sizeof(double) * 4 * P);
+        memset(c_opac, 0, sizeof(double) * P); memset(c_color, 0, sizeof(double) * (size_t)P * (M > 0 ? M * 3 : 3));
+        if (others) memset(c_others, 0, sizeof(double) * 2 * P);
+        memset(c_ray_o, 0, sizeof(double) * 3 * R); memset(c_ray_d, 0, sizeof(double) * 3 * R);
+        cA_ = (double *)calloc((size_t)3 * P + 1, sizeof(double)); cB_ = (double *)calloc((size_t)3 * P + 1, sizeof(double));
+        cN_ = (double *)calloc((size_t)3 * P + 1, sizeof(double));
+    }
+    double *u_cA_ = NULL, *u_cB_ = NULL, *u_cN_ = NULL;
+    surfel64_t *S64 = NULL;
+    if (u_c_means) {
+        memset(u_c_means, 0, sizeof(double) * 3 * P); memset(u_c_scales, 0, sizeof(double) * 2 * P); memset(u_c_rots, 0, sizeof(double) * 4 * P);
+        memset(u_c_opac, 0, sizeof(double) * P); memset(u_c_color, 0, sizeof(double) * (size_t)P * (M > 0 ? M * 3 : 3));
+        if (others) memset(u_c_others, 0, sizeof(double) * 2 * P);
+        memset(u_c_ray_o, 0, sizeof(double) * 3 * R); memset(u_c_ray_d, 0, sizeof(double) * 3 * R);
+        u_cA_ = (double *)calloc((size_t)3 * P + 1, sizeof(double)); u_cB_ = (double *)calloc((size_t)3 * P + 1, sizeof(double));
+        u_cN_ = (double *)calloc((size_t)3 * P + 1, sizeof(double));
+        S64 = (surfel64_t *)malloc(sizeof(surfel64_t) * (P ? P : 1));
+        for (int i = 0; i < P; i++) make_surfel64(cfg, i, means, scales, rots, opac, &S64[i]);
+    }
 #define ACC(arr, idx, v) do { double v__ = (double)(v); _Pragma("omp atomic") arr[idx] += v__; } while (0)
+#define CACC(arr, idx, v) do { if (c_means) { double v__ = fabs((double)(v)); _Pragma("omp atomic") arr[idx] += v__; \
+                               if (u_c_means) { double w__ = rho * v__; _Pragma("omp atomic") u_##arr[idx] += w__; } } } while (0)
 #pragma omp parallel
     {
         ent_t *ents = (ent_t *)malloc(sizeof(ent_t) * (P ? P : 1));
@@ -446,14 +482,33 @@ void trc_backward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, co
             const float gD = dL_ddpt[r], gA = dL_dacc[r];
             const float gN[3] = {dL_dnorm[3 * r], dL_dnorm[3 * r + 1], dL_dnorm[3 * r + 2]};
             const float gX[2] = {dL_daux[2 * r], dL_daux[2 * r + 1]};
-            /* running prefix sums (through hit k) of the composited quantities */
-            float T = 1.0f, crgb[3] = {0, 0, 0}, cD = 0.f, cA = 0.f, cN[3] = {0, 0, 0}, cX[2] = {0, 0};
+            /* running prefix sums (through hit k) of the composited quantities -- in double, as are the totals they are subtracted from
+             * (re-accumulated here: the forward's float totals carry their own rounding), so that the oracle's suffix terms are exact */
+            float T = 1.0f;
+            double crgb[3] = {0, 0, 0}, cD = 0., cA = 0., cN[3] = {0, 0, 0}, cX[2] = {0, 0};
+            double frgb[3] = {0, 0, 0}, fD = 0., fA = 0., fN[3] = {0, 0, 0}, fX[2] = {0, 0};
+            {
+                float Tt = 1.0f;
+                for (int k = 0; k < n; k++) {
+                    const rhit_t *h = &ents[k].h;
+                    const int g = ents[k].id;
+                    const float tt = Tt * (1.0f - h->alpha);
+                    if (tt < T_EPS) break;
+                    const double w = (double)(h->alpha * Tt);
+                    float col[3]; int cl[3];
+                    surfel_color(cfg, g, shs, colors_precomp, basis, col, cl);
+                    const double sg = h->denom < 0.0f ? 1.0 : -1.0;
+                    for (int c = 0; c < 3; c++) { frgb[c] += w * col[c]; fN[c] += w * sg * S[g].n[c]; }
+                    fD += w * h->t; fA += w;
+                    if (others) { fX[0] += w * others[2 * g]; fX[1] += w * others[2 * g + 1]; }
+                    Tt = tt;
+                }
+            }
             float bgdot = 0.f;
             for (int c = 0; c < 3; c++) bgdot += (c < cfg->bg_len ? bg[c] : 0.0f) * gR[c];
-            /* final sums WITHOUT the background term */
-            float frgb[3];
-            for (int c = 0; c < 3; c++) frgb[c] = fin.rgb[c] - fin.T * (c < cfg->bg_len ? bg[c] : 0.0f);
             double ddir[3] = {0, 0, 0}, dO[3] = {0, 0, 0}, dD[3] = {0, 0, 0};
+            double nddir[3] = {0, 0, 0}, nO[3] = {0, 0, 0}, nD[3] = {0, 0, 0};
+            double uddir[3] = {0, 0, 0}, uO[3] = {0, 0, 0}, uD[3] = {0, 0, 0}, T64 = 1.0, rho = 0.0;
             for (int k = 0; k < n; k++) {
                 const rhit_t *h = &ents[k].h;
                 const int g = ents[k].id;
@@ -462,6 +517,19 @@ void trc_backward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, co
                 const float test_T = T * (1.0f - alpha);
                 if (test_T < T_EPS) break;
                 const float w = alpha * T;
+                if (S64) {
+                    const surfel64_t *z = &S64[g];
+                    const double den = z->n[0] * d[0] + z->n[1] * d[1] + z->n[2] * d[2];
+                    const double t64 = (z->n[0] * (z->mu[0] - o[0]) + z->n[1] * (z->mu[1] - o[1]) + z->n[2] * (z->mu[2] - o[2])) / den;
+                    const double qx64 = o[0] + t64 * d[0] - z->mu[0], qy64 = o[1] + t64 * d[1] - z->mu[1], qz64 = o[2] + t64 * d[2] - z->mu[2];
+                    const double u64 = (z->a[0] * qx64 + z->a[1] * qy64 + z->a[2] * qz64) / z->su, v64 = (z->b[0] * qx64 + z->b[1] * qy64 + z->b[2] * qz64) / z->sv;
+                    double a64 = z->opa * exp(-0.5 * (u64 * u64 + v64 * v64));
+                    if (a64 > (double)ALPHA_CAP) a64 = (double)ALPHA_CAP;
+                    const double w64 = a64 * T64;
+                    rho = fabs((double)w - w64) / (w64 > 1e-30 ? w64 : 1e-30) + fabs((double)alpha - a64) / a64 +
+                          (fabs((double)h->u - u64) + fabs((double)h->v - v64)) / (fabs(u64) + fabs(v64) + 0.01);
+                    T64 *= (1.0 - a64);
+                }
                 float col[3]; int cl[3];
                 surfel_color(cfg, g, shs, colors_precomp, basis, col, cl);
                 const float sgn = h->denom < 0.0f ? 1.0f : -1.0f;
@@ -472,15 +540,22 @@ void trc_backward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, co
                 cD += w * h->t; cA += w;
                 for (int c = 0; c < 3; c++) cN[c] += w * nf[c];
                 cX[0] += w * ox0; cX[1] += w * ox1;
-                /* dL/dalpha_k = T_k * value_k - (suffix after k) / (1 - alpha_k) */
-                const float inv1m = 1.0f / (1.0f - alpha);
-                float dLa = 0.f;
-                for (int c = 0; c < 3; c++) dLa += gR[c] * (T * col[c] - (frgb[c] - crgb[c]) * inv1m);
-                dLa += gD * (T * h->t - (fin.dpt - cD) * inv1m);
-                dLa += gA * (T - (fin.acc - cA) * inv1m);
-                for (int c = 0; c < 3; c++) dLa += gN[c] * (T * nf[c] - (fin.nrm[c] - cN[c]) * inv1m);
-                dLa += gX[0] * (T * ox0 - (fin.aux[0] - cX[0]) * inv1m) + gX[1] * (T * ox1 - (fin.aux[1] - cX[1]) * inv1m);
-                dLa += -(fin.T * inv1m) * bgdot;
+                /* dL/dalpha_k = T_k * value_k - (suffix after k) / (1 - alpha_k);  nLa = the magnitudes this is a difference of */
+                const double inv1m = 1.0 / (1.0 - (double)alpha);
+                double dLa = 0., nLa = 0.;
+                for (int c = 0; c < 3; c++) {
+                    dLa += gR[c] * ((double)T * col[c] - (frgb[c] - crgb[c]) * inv1m);
+                    nLa += fabs(gR[c]) * ((double)T * fabs(col[c]) + (fabs(frgb[c]) + fabs(crgb[c])) * inv1m);
+                }
+                dLa += gD * ((double)T * h->t - (fD - cD) * inv1m);                 nLa += fabs(gD) * ((double)T * fabs(h->t) + (fabs(fD) + fabs(cD)) * inv1m);
+                dLa += gA * ((double)T - (fA - cA) * inv1m);                        nLa += fabs(gA) * ((double)T + (fabs(fA) + fabs(cA)) * inv1m);
+                for (int c = 0; c < 3; c++) {
+                    dLa += gN[c] * ((double)T * nf[c] - (fN[c] - cN[c]) * inv1m);
+                    nLa += fabs(gN[c]) * ((double)T * fabs(nf[c]) + (fabs(fN[c]) + fabs(cN[c])) * inv1m);
+                }
+                dLa += gX[0] * ((double)T * ox0 - (fX[0] - cX[0]) * inv1m) + gX[1] * ((double)T * ox1 - (fX[1] - cX[1]) * inv1m);
+                nLa += fabs(gX[0]) * ((double)T * fabs(ox0) + (fabs(fX[0]) + fabs(cX[0])) * inv1m) + fabs(gX[1]) * ((double)T * fabs(ox1) + (fabs(fX[1]) + fabs(cX[1])) * inv1m);
+                dLa += -((double)fin.T * inv1m) * bgdot;                            nLa += fabs((double)fin.T * inv1m * bgdot);
                 /* direct terms */
                 float dcol[3];
                 for (int c = 0; c < 3; c++) dcol[c] = cl[c] ? 0.f : w * gR[c];
@@ -490,36 +565,48 @@ void trc_backward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, co
                     for (int kk = 0; kk < nb; kk++)
                         for (int c = 0; c < 3; c++) {
                             ACC(dshs, ((size_t)g * M + kk) * 3 + c, basis[kk] * dcol[c]);
-                            ddir[0] += (double)(bgx[kk] * sh[kk * 3 + c] * dcol[c]);
-                            ddir[1] += (double)(bgy[kk] * sh[kk * 3 + c] * dcol[c]);
-                            ddir[2] += (double)(bgz[kk] * sh[kk * 3 + c] * dcol[c]);
+                            CACC(c_color, ((size_t)g * M + kk) * 3 + c, basis[kk] * dcol[c]);
+                            ddir[0] += (double)(bgx[kk] * sh[kk * 3 + c] * dcol[c]); nddir[0] += fabs((double)(bgx[kk] * sh[kk * 3 + c] * dcol[c])); uddir[0] += rho * fabs((double)(bgx[kk] * sh[kk * 3 + c] * dcol[c]));
+                            ddir[1] += (double)(bgy[kk] * sh[kk * 3 + c] * dcol[c]); nddir[1] += fabs((double)(bgy[kk] * sh[kk * 3 + c] * dcol[c])); uddir[1] += rho * fabs((double)(bgy[kk] * sh[kk * 3 + c] * dcol[c]));
+                            ddir[2] += (double)(bgz[kk] * sh[kk * 3 + c] * dcol[c]); nddir[2] += fabs((double)(bgz[kk] * sh[kk * 3 + c] * dcol[c])); uddir[2] += rho * fabs((double)(bgz[kk] * sh[kk * 3 + c] * dcol[c]));
                         }
                 } else {
-                    for (int c = 0; c < 3; c++) ACC(dcolors, 3 * (size_t)g + c, dcol[c]);
+                    for (int c = 0; c < 3; c++) { ACC(dcolors, 3 * (size_t)g + c, dcol[c]); CACC(c_color, 3 * (size_t)g + c, dcol[c]); }
                 }
-                if (others) { ACC(dothers, 2 * (size_t)g, w * gX[0]); ACC(dothers, 2 * (size_t)g + 1, w * gX[1]); }
-                for (int c = 0; c < 3; c++) ACC(dN, 3 * (size_t)g + c, w * sgn * gN[c]);
-                float dLt = w * gD;
+                if (others) {
+                    ACC(dothers, 2 * (size_t)g, w * gX[0]); ACC(dothers, 2 * (size_t)g + 1, w * gX[1]);
+                    CACC(c_others, 2 * (size_t)g, w * gX[0]); CACC(c_others, 2 * (size_t)g + 1, w * gX[1]);
+                }
+                for (int c = 0; c < 3; c++) { ACC(dN, 3 * (size_t)g + c, w * sgn * gN[c]); CACC(cN_, 3 * (size_t)g + c, w * gN[c]); }
+                const double dLt = (double)w * gD;
                 /* alpha = opa * G ; G = exp(-(u^2+v^2)/2) */
-                ACC(dopac, g, h->G * dLa);
-                const float dLG = s->opa * dLa;
-                const float dLu = dLG * (-h->G * h->u), dLv = dLG * (-h->G * h->v);
+                ACC(dopac, g, h->G * dLa); CACC(c_opac, g, h->G * nLa);
+                const double dLG = s->opa * dLa, nLG = s->opa * nLa;
+                const double dLu = dLG * (-h->G * h->u), dLv = dLG * (-h->G * h->v);
+                const double nLu = nLG * fabs(h->G * h->u), nLv = nLG * fabs(h->G * h->v);
                 const float qx = o[0] + h->t * d[0] - s->mu[0], qy = o[1] + h->t * d[1] - s->mu[1], qz = o[2] + h->t * d[2] - s->mu[2];
                 const float q[3] = {qx, qy, qz};
-                const float cu = dLu / s->su, cv = dLv / s->sv;
-                float dq[3];
-                for (int c = 0; c < 3; c++) dq[c] = cu * s->a[c] + cv * s->b[c];
-                for (int c = 0; c < 3; c++) { ACC(dA, 3 * (size_t)g + c, cu * q[c]); ACC(dB, 3 * (size_t)g + c, cv * q[c]); }
+                const double cu = dLu / s->su, cv = dLv / s->sv, ncu = nLu / s->su, ncv = nLv / s->sv;
+                double dq[3], nq[3];
+                for (int c = 0; c < 3; c++) { dq[c] = cu * s->a[c] + cv * s->b[c]; nq[c] = ncu * fabs(s->a[c]) + ncv * fabs(s->b[c]); }
+                for (int c = 0; c < 3; c++) {
+                    ACC(dA, 3 * (size_t)g + c, cu * q[c]); ACC(dB, 3 * (size_t)g + c, cv * q[c]);
+                    CACC(cA_, 3 * (size_t)g + c, ncu * q[c]); CACC(cB_, 3 * (size_t)g + c, ncv * q[c]);
+                }
                 ACC(dscales, 2 * (size_t)g, -dLu * h->u / s->su * cfg->scale_modifier);
                 ACC(dscales, 2 * (size_t)g + 1, -dLv * h->v / s->sv * cfg->scale_modifier);
+                CACC(c_scales, 2 * (size_t)g, nLu * h->u / s->su * cfg->scale_modifier);
+                CACC(c_scales, 2 * (size_t)g + 1, nLv * h->v / s->sv * cfg->scale_modifier);
                 /* q = o + t d - mu */
-                const float dLt_tot = dLt + dq[0] * d[0] + dq[1] * d[1] + dq[2] * d[2];
-                const float k_t = dLt_tot / h->denom;
+                const double dLt_tot = dLt + dq[0] * d[0] + dq[1] * d[1] + dq[2] * d[2];
+                const double nLt_tot = fabs(dLt) + nq[0] * fabs(d[0]) + nq[1] * fabs(d[1]) + nq[2] * fabs(d[2]);
+                const double k_t = dLt_tot / h->denom, nk_t = nLt_tot / fabs(h->denom);
                 for (int c = 0; c < 3; c++) {
                     ACC(dmeans, 3 * (size_t)g + c, -dq[c] + k_t * s->n[c]);
-                    dO[c] += (double)(dq[c] - k_t * s->n[c]);
-                    dD[c] += (double)(h->t * dq[c] - k_t * h->t * s->n[c]);
-                    ACC(dN, 3 * (size_t)g + c, -k_t * q[c]);
+                    CACC(c_means, 3 * (size_t)g + c, nq[c] + nk_t * fabs(s->n[c]));
+                    dO[c] += (double)(dq[c] - k_t * s->n[c]);                   nO[c] += nq[c] + nk_t * fabs(s->n[c]);                    uO[c] += rho * (nq[c] + nk_t * fabs(s->n[c]));
+                    dD[c] += (double)(h->t * dq[c] - k_t * h->t * s->n[c]);     nD[c] += fabs(h->t) * (nq[c] + nk_t * fabs(s->n[c]));     uD[c] += rho * fabs(h->t) * (nq[c] + nk_t * fabs(s->n[c]));
+                    ACC(dN, 3 * (size_t)g + c, -k_t * q[c]); CACC(cN_, 3 * (size_t)g + c, nk_t * q[c]);
                 }
                 T = test_T;
             }
@@ -532,10 +619,24 @@ void trc_backward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, co
                 dD[2] += (-d[0] * d[2] * dd0 - d[1] * d[2] * dd1 + (dl2 - d[2] * d[2]) * dd2) * inv3;
             }
             for (int c = 0; c < 3; c++) { dray_o[3 * r + c] = dO[c]; dray_d[3 * r + c] = dD[c]; }
+            if (c_means) {
+                double inv3 = 1.0 / ((double)dl2 * (double)dl);
+                for (int c = 0; c < 3; c++) {
+                    double sd = 0.;
+                    for (int e = 0; e < 3; e++) sd += fabs((e == c ? (double)dl2 : 0.0) - (double)d[c] * d[e]) * nddir[e];
+                    c_ray_o[3 * r + c] = nO[c]; c_ray_d[3 * r + c] = nD[c] + sd * inv3;
+                    if (u_c_means) {
+                        double su_ = 0.;
+                        for (int e = 0; e < 3; e++) su_ += fabs((e == c ? (double)dl2 : 0.0) - (double)d[c] * d[e]) * uddir[e];
+                        u_c_ray_o[3 * r + c] = uO[c]; u_c_ray_d[3 * r + c] = uD[c] + su_ * inv3;
+                    }
+                }
+            }
         }
         free(ents);
     }
 #undef ACC
+#undef CACC
     /* columns a,b,n of R -> unit quaternion gradient (no projection through the normalisation) */
     for (int i = 0; i < P; i++) {
         const float *q = rots + 4 * i;
@@ -547,6 +648,23 @@ void trc_backward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, co
         drots[4 * i + 1] = 2. * (-2. * x * (V[1][1] + V[2][2]) + y * (V[1][0] + V[0][1]) + z * (V[2][0] + V[0][2]) + r * (V[2][1] - V[1][2]));
         drots[4 * i + 2] = 2. * (x * (V[1][0] + V[0][1]) - 2. * y * (V[0][0] + V[2][2]) + z * (V[2][1] + V[1][2]) + r * (V[0][2] - V[2][0]));
         drots[4 * i + 3] = 2. * (x * (V[2][0] + V[0][2]) + y * (V[2][1] + V[1][2]) - 2. * z * (V[0][0] + V[1][1]) + r * (V[1][0] - V[0][1]));
+        if (c_means) {
+            double W[3][3], ar = fabs(r), ax = fabs(x), ay = fabs(y), az = fabs(z);
+            for (int rr = 0; rr < 3; rr++) { W[rr][0] = cA_[3 * i + rr]; W[rr][1] = cB_[3 * i + rr]; W[rr][2] = cN_[3 * i + rr]; }
+            c_rots[4 * i + 0] = 2. * (ax * (W[2][1] + W[1][2]) + ay * (W[0][2] + W[2][0]) + az * (W[1][0] + W[0][1]));
+            c_rots[4 * i + 1] = 2. * (2. * ax * (W[1][1] + W[2][2]) + ay * (W[1][0] + W[0][1]) + az * (W[2][0] + W[0][2]) + ar * (W[2][1] + W[1][2]));
+            c_rots[4 * i + 2] = 2. * (ax * (W[1][0] + W[0][1]) + 2. * ay * (W[0][0] + W[2][2]) + az * (W[2][1] + W[1][2]) + ar * (W[0][2] + W[2][0]));
+            c_rots[4 * i + 3] = 2. * (ax * (W[2][0] + W[0][2]) + ay * (W[2][1] + W[1][2]) + 2. * az * (W[0][0] + W[1][1]) + ar * (W[1][0] + W[0][1]));
+            if (u_c_means) {
+                for (int rr = 0; rr < 3; rr++) { W[rr][0] = u_cA_[3 * i + rr]; W[rr][1] = u_cB_[3 * i + rr]; W[rr][2] = u_cN_[3 * i + rr]; }
+                u_c_rots[4 * i + 0] = 2. * (ax * (W[2][1] + W[1][2]) + ay * (W[0][2] + W[2][0]) + az * (W[1][0] + W[0][1]));
+                u_c_rots[4 * i + 1] = 2. * (2. * ax * (W[1][1] + W[2][2]) + ay * (W[1][0] + W[0][1]) + az * (W[2][0] + W[0][2]) + ar * (W[2][1] + W[1][2]));
+                u_c_rots[4 * i + 2] = 2. * (ax * (W[1][0] + W[0][1]) + 2. * ay * (W[0][0] + W[2][2]) + az * (W[2][1] + W[1][2]) + ar * (W[0][2] + W[2][0]));
+                u_c_rots[4 * i + 3] = 2. * (ax * (W[2][0] + W[0][2]) + ay * (W[2][1] + W[1][2]) + 2. * az * (W[0][0] + W[1][1]) + ar * (W[1][0] + W[0][1]));
+            }
+        }
     }
     free(dA); free(dB); free(dN); free(S);
+    if (cA_) { free(cA_); free(cB_); free(cN_); }
+    if (u_cA_) { free(u_cA_); free(u_cB_); free(u_cN_); free(S64); }
 }

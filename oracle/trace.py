@@ -57,7 +57,8 @@ def trace_audit(ray_o, ray_d, means3D, scales, rotations, opacities, *, others=N
     return dict(fragile=fragile[:R].astype(bool), ids=ids[:R], tbits=tbits[:R], nhit=nhit[:R])
 
 
-def trace_backward(fwd, dL_drgb, dL_ddpt, dL_dacc, dL_dnorm, dL_daux):
+def trace_backward(fwd, dL_drgb, dL_ddpt, dL_dacc, dL_dnorm, dL_daux, want_cond=False):
+    """want_cond: additionally `cond` = the noise scale of every gradient element (see trc_backward's comment), same keys."""
     L = lib()
     cfg = fwd["cfg"]; i = fwd["inputs"]
     P, R, M = cfg.P, cfg.R, cfg.M
@@ -65,10 +66,18 @@ def trace_backward(fwd, dL_drgb, dL_ddpt, dL_dacc, dL_dnorm, dL_daux):
     dmeans = np.zeros((P, 3)); dscales = np.zeros((P, 2)); drots = np.zeros((P, 4)); dopac = np.zeros(P)
     dshs = np.zeros((P, max(M, 1), 3)); dcolors = np.zeros((P, 3)); dothers = np.zeros((P, 2))
     dro = np.zeros((R, 3)); drd = np.zeros((R, 3))
+    cnd = [np.zeros_like(x) for x in (dmeans, dscales, drots, dopac, (dshs if M > 0 else dcolors), dothers, dro, drd)]
+    unc = [np.zeros_like(x) for x in cnd]
     L.trc_backward(ctypes.byref(cfg), _p(i["ray_o"]), _p(i["ray_d"]), _p(i["means3D"]), _p(i["scales"]), _p(i["rotations"]),
                    _p(i["opacities"]), _p(i["shs"]), _p(i["colors_precomp"]), _p(i["others"]), _p(fwd["bg"]), _p(g[0]), _p(g[1]),
                    _p(g[2]), _p(g[3]), _p(g[4]), _p(dmeans), _p(dscales), _p(drots), _p(dopac), _p(dshs), _p(dcolors), _p(dothers),
-                   _p(dro), _p(drd))
-    return dict(dmeans3D=dmeans, dscales=dscales, drots=drots, dopacities=dopac, dshs=dshs if M > 0 else None,
-                dcolors=dcolors if M == 0 else None, dothers=dothers if i["others"] is not None else None,
-                dray_o=dro, dray_d=drd)
+                   _p(dro), _p(drd), *[_p(x) for x in ((cnd + unc) if want_cond else [None] * 16)])
+    out = dict(dmeans3D=dmeans, dscales=dscales, drots=drots, dopacities=dopac, dshs=dshs if M > 0 else None,
+               dcolors=dcolors if M == 0 else None, dothers=dothers if i["others"] is not None else None,
+               dray_o=dro, dray_d=drd)
+    if want_cond:
+        out["cond"] = dict(dmeans3D=cnd[0], dscales=cnd[1], drots=cnd[2], dopacities=cnd[3], dshs=cnd[4] if M > 0 else None,
+                           dcolors=cnd[4] if M == 0 else None, dothers=cnd[5] if i["others"] is not None else None, dray_o=cnd[6], dray_d=cnd[7])
+        out["unc"] = dict(dmeans3D=unc[0], dscales=unc[1], drots=unc[2], dopacities=unc[3], dshs=unc[4] if M > 0 else None,
+                          dcolors=unc[4] if M == 0 else None, dothers=unc[5] if i["others"] is not None else None, dray_o=unc[6], dray_d=unc[7])
+    return out

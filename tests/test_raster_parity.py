@@ -50,7 +50,7 @@ def _mod_for(C):
     return importlib.import_module({3: "diff_surfel_rasterization_wet", 5: "diff_surfel_rasterization_wet_ch05", 7: "diff_surfel_rasterization_wet_ch07"}[C])
 
 
-def _compare_forward(test, outs, saved, ref, aud, sh, check_sets):
+def _compare_forward(test, outs, saved, ref, aud, sh, check_sets, tail=None):
     """Index work bit-exact; contributor sets / n_contrib bit-exact and values within 1e-4 on every non-fragile pixel."""
     from envgs_amd import raster
     N = ref["N"]
@@ -58,7 +58,7 @@ def _compare_forward(test, outs, saved, ref, aud, sh, check_sets):
     frag = aud["fragile"]; ok = ~frag
     nfr = int(frag.sum())
     record(test, "fragile_px", frag.mean(), "(%d of %d pixels)" % (nfr, frag.size))
-    assert frag.mean() < 5e-3, "too many fragile pixels for the comparison to mean anything: %g" % frag.mean()
+    assert frag.mean() < 2e-2, "too many fragile pixels for the comparison to mean anything: %g" % frag.mean()
 
     # R1: integer outputs bit-exact, geom bit-exact (same op order, no FMA)
     np.testing.assert_array_equal(saved["radii"].cpu().numpy(), ref["radii"])
@@ -92,9 +92,9 @@ def _compare_forward(test, outs, saved, ref, aud, sh, check_sets):
         assert torch.equal(nc_a, saved["n_contrib"]) and torch.equal(col_a, outs[0])      # the audit instantiation IS the product kernel
     # R6 values
     color, radii, allmap, weight = [o.cpu().numpy() for o in outs]
-    check_close(test, "color", color[:, ok], ref["out_color"][:, ok], excluded=nfr)
+    check_close(test, "color", color[:, ok], ref["out_color"][:, ok], excluded=nfr, tail=tail)
     for ch, nm in ((0, "depth"), (1, "alpha"), (2, "normal.x"), (3, "normal.y"), (4, "normal.z"), (5, "median")):
-        check_close(test, "allmap." + nm, allmap[ch][ok], ref["allmap"][ch][ok], excluded=nfr)
+        check_close(test, "allmap." + nm, allmap[ch][ok], ref["allmap"][ch][ok], excluded=nfr, tail=tail)
     # distortion: sum_i w_i (m_i^2 A + M2 - 2 m_i M1) cancels catastrophically in fp32 in BOTH implementations (tests/test_oracle_grad.py);
     # its floor is the magnitude of what is summed (~ the alpha channel), not of the remainder
     check_close(test, "allmap.dist", allmap[6][ok], ref["allmap"][6][ok], floor=float(np.abs(ref["allmap"][1][ok]).mean()), excluded=nfr)
@@ -167,12 +167,12 @@ def test_backward_vs_oracle(case, request):
     loss.backward()
     torch.cuda.synchronize()
 
-    rb = orc.raster_backward(ref, dcol.numpy(), dall.numpy())
+    rb = orc.raster_backward(ref, dcol.numpy(), dall.numpy(), want_cond=True)
     test = request.node.name
     nfr = int(aud["fragile"].sum())
     grads = dict(leaves, means2D=means2D)
     for k_hip, k_ref in GRAD_NAMES + ((("shs", "dshs"),) if case["sh"] else (("colors_precomp", "dcolors"),)):
-        check_close(test, k_ref, grads[k_hip].grad.cpu().numpy().reshape(rb[k_ref].shape), rb[k_ref], excluded=nfr)
+        check_close(test, k_ref, grads[k_hip].grad.cpu().numpy().reshape(rb[k_ref].shape), rb[k_ref], excluded=nfr, cond=rb["cond"][k_ref], unc=rb["unc"][k_ref])
 
 def test_precomputed_transmat_path():
     """cov3D_precomp (the python transMat of gaussian2d_utils.py:1050-1061) instead of scales/rotations."""
@@ -195,12 +195,12 @@ def test_precomputed_transmat_path():
     aud = orc.raster_audit(ref)
     dcol, dall = _masked_upstream(3, 64, 64, 5, aud["fragile"])
     ((color * dcol.to(dev)).sum() + (allmap * dall.to(dev)).sum()).backward()
-    rb = orc.raster_backward(ref, dcol.numpy(), dall.numpy())
+    rb = orc.raster_backward(ref, dcol.numpy(), dall.numpy(), want_cond=True)
     ok = ~aud["fragile"]
     check_close("precomputed_transmat", "color", color.detach().cpu().numpy()[:, ok], ref["out_color"][:, ok], excluded=int((~ok).sum()))
-    check_close("precomputed_transmat", "dtransmat", tmd.grad.cpu().numpy(), rb["dtransmat_precomp"])
-    check_close("precomputed_transmat", "dmeans3D", m3.grad.cpu().numpy(), rb["dmeans3D"])          # SH view-direction term only
-    check_close("precomputed_transmat", "dshs", shs.grad.cpu().numpy(), rb["dshs"])
+    check_close("precomputed_transmat", "dtransmat", tmd.grad.cpu().numpy(), rb["dtransmat_precomp"], cond=rb["cond"]["dtransmat_precomp"], unc=rb["unc"]["dtransmat_precomp"])
+    check_close("precomputed_transmat", "dmeans3D", m3.grad.cpu().numpy(), rb["dmeans3D"], cond=rb["cond"]["dmeans3D"], unc=rb["unc"]["dmeans3D"])          # SH view-direction term only
+    check_close("precomputed_transmat", "dshs", shs.grad.cpu().numpy(), rb["dshs"], cond=rb["cond"]["dshs"], unc=rb["unc"]["dshs"])
 
 
 def test_edge_cases():
@@ -266,13 +266,14 @@ def test_full_size_baseline_config_vs_oracle():
     ref = orc.raster_forward(g["means3D"].numpy(), g["opacities"].numpy(), ca["viewmatrix"].numpy(), ca["projmatrix"].numpy(),
                              ca["campos"].numpy(), W, H, scales=g["scales"].numpy(), rotations=g["rotations"].numpy(),
                              shs=g["shs"].numpy(), sh_degree=3, bg=bg.numpy())
-    aud = orc.raster_audit(ref)
+    aud = orc.raster_audit(ref, want_contrib=True)             # contributor sets too: 640 k pixels x the longest tile list (~1.2 GB of flags per side)
     test = "full_size_300k_800x800"
-    _compare_forward(test, outs, saved, ref, aud, True, check_sets=False)
+    _compare_forward(test, outs, saved, ref, aud, True, check_sets=True, tail=(2e-5, 1e-3))
     # gradients: upstream zeroed at the fragile pixels for both implementations
     dcol, dall = _masked_upstream(3, H, W, 1, aud["fragile"])
     grads = raster.rasterize_backward(saved, dcol.to(dev), dall.to(dev))
     torch.cuda.synchronize()
-    rb = orc.raster_backward(ref, dcol.numpy(), dall.numpy())
+    rb = orc.raster_backward(ref, dcol.numpy(), dall.numpy(), want_cond=True)
     for k_hip, k_ref in GRAD_NAMES + (("shs", "dshs"),):
-        check_close(test, k_ref, grads[k_hip].cpu().numpy().reshape(rb[k_ref].shape), rb[k_ref], excluded=int(aud["fragile"].sum()))
+        check_close(test, k_ref, grads[k_hip].cpu().numpy().reshape(rb[k_ref].shape), rb[k_ref], excluded=int(aud["fragile"].sum()), cond=rb["cond"][k_ref], unc=rb["unc"][k_ref],
+                    tail=(2e-5, 1e-3))
