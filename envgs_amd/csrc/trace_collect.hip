@@ -282,9 +282,9 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
         }
         if (ovf) {
             // a postponed child was dropped: this batch's lists are incomplete.  Mark every ray as overflowed (hit_cnt > cap) so that it is
-            // traced by the K-buffer kernels instead (per-lane stacks, no packet stack), and count the event (counters[10]).
+            // traced by the K-buffer kernels instead (per-lane stacks, no packet stack), and count the event (counters[20]).
             n = A.cap + 1;
-            if (lane == 0) atomicAdd(A.counter + 10, 1u);
+            if (lane == 0) atomicAdd(A.counter + 20, 1u);
         }
         if (valid) { A.hit_cnt[r] = n; found_tot += (unsigned)n; }
         int mx = n;
@@ -309,6 +309,7 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
     const int lane = threadIdx.x;
     const int slimit = (A.exp & 1024) ? 2 : PSTACK;       // (test switch: forces the overflow hand-off)
     unsigned visits = 0, found_tot = 0;
+    unsigned psteps = 0, pleaves = 0;                     // per-PACKET counts: wide nodes fetched, surfel records fetched (deduplicated byte model of bench.py)
     float rlx, rly, rlz, rhx, rhy, rhz;                   // the scene box = union of the root's two child boxes
     {
         const float4 n0 = nodes[0], n1 = nodes[1], n2 = nodes[2];
@@ -359,6 +360,7 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
                 cur = __builtin_amdgcn_readfirstlane(stk[sp]);
             }
             const float4 *nd = nodes4 + (size_t)cur * 8;
+            psteps++;
             float4 qa[4], qb[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) { qa[c] = nd[2 * c]; qb[c] = nd[2 * c + 1]; }
@@ -377,6 +379,7 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
                 if (m != 0ull) {
                     if (ch < 0) {
                         const int sid = ~ch;
+                        pleaves++;
                         const float4 *sr = srec + (size_t)sid * 4;
                         const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], sr[3], ox, oy, oz, dx, dy, dz);
                         if (hit && h.ok && h.t > tmin && h.t <= tkill) {
@@ -422,9 +425,9 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
         }
         if (ovf) {
             // a postponed child was dropped: this batch's lists are incomplete.  Mark every ray as overflowed (hit_cnt > cap) so that it is
-            // traced by the K-buffer kernels instead (per-lane stacks, no packet stack), and count the event (counters[10]).
+            // traced by the K-buffer kernels instead (per-lane stacks, no packet stack), and count the event (counters[20]).
             n = A.cap + 1;
-            if (lane == 0) atomicAdd(A.counter + 10, 1u);
+            if (lane == 0) atomicAdd(A.counter + 20, 1u);
         }
         if (valid) { A.hit_cnt[r] = n; found_tot += (unsigned)n; }
         int mx = n;
@@ -433,7 +436,10 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
     }
     if (A.stats) {
         const float ff = wave_sum((float)found_tot);
-        if (lane == 0) { atomicAdd(A.stats + 1, (unsigned long long)visits); atomicAdd(A.stats + 3, (unsigned long long)ff); }
+        if (lane == 0) {
+            atomicAdd(A.stats + 1, (unsigned long long)visits); atomicAdd(A.stats + 3, (unsigned long long)ff);
+            atomicAdd(A.stats + 4, (unsigned long long)psteps); atomicAdd(A.stats + 5, (unsigned long long)pleaves);
+        }
     }
 }
 

@@ -123,7 +123,7 @@ struct TraceArgs {
     const float *shs, *colors, *others, *bg;
     const float *ray_o, *ray_d;
     unsigned *counter;
-    unsigned long long *stats;      // [hits, node visits, rounds] totals of the forward (diagnostics)
+    unsigned long long *stats;      // [hits, per-ray node visits, rounds, hits found, wide nodes fetched per packet, surfel records fetched per packet]
     // forward outputs
     float *rgb, *dpt, *acc, *norm, *dist, *aux, *mid, *wet, *final_T;
     // backward inputs / outputs
@@ -556,7 +556,7 @@ constexpr float KILL_OD = 9.2104f * 1.03f + 0.05f;       // -ln(1e-4) with margi
 
 // Wave-uniform stack of the packet kernels, in LDS.  Sized so that it does not overflow: the LBVH is at most 63 levels deep (62-bit unique Morton keys),
 // the binary walk holds one postponed child per level and the 4-wide walk at most three per TWO levels.  Should a child ever not fit, the batch is
-// flagged: its rays are handed to the K-buffer kernels (per-lane stacks) and counters[10] counts the event -- never a silently dropped subtree.
+// flagged: its rays are handed to the K-buffer kernels (per-lane stacks) and counters[20] counts the event -- never a silently dropped subtree.
 constexpr int PSTACK = 128;
 constexpr int SORT_MAX = 1024;  // longest list the sort / composite pass takes (16 keys per lane)
 constexpr int RH_W = 8;         // register_hits: wavefronts per batch -- wave q takes list positions q, q + RH_W, ... of every ray

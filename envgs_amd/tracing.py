@@ -426,6 +426,6 @@ def last_trace_counts():
     if c is None:
         return None
     w = c.cpu()
-    v = w[2:10].view(torch.int64)
-    return dict(hits=int(v[0]), node_visits=int(v[1]), rounds=int(v[2]), found=int(v[3]), max_list=int(w[1]), cap=HIT_CAP["cap"],
-                rays=LAST_STATS["R"], stack_overflows=int(w[10]))
+    v = w[2:14].view(torch.int64)
+    return dict(hits=int(v[0]), node_visits=int(v[1]), rounds=int(v[2]), found=int(v[3]), packet_nodes=int(v[4]), packet_leaves=int(v[5]),
+                max_list=int(w[1]), cap=HIT_CAP["cap"], rays=LAST_STATS["R"], stack_overflows=int(w[20]))
