@@ -12,9 +12,13 @@ the flat per-Gaussian gradient buffer is all-reduced once per step over RCCL/xGM
 Inputs are synthetic and resident in HBM before the timed region starts.
 
 Besides the driver's contract fields the line carries
-  roofline     : dominant kernel (most time per step), algorithmic bytes / HIP-event launch time vs the 8 TB/s HBM peak
-  cpu_baseline : the CPU oracle (oracle/, OpenMP over the host cores) on the same scene, rank 0, N=1 only
+  roofline     : dominant kernel (most time per step): DEDUPLICATED algorithmic HBM bytes (what one launch must move at minimum: every
+                 input structure once, every output once) / HIP-event launch time vs the 8 TB/s HBM peak -- every frac <= 1 and the sum over
+                 the step stays below the peak; `traffic` = measured HBM bytes (PMC), `issue` = the instruction-issue roofline of the same
+                 kernel (VALU / SALU wave-instructions per second against the issue peaks) from the tracked SQ counter summary in profiles/
+  cpu_baseline : the CPU oracle (oracle/, OpenMP over the host cores) on the same scene + the PyTorch-eager config-1 figure, rank 0, N=1 only
   kernels      : per-kernel ms/launch and achieved GB/s from HIP events on the launch stream
+  caller       : --caller fused (default: HIP glue) | twin (torch glue) | reference (the expression forms the unchanged EasyVolcap caller runs)
 """
 import argparse
 import ctypes
@@ -46,23 +50,47 @@ def algorithmic_bytes(kernel, P, N, HW, C, sh_in_kernel):
     return 0
 
 
-def trace_algorithmic_bytes(kernel, tc, P_env, R):
-    """DESIGN.md "tracer byte model" = SURVEY.md 8(d)'s per-unit figures x the kernel's own counters: a node visit of a ray = one 64 B
-    node; a leaf test / composited hit reads the 64 B surfel record; SH degree 3 = 192 B per shaded hit; a backward hit
-    read-modify-writes 63 gradient words (48 SH + 15 geometry).  These are per-RAY units: the packet / batch kernels serve most of them
-    from one fetch per 64 rays, so bytes/time can exceed the HBM peak -- `traffic` (PMC) is what actually crossed the HBM interface."""
+def trace_algorithmic_bytes(kernel, tc, P_env, R, entries, others=False):
+    """Deduplicated algorithmic HBM bytes of the tracer kernels PER STEP: what the kernel must move at minimum -- each input structure
+    read ONCE (BVH nodes 64 B + wide nodes 128 B + surfel record 64 B + SH block 192 B per env surfel, 24 B + 4 B order per ray), each
+    list / state / record element read or written once -- however often the implementation re-fetches them from L2 / MALL.
+    (SURVEY.md 8(d)'s per-RAY units -- 64 B per node visit of every ray -- counted a node once per ray although a 64-ray packet fetches it
+    once, which put 'achieved' above the HBM peak; those units are kept only as the `per_ray_model_MB` diagnostic.)
+    hits = composited hits, found = collected hits, entries = distinct (batch, surfel) pairs of the backward."""
+    hits, found = tc["hits"], tc["found"]
+    st = 48 if others else 32
+    if kernel == "trace.collect_hits":
+        return P_env * (64 + 128 + 64) + R * (24 + 4 + 4) + found * 8
+    if kernel == "trace.sort_composite_fwd":
+        return found * 8 + hits * (8 + st) + P_env * (64 + 192) + R * (24 + 4 + 4 + 4 * (3 + 1 + 1 + 3 + 1 + 2 + 16 + 1))
+    if kernel == "trace.register_hits":
+        return hits * (8 + 4) + entries * 8 + R * 4 + P_env * 8 * 16
+    if kernel == "trace.batch_surfel_bwd":
+        return hits * (st + 4) + entries * (8 + 256) + P_env * (64 + 192) + R * (24 + 48 + 48 + 24)
+    if kernel == "trace.reduce_surfel_records":
+        return entries * 256 + P_env * (32 + 192 + 64)
+    if kernel == "bvh_build":
+        return P_env * (48 + 24 + 6 * 16 + 64 + 64 + 128)
+    return 0
+
+
+def trace_per_ray_model_bytes(kernel, tc, R):
+    """Round 1's per-RAY byte model (SURVEY.md 8(d) units x the kernel's counters), kept as a diagnostic only: it is NOT a roofline input."""
     hits, visits, found = tc["hits"], tc["node_visits"], tc["found"]
     if kernel == "trace.collect_hits":
         return visits * 64 + found * (64 + 8) + R * 24
     if kernel == "trace.sort_composite_fwd":
         return found * 16 + hits * (8 + 64 + 192 + 48) + R * (24 + 4 * (11 + 16 + 1))
-    if kernel == "trace.register_hits":
-        return hits * (8 + 4 + 4)
     if kernel == "trace.batch_surfel_bwd":
         return hits * (8 + 48 + 64 + 192 + 8 * 63) + R * (24 + 4 * 12 + 4 * 12 + 24)
-    if kernel == "bvh_build":
-        return P_env * (48 + 24 + 6 * 16 + 64 + 64)
     return 0
+
+
+# instruction-issue peaks (MI355X_MICROARCH.md): a 64-lane VALU instruction occupies a SIMD-32 for 2 cycles -> 4 SIMDs x 0.5 = 2 VALU
+# wave-instructions per cycle per CU; one scalar unit per CU -> 1 SALU instruction per cycle per CU; 256 CUs x 2.4 GHz
+VALU_PEAK_GINST = 256 * 2 * 2.4
+SALU_PEAK_GINST = 256 * 1 * 2.4
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_envgs.json")
 
 
 def main():
@@ -79,7 +107,15 @@ def main():
     ap.add_argument("--width", type=int, default=0, help="image width if not square (default: --res)")
     ap.add_argument("--channels", type=int, default=5, choices=[5, 7], help="envgs workload: -ch05 (1 specular channel, EnvGS) or -ch07 (3, BASELINE configs[4])")
     ap.add_argument("--trace-depth", type=int, default=0, help="specular bounces of the env trace (EnvGS: 0; BASELINE configs[4]: 2); uses random 'others'")
-    ap.add_argument("--torch-glue", action="store_true", help="keep the reference's torch expressions for the caller-side glue (default: fused HIP, SURVEY 8(f).1)")
+    ap.add_argument("--caller", default="fused", choices=["fused", "twin", "reference"],
+                    help="caller-side glue of the envgs workload: fused = envgs_amd.fused HIP kernels (SURVEY 8(f).1); twin = torch expressions "
+                         "(envgs_amd/envgs_step.py, pinned against the reference's own render() / render_gaussians() by tests/test_caller_contract.py); "
+                         "reference = twin + the expression forms the UNCHANGED EasyVolcap caller executes (batched-matmul get_disks, render()'s "
+                         "regulariser maps) -- the step a drop-in user pays")
+    ap.add_argument("--torch-glue", action="store_true", help="alias of --caller twin")
+    ap.add_argument("--keep-blas", action="store_true", help="do not let diff_surfel_tracing select rocBLAS for torch's tiny-K batched matmuls (INTEGRATION.md section 5)")
+    ap.add_argument("--debug-trace", type=int, default=0, help="ENVGS_DBG_TRACE diagnostic switch mask (include/envgs_raster.h); reported in the JSON line")
+    ap.add_argument("--debug-segments", type=int, default=0, help="ENVGS_DBG_SEGMENTS diagnostic switch; reported in the JSON line")
     ap.add_argument("--optim", default="fused", choices=["fused", "torch", "none"],
                     help="optimizer step inside the timed iteration: sparse fused Adam (envgs_amd.optim, SURVEY 8(f).2), torch.optim.Adam, or none")
     ap.add_argument("--no-overlap-allreduce", action="store_true", help="N > 1: exchange the gradient buckets after backward() instead of launching them from backward hooks")
@@ -91,6 +127,10 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the same view traced by the brute-force CPU oracle (bounded sample)")
     args = ap.parse_args()
 
+    if args.torch_glue and args.caller == "fused":
+        args.caller = "twin"
+    if args.keep_blas:
+        os.environ["ENVGS_KEEP_BLAS"] = "1"
     from envgs_amd import dist as edist, synth, raster, tracing, _lib
     rank, world, local = edist.init_from_env()
     if world != args.gpus:
@@ -101,6 +141,7 @@ def main():
     dev = torch.device("cuda", local % torch.cuda.device_count())     # (a functional test may run 2 gloo ranks on one GPU)
     torch.cuda.set_device(dev)
     lib = _lib.load()
+    lib.envgs_debug_set(0, args.debug_trace); lib.envgs_debug_set(1, args.debug_segments)
     import torch.distributed as dist
 
     P, H, W = args.gaussians, (args.height or args.res), (args.width or args.res)
@@ -134,7 +175,9 @@ def main():
         pkg = importlib.import_module("diff_surfel_rasterization_wet_ch0%d" % C)
         import diff_surfel_tracing as tpkg
         from envgs_amd import envgs_step
-        envgs_step.FUSED["on"] = not args.torch_glue
+        envgs_step.FUSED["on"] = args.caller == "fused"
+        envgs_step.REFERENCE_FORMS["on"] = args.caller == "reference"
+        dnorm_hw = (torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)) / HW).to(dev)
         tracer = tpkg.SurfelTracer()
         rays = [synth.get_rays(c) for c in cams]
         env_bg = torch.zeros(3, device=dev)
@@ -185,6 +228,8 @@ def main():
             last_rays[0], last_rays[1] = out["ref_o"].detach(), out["ref_d"].detach()
             allmap = out["base"]["allmap"]
             loss = (out["rgb"] * dcol_hw3).sum() + (allmap * dall).sum()
+            if args.caller == "reference":        # the normal-consistency term consumes render()'s regulariser maps (volumetric_video_supervisor)
+                loss = loss + (out["base"]["surf_normal"] * dnorm_hw).sum()
         else:
             means2D = torch.zeros_like(params["means3D"], requires_grad=True)
             color, radii, allmap, weight = pkg.GaussianRasterizer(raster_settings=settings(cam))(
@@ -233,6 +278,7 @@ def main():
     # per-kernel HIP-event times (this rank)
     N_avg = n_acc["N"] / max(n_acc["steps"], 1)
     tcounts = tracing.last_trace_counts() if envgs else None
+    entries = sum(tracing.last_entry_counts()) if envgs else 0
 
     # the metric's second half, "render Mpix/s": forward only under no_grad (inference: no per-hit state, no entries), outside the timed region
     def render(it):
@@ -266,8 +312,10 @@ def main():
             name = lib.envgs_prof_kernel_name(k).decode()
             ms = t_.value / c_.value
             ab = algorithmic_bytes(name, P, N_avg, HW, C, not envgs)
+            pr = 0
             if not ab and envgs and tcounts:
-                ab = trace_algorithmic_bytes(name, tcounts, args.env_gaussians, HW)
+                ab = trace_algorithmic_bytes(name, tcounts, args.env_gaussians, HW, entries, others=args.trace_depth > 0)
+                pr = trace_per_ray_model_bytes(name, tcounts, HW)
             if name == "fused_adam_multi":        # 28 B per updated element (p,g,m,v in; p,m,v out), 4 B per skipped one (g only)
                 nz = sum(int((g_ != 0).sum()) for g_ in last_grads if g_ is not None)
                 tot = sum(g_.numel() for g_ in last_grads if g_ is not None)
@@ -276,6 +324,8 @@ def main():
             ab = ab / per_step                                               # (2 segments on 2 streams, overlapping): bytes per LAUNCH
             kernels[name] = {"ms": round(ms, 4), "launches": c_.value, "alg_MB": round(ab / 1e6, 2),
                              "GBps": round(ab / 1e9 / (ms / 1e3), 1) if ab and ms > 0 else None}
+            if pr:
+                kernels[name]["per_ray_model_MB"] = round(pr / per_step / 1e6, 1)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -283,27 +333,46 @@ def main():
         leaf = {k: v for k, v in kernels.items() if k not in ("trace_fwd", "trace_bwd") and v["GBps"]}
         dom = max(leaf, key=lambda k: leaf[k]["ms"] * leaf[k]["launches"]) if leaf else None      # most time per step (launches included)
         roof = None
+        pm = {}
+        try:                                   # tracked PMC summary of the same workload (profiles/summarize.py; separate --pmc passes)
+            pm = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))["kernels"] if envgs else {}
+        except Exception:
+            pm = {}
+
+        def issue_of(name):
+            """Instruction-issue roofline of one kernel: wave-instructions per launch (SQ_INSTS_*, from the tracked counter summary) over the
+            launch time measured in THIS run, against the issue peaks."""
+            r = pm.get(name)
+            if not r or "SQ_INSTS_VALU" not in r or name not in kernels:
+                return None
+            t = kernels[name]["ms"] / 1e3
+            valu, salu = r["SQ_INSTS_VALU"], r.get("SQ_INSTS_SALU", 0.0)
+            out = {"valu_insts_per_launch": int(valu), "salu_insts_per_launch": int(salu),
+                   "valu_ginst_per_s": round(valu / t / 1e9, 1), "valu_peak_ginst_per_s": VALU_PEAK_GINST, "valu_util": round(valu / t / 1e9 / VALU_PEAK_GINST, 4),
+                   "salu_ginst_per_s": round(salu / t / 1e9, 1), "salu_peak_ginst_per_s": SALU_PEAK_GINST, "salu_util": round(salu / t / 1e9 / SALU_PEAK_GINST, 4)}
+            if r.get("SQ_BUSY_CU_CYCLES") and r.get("SQ_ACTIVE_INST_VALU"):
+                out["valu_busy"] = round(4.0 * r["SQ_ACTIVE_INST_VALU"] / r["SQ_BUSY_CU_CYCLES"] / 4.0, 4)     # quad-cycles -> cycles, per SIMD (4 per CU)
+            out["source"] = PMC_SUMMARY
+            return out
+
         if dom:
             A = kernels[dom]["GBps"]
-            traffic = None
-            try:                                   # HBM bytes per launch from the committed PMC passes (profiles/, same workload)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_envgs.json")))["kernels"]
-                if envgs and dom in pm:
-                    traffic = pm[dom]["hbm_bytes"]
-            except Exception:
-                traffic = None
+            traffic = pm.get(dom, {}).get("hbm_bytes")
             roof = {"kernel": dom, "bound": "hbm", "achieved": A, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(A / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "alg_bytes_per_launch": int(kernels[dom]["alg_MB"] * 1e6), "ms_per_launch": kernels[dom]["ms"],
-                    "tile_instances_N": int(N_avg),
-                    "note": "dominant kernel = most HIP-event time per step (duration x launches); algorithmic bytes per DESIGN.md (raster: SURVEY.md 8d formulas; tracer: "
-                            "the per-ray byte model of SURVEY.md 8d over the kernel's own hit / node-visit counters -- a 64-ray packet or a (batch, surfel) entry fetches "
-                            "a record once for all its rays, so a kernel can exceed the model's bytes per second without moving them).  Gather-heavy and VALU/latency bound rather "
-                            "than streaming: the HBM fraction is reported as mandated; traffic = (2*FETCH_SIZE + WRITE_SIZE) per launch from "
-                            "profiles/r01_pmc_envgs.json (separate --pmc passes), null if that profile has no row for this kernel"}
+                    "tile_instances_N": int(N_avg), "issue": issue_of(dom),
+                    "step_total": {"alg_MB": round(sum(v["alg_MB"] * max(1, round(v["launches"] / max(n_acc["steps"], 1))) for v in leaf.values()), 1),
+                                   "GBps_over_step": round(sum(v["alg_MB"] * max(1, round(v["launches"] / max(n_acc["steps"], 1))) for v in leaf.values()) / 1e3 / (ms_per_step / 1e3), 1)},
+                    "note": "dominant kernel = most HIP-event time per step (duration x launches).  achieved = DEDUPLICATED algorithmic HBM bytes per launch (every "
+                            "input structure once, every list / state / record element once: bench.py:trace_algorithmic_bytes; raster: SURVEY.md 8d formulas) / launch time; "
+                            "traffic = (2*FETCH_SIZE + WRITE_SIZE) per launch from " + PMC_SUMMARY + " (separate --pmc passes).  The tracer and compositing kernels are "
+                            "instruction-issue bound, not HBM bound: `issue` carries their VALU / SALU issue rates against the issue peaks (2 VALU + 1 SALU "
+                            "wave-instructions per cycle per CU, 256 CUs, 2.4 GHz)"}
             rb = kernels.get("composite_bwd")
             if rb and rb["GBps"]:
-                roof["raster_composite_bwd"] = {"achieved": rb["GBps"], "frac": round(rb["GBps"] / HBM_PEAK_GBS, 5), "ms_per_launch": rb["ms"]}
+                roof["raster_composite_bwd"] = {"achieved": rb["GBps"], "frac": round(rb["GBps"] / HBM_PEAK_GBS, 5), "ms_per_launch": rb["ms"],
+                                                "traffic": pm.get("composite_bwd", {}).get("hbm_bytes"), "issue": issue_of("composite_bwd")}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(g, cams[0], bg, dcol, dall, H, W, args.cpu_reps, C,
@@ -318,12 +387,15 @@ def main():
                        "gaussians": P, "env_gaussians": (args.env_gaussians if envgs else 0), "resolution": [H, W], "trace_depth": (args.trace_depth if envgs else None), "channels": C, "views": 8,
                        "parallelism": "dp%d (camera batch sharded, %s)" % (world, ("env / base flat grad buffers, %s, %s" % (args.exchange, "launched from backward hooks" if not args.no_overlap_allreduce else "after backward")) if reducer is not None else "single GPU"),
                        "optimizer": {"fused": "sparse fused Adam, one launch (envgs_amd.optim)", "torch": "torch.optim.Adam", "none": "none"}[args.optim],
-                       "caller_glue": ("torch (reference expressions)" if (not envgs or args.torch_glue) else "fused HIP (envgs_amd.fused)"),
+                       "caller_glue": ("n/a (raster only)" if not envgs else {"fused": "fused HIP (envgs_amd.fused)", "twin": "torch expressions (envgs_amd/envgs_step.py)",
+                                       "reference": "the unchanged EasyVolcap caller's expression forms (batched-matmul get_disks, render()'s regulariser maps + normal term)"}[args.caller]),
+                       "torch_blas": str(torch.backends.cuda.preferred_blas_library()).split(".")[-1],
+                       "debug_switches": {"trace": args.debug_trace, "segments": args.debug_segments},
                        "allreduce_bytes_per_step": int(ar_bytes)},
             "train_mpix_per_s": round(value * HW / 1e6, 2),
             "render_mpix_per_s": (round(world * HW / render_s / 1e6, 2) if n_render else None),
             "render_ms_per_view": (round(render_s * 1e3, 4) if n_render else None),
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "trace_counts": tcounts,
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "trace_counts": (dict(tcounts, entries=entries) if tcounts else None),
         }
         print(json.dumps(line))
     if world > 1:
@@ -369,10 +441,41 @@ def cpu_baseline(g, cam, bg, dcol, dall, H, W, reps, C, env=None):
             sample += "; + brute-force tracer oracle (oracle/surfel_trace_oracle.c) fwd+bwd on %d of the %d reflected rays x %d env surfels, scaled to the full view (%.1f s/iter)" % (
                 nr, H * W, e["means3D"].shape[0], dtt)
             dt += dtt
-        return {"value": round(1.0 / dt, 5), "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
-                "sample": sample + "; OpenMP over all host cores"}
+        out = {"value": round(1.0 / dt, 5), "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
+               "sample": sample + "; OpenMP over all host cores", "raster_s_per_iter": round(dt - (dtt if env is not None else 0.0), 3)}
+        if env is not None:
+            out["tracer_s_per_iter"] = round(dtt, 1)
+            out["tracer_note"] = "BRUTE FORCE: the tracer oracle tests every ray against every surfel (no acceleration structure), %.0f %% of this figure" % (100.0 * dtt / dt)
+        out["eager_config1"] = eager_config1()
+        return out
     except Exception as e:                       # the baseline is a reported figure, never a reason to lose the GPU number
         return {"value": None, "unit": "iters/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+
+
+def eager_config1(reps=1, warm=0):
+    """BASELINE configs[0] / north_star: "PyTorch-eager CPU project + alpha-blend" -- 2 000 surfels, 256x256, forward only, oracle/eager.py
+    (dense per-pixel blend in pixel chunks, fp32), torch.set_num_threads(all host cores); the figure SURVEY.md 8(d) asks for next to the C port."""
+    try:
+        from envgs_amd import synth
+        from oracle import eager
+        P, H, W = 2000, 256, 256
+        g = synth.base_gaussians(P, seed=0)
+        g["scales"] = g["scales"] * 2.0
+        cam = synth.orbit_camera(0, H=H, W=W, fx=1111.1 * W / 800.0)
+        old = torch.get_num_threads()
+        torch.set_num_threads(os.cpu_count() or 1)
+        run = lambda: eager.rasterize(g["means3D"], g["opacities"], cam.world_view_transform, cam.full_proj_transform, cam.camera_center, W, H,
+                                      scales=g["scales"], rotations=g["rotations"], shs=g["shs"], sh_degree=3, bg=torch.ones(3), pix_chunk=8192)
+        with torch.no_grad():
+            for _ in range(warm): run()
+            t0 = time.perf_counter()
+            for _ in range(reps): run()
+            dt = (time.perf_counter() - t0) / reps
+        torch.set_num_threads(old)
+        return {"value": round(1.0 / dt, 3), "unit": "renders/s", "mpix_per_s": round(H * W / dt / 1e6, 4), "threads": os.cpu_count(),
+                "sample": "%d x forward of 2000 surfels at 256x256 (BASELINE configs[0]), oracle/eager.py, torch eager fp32" % reps}
+    except Exception as e:
+        return {"value": None, "sample": "failed: %r" % (e,)}
 
 
 if __name__ == "__main__":

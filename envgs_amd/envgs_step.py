@@ -116,6 +116,8 @@ def visibility_filter(wet, means3D=None, K=None, R=None, T=None, H=None, W=None,
         return vis.detach().clone()
 
 
+REFERENCE_FORMS = {"on": False}    # bench.py --caller reference: the expression forms the unchanged EasyVolcap caller executes (batched-matmul get_disks,
+                                   # the regulariser maps of render()'s tail) instead of this module's cheaper equivalents
 TRACE = {"depth": 0, "specular_threshold": 0.0}    # EnvGS hard-codes 0 bounces (envgs_sampler.py:510,548); bench.py --trace-depth overrides
 
 
@@ -126,7 +128,7 @@ def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree):
         scale_modifier=1.0, viewmatrix=cam.world_view_transform.contiguous(), projmatrix=cam.full_proj_transform.contiguous(),
         sh_degree=sh_degree, campos=cam.camera_center.contiguous(), prefiltered=False, debug=False, max_trace_depth=int(TRACE["depth"]),
         specular_threshold=float(TRACE["specular_threshold"]))
-    v, f = synth.get_disks(env["means3D"], env["scales"], env["rotations"])
+    v, f = (synth.get_disks_reference_form if REFERENCE_FORMS["on"] else synth.get_disks)(env["means3D"], env["scales"], env["rotations"])
     tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
     grads3D = torch.zeros_like(env["means3D"], requires_grad=True) + 0
     return tracer(ref_o.contiguous(), ref_d.contiguous(), v, means3D=env["means3D"].contiguous(), grads3D=grads3D,
@@ -148,6 +150,8 @@ def envgs_forward(pkg, tpkg, tracer, cam, rays, base, env, bg, env_bg, sh_degree
         spec = b["spec"].permute(1, 2, 0)
         rgb = (1 - spec) * b["rgb"].permute(1, 2, 0) + spec * rgb_env
         return dict(rgb=rgb, base=b, rgb_env=rgb_env, env_wet=wet, ref_o=ref_o, ref_d=ref_d)
+    if REFERENCE_FORMS["on"]:                                      # render() always builds these (gaussian2d_utils.py:1125-1142); the supervisor consumes them
+        b["surf_depth"], b["surf_normal"] = surface_maps(cam, b["allmap"], 0.0)
     nrm = b["normal"].permute(1, 2, 0)
     nrm = nrm / (nrm.norm(dim=-1, keepdim=True) + 1e-8)            # easyvolcap/utils/math_utils.py:6-8
     ref_d = ray_d - 2 * (ray_d * nrm).sum(-1, keepdim=True) * nrm

@@ -2,7 +2,7 @@
 import collections, csv, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def short(n):
@@ -55,6 +55,28 @@ def pmc():
         if fv_:
             fv = sum(fv_) / len(fv_); wv = sum(wv_) / len(wv_) if wv_ else 0
             out["kernels"][v] = {"FETCH_SIZE_KB": round(fv, 1), "WRITE_SIZE_KB": round(wv, 1), "hbm_bytes": int((2 * fv + wv) * 1024)}
+    # every other counter pass (gpurun_out/pmc_<anything>/**/*counter_collection.csv): per-launch averages per kernel
+    import glob
+    other = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in glob.glob(os.path.join(ROOT, 'gpurun_out', 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r['Counter_Name'] in ('FETCH_SIZE', 'WRITE_SIZE'):
+                continue
+            other[re.sub(r'\(.*', '', r['Kernel_Name'].replace('void ', ''))][r['Counter_Name']].append(float(r['Counter_Value']))
+    for k, v in names.items():
+        agg = collections.defaultdict(list)
+        for name, ctrs in other.items():
+            if name == k or name.startswith(k + '<'):
+                for c, vals in ctrs.items():
+                    agg[c] += vals
+        if agg:
+            out["kernels"].setdefault(v, {})
+            for c, vals in sorted(agg.items()):
+                out["kernels"][v][c] = round(sum(vals) / len(vals), 1)
+            out["kernels"][v]["launches_sampled"] = len(next(iter(agg.values())))
+    out["_sq"] = ("SQ_* = per-launch averages of separate `rocprofv3 --pmc <4-8 SQ counters> --kernel-trace` passes over the same command "
+                  "(profiles/collect_profiles.sh); SQ_INSTS_* count wave-level instructions, SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count "
+                  "quad-cycles, SQ_BUSY_CU_CYCLES counts cycles summed over CUs (MI355X_MICROARCH.md, rocprofv3 PMC slots)")
     if out["kernels"]:
         json.dump(out, open(os.path.join(ROOT, 'profiles', '%s_pmc_envgs.json' % TAG), 'w'), indent=1)
 
@@ -62,7 +84,7 @@ def pmc():
 stats('envgs', 24, 'full EnvGS step: 300k base surfels ch05 raster + 163840 env surfels LBVH trace, 800x800; python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-render (the tracer forward runs as two batch segments on two streams: 2 launches per step, overlapping, so the kernel times sum to more than the step)')
 stats('raster', 34, 'raster only: 300k surfels, SH deg 3 in-kernel, 800x800; python bench.py --workload raster --steps 30 --warmup 4 --no-cpu-baseline --no-render')
 pmc()
-for n in ('envgs', 'raster', 'env700k', 'config5'):
+for n in ('envgs', 'envgs_reference_caller', 'envgs_twin_caller', 'raster', 'env700k', 'config5'):
     src = os.path.join(ROOT, 'gpurun_out', 'bench_%s_final.json' % n)
     if os.path.exists(src) and os.path.getsize(src) > 10:
         open(os.path.join(ROOT, 'profiles', '%s_bench_%s.json' % (TAG, n)), 'w').write(open(src).read())
