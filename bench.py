@@ -463,7 +463,8 @@ def eager_config1(reps=1, warm=0):
         g["scales"] = g["scales"] * 2.0
         cam = synth.orbit_camera(0, H=H, W=W, fx=1111.1 * W / 800.0)
         old = torch.get_num_threads()
-        torch.set_num_threads(os.cpu_count() or 1)
+        nthreads = min(os.cpu_count() or 1, 16)                 # (dense eager kernels on 2 000 x 8 192 tiles stop scaling -- and oversubscribe -- long before 256 threads)
+        torch.set_num_threads(nthreads)
         run = lambda: eager.rasterize(g["means3D"], g["opacities"], cam.world_view_transform, cam.full_proj_transform, cam.camera_center, W, H,
                                       scales=g["scales"], rotations=g["rotations"], shs=g["shs"], sh_degree=3, bg=torch.ones(3), pix_chunk=8192)
         with torch.no_grad():
@@ -472,7 +473,7 @@ def eager_config1(reps=1, warm=0):
             for _ in range(reps): run()
             dt = (time.perf_counter() - t0) / reps
         torch.set_num_threads(old)
-        return {"value": round(1.0 / dt, 3), "unit": "renders/s", "mpix_per_s": round(H * W / dt / 1e6, 4), "threads": os.cpu_count(),
+        return {"value": round(1.0 / dt, 3), "unit": "renders/s", "mpix_per_s": round(H * W / dt / 1e6, 4), "threads": nthreads, "host_cores": os.cpu_count(),
                 "sample": "%d x forward of 2000 surfels at 256x256 (BASELINE configs[0]), oracle/eager.py, torch eager fp32" % reps}
     except Exception as e:
         return {"value": None, "sample": "failed: %r" % (e,)}

@@ -49,13 +49,17 @@ __device__ __forceinline__ Hit eval_splat(const float4 r0, const float4 r1, cons
     return h;
 }
 
-template <int C>
+template <int C, int B = 256>
 struct TileLds {
-    float4 rec[4][256];
-    float col[C][256];
-    uint32_t id[256];
-    uint32_t qmask[256];      // bit q set: quadrant (wavefront) q can see alpha >= 1/255 from this splat
+    float4 rec[4][B];
+    float col[C][B];
+    uint32_t id[B];
+    uint32_t qmask[B];        // bit q set: quadrant (wavefront) q can see alpha >= 1/255 from this splat
 };
+
+// R7 stages BWD_BATCH splats per round: 192 x (64 B record + 4C B colours + 8 B + (15 + C) x 4 B accumulator) = 33 KB at C = 5, so FOUR tiles
+// are resident per CU (160 KB LDS) instead of three with 256-splat batches (44 KB).
+constexpr int BWD_BATCH = 192;
 
 // XCD-aware tile order: consecutive workgroup ids land on different XCDs (b % 8), each with a private L2.  Give every
 // XCD one contiguous run of tiles so neighbouring tiles -- which share most of their splats -- hit the same L2.
@@ -200,43 +204,41 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
 }
 
 // ------------------------------------------------------------------------------------------ R7 ---
-template <int C>
-__global__ void __launch_bounds__(256)
-composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-              const float *__restrict__ geom, const float *__restrict__ colors, const float *__restrict__ bg,
-              const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
-              const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap, float *__restrict__ grad_rec)
+// The per-pixel state of the back-to-front walk is ONE recurrence.  Every channel the forward blends (C colours, depth, alpha, 3 normal
+// components, and -- when the distortion map has an upstream gradient -- the distortion weight) enters dL/dalpha as
+// (value_j - blend of the values behind j) * upstream, and all of these "blends behind j" obey the same recurrence
+//     acc_j = alpha_{j+1} * value_{j+1} + (1 - alpha_{j+1}) * acc_{j+1},
+// so the dot product with the upstream gradients is taken FIRST (X_j = sum_ch value_j[ch] * dL/dch) and a single scalar accX is carried:
+// dL/dalpha_j = T_j * (X_j - accX_j) - T_final / (1 - alpha_j) * <bg, dL/dpix>.   (10 + C recurrences of the textbook form -> 1.)
+// 1 / (1 - alpha), 1 / p.z and 1 / depth are v_rcp_f32 (1 ulp): the kernel is VALU-issue bound, and an IEEE division is ~12 instructions.
+// DIST = the distortion map carries an upstream gradient somewhere in this tile (decided per tile at run time; the shipped EnvGS
+// configuration trains with lambda_dist = 0, configs/models/envgs.yaml:73, and then skips the m_d terms altogether).
+template <int C, bool DIST>
+__device__ __forceinline__ void composite_bwd_tile(TileLds<C, BWD_BATCH> &lds, float (*gacc)[15 + C], const int W, const int H, const int bg_len,
+                                                   const uint32_t *__restrict__ point_list, const float *__restrict__ geom,
+                                                   const float *__restrict__ colors, const float *__restrict__ bg,
+                                                   const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
+                                                   const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap,
+                                                   float *__restrict__ grad_rec, const uint32_t r0, const int tx, const int ty, const int max_last)
 {
     constexpr int V = 15 + C;          // gradient words per surfel
     constexpr int N4 = (V + 3) / 4;    // registers left after the transpose-reduce (4 words each)
-    __shared__ TileLds<C> lds;
-    // Per-batch gradient accumulator: the 4 wavefronts add their DPP-reduced words here (ds_add_f32), and the tile sends
-    // ONE global atomic per (splat, word).  The L2 atomic units retire roughly one dword per clock per channel
-    // (~0.12 T dword-atomics/s measured), so the number of global atomic dwords -- not bytes -- is what R7 pays for.
-    __shared__ float gacc[256][V];
-    __shared__ int s_max_last;
-    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    const int tile = xcd_tile(blockIdx.x, gx * gy);
-    if (tile >= gx * gy) return;
-    const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int pxi = tx * TILE + (wave & 1) * 8 + (lane & 7);
     const int pyi = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = pxi < W && pyi < H;
     const float px = (float)pxi, py = (float)pyi;
-    const uint32_t r0 = ranges[2 * tile];
     const size_t HW = (size_t)H * W, pid = (size_t)(inside ? pyi : 0) * W + (inside ? pxi : 0);
 
     const float T_final = inside ? final_T[pid] : 0.f;
     float T = T_final;
     const int32_t last = inside ? n_contrib[pid] : 0;
     const int32_t medc = inside ? n_contrib[HW + pid] : 0;
-    float dpix[C], accum_rec[C], last_color[C];
+    float dpix[C];
     float bg_dot = 0.f;
 #pragma unroll
     for (int c = 0; c < C; c++) {
         dpix[c] = inside ? dL_dcolor[c * HW + pid] : 0.f;
-        accum_rec[c] = 0.f; last_color[c] = 0.f;
         bg_dot += (c < bg_len ? bg[c] : 0.0f) * dpix[c];
     }
     const float dL_ddepth = inside ? dL_dallmap[0 * HW + pid] : 0.f;
@@ -245,30 +247,18 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
     const float dL_dn1 = inside ? dL_dallmap[3 * HW + pid] : 0.f;
     const float dL_dn2 = inside ? dL_dallmap[4 * HW + pid] : 0.f;
     const float dL_dmed = inside ? dL_dallmap[5 * HW + pid] : 0.f;
-    const float dL_dreg = inside ? dL_dallmap[6 * HW + pid] : 0.f;
-    const float final_D = inside ? final_T[HW + pid] : 0.f;
-    const float final_D2 = inside ? final_T[2 * HW + pid] : 0.f;
+    const float dL_dreg = (DIST && inside) ? dL_dallmap[6 * HW + pid] : 0.f;
+    const float final_D = (DIST && inside) ? final_T[HW + pid] : 0.f;
+    const float final_D2 = (DIST && inside) ? final_T[2 * HW + pid] : 0.f;
     const float final_A = 1.0f - T_final;
-    float last_alpha = 0.f, last_depth = 0.f, ln0 = 0.f, ln1 = 0.f, ln2 = 0.f, accum_depth_rec = 0.f, accum_alpha_rec = 0.f,
-          an0 = 0.f, an1 = 0.f, an2 = 0.f, last_dL_dT = 0.f;
+    const float bgT = -T_final * bg_dot;
+    float last_alpha = 0.f, lastX = 0.f, accX = 0.f;
+    constexpr float MD_A = FAR_N / (FAR_N - NEAR_N), MD_B = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
 
-    // Entries behind the deepest last-contributor of this tile were never blended by any pixel: skip them.
-    if (tid == 0) s_max_last = 0;
-    for (int i = tid; i < 256 * V; i += 256) (&gacc[0][0])[i] = 0.f;
-    __syncthreads();
-    {
-        int m = last;
-        m = max(m, __shfl_xor(m, 1)); m = max(m, __shfl_xor(m, 2)); m = max(m, __shfl_xor(m, 4));
-        m = max(m, __shfl_xor(m, 8)); m = max(m, __shfl_xor(m, 16)); m = max(m, __shfl_xor(m, 32));
-        if (lane == 0) atomicMax(&s_max_last, m);
-    }
-    __syncthreads();
-    const int max_last = s_max_last;
-
-    for (int top = max_last; top > 0; top -= 256) {
-        // stage entries [top-256, top) in reverse: LDS slot t holds list index top-1-t
+    for (int top = max_last; top > 0; top -= BWD_BATCH) {
+        // stage entries [top-BWD_BATCH, top) in reverse: LDS slot t holds list index top-1-t
         __syncthreads();
-        if (top - 1 - tid >= 0) {
+        if (tid < BWD_BATCH && top - 1 - tid >= 0) {
             const uint32_t g = point_list[r0 + (uint32_t)(top - 1 - tid)];
             const float4 *gp = reinterpret_cast<const float4 *>(geom + (size_t)g * GEOM);
             const float4 a0 = gp[0], a1 = gp[1], a2 = gp[2], a3 = gp[3];
@@ -279,7 +269,7 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
             for (int c = 0; c < C; c++) lds.col[c][tid] = colors[(size_t)g * C + c];
         }
         __syncthreads();
-        const int count = min(256, top);
+        const int count = min(BWD_BATCH, top);
         for (int j = 0; j < count; j++) {
             if (!((lds.qmask[j] >> wave) & 1u)) continue;
             const int ci = top - 1 - j;                       // 0-based position in the tile list
@@ -297,43 +287,35 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
                 const float Twx = q1.z, Twy = q1.w, opa = q3.z;
                 const float nrm0 = q2.w, nrm1 = q3.x, nrm2 = q3.y;
                 const float alpha = h.alpha, G = h.G;
-                T = T / (1.0f - alpha);
+                const float r1 = __builtin_amdgcn_rcpf(1.0f - alpha);
+                T = T * r1;                                    // transmittance in front of this splat
                 const float w = alpha * T;
-                float dL_dalpha = 0.f;
+                // X_j: this splat's blended values dotted with their upstream gradients
+                float X = h.depth * dL_ddepth + dL_daccum;
+                X += nrm0 * dL_dn0; X += nrm1 * dL_dn1; X += nrm2 * dL_dn2;
 #pragma unroll
                 for (int c = 0; c < C; c++) {
-                    const float col = lds.col[c][j];
-                    accum_rec[c] = last_alpha * last_color[c] + (1.f - last_alpha) * accum_rec[c];
-                    last_color[c] = col;
-                    dL_dalpha += (col - accum_rec[c]) * dpix[c];
+                    X += lds.col[c][j] * dpix[c];
                     gv[15 + c] = w * dpix[c];
                 }
-                float dL_dz = 0.f;
-                const float m_d = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / h.depth);
-                const float dmd_dd = (FAR_N * NEAR_N) / ((FAR_N - NEAR_N) * h.depth * h.depth);
+                float dL_dz = w * dL_ddepth;
                 if (ci == medc - 1) dL_dz += dL_dmed;
-                const float dL_dweight = (final_D2 + m_d * m_d * final_A - 2.0f * m_d * final_D) * dL_dreg;
-                dL_dalpha += dL_dweight - last_dL_dT;
-                last_dL_dT = dL_dweight * alpha + (1.0f - alpha) * last_dL_dT;
-                const float dL_dmd = 2.0f * (T * alpha) * (m_d * final_A - final_D) * dL_dreg;
-                dL_dz += dL_dmd * dmd_dd;
-                accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
-                last_depth = h.depth;
-                dL_dalpha += (h.depth - accum_depth_rec) * dL_ddepth;
-                accum_alpha_rec = last_alpha * 1.0f + (1.f - last_alpha) * accum_alpha_rec;
-                dL_dalpha += (1.0f - accum_alpha_rec) * dL_daccum;
-                an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = nrm0; dL_dalpha += (nrm0 - an0) * dL_dn0;
-                an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = nrm1; dL_dalpha += (nrm1 - an1) * dL_dn1;
-                an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = nrm2; dL_dalpha += (nrm2 - an2) * dL_dn2;
-                gv[9] = w * dL_dn0; gv[10] = w * dL_dn1; gv[11] = w * dL_dn2;
-                dL_dalpha *= T;
+                if (DIST) {
+                    const float idep = __builtin_amdgcn_rcpf(h.depth);
+                    const float m_d = MD_A * (1.0f - NEAR_N * idep);
+                    X += (final_D2 + m_d * m_d * final_A - 2.0f * m_d * final_D) * dL_dreg;           // the distortion weight joins the recurrence
+                    dL_dz += 2.0f * w * (m_d * final_A - final_D) * dL_dreg * (MD_B * idep * idep);
+                }
+                accX = last_alpha * lastX + (1.f - last_alpha) * accX;
+                lastX = X;
                 last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                const float dL_dG = opa * dL_dalpha;
-                dL_dz += w * dL_ddepth;
+                const float dL_dalpha = (X - accX) * T + bgT * r1;
+                gv[9] = w * dL_dn0; gv[10] = w * dL_dn1; gv[11] = w * dL_dn2;
+                gv[12] = G * dL_dalpha;
+                const float nGd = -(opa * dL_dalpha) * G;        // dL/dG * dG/d(rho/2-ish): -G * dL/dG
                 if (h.rho3d <= h.rho2d) {
-                    const float dsx = dL_dG * -G * h.sx + dL_dz * Twx;
-                    const float dsy = dL_dG * -G * h.sy + dL_dz * Twy;
+                    const float dsx = nGd * h.sx + dL_dz * Twx;
+                    const float dsy = nGd * h.sy + dL_dz * Twy;
                     const float ipz = __builtin_amdgcn_rcpf(h.pz);
                     const float dpx = dsx * ipz, dpy = dsy * ipz, dpz = -(dpx * h.sx + dpy * h.sy);
                     const float dkx = h.ly * dpz - h.lz * dpy, dky = h.lz * dpx - h.lx * dpz, dkz = h.lx * dpy - h.ly * dpx;
@@ -344,11 +326,10 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
                     gv[7] = px * dky + py * dly + dL_dz * h.sy;
                     gv[8] = px * dkz + py * dlz + dL_dz;
                 } else {
-                    gv[13] = dL_dG * (-G * FILTER_INV_SQ * h.dx);
-                    gv[14] = dL_dG * (-G * FILTER_INV_SQ * h.dy);
+                    gv[13] = nGd * (FILTER_INV_SQ * h.dx);
+                    gv[14] = nGd * (FILTER_INV_SQ * h.dy);
                     gv[8] = dL_dz;
                 }
-                gv[12] = G * dL_dalpha;
             }
             // wavefront transpose-reduce (permlane swaps + DPP): lane r*16+k ends up owning the sum of word k + r*N4, then one LDS atomic instruction
             const float mine = wave_transpose_reduce<N4>(gv, lane);
@@ -363,6 +344,52 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
             if (val != 0.0f) { atomic_add_f32(grad_rec + (size_t)lds.id[j] * GREC + v, val); gacc[j][v] = 0.f; }
         }
     }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+              const float *__restrict__ geom, const float *__restrict__ colors, const float *__restrict__ bg,
+              const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
+              const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap, float *__restrict__ grad_rec)
+{
+    constexpr int V = 15 + C;
+    __shared__ TileLds<C, BWD_BATCH> lds;
+    // Per-batch gradient accumulator: the 4 wavefronts add their DPP-reduced words here (ds_add_f32), and the tile sends
+    // ONE global atomic per (splat, word).  The L2 atomic units retire roughly one dword per clock per channel
+    // (~0.12 T dword-atomics/s measured), so the number of global atomic dwords -- not bytes -- is what R7 pays for.
+    __shared__ float gacc[BWD_BATCH][V];
+    __shared__ int s_max_last, s_dist;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int tile = xcd_tile(blockIdx.x, gx * gy);
+    if (tile >= gx * gy) return;
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int pxi = tx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int pyi = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    const size_t HW = (size_t)H * W, pid = (size_t)(inside ? pyi : 0) * W + (inside ? pxi : 0);
+    const int32_t last = inside ? n_contrib[pid] : 0;
+    const bool reg = inside && dL_dallmap[6 * HW + pid] != 0.0f;
+
+    // Entries behind the deepest last-contributor of this tile were never blended by any pixel: skip them.
+    if (tid == 0) { s_max_last = 0; s_dist = 0; }
+    for (int i = tid; i < BWD_BATCH * V; i += 256) (&gacc[0][0])[i] = 0.f;
+    __syncthreads();
+    {
+        int m = last;
+        m = max(m, __shfl_xor(m, 1)); m = max(m, __shfl_xor(m, 2)); m = max(m, __shfl_xor(m, 4));
+        m = max(m, __shfl_xor(m, 8)); m = max(m, __shfl_xor(m, 16)); m = max(m, __shfl_xor(m, 32));
+        if (lane == 0) atomicMax(&s_max_last, m);
+        if (lane == 0 && __builtin_amdgcn_ballot_w64(reg) != 0) s_dist = 1;
+    }
+    __syncthreads();
+    const int max_last = s_max_last;
+    const uint32_t r0 = ranges[2 * tile];
+    if (s_dist)
+        composite_bwd_tile<C, true>(lds, gacc, W, H, bg_len, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, r0, tx, ty, max_last);
+    else
+        composite_bwd_tile<C, false>(lds, gacc, W, H, bg_len, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, r0, tx, ty, max_last);
 }
 
 // ------------------------------------------------------------------------------------ launchers ---
