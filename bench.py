@@ -113,6 +113,9 @@ def main():
                          "reference = twin + the expression forms the UNCHANGED EasyVolcap caller executes (batched-matmul get_disks, render()'s "
                          "regulariser maps) -- the step a drop-in user pays")
     ap.add_argument("--torch-glue", action="store_true", help="alias of --caller twin")
+    ap.add_argument("--feature-dtype", default="f32", choices=["f32", "f16"],
+                    help="storage of the per-surfel feature arrays the extensions read (base colours / SH, env SH): f16 = BASELINE configs[4]'s storage variant "
+                         "(fp32 master parameters in the optimizer, a half copy per step for the render path; arithmetic and gradients stay fp32)")
     ap.add_argument("--keep-blas", action="store_true", help="do not let diff_surfel_tracing select rocBLAS for torch's tiny-K batched matmuls (INTEGRATION.md section 5)")
     ap.add_argument("--debug-trace", type=int, default=0, help="ENVGS_DBG_TRACE diagnostic switch mask (include/envgs_raster.h); reported in the JSON line")
     ap.add_argument("--debug-segments", type=int, default=0, help="ENVGS_DBG_SEGMENTS diagnostic switch; reported in the JSON line")
@@ -189,6 +192,10 @@ def main():
     env_in = dict(env_params)
     if envgs and args.trace_depth > 0:
         env_in["others"] = env_others
+    half = args.feature_dtype == "f16"
+    if half and envgs:
+        from envgs_amd import envgs_step as _es2
+        _es2.FEATURE_F16["on"] = True
 
     def settings(cam):
         return pkg.GaussianRasterizationSettings(
@@ -233,7 +240,7 @@ def main():
         else:
             means2D = torch.zeros_like(params["means3D"], requires_grad=True)
             color, radii, allmap, weight = pkg.GaussianRasterizer(raster_settings=settings(cam))(
-                means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
+                means3D=params["means3D"], means2D=means2D, shs=(params["shs"].half() if half else params["shs"]), colors_precomp=None,
                 opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"], cov3D_precomp=None)
             loss = (color * dcol).sum() + (allmap * dall).sum()
         n_acc["N"] += raster.LAST_STATS["N"]; n_acc["steps"] += 1
@@ -381,7 +388,7 @@ def main():
             "metric": "train iters/s (fwd+bwd of the render hot path + Adam step, one %dx%d view per GPU per iter) + render Mpix/s" % (W, H),
             "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded, BASELINE.md section 3; random-init Gaussians)",
+            "dtype": ("f32" if not half else "f16-storage/f32-acc (feature arrays stored as half, fp32 arithmetic, accumulation and gradients)"), "data": "synthetic (seeded, BASELINE.md section 3; random-init Gaussians)",
             "config": {"workload": (("Ref-Real sedan-like full EnvGS (ch0%d raster + env LBVH trace)" % C) if envgs else
                                     "Ref-NeRF toaster-like base 2DGS raster only (BASELINE configs[1]), SH deg 3 in-kernel"),
                        "gaussians": P, "env_gaussians": (args.env_gaussians if envgs else 0), "resolution": [H, W], "trace_depth": (args.trace_depth if envgs else None), "channels": C, "views": 8,

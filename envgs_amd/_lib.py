@@ -16,7 +16,7 @@ class RasterCfg(ctypes.Structure):
     _fields_ = [("P", ctypes.c_int32), ("sh_degree", ctypes.c_int32), ("sh_coeffs", ctypes.c_int32),
                 ("channels", ctypes.c_int32), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
                 ("bg_len", ctypes.c_int32), ("debug", ctypes.c_int32), ("scale_modifier", ctypes.c_float),
-                ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float)]
+                ("tanfovx", ctypes.c_float), ("tanfovy", ctypes.c_float), ("feature_f16", ctypes.c_int32)]
 
 
 class AdamTensor(ctypes.Structure):
@@ -47,7 +47,7 @@ class TraceCfg(ctypes.Structure):
                 ("sh_coeffs", ctypes.c_int32), ("max_trace_depth", ctypes.c_int32), ("start_from_first", ctypes.c_int32),
                 ("has_others", ctypes.c_int32), ("bg_len", ctypes.c_int32), ("debug", ctypes.c_int32),
                 ("ray_h", ctypes.c_int32), ("ray_w", ctypes.c_int32),
-                ("scale_modifier", ctypes.c_float), ("specular_threshold", ctypes.c_float)]
+                ("scale_modifier", ctypes.c_float), ("specular_threshold", ctypes.c_float), ("feature_f16", ctypes.c_int32)]
 
 
 # every symbol include/*.h declares: name -> (restype, argtypes)

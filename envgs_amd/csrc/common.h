@@ -1,6 +1,7 @@
 // common.h -- shared device helpers for the gfx950 surfel kernels (wave64, CDNA4).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 
 #include "../../include/envgs_raster.h"
@@ -18,6 +19,17 @@ constexpr float FILTER_INV_SQ = 2.0f;
 constexpr float ALPHA_CAP = 0.99f;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_EPS = 0.0001f;
+
+// Per-surfel FEATURE arrays (SH coefficients, precomputed colours) may be stored in fp32 or fp16 (cfg->feature_f16); they are converted on
+// load and everything downstream is fp32.  `h` is wave-uniform.
+struct Feat {
+    const void *p;
+    bool h;
+    __device__ __forceinline__ float operator[](size_t i) const {
+        return h ? __half2float(reinterpret_cast<const __half *>(p)[i]) : reinterpret_cast<const float *>(p)[i];
+    }
+    __device__ __forceinline__ Feat at(size_t i) const { return Feat{reinterpret_cast<const char *>(p) + i * (h ? 2 : 4), h}; }
+};
 
 #define ENVGS_CHECK_LAUNCH(cfg, stream)                                             \
     do {                                                                            \
@@ -147,10 +159,10 @@ int launch_bin(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const
                void *sort_temp, size_t sort_temp_bytes, uint32_t *ranges, hipStream_t stream);
 int launch_render_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                       const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
-                      int32_t *n_contrib, float *weight, hipStream_t stream, uint8_t *audit_contrib = nullptr, int audit_lmax = 0);
+                      int32_t *n_contrib, float *weight, hipStream_t stream, uint8_t *audit_contrib = nullptr, int audit_lmax = 0, int colors_f16 = 0);
 int launch_render_bwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                       const float *colors, const float *bg, const float *final_T, const int32_t *n_contrib,
-                      const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream);
+                      const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream, int colors_f16 = 0);
 int launch_project_bwd(const envgs_raster_cfg *cfg, const float *geom, const float *means3D, const float *scales,
                        const float *rotations, const float *shs, const uint8_t *clamped, const float *transmat_precomp,
                        const int32_t *radii, const float *viewmatrix, const float *projmatrix, const float *campos,

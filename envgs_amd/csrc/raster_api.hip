@@ -65,7 +65,9 @@ int envgs_raster_bin_and_render(const envgs_raster_cfg *cfg, uint32_t N, const f
     rc = launch_bin(cfg, N, geom, radii, offsets, keys_unsorted, vals_unsorted, keys_sorted, point_list, sort_temp,
                     sort_temp_bytes_, ranges, stream);
     if (rc) return rc;
-    return launch_render_fwd(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream);
+    // `colors` is the caller's (possibly half) colors_precomp only when no SH were given; the SH -> RGB result of _project is fp32
+    return launch_render_fwd(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream, nullptr, 0,
+                             (cfg->feature_f16 && cfg->sh_coeffs == 0) ? 1 : 0);
 }
 
 int envgs_raster_render_audit(const envgs_raster_cfg *cfg, const float *geom, const float *colors, const float *bg,
@@ -79,7 +81,8 @@ int envgs_raster_render_audit(const envgs_raster_cfg *cfg, const float *geom, co
     hipStream_t stream = (hipStream_t)stream_;
     hipError_t e = hipMemsetAsync(contrib, 0, (size_t)cfg->width * cfg->height * (size_t)lmax, stream);
     if (e != hipSuccess) return (int)e;
-    return launch_render_fwd(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream, contrib, lmax);
+    return launch_render_fwd(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream, contrib, lmax,
+                             (cfg->feature_f16 && cfg->sh_coeffs == 0) ? 1 : 0);
 }
 
 int envgs_raster_backward(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const float *colors, const float *bg,
@@ -101,7 +104,8 @@ int envgs_raster_backward(const envgs_raster_cfg *cfg, uint32_t N, const float *
     if (shs ? (!dshs || !clamped || !campos || !means3D) : !dcolors) return ENVGS_ERR_BAD_ARG;
     if (transmat_precomp ? !dtransmat_precomp : (!scales || !rotations || !means3D || !dmeans3D || !dscales || !drots)) return ENVGS_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
-    rc = launch_render_bwd(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream);
+    rc = launch_render_bwd(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream,
+                           (cfg->feature_f16 && !shs) ? 1 : 0);
     if (rc) return rc;
     return launch_project_bwd(cfg, geom, means3D, scales, rotations, shs, clamped, transmat_precomp, radii, viewmatrix,
                               projmatrix, campos, grad_rec, dmeans3D, dmeans2D, dscales, drots, dshs, dcolors, dopacities,

@@ -23,7 +23,7 @@ constexpr float kC1 = 0.4886025119029199f;
 __device__ __forceinline__ int clampi(int a, int lo, int hi) { return a < lo ? lo : (a > hi ? hi : a); }
 
 __global__ void __launch_bounds__(256)
-project_surfels(int P, int D, int M, int C, int W, int H, float mod,
+project_surfels(int P, int D, int M, int f16, int C, int W, int H, float mod,
                 const float *__restrict__ means3D, const float *__restrict__ scales,
                 const float *__restrict__ rotations, const float *__restrict__ opacities,
                 const float *__restrict__ shs, const float *__restrict__ transmat_precomp,
@@ -114,7 +114,7 @@ project_surfels(int P, int D, int M, int C, int W, int H, float mod,
         const float dx = p0 - campos[0], dy = p1 - campos[1], dz = p2 - campos[2];
         const float len = sqrtf(dx * dx + dy * dy + dz * dz);
         const float x = dx / len, y = dy / len, z = dz / len;
-        const float *sh = shs + (size_t)i * M * 3;
+        const Feat sh = Feat{shs, f16 != 0}.at((size_t)i * M * 3);          // fp32 or fp16 storage, converted on load
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             float r = kC0 * sh[0 * 3 + c];
@@ -157,7 +157,7 @@ int launch_project(const envgs_raster_cfg *cfg, const float *means3D, const floa
     if (P <= 0) return 0;
     const int blocks = (P + 255) / 256;
     ProfScope prof_(K_PROJECT, stream);
-    hipLaunchKernelGGL(project_surfels, dim3(blocks), dim3(256), 0, stream, P, cfg->sh_degree, cfg->sh_coeffs,
+    hipLaunchKernelGGL(project_surfels, dim3(blocks), dim3(256), 0, stream, P, cfg->sh_degree, cfg->sh_coeffs, cfg->feature_f16,
                        cfg->channels, cfg->width, cfg->height, cfg->scale_modifier, means3D, scales, rotations,
                        opacities, shs, transmat_precomp, viewmatrix, projmatrix, campos, geom, rgb, clamped, radii,
                        tiles_touched);

@@ -18,7 +18,7 @@ __device__ __constant__ float bC3[7] = {-0.5900435899266435f, 2.890611442640554f
                                         -0.5900435899266435f};
 
 __global__ void __launch_bounds__(256)
-project_surfels_bwd(int P, int D, int M, int C, int W, int H, float mod, const float *__restrict__ geom,
+project_surfels_bwd(int P, int D, int M, int f16, int C, int W, int H, float mod, const float *__restrict__ geom,
                     const float *__restrict__ means3D, const float *__restrict__ scales,
                     const float *__restrict__ rotations, const float *__restrict__ shs,
                     const uint8_t *__restrict__ clamped, const float *__restrict__ transmat_precomp,
@@ -122,7 +122,7 @@ project_surfels_bwd(int P, int D, int M, int C, int W, int H, float mod, const f
 
         if (shs) {
             const float p0 = means3D[3 * i], p1 = means3D[3 * i + 1], p2 = means3D[3 * i + 2];
-            const float *sh = shs + (size_t)i * M * 3;
+            const Feat sh = Feat{shs, f16 != 0}.at((size_t)i * M * 3);          // fp32 or fp16 storage, converted on load
             float *dsh = dshs + (size_t)i * M * 3;
             const float dirx = p0 - campos[0], diry = p1 - campos[1], dirz = p2 - campos[2];
             const float sum2 = dirx * dirx + diry * diry + dirz * dirz;
@@ -203,7 +203,7 @@ int launch_project_bwd(const envgs_raster_cfg *cfg, const float *geom, const flo
     const int P = cfg->P;
     if (P <= 0) return 0;
     ProfScope prof_(K_PROJECT_BWD, stream);
-    hipLaunchKernelGGL(project_surfels_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, cfg->sh_degree, cfg->sh_coeffs,
+    hipLaunchKernelGGL(project_surfels_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, cfg->sh_degree, cfg->sh_coeffs, cfg->feature_f16,
                        cfg->channels, cfg->width, cfg->height, cfg->scale_modifier, geom, means3D, scales, rotations, shs,
                        clamped, transmat_precomp, radii, viewmatrix, projmatrix, campos, grad_rec, dmeans3D, dmeans2D,
                        dscales, drots, dshs, dcolors, dopacities, dtransmat_precomp);

@@ -111,7 +111,7 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float4 r0, const float4 
 template <int C, bool AUDIT>
 __global__ void __launch_bounds__(256)
 composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-              const float *__restrict__ geom, const float *__restrict__ colors, const float *__restrict__ bg,
+              const float *__restrict__ geom, const Feat colors, const float *__restrict__ bg,
               float *__restrict__ out_color, float *__restrict__ allmap, float *__restrict__ final_T,
               int32_t *__restrict__ n_contrib, float *__restrict__ weight, uint8_t *__restrict__ audit_contrib, int audit_lmax)
 {
@@ -216,7 +216,7 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
 template <int C, bool DIST>
 __device__ __forceinline__ void composite_bwd_tile(TileLds<C, BWD_BATCH> &lds, float (*gacc)[15 + C], const int W, const int H, const int bg_len,
                                                    const uint32_t *__restrict__ point_list, const float *__restrict__ geom,
-                                                   const float *__restrict__ colors, const float *__restrict__ bg,
+                                                   const Feat colors, const float *__restrict__ bg,
                                                    const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
                                                    const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap,
                                                    float *__restrict__ grad_rec, const uint32_t r0, const int tx, const int ty, const int max_last)
@@ -349,7 +349,7 @@ __device__ __forceinline__ void composite_bwd_tile(TileLds<C, BWD_BATCH> &lds, f
 template <int C>
 __global__ void __launch_bounds__(256)
 composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-              const float *__restrict__ geom, const float *__restrict__ colors, const float *__restrict__ bg,
+              const float *__restrict__ geom, const Feat colors, const float *__restrict__ bg,
               const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
               const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap, float *__restrict__ grad_rec)
 {
@@ -396,33 +396,34 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
 template <int C>
 static int run_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                    const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
-                   int32_t *n_contrib, float *weight, uint8_t *audit_contrib, int audit_lmax, hipStream_t stream)
+                   int32_t *n_contrib, float *weight, uint8_t *audit_contrib, int audit_lmax, hipStream_t stream, int colors_f16)
 {
     const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
     ProfScope prof_(K_COMPOSITE_FWD, stream);
     const dim3 grid(8 * ((gx * gy + 7) / 8)), block(256);
+    const Feat colors_{colors, colors_f16 != 0};
     if (audit_contrib)
         hipLaunchKernelGGL((composite_fwd<C, true>), grid, block, 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
-                           point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax);
+                           point_list, geom, colors_, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax);
     else
         hipLaunchKernelGGL((composite_fwd<C, false>), grid, block, 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
-                           point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, (uint8_t *)nullptr, 0);
+                           point_list, geom, colors_, bg, out_color, allmap, final_T, n_contrib, weight, (uint8_t *)nullptr, 0);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;
 }
 
 int launch_render_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                       const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
-                      int32_t *n_contrib, float *weight, hipStream_t stream, uint8_t *audit_contrib, int audit_lmax)
+                      int32_t *n_contrib, float *weight, hipStream_t stream, uint8_t *audit_contrib, int audit_lmax, int colors_f16)
 {
     if (cfg->P > 0) {
         hipError_t e = hipMemsetAsync(weight, 0, sizeof(float) * (size_t)cfg->P, stream);
         if (e != hipSuccess) return (int)e;
     }
     switch (cfg->channels) {
-    case 3: return run_fwd<3>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream);
-    case 5: return run_fwd<5>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream);
-    case 7: return run_fwd<7>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream);
+    case 3: return run_fwd<3>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16);
+    case 5: return run_fwd<5>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16);
+    case 7: return run_fwd<7>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16);
     default: return ENVGS_ERR_BAD_ARG;
     }
 }
@@ -430,27 +431,27 @@ int launch_render_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const
 template <int C>
 static int run_bwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                    const float *colors, const float *bg, const float *final_T, const int32_t *n_contrib,
-                   const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream)
+                   const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream, int colors_f16)
 {
     const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
     ProfScope prof_(K_COMPOSITE_BWD, stream);
     hipLaunchKernelGGL(composite_bwd<C>, dim3(8 * ((gx * gy + 7) / 8)), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
-                       point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec);
+                       point_list, geom, Feat{colors, colors_f16 != 0}, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;
 }
 
 int launch_render_bwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                       const float *colors, const float *bg, const float *final_T, const int32_t *n_contrib,
-                      const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream)
+                      const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream, int colors_f16)
 {
     if (cfg->P <= 0) return 0;
     hipError_t e = hipMemsetAsync(grad_rec, 0, sizeof(float) * GREC * (size_t)cfg->P, stream);
     if (e != hipSuccess) return (int)e;
     switch (cfg->channels) {
-    case 3: return run_bwd<3>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream);
-    case 5: return run_bwd<5>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream);
-    case 7: return run_bwd<7>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream);
+    case 3: return run_bwd<3>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream, colors_f16);
+    case 5: return run_bwd<5>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream, colors_f16);
+    case 7: return run_bwd<7>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream, colors_f16);
     default: return ENVGS_ERR_BAD_ARG;
     }
 }

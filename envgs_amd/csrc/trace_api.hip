@@ -97,6 +97,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     A.bg = bg; A.ray_o = ray_o; A.ray_d = ray_d; A.counter = counters; A.stats = (unsigned long long *)(counters + 2);
     A.rgb = rgb; A.dpt = dpt; A.acc = acc; A.norm = norm; A.dist = dist; A.aux = aux; A.mid = mid; A.wet = wet; A.final_T = final_T;
     A.mod = cfg->scale_modifier;
+    A.f16 = cfg->feature_f16;
     A.exp = debug_switch(ENVGS_DBG_TRACE);
     int rh, rw; ray_layout(cfg, &rh, &rw);
     const bool lists = lists_usable(cfg, L);
@@ -244,6 +245,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     A.g_rgb = dL_drgb; A.g_dpt = dL_ddpt; A.g_acc = dL_dacc; A.g_norm = dL_dnorm; A.g_aux = dL_daux;
     A.geo_rec = geo_rec; A.dshs = dshs; A.dcolors = dcolors;
     A.exp = debug_switch(ENVGS_DBG_TRACE);
+    A.f16 = cfg->feature_f16;
     A.dothers = dothers; A.dray_o = dray_o; A.dray_d = dray_d; A.mod = cfg->scale_modifier;
     int rh, rw; ray_layout(cfg, &rh, &rw);
     {

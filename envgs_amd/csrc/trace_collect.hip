@@ -365,6 +365,7 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
 #pragma unroll
             for (int c = 0; c < 4; c++) { qa[c] = nd[2 * c]; qb[c] = nd[2 * c + 1]; }
             int key[4], ref[4];
+            int ninner = 0;                                   // internal children some ray enters
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int ch = __builtin_amdgcn_readfirstlane(__float_as_int(qb[c].z));
@@ -399,7 +400,7 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
                         const int fl = (int)__builtin_ctzll(m);
                         key[c] = __builtin_amdgcn_readlane(__float_as_int(fmaxf(tn, 0.0f)), fl);
                         ref[c] = ch;
-                        visits += 2u * (unsigned)__popcll(m);
+                        ninner++;
                     }
                 }
             }
@@ -415,13 +416,17 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
             // sort the (at most four) internal children by key: 5 scalar compare-exchanges; unused slots carry INT_MAX and end up last
 #define ENVGS_CSWAP(a, b) { const bool sw = key[a] > key[b]; const int ka = sw ? key[b] : key[a], kb2 = sw ? key[a] : key[b], \
                                        ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b]; key[a] = ka; key[b] = kb2; ref[a] = ra; ref[b] = rb; }
-            ENVGS_CSWAP(0, 1) ENVGS_CSWAP(2, 3) ENVGS_CSWAP(0, 2) ENVGS_CSWAP(1, 3) ENVGS_CSWAP(1, 2)
-#undef ENVGS_CSWAP
-            // nearest next; the others go on the stack far to near
+            if (ninner >= 2) {                                // (most steps enter at most one internal child: nothing to order, nothing to push)
+                ENVGS_CSWAP(0, 1) ENVGS_CSWAP(2, 3) ENVGS_CSWAP(0, 2) ENVGS_CSWAP(1, 3) ENVGS_CSWAP(1, 2)
+                // nearest next; the others go on the stack far to near
 #pragma unroll
-            for (int c = 3; c >= 1; c--)
-                if (ref[c] >= 0) { if (sp < slimit) stk[sp++] = ref[c]; else ovf = true; }
-            cur = ref[0];
+                for (int c = 3; c >= 1; c--)
+                    if (ref[c] >= 0) { if (sp < slimit) stk[sp++] = ref[c]; else ovf = true; }
+                cur = ref[0];
+            } else {
+                cur = max(max(ref[0], ref[1]), max(ref[2], ref[3]));      // the one entered child, or -1
+            }
+#undef ENVGS_CSWAP
         }
         if (ovf) {
             // a postponed child was dropped: this batch's lists are incomplete.  Mark every ray as overflowed (hit_cnt > cap) so that it is

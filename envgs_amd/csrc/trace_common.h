@@ -117,6 +117,7 @@ __device__ __forceinline__ float first_tmin(int start_from_first) { return start
 
 struct TraceArgs {
     int P, R, D, M, ND, start_from_first, has_others, bg_len;
+    int f16;            // shs / colors are stored as IEEE half (converted on load; see Feat in common.h)
     float spec_thr;
     const float4 *nodes;
     const float4 *srec;
@@ -238,10 +239,32 @@ __device__ __forceinline__ void traverse(const TraceArgs &A, int (*stk)[64], con
 
 struct StageSums { float rgb[3], dpt, acc, nrm[3], dist, aux[2], T, M1, M2; };
 
-// SH block of one surfel into registers (zeros beyond the active degree).
+// 8 halves (one 16 B load) -> 8 floats
+__device__ __forceinline__ void unpack_h8(const uint4 x, float *v)
+{
+    const unsigned w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        v[2 * q] = __half2float(__ushort_as_half((unsigned short)(w[q] & 0xFFFFu)));
+        v[2 * q + 1] = __half2float(__ushort_as_half((unsigned short)(w[q] >> 16)));
+    }
+}
+
+// SH block of one surfel into registers (zeros beyond the active degree).  fp16 storage: 96 B per surfel = six 16 B loads instead of twelve.
 __device__ __forceinline__ void load_sh(const TraceArgs &A, const int sid, const int nb, float *v)
 {
-    if (A.M == 16) {
+    if (A.M == 16 && A.f16) {
+        const uint4 *s8 = reinterpret_cast<const uint4 *>(reinterpret_cast<const __half *>(A.shs) + (size_t)sid * 48);
+        const int nq = (nb * 3 + 7) >> 3;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            uint4 x = make_uint4(0u, 0u, 0u, 0u);
+            if (q < nq) x = s8[q];
+            unpack_h8(x, v + 8 * q);
+        }
+#pragma unroll
+        for (int k = 0; k < 48; k++) if (k >= nb * 3) v[k] = 0.f;
+    } else if (A.M == 16) {
         const float4 *s4 = reinterpret_cast<const float4 *>(A.shs + (size_t)sid * 48);
         const int nq = (nb * 3 + 3) >> 2;
 #pragma unroll
@@ -251,7 +274,7 @@ __device__ __forceinline__ void load_sh(const TraceArgs &A, const int sid, const
             v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
         }
     } else {
-        const float *sh = A.shs + (size_t)sid * A.M * 3;
+        const Feat sh = Feat{A.shs, A.f16 != 0}.at((size_t)sid * A.M * 3);
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const bool in = k < nb;
@@ -265,29 +288,18 @@ __device__ __forceinline__ void surfel_color(const TraceArgs &A, int sid, const 
     if (A.M > 0) {
         const int nb = (A.D + 1) * (A.D + 1);
         float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-        if (A.M == 16) {
-            // the usual layout (16 coefficients x RGB = 192 B, 16 B aligned): 12 x 16 B loads instead of 48 x 4 B gathers
-            const float4 *s4 = reinterpret_cast<const float4 *>(A.shs + (size_t)sid * 48);
-            const int nq = (nb * 3 + 3) >> 2;
-            float v[48];
+        // the usual layout (16 coefficients x RGB, 16 B aligned): 12 x 16 B loads (6 with fp16 storage) instead of 48 x 4 B gathers
+        float v[48];
+        load_sh(A, sid, nb, v);
 #pragma unroll
-            for (int q = 0; q < 12; q++) {
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (q < nq) x = s4[q];
-                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; k++)
-                if (k < nb) { const float b = basis[k]; r0 += b * v[k * 3]; r1 += b * v[k * 3 + 1]; r2 += b * v[k * 3 + 2]; }
-        } else {
-            const float *sh = A.shs + (size_t)sid * A.M * 3;
-            for (int k = 0; k < nb; k++) { const float b = basis[k]; r0 += b * sh[k * 3]; r1 += b * sh[k * 3 + 1]; r2 += b * sh[k * 3 + 2]; }
-        }
+        for (int k = 0; k < 16; k++)
+            if (k < nb) { const float b = basis[k]; r0 += b * v[k * 3]; r1 += b * v[k * 3 + 1]; r2 += b * v[k * 3 + 2]; }
         r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
         cl[0] = r0 < 0.f; cl[1] = r1 < 0.f; cl[2] = r2 < 0.f;
         col[0] = cl[0] ? 0.f : r0; col[1] = cl[1] ? 0.f : r1; col[2] = cl[2] ? 0.f : r2;
     } else {
-        col[0] = A.colors[3 * sid]; col[1] = A.colors[3 * sid + 1]; col[2] = A.colors[3 * sid + 2];
+        const Feat c = Feat{A.colors, A.f16 != 0}.at((size_t)sid * 3);
+        col[0] = c[0]; col[1] = c[1]; col[2] = c[2];
         cl[0] = cl[1] = cl[2] = false;
     }
 }

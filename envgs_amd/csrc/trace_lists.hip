@@ -225,7 +225,6 @@ register_hits(const TraceArgs A)
                                                      // returning ds_add_rtn_u64 per hit gives its rank; after the flush: offset of its first pair
     __shared__ unsigned nfail, ndense;
     __shared__ unsigned short hod[RH_TAB];           // table slot of the d-th distinct surfel, in order of first appearance
-    __shared__ unsigned kmin[RH_TAB];                // smallest list position at which any ray of the batch blends the surfel of this slot
     __shared__ unsigned pstage[RH_STAGE];            // the batch's pairs, assembled here and written out as one contiguous run (a scattered 4 B
                                                      // store costs a whole 32 B sector of write traffic)
     __shared__ unsigned ptotal;
@@ -238,7 +237,7 @@ register_hits(const TraceArgs A)
         unsigned long long *ent = A.entries ? A.entries + (size_t)batch * region : nullptr;
         unsigned *prs = A.pairs ? A.pairs + (size_t)batch * region : nullptr;
         __syncthreads();
-        for (int i = threadIdx.x; i < RH_TAB; i += 64 * RH_W) { key[i] = -1; acc[i] = 0ull; kmin[i] = 0xFFFFFFFFu; }
+        for (int i = threadIdx.x; i < RH_TAB; i += 64 * RH_W) { key[i] = -1; acc[i] = 0ull; }
         if (threadIdx.x == 0) { nfail = 0u; ndense = 0u; }
         __syncthreads();
         const int r = ray_of(A, base + lane);
@@ -272,7 +271,6 @@ register_hits(const TraceArgs A)
                 }
                 unsigned x = 0xFFFFFFFFu;
                 if (ok) {
-                    if ((unsigned)k < kmin[h]) atomicMin(&kmin[h], (unsigned)k);           // (the read filters most of the atomics)
                     const unsigned rank = (unsigned)(atomicAdd(&acc[h], (wq << 8) | 1ull) & 0xFFull);
                     x = (h << 8) | rank;                                  // rank < 64: a ray meets a planar surfel once
                 } else {                                                  // table full around h: an entry of its own
@@ -285,34 +283,9 @@ register_hits(const TraceArgs A)
             }
         }
         __syncthreads();
-        // Flush the entries in order of their SMALLEST LIST POSITION over the batch's rays (front to back): the backward then meets each ray's
-        // hits in ascending list position, so the 32 B of per-hit state it gathers are consumed cache line by cache line (4 hits per 128 B
-        // line) instead of at random -- the eight wavefronts insert concurrently, so the order of first appearance alone jitters by ~32
-        // positions and every gather of the backward missed L2 (8.2 GB fetched for 2 GB of state).  Counting sort over the positions
-        // (< cap <= 1024), in LDS that the pair staging only needs afterwards.
+        // Flush in order of FIRST APPEARANCE along the rays (~ front to back): the backward then meets each ray's hits in roughly ascending
+        // list position, so the per-hit state it gathers is consumed cache line by cache line instead of at random.
         const unsigned D = ndense;
-        {
-            unsigned *cnt = pstage;                                                   // [1024] histogram -> running offsets
-            unsigned short *hod2 = reinterpret_cast<unsigned short *>(pstage + 1024); // [1024] table slots in sorted order
-            for (int i = threadIdx.x; i < 1024; i += 64 * RH_W) cnt[i] = 0u;
-            __syncthreads();
-            for (unsigned d = threadIdx.x; d < D; d += 64 * RH_W) atomicAdd(&cnt[min(kmin[hod[d]], 1023u)], 1u);
-            __syncthreads();
-            if (part == 0) {
-                unsigned carry = 0u;
-                for (int c = 0; c < 1024; c += 64) {
-                    const unsigned v = cnt[c + lane];
-                    const unsigned incl = (unsigned)wave_scan_add((float)v);           // exact: D <= 1024
-                    cnt[c + lane] = carry + incl - v;
-                    carry += (unsigned)wave_bcast((float)incl, 63);
-                }
-            }
-            __syncthreads();
-            for (unsigned d = threadIdx.x; d < D; d += 64 * RH_W) { const unsigned short h = hod[d]; hod2[atomicAdd(&cnt[min(kmin[h], 1023u)], 1u)] = h; }
-            __syncthreads();
-            for (unsigned d = threadIdx.x; d < D; d += 64 * RH_W) hod[d] = hod2[d];
-            __syncthreads();
-        }
         if (part == 0) {
             unsigned carry_off = 0u;
             for (unsigned c = 0; c < D; c += 64) {

@@ -116,7 +116,22 @@ batch_surfel_bwd(const TraceArgs A)
                 d = e < D ? ent[e] : ent[region - 1 - (size_t)(e - D)];
                 const int sid = (int)(d & 0xFFFFFFull);
                 sdat[buf][el][part] = A.srec[(size_t)sid * 4 + part];
-                if (A.M == 16) {
+                if (A.M == 16 && A.f16) {
+                    // fp16 storage: this lane's 12 coefficients are 24 B = three 8 B loads, each converted into one staged float4
+                    const uint2 *s2 = reinterpret_cast<const uint2 *>(reinterpret_cast<const __half *>(A.shs) + (size_t)sid * 48);
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        const uint2 h = s2[part * 3 + q];
+                        float4 x = make_float4(__half2float(__ushort_as_half((unsigned short)(h.x & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(h.x >> 16))),
+                                               __half2float(__ushort_as_half((unsigned short)(h.y & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(h.y >> 16))));
+                        const int i0 = (part * 3 + q) * 4;
+                        if (i0 + 0 >= nb * 3) x.x = 0.f;
+                        if (i0 + 1 >= nb * 3) x.y = 0.f;
+                        if (i0 + 2 >= nb * 3) x.z = 0.f;
+                        if (i0 + 3 >= nb * 3) x.w = 0.f;
+                        sdat[buf][el][4 + part * 3 + q] = x;
+                    }
+                } else if (A.M == 16) {
                     const float4 *s4 = reinterpret_cast<const float4 *>(A.shs + (size_t)sid * 48);
 #pragma unroll
                     for (int q = 0; q < 3; q++) {
@@ -129,13 +144,14 @@ batch_surfel_bwd(const TraceArgs A)
                         sdat[buf][el][4 + part * 3 + q] = x;
                     }
                 } else {
+                    const Feat fsh = Feat{A.shs, A.f16 != 0}.at(A.M > 0 ? (size_t)sid * A.M * 3 : 0), fcol = Feat{A.colors, A.f16 != 0}.at(A.M > 0 ? 0 : (size_t)sid * 3);
 #pragma unroll
                     for (int q = 0; q < 3; q++) {
                         float v[4];
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
                             const int idx = (part * 3 + q) * 4 + c;
-                            v[c] = A.M > 0 ? (idx < nb * 3 ? A.shs[(size_t)sid * A.M * 3 + idx] : 0.f) : (idx < 3 ? A.colors[(size_t)sid * 3 + idx] : 0.f);
+                            v[c] = A.M > 0 ? (idx < nb * 3 ? fsh[idx] : 0.f) : (idx < 3 ? fcol[idx] : 0.f);
                         }
                         sdat[buf][el][4 + part * 3 + q] = make_float4(v[0], v[1], v[2], v[3]);
                     }

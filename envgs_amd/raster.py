@@ -47,6 +47,16 @@ def _f32c(t):
     return t.contiguous()
 
 
+def _featc(t):
+    """Per-surfel FEATURE arrays (shs, colors_precomp) keep fp16 storage when the caller passes half tensors (cfg.feature_f16: converted
+    on load inside the kernels, fp32 arithmetic and fp32 gradient buffers); anything else is fp32."""
+    if t is None:
+        return None
+    if t.dtype != torch.float16:
+        return _f32c(t)
+    return t.contiguous()
+
+
 def _stream(dev):
     return _lib.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
@@ -75,11 +85,11 @@ def sh_degree_of(deg):
     return v
 
 
-def _cfg(settings, P, C, sh_coeffs, bg_len):
+def _cfg(settings, P, C, sh_coeffs, bg_len, f16=False):
     deg = sh_degree_of(settings.sh_degree)
     return _lib.RasterCfg(P, deg, sh_coeffs, C, int(settings.image_width), int(settings.image_height), bg_len,
                           1 if settings.debug else 0, float(settings.scale_modifier), float(settings.tanfovx),
-                          float(settings.tanfovy))
+                          float(settings.tanfovy), 1 if f16 else 0)
 
 
 def rasterize_forward(C, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings,
@@ -92,7 +102,8 @@ def rasterize_forward(C, means3D, shs, colors_precomp, opacities, scales, rotati
     P = means3D.shape[0]
     H, W = int(settings.image_height), int(settings.image_width)
     means3D = _f32c(means3D); opacities = _f32c(opacities)
-    shs = _f32c(shs); colors_precomp = _f32c(colors_precomp)
+    shs = _featc(shs); colors_precomp = _featc(colors_precomp)
+    f16 = (shs if shs is not None else colors_precomp).dtype == torch.float16
     scales = _f32c(scales); rotations = _f32c(rotations); cov3D_precomp = _f32c(cov3D_precomp)
     if shs is not None and C != 3:
         raise RuntimeError("in-kernel SH evaluation produces 3 channels; the %d-channel rasterizer needs colors_precomp" % C)
@@ -102,7 +113,7 @@ def rasterize_forward(C, means3D, shs, colors_precomp, opacities, scales, rotati
     view = _f32c(settings.viewmatrix).to(dev); proj = _f32c(settings.projmatrix).to(dev)
     campos = _f32c(settings.campos).reshape(-1).to(dev)
     sh_coeffs = 0 if shs is None else int(shs.shape[1])
-    cfg = _cfg(settings, P, C, sh_coeffs, min(int(bg.numel()), C))
+    cfg = _cfg(settings, P, C, sh_coeffs, min(int(bg.numel()), C), f16)
     stream = _stream(dev)
     f32 = dict(dtype=torch.float32, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
@@ -183,7 +194,7 @@ def rasterize_backward(saved, dL_dcolor, dL_dallmap):
     dscales = torch.empty(P, 2, **f32) if cov is None else None
     drots = torch.empty(P, 4, **f32) if cov is None else None
     dcov = torch.empty(P, 9, **f32) if cov is not None else None
-    dshs = torch.empty_like(shs) if shs is not None else None
+    dshs = torch.empty(shs.shape, **f32) if shs is not None else None            # gradients are fp32 whatever the feature storage
     dcolors = torch.empty(P, C, **f32) if shs is None else None
     p = _lib.ptr
     _lib.check(lib.envgs_raster_backward(cfg, saved["N"], p(saved["geom"]), p(saved["colors"]), p(saved["bg"]),

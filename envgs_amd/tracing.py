@@ -79,14 +79,14 @@ def build_bvh(vertices, opacities=None, debug=False):
     return nodes, P
 
 
-def _cfg(settings, P, R, shs, others, start_from_first, ray_shape):
+def _cfg(settings, P, R, shs, others, start_from_first, ray_shape, f16=False):
     from .raster import sh_degree_of
     deg = sh_degree_of(settings.sh_degree)
     rh, rw = (int(ray_shape[0]), int(ray_shape[1])) if len(ray_shape) == 2 else (0, 0)
     bg_len = min(int(settings.bg.numel()), 3)
     return _lib.TraceCfg(P, R, deg, 0 if shs is None else int(shs.shape[1]), int(settings.max_trace_depth),
                          (2 if start_from_first == 2 else (1 if start_from_first else 0)), 0 if others is None else 1, bg_len, 1 if settings.debug else 0,
-                         rh, rw, float(settings.scale_modifier), float(settings.specular_threshold))
+                         rh, rw, float(settings.scale_modifier), float(settings.specular_threshold), 1 if f16 else 0)
 
 
 NCOPY = 8                    # must equal NCOPY in csrc/trace_common.h
@@ -129,9 +129,11 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     ro = _f32c(ray_o).reshape(-1, 3); rd = _f32c(ray_d).reshape(-1, 3)
     R, P = ro.shape[0], means3D.shape[0]
     means3D = _f32c(means3D); opacities = _f32c(opacities); scales = _f32c(scales); rotations = _f32c(rotations)
-    shs = _f32c(shs); colors_precomp = _f32c(colors_precomp); others_precomp = _f32c(others_precomp)
+    from .raster import _featc
+    shs = _featc(shs); colors_precomp = _featc(colors_precomp); others_precomp = _f32c(others_precomp)       # features may stay in fp16 storage
+    f16 = (shs if shs is not None else colors_precomp).dtype == torch.float16
     bg = _f32c(settings.bg).reshape(-1).to(dev)
-    cfg = _cfg(settings, P, R, shs, others_precomp, start_from_first, lead)
+    cfg = _cfg(settings, P, R, shs, others_precomp, start_from_first, lead, f16)
     ND = cfg.max_trace_depth + 1
     f32 = dict(dtype=torch.float32, device=dev)
     srec = torch.empty(max(P, 1), 16, **f32)
@@ -198,7 +200,7 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
     geo_rec = torch.empty(max(P, 1), 16, **f32)
     dmeans = torch.empty(P, 3, **f32); dgrads3D = torch.empty(P, 3, **f32); dscales = torch.empty(P, 2, **f32)
     drots = torch.empty(P, 4, **f32); dopac = torch.empty(P, 1, **f32)
-    dshs = torch.empty_like(shs) if shs is not None else None
+    dshs = torch.empty(shs.shape, **f32) if shs is not None else None            # gradients are fp32 whatever the feature storage
     dcolors = torch.empty(P, 3, **f32) if shs is None else None
     dothers = torch.empty(P, 2, **f32) if others is not None else None
     dro = torch.empty(R, 3, **f32); drd = torch.empty(R, 3, **f32)

@@ -19,7 +19,7 @@
  *                     [0..2] Tu  [3..5] Tv  [6..8] Tw   (transMat rows: coefficients of u, v, 1)
  *                     [9..10] screen centre x,y  [11..13] view-space normal (camera facing)
  *                     [14] opacity  [15] view depth (sort key)
- *   colors    (P,C)   the caller's colors_precomp, or `rgb` (P,3) produced from SH by _project
+ *   colors    (P,C)   the caller's colors_precomp (fp32, or half when cfg->feature_f16), or `rgb` (P,3) fp32 produced from SH by _project
  *   grad_rec  (P,32)  per-surfel gradient record, 128 B aligned, accumulated by _backward:
  *                     [0..8] dL/dtransMat  [9..11] dL/dnormal  [12] dL/dopacity  [13..14] dL/dmean2D
  *                     [15..15+C) dL/dcolour
@@ -64,6 +64,9 @@ typedef struct envgs_raster_cfg {
     int32_t debug;          /* settings.debug: synchronise + check after every kernel */
     float scale_modifier;   /* settings.scale_modifier */
     float tanfovx, tanfovy; /* carried for API completeness; the projection uses projmatrix */
+    int32_t feature_f16;    /* 1: the per-surfel FEATURE array the caller passes (shs, or colors_precomp when shs == NULL) is stored as IEEE half
+                               (same shape); converted on load, all arithmetic, accumulation and every gradient output stay fp32.  The storage
+                               variant of BASELINE configs[4]; the reference has no counterpart. */
 } envgs_raster_cfg;
 
 /* Bytes of scratch the prefix sum over P counters and the pair sort over N tile instances need. */

@@ -58,6 +58,7 @@ typedef struct envgs_trace_cfg {
     int32_t ray_h, ray_w;      /* if the rays are an (H,W) image (ray_h*ray_w == num_rays) wavefronts take 8x8 pixel blocks; else 0 */
     float scale_modifier;
     float specular_threshold;
+    int32_t feature_f16;       /* 1: shs / colors_precomp are stored as IEEE half (same shapes); arithmetic and gradient outputs stay fp32 */
 } envgs_trace_cfg;
 
 /*

@@ -37,8 +37,8 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_struct_layouts_match_headers():
     from envgs_amd import _lib
-    assert ctypes.sizeof(_lib.RasterCfg) == 8 * 4 + 3 * 4
-    assert ctypes.sizeof(_lib.TraceCfg) == 11 * 4 + 2 * 4
+    assert ctypes.sizeof(_lib.RasterCfg) == 8 * 4 + 3 * 4 + 4
+    assert ctypes.sizeof(_lib.TraceCfg) == 11 * 4 + 2 * 4 + 4
     hdr = open(os.path.join(ROOT, "include", "envgs_raster.h")).read()
     fields = re.findall(r"^\s+(?:int32_t|float)\s+([\w, ]+);", hdr[hdr.index("typedef struct envgs_raster_cfg"):hdr.index("} envgs_raster_cfg")], re.M)
     flat = [f.strip() for grp in fields for f in grp.split(",")]
@@ -54,12 +54,12 @@ def test_bad_arguments_are_rejected_before_any_gpu_work(lib):
     n = ctypes.c_uint32(7)
     null = [None] * 15
     for bad in (dict(channels=4), dict(sh_degree=5), dict(width=0)):
-        kw = dict(P=10, sh_degree=0, sh_coeffs=0, channels=3, width=64, height=64, bg_len=3, debug=0, scale_modifier=1.0, tanfovx=1.0, tanfovy=1.0)
+        kw = dict(P=10, sh_degree=0, sh_coeffs=0, channels=3, width=64, height=64, bg_len=3, debug=0, scale_modifier=1.0, tanfovx=1.0, tanfovy=1.0, feature_f16=0)
         kw.update(bad)
         cfg = _lib.RasterCfg(*[kw[k] for k, _ in _lib.RasterCfg._fields_])
         rc = lib.envgs_raster_project(cfg, *null, None, 0, n, None)
         assert rc == -1
-    tcfg = _lib.TraceCfg(10, 10, 9, 0, 0, 1, 0, 3, 0, 0, 0, 1.0, 0.0)      # sh_degree 9
+    tcfg = _lib.TraceCfg(10, 10, 9, 0, 0, 1, 0, 3, 0, 0, 0, 1.0, 0.0, 0)      # sh_degree 9
     assert lib.envgs_trace_forward(tcfg, *([None] * 22), None, None) == -1
     assert lib.envgs_bvh_build(-1, None, None, None, None, 0, 0, None) == -1
     assert lib.envgs_prof_kernel_name(6) == b"composite_bwd" and lib.envgs_prof_kernel_name(999) == b""
