@@ -8,6 +8,8 @@
 
 namespace envgs {
 
+constexpr int MAX_SEG = 4;      // forward batch segments that may run concurrently (own stream and fetch counters each)
+
 static int persistent_grid(int R, int per_cu = 8)
 {
     int dev = 0, cus = 256;
@@ -129,36 +131,42 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         // kernel is a persistent grid whose wavefronts drain over the time of one whole batch, and the second segment's wavefronts
         // (and the first segment's next kernel) move into the CUs it leaves idle.
         const int nbatch_all = (cfg->num_rays + 63) / 64;
-        int nseg = 2;                                         // measured: 1 -> 18.3 ms / step, 2 -> 17.5, 4 -> 19.4 (each collection launch lasts at least one batch)
+        int nseg = 2;                                         // measured (round 1): 1 -> 18.3 ms / step, 2 -> 17.5, 4 -> 19.4 (each collection launch lasts at least one batch)
         if (debug_switch(ENVGS_DBG_SEGMENTS) > 0) nseg = debug_switch(ENVGS_DBG_SEGMENTS);
-        if (nseg > 2) nseg = 2;                               // (the stack-spill slab and the fetch counters are sized for two)
-        while (nseg > 1 && nbatch_all / nseg < 256) nseg >>= 1;
+        if (nseg > MAX_SEG) nseg = MAX_SEG;                   // (fetch counters: 8 words per segment from counters[32])
+        while (nseg > 1 && nbatch_all / nseg < 256) nseg--;
         if (nseg < 1) nseg = 1;
-        hipStream_t aux = nullptr;
-        hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+        hipStream_t aux[MAX_SEG] = {};
+        hipEvent_t ev_fork = nullptr, ev_join[MAX_SEG] = {};
         if (nseg > 1) {
-            // one auxiliary stream + fork / join events per device, created on first use (one process drives one GPU in this design,
+            // auxiliary streams + fork / join events per device, created on first use (one process drives one GPU in this design,
             // but nothing here assumes it)
-            static hipStream_t s_aux[16] = {};
-            static hipEvent_t s_fork[16] = {}, s_join[16] = {};
-            static std::mutex s_mu;                               // the per-device stream / events are created once, under a lock
+            static hipStream_t s_aux[16][MAX_SEG] = {};
+            static hipEvent_t s_fork[16] = {}, s_join[16][MAX_SEG] = {};
+            static std::mutex s_mu;                               // the per-device streams / events are created once, under a lock
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) nseg = 1;
             else {
                 std::lock_guard<std::mutex> lk(s_mu);
-                if (!s_aux[dev]) {
-                    if (hipStreamCreateWithFlags(&s_aux[dev], hipStreamNonBlocking) != hipSuccess ||
-                        hipEventCreateWithFlags(&s_fork[dev], hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&s_join[dev], hipEventDisableTiming) != hipSuccess) { s_aux[dev] = nullptr; nseg = 1; }
+                if (!s_fork[dev]) {
+                    bool ok = hipEventCreateWithFlags(&s_fork[dev], hipEventDisableTiming) == hipSuccess;
+                    for (int i = 1; i < MAX_SEG && ok; i++)
+                        ok = hipStreamCreateWithFlags(&s_aux[dev][i], hipStreamNonBlocking) == hipSuccess &&
+                             hipEventCreateWithFlags(&s_join[dev][i], hipEventDisableTiming) == hipSuccess;
+                    if (!ok) { s_fork[dev] = nullptr; nseg = 1; }
                 }
             }
             if (nseg > 1) {
-                aux = s_aux[dev]; ev_fork = s_fork[dev]; ev_join = s_join[dev];
-                if (hipEventRecord(ev_fork, stream) != hipSuccess || hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+                ev_fork = s_fork[dev];
+                if (hipEventRecord(ev_fork, stream) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+                for (int i = 1; i < nseg; i++) {
+                    aux[i] = s_aux[dev][i]; ev_join[i] = s_join[dev][i];
+                    if (hipStreamWaitEvent(aux[i], ev_fork, 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+                }
             }
         }
-        for (int sg = 0; sg < nseg; sg++) {                   // even segments on the caller's stream, odd ones on the auxiliary stream
-            hipStream_t st = (sg & 1) ? aux : stream;
+        for (int sg = 0; sg < nseg; sg++) {                   // segment 0 on the caller's stream, the others on auxiliary streams
+            hipStream_t st = sg ? aux[sg] : stream;
             TraceArgs S = A;
             S.seg = sg;
             S.spill_stride = persistent_grid(cfg->num_rays, 24);     // >= this segment's grid; matches envgs_trace_stack_spill_ints
@@ -190,9 +198,8 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             { ProfScope p8(K_TRACE_REGISTER, st); hipLaunchKernelGGL(register_hits, dim3(stride_grid(rays_seg, 64)), dim3(64 * RH_W), 0, st, S); }
             ENVGS_CHECK_LAUNCH(dcfg, st);
         }
-        if (nseg > 1) {
-            if (hipEventRecord(ev_join, aux) != hipSuccess || hipStreamWaitEvent(stream, ev_join, 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
-        }
+        for (int i = 1; i < nseg; i++)
+            if (hipEventRecord(ev_join[i], aux[i]) != hipSuccess || hipStreamWaitEvent(stream, ev_join[i], 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
         hipLaunchKernelGGL(unpack_surfel_acc, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, A.wfrac, A.surf_acc, L->surf_cnt, wet);
         ENVGS_CHECK_LAUNCH(dcfg, stream);
         {   // records of the backward are addressed through the inclusive scan of the per-surfel hit counts

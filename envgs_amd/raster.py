@@ -103,7 +103,7 @@ def rasterize_forward(C, means3D, shs, colors_precomp, opacities, scales, rotati
     H, W = int(settings.image_height), int(settings.image_width)
     means3D = _f32c(means3D); opacities = _f32c(opacities)
     shs = _featc(shs); colors_precomp = _featc(colors_precomp)
-    f16 = (shs if shs is not None else colors_precomp).dtype == torch.float16
+    f16 = any(t is not None and t.dtype == torch.float16 for t in (shs, colors_precomp))
     scales = _f32c(scales); rotations = _f32c(rotations); cov3D_precomp = _f32c(cov3D_precomp)
     if shs is not None and C != 3:
         raise RuntimeError("in-kernel SH evaluation produces 3 channels; the %d-channel rasterizer needs colors_precomp" % C)

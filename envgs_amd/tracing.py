@@ -131,7 +131,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     means3D = _f32c(means3D); opacities = _f32c(opacities); scales = _f32c(scales); rotations = _f32c(rotations)
     from .raster import _featc
     shs = _featc(shs); colors_precomp = _featc(colors_precomp); others_precomp = _f32c(others_precomp)       # features may stay in fp16 storage
-    f16 = (shs if shs is not None else colors_precomp).dtype == torch.float16
+    f16 = any(t is not None and t.dtype == torch.float16 for t in (shs, colors_precomp))
     bg = _f32c(settings.bg).reshape(-1).to(dev)
     cfg = _cfg(settings, P, R, shs, others_precomp, start_from_first, lead, f16)
     ND = cfg.max_trace_depth + 1
