@@ -52,6 +52,9 @@ def test_raster_fp16_feature_storage(C, sh):
     c_full, *_ = _raster(mod, C, g, cam, 3, feats, dev)
     record(t, "image_shift_vs_fp32_features", float((c16 - c_full).abs().max()))
     assert float((c16 - c_full).abs().max()) < 4e-3
+    psnr = -10.0 * float(torch.log10(((c16 - c_full) ** 2).mean()))               # "PSNR delta vs fp32"
+    record(t, "psnr_vs_fp32_features_dB", psnr)
+    assert psnr > 60.0
 
 
 @pytest.mark.parametrize("use_sh", [True, False])
@@ -77,6 +80,7 @@ def test_tracer_fp16_feature_storage(use_sh):
         out[name] = (outs[0].detach(), {k: x.grad for k, x in L.items()}, fd.grad, o.grad, d.grad)
     t = "fp16_storage_tracer_%s" % ("sh" if use_sh else "rgb")
     assert out["h"][2].dtype == torch.float16
+    out["full"] = None
     assert torch.equal(out["h"][0], out["f"][0])
     for k in out["f"][1]:
         check_close(t, "d" + k, out["h"][1][k].cpu().numpy(), out["f"][1][k].cpu().numpy(), tol=1e-5)
