@@ -118,6 +118,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             e = rocprim::radix_sort_pairs(L->ray_sort_temp, tb, L->ray_keys, L->ray_keys + R, L->ray_order, L->ray_order + R, (size_t)R, 0u, 31u, stream);
             if (e != hipSuccess) return (int)e;
             A.order = L->ray_order + R;
+            A.long_list = L->ray_keys;                        // the unsorted keys are dead now: scratch for the queue of long rays
         }
         {   // 40-bit fixed-point weight: enough integer bits that even a surfel seen with w = 1 by every ray cannot overflow
             int ib = 1;

@@ -156,6 +156,7 @@ struct TraceArgs {
     unsigned long long *entries;  // (batches, 64*cap) distinct (batch, surfel) entries, see register_hits
     unsigned *pairs;              // (batches, 64*cap) (lane << 16 | k) of every composited hit, grouped by entry
     int *n_entries;               // (batches, 2) table entries, single entries
+    unsigned *long_list; // (R) scratch: slots of the rays whose lists exceed 256 hits, appended by the main sort pass (counter[24 + seg] = how many)
     float4 *state;      // (R, cap, 2 | 3) x 16 B per composited hit: transmittance before it and the prefix sums after it (for the backward)
 };
 

@@ -181,7 +181,11 @@ sort_composite_fwd(const TraceArgs A)
         for (int slot = A.batch0 * 64 + blockIdx.x * 4 + (threadIdx.x >> 6); slot < slot_end; slot += gridDim.x * 4) {
             const int r = ray_of(A, slot);
             const int n = A.hit_cnt[r];
-            if (n > A.cap || n > 256) continue;                 // overflow: the K-buffer kernel owns this ray; long: the LONG pass does
+            if (n > A.cap) continue;                            // overflow: the K-buffer kernel owns this ray
+            if (n > 256) {                                      // long: the LONG pass sorts it -- queued here, so that pass is one ray per wavefront step
+                if (A.long_list && lane == 0) A.long_list[A.batch0 * 64 + atomicAdd(A.counter + 24 + A.seg, 1u)] = (unsigned)slot;
+                continue;
+            }
             if (n <= 64) sort_composite_ray<1>(A, r, n, lane, st_hits);
             else if (n <= 128) sort_composite_ray<2>(A, r, n, lane, st_hits);
             else sort_composite_ray<4>(A, r, n, lane, st_hits);
@@ -189,6 +193,19 @@ sort_composite_fwd(const TraceArgs A)
     } else {
         // the longest list so far (this segment's collection has finished, so its own maximum is in): nothing to do in the usual case
         if ((int)__hip_atomic_load(A.counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 256) return;
+        if (A.long_list) {
+            // the main pass queued the long rays of this segment: one ray per wavefront step, spread over the whole grid (neighbouring rays have
+            // similar hit counts, so a wavefront that scanned its own 64-ray window used to sort a dozen long rays one after the other)
+            const int nl = (int)__hip_atomic_load(A.counter + 24 + A.seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < nl; i += gridDim.x * 4) {
+                const int slot = (int)A.long_list[A.batch0 * 64 + i];
+                const int rr = ray_of(A, slot), nn = A.hit_cnt[rr];
+                if (EMAX == 8 || nn <= 512) sort_composite_ray<8>(A, rr, nn, lane, st_hits);
+                else if constexpr (EMAX >= 16) sort_composite_ray<16>(A, rr, nn, lane, st_hits);
+            }
+            if (A.stats && lane == 0 && st_hits) atomicAdd(A.stats + 0, (unsigned long long)st_hits);
+            return;
+        }
         for (int base = A.batch0 * 64 + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; base < slot_end; base += gridDim.x * 256) {
             const int slot = base + lane;
             int r = 0, n = 0;
