@@ -115,8 +115,11 @@ ENVGS_API int envgs_bvh_build(int32_t P, const float *vertices, const float *opa
 /*
  * SurfelTracer.forward (optix_utils.py:188-201): trace R rays through the surfel set, composite front to back.
  * srec (P,16) is scratch written here (and read again by the backward).  counters: 96 uint32 of scratch; after the
- * forward, words [2..7] hold three uint64 totals: composited hits, BVH node visits, traversal rounds (diagnostics that
- * the roofline accounting of bench.py needs: BASELINE.md section 4 "hits / node_visits are data dependent").
+ * forward, words [2..13] hold six uint64 totals: composited hits, (unused), K-buffer traversal rounds, hits found, wide nodes
+ * visited by the packet traversal, leaf tests of the packet traversal (diagnostics that the roofline accounting of bench.py
+ * needs: BASELINE.md section 4 "hits / node_visits are data dependent").  Word [20] counts the 64-ray batches whose packet
+ * traversal ran out of its shared stack (their rays were handed to the K-buffer kernels, nothing is dropped); words [24..27]
+ * are the per-segment queues of rays with more than 256 hits.
  * final_T (R): stage-0 transmittance, kept for the backward.
  * List path (lists != NULL, lists->cap > 0, max_trace_depth == 0): each ray's hits are collected in ONE unordered traversal,
  * sorted by (t, id) in LDS and walked front to back; the backward walks the same lists and never touches the BVH.  Rays with

@@ -17,5 +17,6 @@ python bench.py --caller twin --no-cpu-baseline > $O/bench_envgs_twin_caller_fin
 python bench.py --workload raster > $O/bench_raster_final.json 2> $O/bench_raster_final.err
 # SURVEY.md 8(d)'s other sizes: the env set at its 700 000-surfel cap, and a configs[4]-like run (1200x1600, -ch07 raster, two specular bounces)
 python bench.py --env-gaussians 700000 --no-cpu-baseline --steps 15 --warmup 4 > $O/bench_env700k_final.json 2> $O/bench_env700k_final.err
-python bench.py --height 1200 --width 1600 --trace-depth 2 --channels 7 --no-cpu-baseline --steps 8 --warmup 3 > $O/bench_config5_final.json 2> $O/bench_config5_final.err
+python bench.py --feature-dtype f16 --no-cpu-baseline > $O/bench_envgs_f16_final.json 2> $O/bench_envgs_f16_final.err
+python bench.py --height 1200 --width 1600 --trace-depth 2 --channels 7 --feature-dtype f16 --no-cpu-baseline --steps 8 --warmup 3 > $O/bench_config5_final.json 2> $O/bench_config5_final.err
 ls $O/p_envgs $O/pmc_fetch $O/pmc_insts | head
