@@ -176,7 +176,10 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             const int rays_seg = (S.batch1 - S.batch0) * 64;
             {
                 ProfScope p1(K_TRACE_COLLECT, st);
-                if (S.order && !(S.exp & 512) && !(S.exp & 16))
+                if (S.order && !(S.exp & 512) && !(S.exp & 16) && !(S.exp & 2048))
+                    hipLaunchKernelGGL(collect_hits_coop, dim3(persistent_grid(rays_seg, 8)), dim3(256), 0, st, S, S.nodes,
+                                       S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4, S.srec);
+                else if (S.order && !(S.exp & 512) && !(S.exp & 16))
                     hipLaunchKernelGGL(collect_hits_packet4, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S, S.nodes,
                                        S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4, S.srec);
                 else if (S.order && !(S.exp & 512))

@@ -587,6 +587,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(64)
 collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ srec);
 __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(64)
 collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec);
+__global__ void __launch_bounds__(256, 8)
+collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec);
 template <int EMAX, bool LONG> __global__ void __launch_bounds__(256) sort_composite_fwd(const TraceArgs A);
 extern template __global__ void __launch_bounds__(256) sort_composite_fwd<4, false>(const TraceArgs A);
 extern template __global__ void __launch_bounds__(256) sort_composite_fwd<8, true>(const TraceArgs A);

@@ -428,6 +428,6 @@ def last_trace_counts():
     if c is None:
         return None
     w = c.cpu()
-    v = w[2:14].view(torch.int64)
-    return dict(hits=int(v[0]), node_visits=int(v[1]), rounds=int(v[2]), found=int(v[3]), packet_nodes=int(v[4]), packet_leaves=int(v[5]),
+    v = w[2:20].view(torch.int64)
+    return dict(coop_cycles=dict(expand=int(v[6]), walk=int(v[7]), wait=int(v[8])), hits=int(v[0]), node_visits=int(v[1]), rounds=int(v[2]), found=int(v[3]), packet_nodes=int(v[4]), packet_leaves=int(v[5]),
                 max_list=int(w[1]), cap=HIT_CAP["cap"], rays=LAST_STATS["R"], stack_overflows=int(w[20]))
