@@ -53,7 +53,7 @@ int envgs_raster_bin_and_render(const envgs_raster_cfg *cfg, uint32_t N, const f
                                 const uint32_t *offsets, const float *colors, const float *bg, uint64_t *keys_unsorted,
                                 uint32_t *vals_unsorted, uint64_t *keys_sorted, uint32_t *point_list, void *sort_temp,
                                 size_t sort_temp_bytes_, uint32_t *ranges, float *out_color, float *allmap,
-                                float *final_T, int32_t *n_contrib, float *weight, void *stream_)
+                                float *final_T, int32_t *n_contrib, float *weight, uint8_t *contrib_mask, void *stream_)
 {
     int rc = check_cfg(cfg);
     if (rc) return rc;
@@ -67,7 +67,7 @@ int envgs_raster_bin_and_render(const envgs_raster_cfg *cfg, uint32_t N, const f
     if (rc) return rc;
     // `colors` is the caller's (possibly half) colors_precomp only when no SH were given; the SH -> RGB result of _project is fp32
     return launch_render_fwd(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream, nullptr, 0,
-                             (cfg->feature_f16 && cfg->sh_coeffs == 0) ? 1 : 0);
+                             (cfg->feature_f16 && cfg->sh_coeffs == 0) ? 1 : 0, contrib_mask);
 }
 
 int envgs_raster_render_audit(const envgs_raster_cfg *cfg, const float *geom, const float *colors, const float *bg,
@@ -87,7 +87,7 @@ int envgs_raster_render_audit(const envgs_raster_cfg *cfg, const float *geom, co
 
 int envgs_raster_backward(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const float *colors, const float *bg,
                           const uint32_t *point_list, const uint32_t *ranges, const float *final_T,
-                          const int32_t *n_contrib, const float *dL_dcolor, const float *dL_dallmap, const float *means3D,
+                          const int32_t *n_contrib, const uint8_t *contrib_mask, const float *dL_dcolor, const float *dL_dallmap, const float *means3D,
                           const float *scales, const float *rotations, const float *shs, const uint8_t *clamped,
                           const float *transmat_precomp, const int32_t *radii, const float *viewmatrix,
                           const float *projmatrix, const float *campos, float *grad_rec, float *dmeans3D, float *dmeans2D,
@@ -105,7 +105,7 @@ int envgs_raster_backward(const envgs_raster_cfg *cfg, uint32_t N, const float *
     if (transmat_precomp ? !dtransmat_precomp : (!scales || !rotations || !means3D || !dmeans3D || !dscales || !drots)) return ENVGS_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     rc = launch_render_bwd(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream,
-                           (cfg->feature_f16 && !shs) ? 1 : 0);
+                           (cfg->feature_f16 && !shs) ? 1 : 0, contrib_mask);
     if (rc) return rc;
     return launch_project_bwd(cfg, geom, means3D, scales, rotations, shs, clamped, transmat_precomp, radii, viewmatrix,
                               projmatrix, campos, grad_rec, dmeans3D, dmeans2D, dscales, drots, dshs, dcolors, dopacities,

@@ -117,10 +117,13 @@ __global__ void __launch_bounds__(256)
 composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list,
               const float *__restrict__ geom, const Feat colors, const float *__restrict__ bg,
               float *__restrict__ out_color, float *__restrict__ allmap, float *__restrict__ final_T,
-              int32_t *__restrict__ n_contrib, float *__restrict__ weight, uint8_t *__restrict__ audit_contrib, int audit_lmax)
+              int32_t *__restrict__ n_contrib, float *__restrict__ weight, uint8_t *__restrict__ audit_contrib, int audit_lmax,
+              uint8_t *__restrict__ contrib_mask)
 {
     __shared__ TileLds<C> lds;
     __shared__ float wacc[256];            // per-splat weight summed over the 4 wavefronts before it leaves the CU
+    __shared__ unsigned char cmk[256][4];  // per splat and quadrant: some pixel of the quadrant blended it (-> contrib_mask, what the backward walks);
+                                           // each wavefront owns its byte: plain stores
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int tile = xcd_tile(blockIdx.x, gx * gy);
     if (tile >= gx * gy) return;
@@ -137,7 +140,7 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
     int32_t last = 0, medc = -1;
 #pragma unroll
     for (int c = 0; c < C; c++) Cacc[c] = 0.f;
-    wacc[tid] = 0.f;
+    wacc[tid] = 0.f; reinterpret_cast<unsigned *>(&cmk[0][0])[tid] = 0u;
 
     for (uint32_t base = r0; base < r1; base += 256) {
         if (__syncthreads_and(done)) break;
@@ -193,7 +196,7 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
             }
             if (__builtin_amdgcn_ballot_w64(contrib) != 0) {
                 const float ws = wave_sum(w);
-                if (lane == 0) atomic_add_f32(&wacc[j], ws);          // LDS atomic: ds_add_f32
+                if (lane == 0) { atomic_add_f32(&wacc[j], ws); cmk[j][wave] = 1; }         // LDS atomic: ds_add_f32
             }
           }
         }
@@ -201,6 +204,12 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
         if (tid < count) {
             const float ws = wacc[tid];
             if (ws != 0.0f) { atomic_add_f32(weight + lds.id[tid], ws); wacc[tid] = 0.f; }
+            if (contrib_mask) {
+                unsigned *cw = reinterpret_cast<unsigned *>(&cmk[0][0]) + tid;
+                const unsigned v = *cw;                            // 0x01 in byte q = quadrant q
+                contrib_mask[base + tid] = (uint8_t)((v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u));
+                if (v) *cw = 0u;
+            }
         }
     }
 
@@ -234,7 +243,8 @@ __device__ __forceinline__ void composite_bwd_tile(TileLds<C, BWD_BATCH> &lds, f
                                                    const Feat colors, const float *__restrict__ bg,
                                                    const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
                                                    const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap,
-                                                   float *__restrict__ grad_rec, const uint32_t r0, const int tx, const int ty, const int max_last)
+                                                   float *__restrict__ grad_rec, const uint32_t r0, const int tx, const int ty, const int max_last,
+                                                   const uint8_t *__restrict__ contrib_mask)
 {
     constexpr int V = 15 + C;          // gradient words per surfel
     constexpr int N4 = (V + 3) / 4;    // registers left after the transpose-reduce (4 words each)
@@ -284,7 +294,9 @@ __device__ __forceinline__ void composite_bwd_tile(TileLds<C, BWD_BATCH> &lds, f
             const float4 a0 = gp[0], a1 = gp[1], a2 = gp[2], a3 = gp[3];
             lds.id[tid] = g;
             lds.rec[0][tid] = a0; lds.rec[1][tid] = a1; lds.rec[2][tid] = a2; lds.rec[3][tid] = a3;
-            qm = quadrant_mask(a0, a1, a2, a3, tx * TILE, ty * TILE);
+            // which quadrants blended this entry: recorded exactly by the forward (so every pass of the loop below has an active lane), or,
+            // without that record, the conservative geometric test the forward itself culls with
+            qm = contrib_mask ? (uint32_t)contrib_mask[r0 + (uint32_t)(top - 1 - tid)] : quadrant_mask(a0, a1, a2, a3, tx * TILE, ty * TILE);
 #pragma unroll
             for (int c = 0; c < C; c++) lds.col[c][tid] = colors[(size_t)g * C + c];
         }
@@ -386,7 +398,8 @@ __global__ void __launch_bounds__(256)
 composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list,
               const float *__restrict__ geom, const Feat colors, const float *__restrict__ bg,
               const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
-              const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap, float *__restrict__ grad_rec)
+              const float *__restrict__ dL_dcolor, const float *__restrict__ dL_dallmap, float *__restrict__ grad_rec,
+              const uint8_t *__restrict__ contrib_mask)
 {
     constexpr int V = 15 + C;
     __shared__ TileLds<C, BWD_BATCH> lds;
@@ -422,16 +435,16 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
     const int max_last = s_max_last;
     const uint32_t r0 = ranges[2 * tile];
     if (s_dist)
-        composite_bwd_tile<C, true>(lds, gacc, W, H, bg_len, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, r0, tx, ty, max_last);
+        composite_bwd_tile<C, true>(lds, gacc, W, H, bg_len, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, r0, tx, ty, max_last, contrib_mask);
     else
-        composite_bwd_tile<C, false>(lds, gacc, W, H, bg_len, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, r0, tx, ty, max_last);
+        composite_bwd_tile<C, false>(lds, gacc, W, H, bg_len, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, r0, tx, ty, max_last, contrib_mask);
 }
 
 // ------------------------------------------------------------------------------------ launchers ---
 template <int C>
 static int run_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                    const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
-                   int32_t *n_contrib, float *weight, uint8_t *audit_contrib, int audit_lmax, hipStream_t stream, int colors_f16)
+                   int32_t *n_contrib, float *weight, uint8_t *audit_contrib, int audit_lmax, hipStream_t stream, int colors_f16, uint8_t *contrib_mask)
 {
     const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
     ProfScope prof_(K_COMPOSITE_FWD, stream);
@@ -439,26 +452,26 @@ static int run_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const ui
     const Feat colors_{colors, colors_f16 != 0};
     if (audit_contrib)
         hipLaunchKernelGGL((composite_fwd<C, true>), grid, block, 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
-                           point_list, geom, colors_, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax);
+                           point_list, geom, colors_, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, contrib_mask);
     else
         hipLaunchKernelGGL((composite_fwd<C, false>), grid, block, 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
-                           point_list, geom, colors_, bg, out_color, allmap, final_T, n_contrib, weight, (uint8_t *)nullptr, 0);
+                           point_list, geom, colors_, bg, out_color, allmap, final_T, n_contrib, weight, (uint8_t *)nullptr, 0, contrib_mask);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;
 }
 
 int launch_render_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                       const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
-                      int32_t *n_contrib, float *weight, hipStream_t stream, uint8_t *audit_contrib, int audit_lmax, int colors_f16)
+                      int32_t *n_contrib, float *weight, hipStream_t stream, uint8_t *audit_contrib, int audit_lmax, int colors_f16, uint8_t *contrib_mask)
 {
     if (cfg->P > 0) {
         hipError_t e = hipMemsetAsync(weight, 0, sizeof(float) * (size_t)cfg->P, stream);
         if (e != hipSuccess) return (int)e;
     }
     switch (cfg->channels) {
-    case 3: return run_fwd<3>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16);
-    case 5: return run_fwd<5>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16);
-    case 7: return run_fwd<7>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16);
+    case 3: return run_fwd<3>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16, contrib_mask);
+    case 5: return run_fwd<5>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16, contrib_mask);
+    case 7: return run_fwd<7>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16, contrib_mask);
     default: return ENVGS_ERR_BAD_ARG;
     }
 }
@@ -466,27 +479,27 @@ int launch_render_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const
 template <int C>
 static int run_bwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                    const float *colors, const float *bg, const float *final_T, const int32_t *n_contrib,
-                   const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream, int colors_f16)
+                   const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream, int colors_f16, const uint8_t *contrib_mask)
 {
     const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
     ProfScope prof_(K_COMPOSITE_BWD, stream);
     hipLaunchKernelGGL(composite_bwd<C>, dim3(8 * ((gx * gy + 7) / 8)), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
-                       point_list, geom, Feat{colors, colors_f16 != 0}, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec);
+                       point_list, geom, Feat{colors, colors_f16 != 0}, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, contrib_mask);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;
 }
 
 int launch_render_bwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                       const float *colors, const float *bg, const float *final_T, const int32_t *n_contrib,
-                      const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream, int colors_f16)
+                      const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream, int colors_f16, const uint8_t *contrib_mask)
 {
     if (cfg->P <= 0) return 0;
     hipError_t e = hipMemsetAsync(grad_rec, 0, sizeof(float) * GREC * (size_t)cfg->P, stream);
     if (e != hipSuccess) return (int)e;
     switch (cfg->channels) {
-    case 3: return run_bwd<3>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream, colors_f16);
-    case 5: return run_bwd<5>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream, colors_f16);
-    case 7: return run_bwd<7>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream, colors_f16);
+    case 3: return run_bwd<3>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream, colors_f16, contrib_mask);
+    case 5: return run_bwd<5>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream, colors_f16, contrib_mask);
+    case 7: return run_bwd<7>(cfg, ranges, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, stream, colors_f16, contrib_mask);
     default: return ENVGS_ERR_BAD_ARG;
     }
 }

@@ -460,13 +460,14 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
 // near the origin.  The bound only ever tightens and a stale (larger) one only collects more, so the collected set is a superset of
 // what the compositing needs whatever the interleaving; the lists are sorted afterwards.
 constexpr int COOP_W = 4;
+constexpr int COOP_NBIN = 32;             // distance bins of the termination bound (LDS: the update is one ds_add_f32 whatever their number)
 constexpr int COOP_STK = 96;
 constexpr int COOP_FRONT = 64;            // stop expanding once a level has this many entered subtrees (the next level holds at most 4x that).  Measured
                                           // (bench scene): 16 -> 93.8 M hits found, collect 2.70 ms; 32 -> 83.3 M, 1.97 ms; 64 -> 79.1 M, 1.87 ms (one wavefront
                                           // per batch, depth first: 85.2 M, 3.35 ms): the ranked frontier is a better visiting order than the local one
 constexpr int COOP_ITEMS = 256;           // >= 4 * (largest front - 1)
 struct CoopLds {
-    float od[NBIN][64];
+    float od[COOP_NBIN][64];
     float odtot[64];
     int cnt[64];
     unsigned long long items[2][COOP_ITEMS];      // entry-distance bits << 32 | wide-node index
@@ -501,7 +502,7 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             if (lane == 0) { L.batch = b; L.nitems[0] = 1; L.nitems[1] = 0; L.items[0][0] = 0ull; L.next = 0; L.ovf = 0; }
         }
 #pragma unroll
-        for (int q = 0; q < NBIN * 64 / (64 * COOP_W); q++) (&L.od[0][0])[q * 64 * COOP_W + tid] = 0.f;
+        for (int q = 0; q < COOP_NBIN * 64 / (64 * COOP_W); q++) (&L.od[0][0])[q * 64 * COOP_W + tid] = 0.f;
         if (tid < 64) { L.odtot[tid] = 0.f; L.cnt[tid] = 0; }
         __syncthreads();
         const int fb = L.batch;
@@ -522,7 +523,7 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             tA = fmaxf(tn, tmin);
             float span = tf - tA;
             if (!(span > 0.0f) || !(span < 1.0e30f)) span = 1.0f;
-            bin_w = span * (1.00001f / (float)(NBIN - 1));
+            bin_w = span * (1.00001f / (float)(COOP_NBIN - 1));
             inv_bin_w = 1.0f / bin_w;
         }
         const float tk_open = valid ? 3.0e38f : -3.0e38f;     // lanes without a ray never pass a slab test
@@ -561,7 +562,7 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
                             if (slot < A.cap) list[slot] = make_uint2(__float_as_uint(h.t), (unsigned)sid);
                             const float x = (h.t - tA) * inv_bin_w;
                             int b = x <= 0.0f ? 0 : (int)ceilf(x + 1e-3f);
-                            b = b > NBIN - 1 ? NBIN - 1 : b;
+                            b = b > COOP_NBIN - 1 ? COOP_NBIN - 1 : b;
                             const float dep = -__logf(1.0f - h.alpha);
                             atomicAdd(&L.od[b][lane], dep);
                             atomicAdd(&L.odtot[lane], dep);
@@ -578,10 +579,10 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             if (pend >= 3) {               // refresh the bound every third leaf test (a stale bound only collects a little more)
                 pend = 0;
                 if (__builtin_amdgcn_ballot_w64(ENVGS_LDS_READ(L.odtot[lane]) >= KILL_OD) != 0ull) {
-                    float cum = 0.f; int kb = NBIN - 1;
+                    float cum = 0.f; int kb = COOP_NBIN - 1;
 #pragma unroll
-                    for (int q = 0; q < NBIN - 1; q++) { cum += ENVGS_LDS_READ(L.od[q][lane]); kb = (cum >= KILL_OD && kb == NBIN - 1) ? q : kb; }
-                    tkill = kb < NBIN - 1 ? tA + (float)kb * bin_w : tk_open;
+                    for (int q = 0; q < COOP_NBIN - 1; q++) { cum += ENVGS_LDS_READ(L.od[q][lane]); kb = (cum >= KILL_OD && kb == COOP_NBIN - 1) ? q : kb; }
+                    tkill = kb < COOP_NBIN - 1 ? tA + (float)kb * bin_w : tk_open;
                 }
             }
             return ninner;

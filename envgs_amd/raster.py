@@ -85,6 +85,9 @@ def sh_degree_of(deg):
     return v
 
 
+CONTRIB_MASK = {"on": True}   # forward records which pixel quadrants blended each tile instance; the backward walks exactly those (tests switch it off to cover the geometric fallback)
+
+
 def _cfg(settings, P, C, sh_coeffs, bg_len, f16=False):
     deg = sh_degree_of(settings.sh_degree)
     return _lib.RasterCfg(P, deg, sh_coeffs, C, int(settings.image_width), int(settings.image_height), bg_len,
@@ -148,12 +151,14 @@ def rasterize_forward(C, means3D, shs, colors_precomp, opacities, scales, rotati
     final_T = torch.empty(3, H, W, **f32)
     n_contrib = torch.empty(2, H, W, **i32)
     weight = torch.empty(P, 1, **f32)
+    # per tile instance: the pixel quadrants that blended it (the backward walks exactly those); only needed when a backward follows
+    cmask = torch.empty(max(N, 1), dtype=torch.uint8, device=dev) if CONTRIB_MASK["on"] else None
     _lib.check(lib.envgs_raster_bin_and_render(cfg, N, p(geom), p(radii), p(offsets), p(colors), p(bg), p(keys_u), p(vals_u),
                                                p(keys_s), p(point_list), p(sort_temp), sort_bytes, p(ranges), p(out_color),
-                                               p(allmap), p(final_T), p(n_contrib), p(weight), stream),
+                                               p(allmap), p(final_T), p(n_contrib), p(weight), p(cmask), stream),
                "envgs_raster_bin_and_render")
     saved = dict(cfg=cfg, N=N, geom=geom, colors=colors, bg=bg, point_list=point_list, ranges=ranges, final_T=final_T,
-                 n_contrib=n_contrib, means3D=means3D, scales=scales, rotations=rotations, shs=shs, clamped=clamped,
+                 n_contrib=n_contrib, contrib_mask=cmask, means3D=means3D, scales=scales, rotations=rotations, shs=shs, clamped=clamped,
                  cov3D_precomp=cov3D_precomp, radii=radii, view=view, proj=proj, campos=campos)
     if keep_binning:
         saved.update(tiles_touched=tiles, offsets=offsets, keys_unsorted=keys_u, vals_unsorted=vals_u, keys_sorted=keys_s)
@@ -199,7 +204,7 @@ def rasterize_backward(saved, dL_dcolor, dL_dallmap):
     p = _lib.ptr
     _lib.check(lib.envgs_raster_backward(cfg, saved["N"], p(saved["geom"]), p(saved["colors"]), p(saved["bg"]),
                                          p(saved["point_list"]), p(saved["ranges"]), p(saved["final_T"]), p(saved["n_contrib"]),
-                                         p(dL_dcolor), p(dL_dallmap), p(saved["means3D"]), p(saved["scales"]), p(saved["rotations"]),
+                                         p(saved.get("contrib_mask")), p(dL_dcolor), p(dL_dallmap), p(saved["means3D"]), p(saved["scales"]), p(saved["rotations"]),
                                          p(shs), p(saved["clamped"]), p(cov), p(saved["radii"]), p(saved["view"]), p(saved["proj"]),
                                          p(saved["campos"]), p(grad_rec), p(dmeans3D), p(dmeans2D), p(dscales), p(drots), p(dshs),
                                          p(dcolors), p(dopac), p(dcov), _stream(dev)), "envgs_raster_backward")

@@ -96,6 +96,9 @@ ENVGS_API int envgs_raster_project(const envgs_raster_cfg *cfg,
  * stable radix sort, per-tile ranges, front-to-back compositing of `channels` colours + the 7 allmap
  * channels + the per-surfel accumulated weight (the "-wet" output, gaussian2d_utils.py:1090,1114).
  * keys_sorted / point_list / ranges are outputs the backward pass (and the parity tests) read.
+ * contrib_mask (N bytes, optional): for every tile instance (= entry of point_list) the set of 8x8 pixel quadrants of its tile in which
+ * some pixel blended it (bit q = quadrant q; row-major 2x2).  Passed to envgs_raster_backward it lets the backward visit exactly the
+ * (quadrant, entry) pairs the forward blended instead of re-deriving them geometrically (most candidates fail the alpha test everywhere).
  */
 ENVGS_API int envgs_raster_bin_and_render(const envgs_raster_cfg *cfg, uint32_t N,
                                 const float *geom, const int32_t *radii, const uint32_t *offsets,
@@ -104,7 +107,7 @@ ENVGS_API int envgs_raster_bin_and_render(const envgs_raster_cfg *cfg, uint32_t 
                                 uint64_t *keys_sorted, uint32_t *point_list,
                                 void *sort_temp, size_t sort_temp_bytes, uint32_t *ranges,
                                 float *out_color, float *allmap, float *final_T, int32_t *n_contrib,
-                                float *weight, void *stream);
+                                float *weight, uint8_t *contrib_mask, void *stream);
 
 /*
  * Parity audit of stage R6 (tests only; no reference counterpart): the SAME compositing kernel, instantiated with one extra store --
@@ -127,7 +130,7 @@ ENVGS_API int envgs_raster_render_audit(const envgs_raster_cfg *cfg, const float
 ENVGS_API int envgs_raster_backward(const envgs_raster_cfg *cfg, uint32_t N,
                           const float *geom, const float *colors, const float *bg,
                           const uint32_t *point_list, const uint32_t *ranges,
-                          const float *final_T, const int32_t *n_contrib,
+                          const float *final_T, const int32_t *n_contrib, const uint8_t *contrib_mask /* may be NULL */,
                           const float *dL_dcolor, const float *dL_dallmap,
                           const float *means3D, const float *scales, const float *rotations,
                           const float *shs, const uint8_t *clamped, const float *transmat_precomp,

@@ -235,6 +235,54 @@ def test_edge_cases():
     assert torch.isfinite(color2).all()
 
 
+def test_contribution_masks_are_exact_and_optional():
+    """The forward's per-instance quadrant masks (envgs_raster.h: contrib_mask) are exactly the contributor sets of the audit kernel,
+    and the backward gives the same gradients whether it walks them or falls back to the geometric quadrant test (mask = NULL)."""
+    from envgs_amd import raster
+    import diff_surfel_rasterization_wet_ch05 as mod
+    dev = torch.device("cuda:0")
+    H, W, C = 90, 104, 5
+    g, cam = small_scene(P=3000, H=H, W=W, seed=21, C=C, sh=False)
+    bg = torch.rand(C)
+    st = _settings(mod, cam, bg, 0, dev)
+    gd = {k: v.to(dev) for k, v in g.items()}
+    args = (C, gd["means3D"], None, gd["colors_precomp"], gd["opacities"], gd["scales"], gd["rotations"], None, st)
+    outs, saved = raster.rasterize_forward(*args, keep_binning=True)
+    N = saved["N"]
+    r = saved["ranges"].cpu().numpy().view(np.uint32).astype(np.int64)
+    lmax = int((r[:, 1] - r[:, 0]).max())
+    contrib, ncon, _ = raster.render_audit(saved, lmax)
+    contrib = contrib.cpu().numpy().reshape(H, W, lmax).astype(bool)
+    mask = saved["contrib_mask"].cpu().numpy()[:N]
+    last = ncon.cpu().numpy()[0]
+    gx = (W + 15) // 16
+    for tile in range(r.shape[0]):
+        tx, ty = tile % gx, tile // gx
+        n = int(r[tile, 1] - r[tile, 0])
+        # entries the forward staged are written; what lies behind the tile's deepest last-contributor is never read by the backward
+        deep = int(last[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16].max())
+        for q in range(4):
+            y0, x0 = ty * 16 + (q >> 1) * 8, tx * 16 + (q & 1) * 8
+            blk = contrib[y0:y0 + 8, x0:x0 + 8, :n].reshape(-1, n).any(0) if (y0 < H and x0 < W) else np.zeros(n, bool)
+            got = ((mask[r[tile, 0]:r[tile, 0] + n] >> q) & 1).astype(bool)
+            assert np.array_equal(got[:deep], blk[:deep]), (tile, q)
+    dcol = torch.randn(C, H, W, device=dev); dall = torch.randn(7, H, W, device=dev); dall[6] = 0
+    ga = raster.rasterize_backward(saved, dcol, dall)
+    saved2 = dict(saved); saved2["contrib_mask"] = None
+    gb = raster.rasterize_backward(saved2, dcol, dall)
+    for k in ("means3D", "means2D", "colors_precomp", "opacities", "scales", "rotations"):
+        a, b = ga[k].cpu().numpy(), gb[k].cpu().numpy()
+        assert np.abs(a - b).max() <= 2e-5 * (np.abs(b).max() + 1e-30), k     # same terms, summed by LDS / L2 atomics in a different order
+    raster.CONTRIB_MASK["on"] = False
+    try:
+        _, saved3 = raster.rasterize_forward(*args)
+        assert saved3["contrib_mask"] is None
+        gc = raster.rasterize_backward(saved3, dcol, dall)
+        assert np.abs(gc["means3D"].cpu().numpy() - gb["means3D"].cpu().numpy()).max() <= 2e-5 * np.abs(gb["means3D"].cpu().numpy()).max()
+    finally:
+        raster.CONTRIB_MASK["on"] = True
+
+
 def test_full_size_baseline_config_vs_oracle():
     """BASELINE configs[1] at full size: 300 k surfels, 800x800, SH degree 3 -- forward indices bit-exact,
     pixels and gradients within tolerance, plus size-independent properties (sortedness, range partition)."""
