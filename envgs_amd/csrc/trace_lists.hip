@@ -56,6 +56,22 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long (&k)[E], const i
     bitonic_merge<E, SIZE, SIZE / 2>(k, lane);
 }
 
+// 192 keys in three registers per lane: the 256-key network with its fourth block known to be +inf, which removes every operation on that
+// block (a quarter of the cross-lane layers).  Blocks 0-2 are sorted as in the full network up to size 64; at size 128 the pair (2, inf)
+// merges DOWNWARD -- the keys move to block 3, which only changes their direction: block 2 is sorted descending in place; at size 256
+// block 0 meets the inf block (nothing to do), block 1 meets the keys of block 3, then (0, 1) and (keys, inf) at stride 64 -- the keys
+// return to block 2 -- and the six cross-lane layers finish the three blocks.
+__device__ __forceinline__ void bitonic_sort_192(unsigned long long (&k)[3], const int lane)
+{
+    auto ce = [](unsigned long long &a, unsigned long long &b) { const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; };
+    bitonic_sort<3, 64>(k, lane);
+    ce(k[0], k[1]);
+    bitonic_merge<3, 128, 32>(k, lane);
+    ce(k[1], k[2]);
+    ce(k[0], k[1]);
+    bitonic_merge<3, 256, 32>(k, lane);
+}
+
 // Sort AND composite, one wavefront per ray, one LANE per hit.  A lane-per-ray walk is a chain of dependent
 // gathers -- list entry -> surfel record + SH block -> blend -> next entry -- whose length is the ray's hit count; here the 64 hits of
 // a chunk fetch their records independently (all gathers in flight at once) and the front-to-back recurrences (transmittance product,
@@ -75,7 +91,8 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
         if (i < n) { const uint2 q = list[i]; kk = ((unsigned long long)q.x << 32) | q.y; }
         kreg[e] = kk;
     }
-    bitonic_sort<E, E * 64>(kreg, lane);
+    if constexpr (E == 3) bitonic_sort_192(kreg, lane);
+    else bitonic_sort<E, E * 64>(kreg, lane);
     const float ox = A.ray_o[3 * r], oy = A.ray_o[3 * r + 1], oz = A.ray_o[3 * r + 2];
     const float dx = A.ray_d[3 * r], dy = A.ray_d[3 * r + 1], dz = A.ray_d[3 * r + 2];
     float basis[16];
@@ -188,6 +205,7 @@ sort_composite_fwd(const TraceArgs A)
             }
             if (n <= 64) sort_composite_ray<1>(A, r, n, lane, st_hits);
             else if (n <= 128) sort_composite_ray<2>(A, r, n, lane, st_hits);
+            else if (n <= 192) sort_composite_ray<3>(A, r, n, lane, st_hits);       // (a third of the rays of the bench scene)
             else sort_composite_ray<4>(A, r, n, lane, st_hits);
         }
     } else {

@@ -468,6 +468,7 @@ def test_trace_very_long_lists(force_cap, request):
                   which=("dmeans3D", "dopacities", "dcolor", "dothers", "dray_o", "dray_d"), )
     nh = res["ref"]["nhits"]
     assert nh.max() > 512 and ((nh > 256) & (nh <= 512)).sum() > 10 and (nh <= 256).sum() > 5 and res["cnt"]["max_list"] > 512
+    assert ((nh > 128) & (nh <= 192)).sum() > 0 and ((nh > 64) & (nh <= 128)).sum() > 0      # the 192-key and 128-key networks ran too
 
 
 @pytest.mark.parametrize("P,R", [(50, 0), (0, 64), (0, 0), (1, 64)])
