@@ -89,6 +89,7 @@ def trace_per_ray_model_bytes(kernel, tc, R):
 # instruction-issue peaks (MI355X_MICROARCH.md): a 64-lane VALU instruction occupies a SIMD-32 for 2 cycles -> 4 SIMDs x 0.5 = 2 VALU
 # wave-instructions per cycle per CU; one scalar unit per CU -> 1 SALU instruction per cycle per CU; 256 CUs x 2.4 GHz
 VALU_PEAK_GINST = 256 * 2 * 2.4
+VALU_MEASURED_GINST = 898.0     # what the chip sustains: independent v_fma_f32 / mixed VALU, 8 waves per SIMD (scratch/valu_peak.hip -> profiles/r02_valu_peak.txt)
 SALU_PEAK_GINST = 256 * 1 * 2.4
 PMC_SUMMARY = os.path.join("profiles", "r02_pmc_envgs.json")
 
@@ -357,8 +358,8 @@ def main():
             out = {"valu_insts_per_launch": int(valu), "salu_insts_per_launch": int(salu),
                    "valu_ginst_per_s": round(valu / t / 1e9, 1), "valu_peak_ginst_per_s": VALU_PEAK_GINST, "valu_util": round(valu / t / 1e9 / VALU_PEAK_GINST, 4),
                    "salu_ginst_per_s": round(salu / t / 1e9, 1), "salu_peak_ginst_per_s": SALU_PEAK_GINST, "salu_util": round(salu / t / 1e9 / SALU_PEAK_GINST, 4)}
-            if r.get("SQ_BUSY_CU_CYCLES") and r.get("SQ_ACTIVE_INST_VALU"):
-                out["valu_busy"] = round(4.0 * r["SQ_ACTIVE_INST_VALU"] / r["SQ_BUSY_CU_CYCLES"] / 4.0, 4)     # quad-cycles -> cycles, per SIMD (4 per CU)
+            out["valu_measured_peak_ginst_per_s"] = VALU_MEASURED_GINST
+            out["valu_util_measured_peak"] = round(valu / t / 1e9 / VALU_MEASURED_GINST, 4)
             out["source"] = PMC_SUMMARY
             return out
 

@@ -128,6 +128,13 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         e = hipMemsetAsync(L->surf_acc, 0, sizeof(unsigned long long) * (size_t)cfg->P * NCOPY, stream);
         if (e != hipSuccess) return (int)e;
         A.state = (float4 *)L->hit_state; A.entries = (unsigned long long *)L->entries; A.pairs = L->pairs; A.n_entries = L->n_entries;
+        if (L->sh_perm && shs && cfg->sh_coeffs == 16) {
+            const size_t nw = (size_t)cfg->P * 48;
+            hipLaunchKernelGGL(permute_sh, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, cfg->P, (cfg->sh_degree + 1) * (cfg->sh_degree + 1),
+                               cfg->feature_f16, (const void *)shs, L->sh_perm);
+            ENVGS_CHECK_LAUNCH(dcfg, stream);
+            A.shp = L->sh_perm;
+        }
         // The ray batches are split into two segments that run collect -> sort+composite -> register on two streams: the collection
         // kernel is a persistent grid whose wavefronts drain over the time of one whole batch, and the second segment's wavefronts
         // (and the first segment's next kernel) move into the CUs it leaves idle.

@@ -158,6 +158,7 @@ struct TraceArgs {
     int *n_entries;               // (batches, 2) table entries, single entries
     unsigned *long_list; // (R) scratch: slots of the rays whose lists exceed 256 hits, appended by the main sort pass (counter[24 + seg] = how many)
     float4 *state;      // (R, cap, 2 | 3) x 16 B per composited hit: transmittance before it and the prefix sums after it (for the backward)
+    const void *shp;    // (P, 48) quad-permuted copy of the SH blocks (permute_sh), same storage type as shs; nullptr = per-lane gathers from shs
 };
 
 // K-nearest buffer ordered by (t, id); insertion is a fully unrolled compare-exchange chain (registers only).
@@ -589,6 +590,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(64)
 collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec);
 __global__ void __launch_bounds__(256, 8)
 collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec);
+__global__ void __launch_bounds__(256) permute_sh(int P, int nb, int f16, const void *__restrict__ shs, void *__restrict__ shp);
 template <int EMAX, bool LONG> __global__ void __launch_bounds__(256) sort_composite_fwd(const TraceArgs A);
 extern template __global__ void __launch_bounds__(256) sort_composite_fwd<4, false>(const TraceArgs A);
 extern template __global__ void __launch_bounds__(256) sort_composite_fwd<8, true>(const TraceArgs A);

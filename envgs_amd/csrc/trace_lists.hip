@@ -72,6 +72,80 @@ __device__ __forceinline__ void bitonic_sort_192(unsigned long long (&k)[3], con
     bitonic_merge<3, 256, 32>(k, lane);
 }
 
+// Quad-permuted copy of the (P,16,3) SH blocks for the cooperative colour evaluation below.  The 48 words of a block are split among the four
+// lanes of a quad -- lane q owns coefficients 4q .. 4q+3, i.e. source words [12q, 12q+12) -- and stored so that load i (of three) of the four
+// lanes is ONE contiguous, aligned 64 B run (32 B with fp16 storage): word 4i + j of lane q sits at (4i + q) * 4 + j.  Coefficients beyond the
+// active degree are stored as zeros.  31 MB per step at the bench size: noise next to what it saves (see sort_composite_ray).
+__global__ void __launch_bounds__(256)
+permute_sh(int P, int nb, int f16, const void *__restrict__ shs, void *__restrict__ shp)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)P * 48) return;
+    const int sid = (int)(i / 48), pos = (int)(i % 48);
+    const int piece = pos >> 2, j = pos & 3, ii = piece >> 2, q = piece & 3;
+    const int src = 12 * q + 4 * ii + j;                       // = 3 k + c
+    const bool live = src < nb * 3;
+    if (f16) reinterpret_cast<__half *>(shp)[i] = live ? reinterpret_cast<const __half *>(shs)[(size_t)sid * 48 + src] : __float2half(0.f);
+    else reinterpret_cast<float *>(shp)[i] = live ? reinterpret_cast<const float *>(shs)[(size_t)sid * 48 + src] : 0.f;
+}
+
+template <int CTRL> __device__ __forceinline__ float quad_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+template <int CTRL> __device__ __forceinline__ int quad_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+
+// SH colour of the 64 hits of a chunk, four lanes per surfel.  A lane-per-hit gather of the 192 B blocks is twelve 16 B loads whose 64 lanes
+// touch 64 different cache lines EACH -- the L1's tag pipeline (one line per cycle), not bandwidth or arithmetic, is what the kernel waits
+// for.  All 64 hits belong to ONE ray, so the SH basis is the same in every lane: lane q of a quad takes coefficients 4q .. 4q+3 of all four
+// surfels of its quad (same number of loads and FMAs per lane, but each load instruction now covers 16 lines instead of 64), and the partial
+// sums are transpose-reduced inside the quad with DPP.  bk[m] = basis[4q + m].
+template <bool F16>
+__device__ __forceinline__ void quad_sh_color(const void *shp, const int sid, const bool use, const float (&bk)[4], const int lane, float *col, bool *cl)
+{
+    const int q = lane & 3;
+    float acc[4][3];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int sid_s = s == 0 ? quad_i<0x00>(sid) : s == 1 ? quad_i<0x55>(sid) : s == 2 ? quad_i<0xAA>(sid) : quad_i<0xFF>(sid);
+        const int us = use ? 1 : 0;
+        const int use_s = s == 0 ? quad_i<0x00>(us) : s == 1 ? quad_i<0x55>(us) : s == 2 ? quad_i<0xAA>(us) : quad_i<0xFF>(us);
+        acc[s][0] = acc[s][1] = acc[s][2] = 0.f;
+        if (use_s) {
+            float x[12];
+            if constexpr (F16) {
+                const uint2 *p2 = reinterpret_cast<const uint2 *>(reinterpret_cast<const __half *>(shp) + (size_t)sid_s * 48) + q;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const uint2 h = p2[4 * i];
+                    x[4 * i] = __half2float(__ushort_as_half((unsigned short)(h.x & 0xFFFFu))); x[4 * i + 1] = __half2float(__ushort_as_half((unsigned short)(h.x >> 16)));
+                    x[4 * i + 2] = __half2float(__ushort_as_half((unsigned short)(h.y & 0xFFFFu))); x[4 * i + 3] = __half2float(__ushort_as_half((unsigned short)(h.y >> 16)));
+                }
+            } else {
+                const float4 *p4 = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(shp) + (size_t)sid_s * 48) + q;
+#pragma unroll
+                for (int i = 0; i < 3; i++) { const float4 v = p4[4 * i]; x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w; }
+            }
+#pragma unroll
+            for (int f = 0; f < 12; f++) acc[s][f % 3] += bk[f / 3] * x[f];
+        }
+    }
+    // transpose-reduce inside the quad: lane q ends up with the sums of surfel q
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+    float t[2][3], r[3];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float keep = b0 ? acc[2 * h + 1][c] : acc[2 * h][c], send = b0 ? acc[2 * h][c] : acc[2 * h + 1][c];
+            t[h][c] = keep + quad_f<0xB1>(send);
+        }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float keep = b1 ? t[1][c] : t[0][c], send = b1 ? t[0][c] : t[1][c];
+        r[c] = keep + quad_f<0x4E>(send) + 0.5f;
+        cl[c] = r[c] < 0.f;
+        col[c] = cl[c] ? 0.f : r[c];
+    }
+}
+
 // Sort AND composite, one wavefront per ray, one LANE per hit.  A lane-per-ray walk is a chain of dependent
 // gathers -- list entry -> surfel record + SH block -> blend -> next entry -- whose length is the ray's hit count; here the 64 hits of
 // a chunk fetch their records independently (all gathers in flight at once) and the front-to-back recurrences (transmittance product,
@@ -98,7 +172,15 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
     float basis[16];
     {
         const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+#pragma unroll
+        for (int k = 0; k < 16; k++) basis[k] = 0.f;
         sh_basis(A.D, dx * il, dy * il, dz * il, basis);
+    }
+    float bk[4];                                        // this lane's four basis values of the quad-cooperative colour evaluation
+    {
+        const int q = lane & 3;
+#pragma unroll
+        for (int m = 0; m < 4; m++) bk[m] = q == 0 ? basis[m] : q == 1 ? basis[4 + m] : q == 2 ? basis[8 + m] : basis[12 + m];
     }
     // carried across chunks (wave-uniform): transmittance, the two distortion moments, and the ten blended sums
     // [rgb 3, depth, acc, normal 3, aux 2] -- kept as running PREFIX sums because the backward needs them per hit
@@ -133,7 +215,8 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
         const bool use = has && lane < f;
         const float w = use ? alpha * Tb : 0.f;
         float col[3] = {0.f, 0.f, 0.f}; bool cl[3];
-        if (use) surfel_color(A, sid, basis, col, cl);
+        if (A.shp) { if (A.f16) quad_sh_color<true>(A.shp, sid, use, bk, lane, col, cl); else quad_sh_color<false>(A.shp, sid, use, bk, lane, col, cl); }
+        else if (use) surfel_color(A, sid, basis, col, cl);
         const float tt = t > NEAR_N ? t : NEAR_N;
         const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / tt);
         const float mw = m * w, mmw = m * m * w;

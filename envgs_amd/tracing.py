@@ -118,6 +118,7 @@ def _next_cap(dev):
     return HIT_CAP["cap"]
 
 
+QUAD_SH = {"on": True}       # list path: four lanes share the fetch of a surfel's SH block (tests switch it off to cover the per-lane gathers)
 KEEP_LISTS = {"on": False}   # tests: keep the last forward's per-ray hit lists reachable through last_hit_lists()
 
 
@@ -156,6 +157,8 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
         keep.update(ray_keys=torch.empty(2 * R, **i32), ray_order=torch.empty(2 * R, **i32),
                     ray_sort_temp=torch.empty(max(rb, 1), dtype=torch.uint8, device=dev))
         srt = SORT_RAYS["on"]
+        if shs is not None and shs.shape[1] == 16 and QUAD_SH["on"]:
+            keep["sh_perm"] = torch.empty(P, 48, dtype=shs.dtype, device=dev)      # quad-permuted SH copy (envgs_trace.h: sh_perm)
         if need_grad and USE_RECORDS["on"]:
             # what the record backward needs from the forward: per-hit state, and the (batch, surfel) entries with their (lane, k) pairs
             nbatch = (R + 63) // 64
@@ -165,7 +168,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
                                 keep["spill"].data_ptr(), keep["surf_acc"].data_ptr(), keep["surf_cnt"].data_ptr(), keep["surf_off"].data_ptr(),
                                 keep["scan_temp"].data_ptr(), sb, keep["ray_keys"].data_ptr() if srt else None,
                                 keep["ray_order"].data_ptr() if srt else None, keep["ray_sort_temp"].data_ptr() if srt else None, rb, None, 0,
-                                *[(keep[k].data_ptr() if k in keep else None) for k in ("hit_state", "entries", "pairs", "n_entries")])
+                                *[(keep[k].data_ptr() if k in keep else None) for k in ("hit_state", "entries", "pairs", "n_entries", "sh_perm")])
     p = _lib.ptr
     _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
                                        p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),

@@ -93,6 +93,9 @@ typedef struct envgs_trace_lists {
     uint64_t *entries;       /* (ceil(R/64), 64*cap) distinct surfels of every batch, packed id | hits-1 << 24 | slot << 32 */
     uint32_t *pairs;         /* (ceil(R/64), 64*cap) (lane << 16 | list position) of every composited hit, grouped by entry */
     int32_t *n_entries;      /* (ceil(R/64), 2) entries merged in the batch's table, single entries filed from the top */
+    void *sh_perm;           /* optional scratch, (P, 48) elements of the shs storage type (used when sh_coeffs == 16): a quad-permuted copy of the SH
+                                blocks, rebuilt by every forward, that lets four lanes fetch one surfel's block as contiguous 64 B runs; NULL = each
+                                lane gathers its own block from shs */
 } envgs_trace_lists;
 
 /* Scratch bytes for the Morton sort + build of P surfels. */

@@ -471,6 +471,30 @@ def test_trace_very_long_lists(force_cap, request):
     assert ((nh > 128) & (nh <= 192)).sum() > 0 and ((nh > 64) & (nh <= 128)).sum() > 0      # the 192-key and 128-key networks ran too
 
 
+@pytest.mark.parametrize("deg,half", [(3, False), (1, False), (3, True)])
+def test_trace_quad_cooperative_sh_matches_per_lane_gathers(deg, half):
+    """The list path evaluates SH colours four lanes per surfel from a permuted copy of the blocks (envgs_trace.h: sh_perm); with the copy
+    withheld every lane gathers its own block.  Same products, summed in a different order: the images agree to fp32 rounding."""
+    from envgs_amd import tracing
+    P, R = 3000, 1536
+    e = synth.env_gaussians(P, seed=3)
+    gen = torch.Generator().manual_seed(8)
+    ro = (torch.rand(R, 3, generator=gen) * 2 - 1) * 1.3
+    rd = torch.randn(R, 3, generator=gen); rd = rd / rd.norm(dim=-1, keepdim=True)
+    g = dict(means3D=e["means3D"] * 0.05, scales=e["scales"] * 0.25, rotations=e["rotations"], opacities=e["opacities"], shs=e["shs"].half() if half else e["shs"],
+             others=torch.rand(P, 2, generator=gen))
+    outs = {}
+    for on in (True, False):
+        tracing.QUAD_SH["on"] = on
+        try:
+            outs[on] = [x.detach().cpu().numpy() for x in _run_hip(g, ro, rd, torch.tensor([0.2, 0.3, 0.4]), deg, True, False)[0]]
+        finally:
+            tracing.QUAD_SH["on"] = True
+    assert np.abs(outs[True][0]).max() > 0.05 and (outs[True][2] > 0.5).mean() > 0.2          # the rays do blend something
+    for a, b in zip(outs[True], outs[False]):
+        assert np.abs(a - b).max() <= 2e-6 * (np.abs(b).max() + 1.0)
+
+
 @pytest.mark.parametrize("P,R", [(50, 0), (0, 64), (0, 0), (1, 64)])
 def test_trace_empty_inputs(P, R):
     """No rays, no surfels, neither, and a single surfel: shapes follow the inputs, an empty scene renders the background, backward runs."""
