@@ -127,6 +127,7 @@ def main():
                     help="N > 1: direct reduce-scatter + all-gather over the xGMI mesh (all_to_all + local sum + all_gather), or one all_reduce per bucket")
     ap.add_argument("--no-render", action="store_true", help="skip the forward-only render timing (profiling runs: keeps the kernel statistics to the training steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-times", type=int, default=0, help="diagnostics: after the timed region, run this many extra steps one by one (synchronised) and print their wall times and the allocator statistics to stderr")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the same view traced by the brute-force CPU oracle (bounded sample)")
     args = ap.parse_args()
@@ -282,6 +283,19 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    if args.step_times > 0 and rank == 0:
+        ms0 = torch.cuda.memory_stats(dev)
+        ts = []
+        for it in range(args.step_times):
+            torch.cuda.synchronize(dev); a_ = time.perf_counter()
+            step(args.warmup + args.steps + it)
+            torch.cuda.synchronize(dev); ts.append(round((time.perf_counter() - a_) * 1e3, 2))
+        ms1 = torch.cuda.memory_stats(dev)
+        keys = ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams")
+        print("step times (ms): %s; allocator during them: %s; reserved %.1f GB, peak allocated %.1f GB" % (
+            ts, {k: ms1.get(k, 0) - ms0.get(k, 0) for k in keys}, ms1.get("reserved_bytes.all.current", 0) / 2**30,
+            ms1.get("allocated_bytes.all.peak", 0) / 2**30), file=sys.stderr)
 
     # per-kernel HIP-event times (this rank)
     N_avg = n_acc["N"] / max(n_acc["steps"], 1)

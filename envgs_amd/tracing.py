@@ -118,6 +118,25 @@ def _next_cap(dev):
     return HIT_CAP["cap"]
 
 
+def _scratch(shape, dtype, dev):
+    """Large per-call scratch (hit lists, per-hit state, entries, pairs, gradient records).  Their sizes follow the ray count and the
+    adaptive list capacity, both of which change from call to call (bounce stages, views); asking torch's caching allocator for a
+    different multi-GB size every time makes it go back to hipMalloc (~0.5 s for tens of GB, measured) and pile up reserved memory.  Sizes
+    above 32 MB are therefore rounded up to {1, 1.25, 1.5, 1.75} x 2^k elements -- a handful of distinct sizes that the allocator's cache
+    serves from then on -- and the tensor is a view of the front of that block."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    item = torch.empty(0, dtype=dtype).element_size()
+    if n * item <= (32 << 20):
+        return torch.empty(shape, dtype=dtype, device=dev)
+    k = max(n - 1, 1).bit_length() - 1                   # 2^k < n <= 2^(k+1)
+    for q in (5, 6, 7, 8):
+        if (q << k) >> 2 >= n:
+            return torch.empty((q << k) >> 2, dtype=dtype, device=dev)[:n].view(shape)
+    raise AssertionError
+
+
 QUAD_SH = {"on": True}       # list path: four lanes share the fetch of a surfel's SH block (tests switch it off to cover the per-lane gathers)
 KEEP_LISTS = {"on": False}   # tests: keep the last forward's per-ray hit lists reachable through last_hit_lists()
 
@@ -147,7 +166,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     keep = {}
     if cap:
         i32 = dict(dtype=torch.int32, device=dev)
-        keep = dict(hit_lists=torch.empty(R, cap, 2, **i32), hit_cnt=torch.empty(R, **i32), n_used=torch.empty(R, **i32),
+        keep = dict(hit_lists=_scratch((R, cap, 2), torch.int32, dev), hit_cnt=torch.empty(R, **i32), n_used=torch.empty(R, **i32),
                     spill=torch.empty(lib.envgs_trace_stack_spill_ints(R), **i32), surf_acc=torch.empty(P, NCOPY, dtype=torch.int64, device=dev),
                     surf_cnt=torch.empty(P, NCOPY, **i32),
                     surf_off=torch.empty(P, NCOPY, **i32))
@@ -162,8 +181,8 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
         if need_grad and USE_RECORDS["on"]:
             # what the record backward needs from the forward: per-hit state, and the (batch, surfel) entries with their (lane, k) pairs
             nbatch = (R + 63) // 64
-            keep.update(hit_state=torch.empty(R, cap, 12 if others_precomp is not None else 8, **f32), entries=torch.empty(nbatch, 64 * cap, dtype=torch.int64, device=dev),
-                        pairs=torch.empty(nbatch, 64 * cap, **i32), n_entries=torch.empty(nbatch, 2, **i32))
+            keep.update(hit_state=_scratch((R, cap, 12 if others_precomp is not None else 8), torch.float32, dev), entries=_scratch((nbatch, 64 * cap), torch.int64, dev),
+                        pairs=_scratch((nbatch, 64 * cap), torch.int32, dev), n_entries=torch.empty(nbatch, 2, **i32))
         lists = _lib.TraceLists(keep["hit_lists"].data_ptr(), keep["hit_cnt"].data_ptr(), keep["n_used"].data_ptr(), cap,
                                 keep["spill"].data_ptr(), keep["surf_acc"].data_ptr(), keep["surf_cnt"].data_ptr(), keep["surf_off"].data_ptr(),
                                 keep["scan_temp"].data_ptr(), sb, keep["ray_keys"].data_ptr() if srt else None,
@@ -217,7 +236,7 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
         s["keep"]["n_rec_event"].synchronize()         # copied at the end of the forward; long since complete
         n_rec = int(s["keep"]["n_rec_host"][0]) & 0xFFFFFFFF if P > 0 else 0
         if n_rec > 0:
-            records = torch.empty(n_rec, 64, **f32)
+            records = _scratch((n_rec, 64), torch.float32, dev)
             lists.records = records.data_ptr()
             lists.num_records = n_rec
     _lib.check(lib.envgs_trace_backward(cfg, p(s["nodes"]), p(s["ro"]), p(s["rd"]), p(s["means3D"]), p(s["scales"]), p(s["rotations"]),
