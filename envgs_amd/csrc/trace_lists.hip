@@ -224,7 +224,7 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
         const float M1b = M1 + (S1 - mw), M2b = M2 + (S2 - mmw);        // moments before this hit
         dist += (m * m * (1.0f - Tb) + M2b - 2.0f * m * M1b) * w;
         float x0 = 0.f, x1 = 0.f;
-        if (A.has_others && use) { x0 = A.others[2 * sid]; x1 = A.others[2 * sid + 1]; }
+        if (A.has_others && use) { const float2 xo = reinterpret_cast<const float2 *>(A.others)[sid]; x0 = xo.x; x1 = xo.y; }      // one 8 B gather
         float S[10] = {w * col[0], w * col[1], w * col[2], w * t, w, sg * w * s3.x, sg * w * s3.y, sg * w * s3.z, w * x0, w * x1};
 #pragma unroll
         for (int j = 0; j < 10; j++) S[j] = C[j] + wave_scan_add(S[j]);               // inclusive: this hit already added
