@@ -198,11 +198,12 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             {
                 ProfScope p2(K_TRACE_SORT, st);
                 const dim3 g(stride_grid(rays_seg, 4)), b(256);
-                hipLaunchKernelGGL((sort_composite_fwd<4, false>), g, b, 0, st, S);
+                if (S.shp) hipLaunchKernelGGL((sort_composite_fwd<4, false, true>), g, b, 0, st, S);
+                else hipLaunchKernelGGL((sort_composite_fwd<4, false, false>), g, b, 0, st, S);
                 if (S.cap > 256) {
                     const dim3 gl(min(stride_grid(rays_seg, 256), 512));
-                    if (S.cap <= 512) hipLaunchKernelGGL((sort_composite_fwd<8, true>), gl, b, 0, st, S);
-                    else hipLaunchKernelGGL((sort_composite_fwd<16, true>), gl, b, 0, st, S);
+                    if (S.cap <= 512) { if (S.shp) hipLaunchKernelGGL((sort_composite_fwd<8, true, true>), gl, b, 0, st, S); else hipLaunchKernelGGL((sort_composite_fwd<8, true, false>), gl, b, 0, st, S); }
+                    else { if (S.shp) hipLaunchKernelGGL((sort_composite_fwd<16, true, true>), gl, b, 0, st, S); else hipLaunchKernelGGL((sort_composite_fwd<16, true, false>), gl, b, 0, st, S); }
                 }
             }
             ENVGS_CHECK_LAUNCH(dcfg, st);

@@ -302,9 +302,9 @@ build_wide_nodes(int n_internal, const float *__restrict__ nodes, float *__restr
             }
         }
     }
-    for (; k < 4; k++) {
-        for (int a = 0; a < 3; a++) { lo[k][a] = 1.0e30f; hi[k][a] = 1.0e30f; }
-        ref[k] = ~0;
+    for (; k < 4; k++) {                                   // unused slots (a child that is itself a leaf has no grandchildren): a box no ray reaches,
+        for (int a = 0; a < 3; a++) { lo[k][a] = 1.0e30f; hi[k][a] = 1.0e30f; }      // and WIDE_EMPTY as the reference so that the traversal skips the test
+        ref[k] = ENVGS_WIDE_EMPTY;
     }
     // per slot 8 floats: [lo.x hi.x lo.y hi.y | lo.z hi.z ref 0] -- (lo, hi) of an axis adjacent, so that they arrive as an aligned scalar
     // register PAIR and the slab test's subtract and multiply run as packed fp32 (v_pk_add_f32 / v_pk_mul_f32: both planes in one instruction)

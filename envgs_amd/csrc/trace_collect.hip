@@ -544,13 +544,14 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int ch = __builtin_amdgcn_readfirstlane(__float_as_int(qb[c].z));
+                key[c] = 0x7fffffff; ref[c] = -1;
+                if (ch == WIDE_EMPTY) continue;                  // (a fifth of the slots of the bench tree: bottom nodes with leaf children)
                 const f32x2 sx = (f32x2{qa[c].x, qa[c].y} - o2x) * i2x, sy = (f32x2{qa[c].z, qa[c].w} - o2y) * i2y,
                             sz = (f32x2{qb[c].x, qb[c].y} - o2z) * i2z;
                 const float tn = fmaxf(fmaxf(fmaxf(fminf(sx.x, sx.y), fminf(sy.x, sy.y)), fminf(sz.x, sz.y)), tmin);
                 const float tf = fminf(fminf(fminf(fmaxf(sx.x, sx.y), fmaxf(sy.x, sy.y)), fmaxf(sz.x, sz.y)), tkill);
                 const bool hit = tn <= tf;                        // (tmin <= tkill always, so this is the three-way test of the other kernels)
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-                key[c] = 0x7fffffff; ref[c] = -1;
                 if (m != 0ull) {
                     if (ch < 0) {
                         const int sid = ~ch;

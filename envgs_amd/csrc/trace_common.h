@@ -572,6 +572,7 @@ constexpr float KILL_OD = 9.2104f * 1.03f + 0.05f;       // -ln(1e-4) with margi
 // the binary walk holds one postponed child per level and the 4-wide walk at most three per TWO levels.  Should a child ever not fit, the batch is
 // flagged: its rays are handed to the K-buffer kernels (per-lane stacks) and counters[20] counts the event -- never a silently dropped subtree.
 constexpr int PSTACK = 128;
+constexpr int WIDE_EMPTY = ENVGS_WIDE_EMPTY;   // reference of an unused slot of a 4-wide node (never a surfel: ids are < 2^24 on the list path)
 constexpr int SORT_MAX = 1024;  // longest list the sort / composite pass takes (16 keys per lane)
 constexpr int RH_W = 8;         // register_hits: wavefronts per batch -- wave q takes list positions q, q + RH_W, ... of every ray
 
@@ -591,10 +592,13 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
 __global__ void __launch_bounds__(256, 8)
 collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec);
 __global__ void __launch_bounds__(256) permute_sh(int P, int nb, int f16, const void *__restrict__ shs, void *__restrict__ shp);
-template <int EMAX, bool LONG> __global__ void __launch_bounds__(256) sort_composite_fwd(const TraceArgs A);
-extern template __global__ void __launch_bounds__(256) sort_composite_fwd<4, false>(const TraceArgs A);
-extern template __global__ void __launch_bounds__(256) sort_composite_fwd<8, true>(const TraceArgs A);
-extern template __global__ void __launch_bounds__(256) sort_composite_fwd<16, true>(const TraceArgs A);
+template <int EMAX, bool LONG, bool QSH> __global__ void __launch_bounds__(256) sort_composite_fwd(const TraceArgs A);
+extern template __global__ void __launch_bounds__(256) sort_composite_fwd<4, false, false>(const TraceArgs A);
+extern template __global__ void __launch_bounds__(256) sort_composite_fwd<8, true, false>(const TraceArgs A);
+extern template __global__ void __launch_bounds__(256) sort_composite_fwd<16, true, false>(const TraceArgs A);
+extern template __global__ void __launch_bounds__(256) sort_composite_fwd<4, false, true>(const TraceArgs A);
+extern template __global__ void __launch_bounds__(256) sort_composite_fwd<8, true, true>(const TraceArgs A);
+extern template __global__ void __launch_bounds__(256) sort_composite_fwd<16, true, true>(const TraceArgs A);
 __global__ void __launch_bounds__(64 * RH_W) register_hits(const TraceArgs A);
 __global__ void __launch_bounds__(256) unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, unsigned *__restrict__ cnt,
                                                          float *__restrict__ wet);

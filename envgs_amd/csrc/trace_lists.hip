@@ -153,7 +153,7 @@ __device__ __forceinline__ void quad_sh_color(const void *shp, const int sid, co
 // lane, a bitonic network whose cross-lane layers use DPP / ds_swizzle / permlane32 and whose long strides are register-to-register --
 // so the sorted chunk c is simply register c: no LDS, no barriers, no bank conflicts.  The sorted list is written back only up to the
 // terminating hit.
-template <int E>
+template <int E, bool QSH>
 __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int r, const int n, const int lane, unsigned &st_hits)
 {
     uint2 *list = A.hits + (size_t)r * A.cap;
@@ -215,7 +215,9 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
         const bool use = has && lane < f;
         const float w = use ? alpha * Tb : 0.f;
         float col[3] = {0.f, 0.f, 0.f}; bool cl[3];
-        if (A.shp) { if (A.f16) quad_sh_color<true>(A.shp, sid, use, bk, lane, col, cl); else quad_sh_color<false>(A.shp, sid, use, bk, lane, col, cl); }
+        // (QSH is a KERNEL template parameter: with both colour paths in one kernel the generic one keeps the 16 basis values alive through
+        //  the whole ray -- 124 VGPRs = 4 waves per SIMD instead of 86 = 5, and this kernel spends 60 % of its time waiting for gathers)
+        if constexpr (QSH) { if (A.f16) quad_sh_color<true>(A.shp, sid, use, bk, lane, col, cl); else quad_sh_color<false>(A.shp, sid, use, bk, lane, col, cl); }
         else if (use) surfel_color(A, sid, basis, col, cl);
         const float tt = t > NEAR_N ? t : NEAR_N;
         const float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / tt);
@@ -268,8 +270,8 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
 // lists longer than 256 hits are rare, so the work is split by list length: the main pass (LONG = false) takes every ray with at most 256
 // hits at 4 waves/SIMD; when the capacity allows longer lists a second launch (LONG = true, EMAX = 8 or 16) picks up the few rays
 // beyond 256 -- it scans the hit counts 64 rays per wavefront step and only sorts what the ballot finds.
-template <int EMAX, bool LONG>
-__global__ void __launch_bounds__(256)
+template <int EMAX, bool LONG, bool QSH>
+__global__ void __launch_bounds__(256)         // (QSH main pass: 86 VGPRs = 5 waves per SIMD.  Forcing 6 -- 80 VGPRs, 5 dwords spilled -- measured 2.27 -> 2.47 ms)
 sort_composite_fwd(const TraceArgs A)
 {
     // 4 wavefronts per workgroup take 4 CONSECUTIVE rays of the coherence-sorted order: they blend mostly the same surfels at the same
@@ -286,10 +288,10 @@ sort_composite_fwd(const TraceArgs A)
                 if (A.long_list && lane == 0) A.long_list[A.batch0 * 64 + atomicAdd(A.counter + 24 + A.seg, 1u)] = (unsigned)slot;
                 continue;
             }
-            if (n <= 64) sort_composite_ray<1>(A, r, n, lane, st_hits);
-            else if (n <= 128) sort_composite_ray<2>(A, r, n, lane, st_hits);
-            else if (n <= 192) sort_composite_ray<3>(A, r, n, lane, st_hits);       // (a third of the rays of the bench scene)
-            else sort_composite_ray<4>(A, r, n, lane, st_hits);
+            if (n <= 64) sort_composite_ray<1, QSH>(A, r, n, lane, st_hits);
+            else if (n <= 128) sort_composite_ray<2, QSH>(A, r, n, lane, st_hits);
+            else if (n <= 192) sort_composite_ray<3, QSH>(A, r, n, lane, st_hits);       // (a third of the rays of the bench scene)
+            else sort_composite_ray<4, QSH>(A, r, n, lane, st_hits);
         }
     } else {
         // the longest list so far (this segment's collection has finished, so its own maximum is in): nothing to do in the usual case
@@ -301,8 +303,8 @@ sort_composite_fwd(const TraceArgs A)
             for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < nl; i += gridDim.x * 4) {
                 const int slot = (int)A.long_list[A.batch0 * 64 + i];
                 const int rr = ray_of(A, slot), nn = A.hit_cnt[rr];
-                if (EMAX == 8 || nn <= 512) sort_composite_ray<8>(A, rr, nn, lane, st_hits);
-                else if constexpr (EMAX >= 16) sort_composite_ray<16>(A, rr, nn, lane, st_hits);
+                if (EMAX == 8 || nn <= 512) sort_composite_ray<8, QSH>(A, rr, nn, lane, st_hits);
+                else if constexpr (EMAX >= 16) sort_composite_ray<16, QSH>(A, rr, nn, lane, st_hits);
             }
             if (A.stats && lane == 0 && st_hits) atomicAdd(A.stats + 0, (unsigned long long)st_hits);
             return;
@@ -316,8 +318,8 @@ sort_composite_fwd(const TraceArgs A)
                 const int l = (int)__builtin_ctzll(todo);
                 todo &= todo - 1;
                 const int rr = __shfl(r, l), nn = __shfl(n, l);
-                if (EMAX == 8 || nn <= 512) sort_composite_ray<8>(A, rr, nn, lane, st_hits);
-                else if constexpr (EMAX >= 16) sort_composite_ray<16>(A, rr, nn, lane, st_hits);
+                if (EMAX == 8 || nn <= 512) sort_composite_ray<8, QSH>(A, rr, nn, lane, st_hits);
+                else if constexpr (EMAX >= 16) sort_composite_ray<16, QSH>(A, rr, nn, lane, st_hits);
             }
         }
     }
@@ -465,8 +467,11 @@ unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, 
 }
 
 
-template __global__ void sort_composite_fwd<4, false>(const TraceArgs A);
-template __global__ void sort_composite_fwd<8, true>(const TraceArgs A);
-template __global__ void sort_composite_fwd<16, true>(const TraceArgs A);
+template __global__ void sort_composite_fwd<4, false, false>(const TraceArgs A);
+template __global__ void sort_composite_fwd<8, true, false>(const TraceArgs A);
+template __global__ void sort_composite_fwd<16, true, false>(const TraceArgs A);
+template __global__ void sort_composite_fwd<4, false, true>(const TraceArgs A);
+template __global__ void sort_composite_fwd<8, true, true>(const TraceArgs A);
+template __global__ void sort_composite_fwd<16, true, true>(const TraceArgs A);
 
 }  // namespace envgs

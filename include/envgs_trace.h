@@ -42,6 +42,7 @@ extern "C" {
 #define ENVGS_SREC_STRIDE 16
 #define ENVGS_GEOREC_STRIDE 16
 #define ENVGS_MID_CHANNELS 16
+#define ENVGS_WIDE_EMPTY ((int32_t)0x80000000)   /* `ref` of an unused slot of a 4-wide node (a child that is a leaf has no grandchildren) */
 
 /* Mirrors SurfelTracingSettings (optix_utils.py:104-119) minus the tensors, plus the call's start_from_first. */
 typedef struct envgs_trace_cfg {

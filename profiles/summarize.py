@@ -37,7 +37,7 @@ def pmc():
     w = load(os.path.join(ROOT, 'gpurun_out/pmc_write/w_counter_collection.csv'), 'WRITE_SIZE')
     names = {'envgs::composite_fwd': 'composite_fwd', 'envgs::composite_bwd': 'composite_bwd', 'envgs::project_surfels': 'project_surfels',
              'envgs::project_surfels_bwd': 'project_surfels_bwd', 'envgs::emit_tile_keys': 'emit_tile_keys', 'envgs::find_tile_ranges': 'find_tile_ranges',
-             'envgs::collect_hits_coop': 'trace.collect_hits', 'envgs::collect_hits_packet4': 'trace.collect_hits(one wavefront per batch)', 'envgs::collect_hits_packet': 'trace.collect_hits(binary)', 'envgs::collect_hits': 'trace.collect_hits(per-ray)', 'envgs::sort_composite_fwd<4, false>': 'trace.sort_composite_fwd',
+             'envgs::collect_hits_coop': 'trace.collect_hits', 'envgs::collect_hits_packet4': 'trace.collect_hits(one wavefront per batch)', 'envgs::collect_hits_packet': 'trace.collect_hits(binary)', 'envgs::collect_hits': 'trace.collect_hits(per-ray)', 'envgs::sort_composite_fwd<4, false, true>': 'trace.sort_composite_fwd', 'envgs::sort_composite_fwd<4, false, false>': 'trace.sort_composite_fwd(per-lane SH gathers)',
              'envgs::register_hits': 'trace.register_hits', 'envgs::batch_surfel_bwd': 'trace.batch_surfel_bwd',
              'envgs::reduce_surfel_records': 'trace.reduce_surfel_records'}
     out = {"_how": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / rocprofv3 --pmc WRITE_SIZE --kernel-trace (two separate passes, no other trace domains) -- "
