@@ -39,7 +39,7 @@ size_t sort_temp_bytes(uint32_t n, int end_bit)
 // The tile rect is recomputed from the stored centre and INTEGER radius exactly as R1 did.
 __global__ void __launch_bounds__(256)
 emit_tile_keys(int P, int W, int H, const float *__restrict__ geom, const int32_t *__restrict__ radii,
-               const uint32_t *__restrict__ offsets, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+               const uint32_t *__restrict__ offsets, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t cap)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
@@ -57,16 +57,24 @@ emit_tile_keys(int P, int W, int H, const float *__restrict__ geom, const int32_
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
             const uint64_t key = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
-            keys[off] = key;
-            vals[off] = (uint32_t)i;
+            if (off < cap) { keys[off] = key; vals[off] = (uint32_t)i; }      // (cap < N only when a speculative capacity was too small: the caller repeats the call)
             off++;
         }
 }
 
+// Speculative capacity (launch_bin): the slots [N, cap) of the key buffer sort behind every real key.
 __global__ void __launch_bounds__(256)
-find_tile_ranges(uint32_t N, const uint64_t *__restrict__ keys_sorted, uint32_t *__restrict__ ranges)
+pad_tile_keys(uint32_t cap, const uint32_t *__restrict__ n_dev, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < cap && j >= *n_dev) { keys[j] = ~0ull; vals[j] = 0u; }
+}
+
+__global__ void __launch_bounds__(256)
+find_tile_ranges(uint32_t N, const uint32_t *__restrict__ n_dev, const uint64_t *__restrict__ keys_sorted, uint32_t *__restrict__ ranges)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) N = min(N, *n_dev);
     if (j >= N) return;
     const uint32_t t = (uint32_t)(keys_sorted[j] >> 32);
     if (j == 0 || t != (uint32_t)(keys_sorted[j - 1] >> 32)) ranges[2 * t] = j;
@@ -75,18 +83,25 @@ find_tile_ranges(uint32_t N, const uint64_t *__restrict__ keys_sorted, uint32_t 
 
 int launch_bin(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const int32_t *radii, const uint32_t *offsets,
                uint64_t *keys_unsorted, uint32_t *vals_unsorted, uint64_t *keys_sorted, uint32_t *point_list,
-               void *sort_temp, size_t sort_temp_bytes, uint32_t *ranges, hipStream_t stream)
+               void *sort_temp, size_t sort_temp_bytes, uint32_t *ranges, hipStream_t stream, const uint32_t *n_dev)
 {
+    // n_dev == nullptr: N is the exact number of tile instances.  Otherwise N is a CAPACITY chosen before the count was known on the host
+    // (no host sync between projection and binning) and *n_dev the count: the tail [count, N) is padded with keys that sort last (one more
+    // key bit makes them larger than any tile id), and the ranges are built from the first `count` sorted entries only.
     const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
     hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)gx * gy, stream);
     if (e != hipSuccess) return (int)e;
     if (N == 0 || cfg->P <= 0) return 0;
     prof_begin(K_EMIT_KEYS, stream);
     hipLaunchKernelGGL(emit_tile_keys, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, cfg->width, cfg->height,
-                       geom, radii, offsets, keys_unsorted, vals_unsorted);
+                       geom, radii, offsets, keys_unsorted, vals_unsorted, N);
     ENVGS_CHECK_LAUNCH(cfg, stream);
+    if (n_dev) {
+        hipLaunchKernelGGL(pad_tile_keys, dim3((N + 255) / 256), dim3(256), 0, stream, N, n_dev, keys_unsorted, vals_unsorted);
+        ENVGS_CHECK_LAUNCH(cfg, stream);
+    }
     prof_end(K_EMIT_KEYS, stream);
-    const int end_bit = 32 + tile_bits(cfg->width, cfg->height);
+    const int end_bit = 32 + tile_bits(cfg->width, cfg->height) + (n_dev ? 1 : 0);
     prof_begin(K_SORT, stream);
     size_t need = sort_temp_bytes;
     e = rocprim::radix_sort_pairs(sort_temp, need, keys_unsorted, keys_sorted, vals_unsorted, point_list, (size_t)N, 0u,
@@ -94,7 +109,7 @@ int launch_bin(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const
     prof_end(K_SORT, stream);
     if (e != hipSuccess) return (int)e;
     ProfScope prof_(K_RANGES, stream);
-    hipLaunchKernelGGL(find_tile_ranges, dim3((N + 255) / 256), dim3(256), 0, stream, N, keys_sorted, ranges);
+    hipLaunchKernelGGL(find_tile_ranges, dim3((N + 255) / 256), dim3(256), 0, stream, N, n_dev, keys_sorted, ranges);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;
 }

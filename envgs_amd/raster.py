@@ -85,6 +85,18 @@ def sh_degree_of(deg):
     return v
 
 
+SPECULATIVE_N = {"on": True}  # size the binning buffers from the previous call's instance count instead of waiting for this call's (see rasterize_forward)
+_N_GUESS = {}                  # (device, P, H, W) -> capacity for the next call
+_N_MIRROR = {}
+
+
+def _n_mirror(dev):
+    m = _N_MIRROR.get(dev.index)
+    if m is None:
+        m = _N_MIRROR[dev.index] = dict(host=torch.empty(1, dtype=torch.int32).pin_memory(), event=torch.cuda.Event())
+    return m
+
+
 CONTRIB_MASK = {"on": True}   # forward records which pixel quadrants blended each tile instance; the backward walks exactly those (tests switch it off to cover the geometric fallback)
 
 
@@ -129,34 +141,64 @@ def rasterize_forward(C, means3D, shs, colors_precomp, opacities, scales, rotati
     clamped = torch.empty(P, 3, dtype=torch.uint8, device=dev) if shs is not None else None
     scan_bytes = lib.envgs_raster_scan_temp_bytes(P)
     scan_temp = torch.empty(max(scan_bytes, 1), dtype=torch.uint8, device=dev)
-    n_host = _lib.c_uint32(0)
     p = _lib.ptr
-    _lib.check(lib.envgs_raster_project(cfg, p(means3D), p(scales), p(rotations), p(opacities), p(shs), p(cov3D_precomp),
-                                        p(view), p(proj), p(campos), p(geom), p(rgb), p(clamped), p(radii), p(tiles),
-                                        p(offsets), p(scan_temp), scan_bytes, n_host, stream), "envgs_raster_project")
-    N = int(n_host.value)
-    LAST_STATS.update(N=N, P=P, H=H, W=W, C=C)
-
-    colors = rgb if shs is not None else colors_precomp
     tiles_n = ((W + 15) // 16) * ((H + 15) // 16)
-    keys_u = torch.empty(max(N, 1), dtype=torch.int64, device=dev)
-    keys_s = torch.empty(max(N, 1), dtype=torch.int64, device=dev)
-    vals_u = torch.empty(max(N, 1), **i32)
-    point_list = torch.empty(max(N, 1), **i32)
-    sort_bytes = lib.envgs_raster_sort_temp_bytes(max(N, 1), W, H)
-    sort_temp = torch.empty(max(sort_bytes, 1), dtype=torch.uint8, device=dev)
-    ranges = torch.empty(tiles_n, 2, **i32)
+    colors = rgb if shs is not None else colors_precomp
     out_color = torch.empty(C, H, W, **f32)
     allmap = torch.empty(7, H, W, **f32)
     final_T = torch.empty(3, H, W, **f32)
     n_contrib = torch.empty(2, H, W, **i32)
     weight = torch.empty(P, 1, **f32)
-    # per tile instance: the pixel quadrants that blended it (the backward walks exactly those); only needed when a backward follows
-    cmask = torch.empty(max(N, 1), dtype=torch.uint8, device=dev) if CONTRIB_MASK["on"] else None
-    _lib.check(lib.envgs_raster_bin_and_render(cfg, N, p(geom), p(radii), p(offsets), p(colors), p(bg), p(keys_u), p(vals_u),
-                                               p(keys_s), p(point_list), p(sort_temp), sort_bytes, p(ranges), p(out_color),
-                                               p(allmap), p(final_T), p(n_contrib), p(weight), p(cmask), stream),
-               "envgs_raster_bin_and_render")
+    ranges = torch.empty(tiles_n, 2, **i32)
+
+    def bin_and_render(cap, n_dev):
+        """R3-R6 with N-sized buffers of `cap` entries; n_dev = device pointer to the instance count when cap is a guess."""
+        keys_u = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+        keys_s = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+        vals_u = torch.empty(max(cap, 1), **i32)
+        point_list = torch.empty(max(cap, 1), **i32)
+        sort_bytes = lib.envgs_raster_sort_temp_bytes(max(cap, 1), W, H)
+        sort_temp = torch.empty(max(sort_bytes, 1), dtype=torch.uint8, device=dev)
+        # per tile instance: the pixel quadrants that blended it (the backward walks exactly those)
+        cmask = torch.empty(max(cap, 1), dtype=torch.uint8, device=dev) if CONTRIB_MASK["on"] else None
+        _lib.check(lib.envgs_raster_bin_and_render(cfg, cap, p(geom), p(radii), p(offsets), p(colors), p(bg), p(keys_u), p(vals_u),
+                                                   p(keys_s), p(point_list), p(sort_temp), sort_bytes, p(ranges), p(out_color),
+                                                   p(allmap), p(final_T), p(n_contrib), p(weight), p(cmask), n_dev, stream),
+                   "envgs_raster_bin_and_render")
+        return keys_u, keys_s, vals_u, point_list, cmask
+
+    # The number of tile instances N sizes the binning buffers, and it is known only after the projection.  Waiting for it drains the
+    # GPU's queue at the start of every step (and every launch after it is exposed until the host is ahead again: ~0.5 ms of idle GPU per
+    # EnvGS step, measured from the kernel trace).  So: enqueue the projection, start an asynchronous read-back of N, enqueue R3-R6 with a
+    # CAPACITY guessed from the previous calls of this shape -- and only then look at N, which has long arrived while the GPU still has the
+    # binning and compositing queued.  A guess that was too small (never out of bounds, see envgs_raster.h) repeats R3-R6 with the exact size.
+    key = (dev.index, P, H, W)
+    guess = _N_GUESS.get(key) if SPECULATIVE_N["on"] else None
+    mirror = _n_mirror(dev)
+    if guess is None or P == 0:
+        n_host = _lib.c_uint32(0)
+        _lib.check(lib.envgs_raster_project(cfg, p(means3D), p(scales), p(rotations), p(opacities), p(shs), p(cov3D_precomp),
+                                            p(view), p(proj), p(campos), p(geom), p(rgb), p(clamped), p(radii), p(tiles),
+                                            p(offsets), p(scan_temp), scan_bytes, n_host, stream), "envgs_raster_project")
+        N = int(n_host.value)
+        bufs = bin_and_render(N, None)
+    else:
+        _lib.check(lib.envgs_raster_project(cfg, p(means3D), p(scales), p(rotations), p(opacities), p(shs), p(cov3D_precomp),
+                                            p(view), p(proj), p(campos), p(geom), p(rgb), p(clamped), p(radii), p(tiles),
+                                            p(offsets), p(scan_temp), scan_bytes, None, stream), "envgs_raster_project")
+        mirror["host"].copy_(offsets[P - 1:P], non_blocking=True)
+        mirror["event"].record(torch.cuda.current_stream(dev))
+        cap = guess
+        bufs = bin_and_render(cap, _lib.c_void_p(offsets[P - 1:P].data_ptr()))
+        mirror["event"].synchronize()                        # (the copy was queued BEFORE R3-R6: this does not wait for them)
+        N = int(mirror["host"][0]) & 0xFFFFFFFF
+        if N > cap:
+            LAST_STATS["n_guess_misses"] = LAST_STATS.get("n_guess_misses", 0) + 1
+            bufs = bin_and_render(N, None)
+    keys_u, keys_s, vals_u, point_list, cmask = bufs
+    # next capacity: 15 % above this count (64 k granularity), and not below 97 % of the previous capacity -- views alternate, scenes change slowly
+    _N_GUESS[key] = max(((max(int(N * 1.15), N + 4096) + 65535) // 65536) * 65536, int(0.97 * (guess or 0)))
+    LAST_STATS.update(N=N, P=P, H=H, W=W, C=C)
     saved = dict(cfg=cfg, N=N, geom=geom, colors=colors, bg=bg, point_list=point_list, ranges=ranges, final_T=final_T,
                  n_contrib=n_contrib, contrib_mask=cmask, means3D=means3D, scales=scales, rotations=rotations, shs=shs, clamped=clamped,
                  cov3D_precomp=cov3D_precomp, radii=radii, view=view, proj=proj, campos=campos)

@@ -79,8 +79,8 @@ ENVGS_API size_t envgs_raster_sort_temp_bytes(uint32_t N, int32_t width, int32_t
  * Exactly one of (scales, rotations) / transmat_precomp and one of shs / colours is used:
  *   shs == NULL  -> colours are the caller's colors_precomp (not touched here)
  *   shs != NULL  -> rgb (P,3) and clamped (P,3) uint8 are written
- * Writes the number of tile instances N to *num_rendered_host after synchronising `stream`
- * (the caller sizes the binning buffers with it).
+ * Writes the number of tile instances N to *num_rendered_host after synchronising `stream` (the caller sizes the binning buffers with
+ * it) -- or, with num_rendered_host == NULL, returns without a host sync: N is then offsets[P-1] on the device (see _bin_and_render).
  */
 ENVGS_API int envgs_raster_project(const envgs_raster_cfg *cfg,
                          const float *means3D, const float *scales, const float *rotations,
@@ -96,6 +96,10 @@ ENVGS_API int envgs_raster_project(const envgs_raster_cfg *cfg,
  * stable radix sort, per-tile ranges, front-to-back compositing of `channels` colours + the 7 allmap
  * channels + the per-surfel accumulated weight (the "-wet" output, gaussian2d_utils.py:1090,1114).
  * keys_sorted / point_list / ranges are outputs the backward pass (and the parity tests) read.
+ * num_rendered_dev (optional): when the caller did not wait for the instance count of _project (num_rendered_host == NULL there), N is a
+ * CAPACITY it chose for the N-sized buffers and num_rendered_dev = offsets + P - 1 points at the count on the device: the sort runs over N
+ * slots padded with keys that sort last, ranges are built from the real entries.  If the count turns out larger than N the outputs are
+ * invalid (nothing is written out of bounds) and the caller repeats the call with the exact size.  NULL: N is exact.
  * contrib_mask (N bytes, optional): for every tile instance (= entry of point_list) the set of 8x8 pixel quadrants of its tile in which
  * some pixel blended it (bit q = quadrant q; row-major 2x2).  Passed to envgs_raster_backward it lets the backward visit exactly the
  * (quadrant, entry) pairs the forward blended instead of re-deriving them geometrically (most candidates fail the alpha test everywhere).
@@ -107,7 +111,7 @@ ENVGS_API int envgs_raster_bin_and_render(const envgs_raster_cfg *cfg, uint32_t 
                                 uint64_t *keys_sorted, uint32_t *point_list,
                                 void *sort_temp, size_t sort_temp_bytes, uint32_t *ranges,
                                 float *out_color, float *allmap, float *final_T, int32_t *n_contrib,
-                                float *weight, uint8_t *contrib_mask, void *stream);
+                                float *weight, uint8_t *contrib_mask, const uint32_t *num_rendered_dev, void *stream);
 
 /*
  * Parity audit of stage R6 (tests only; no reference counterpart): the SAME compositing kernel, instantiated with one extra store --

@@ -283,6 +283,43 @@ def test_contribution_masks_are_exact_and_optional():
         raster.CONTRIB_MASK["on"] = True
 
 
+def test_speculative_instance_count_is_exact_and_recovers_from_a_small_guess():
+    """rasterize_forward sizes the binning buffers from the PREVIOUS call's instance count and reads this call's count only after R3-R6 are
+    queued (no host sync in front of them).  A capacity above the count must give bit-identical results (padding keys sort last), a capacity
+    below it must be noticed and repaired."""
+    from envgs_amd import raster
+    import diff_surfel_rasterization_wet as mod
+    dev = torch.device("cuda:0")
+    H, W = 128, 144
+    g, cam = small_scene(P=4000, H=H, W=W, seed=31, C=3, sh=True)
+    st = _settings(mod, cam, torch.rand(3), 3, dev)
+    gd = {k: v.to(dev) for k, v in g.items()}
+    args = (3, gd["means3D"], gd["shs"], None, gd["opacities"], gd["scales"], gd["rotations"], None, st)
+    key = (dev.index, 4000, H, W)
+
+    def run(guess):
+        if guess is None: raster._N_GUESS.pop(key, None)
+        else: raster._N_GUESS[key] = guess
+        outs, saved = raster.rasterize_forward(*args, keep_binning=True)
+        torch.cuda.synchronize()
+        N = saved["N"]
+        return N, [saved["keys_sorted"][:N].cpu(), saved["point_list"][:N].cpu(), saved["ranges"].cpu(), saved["n_contrib"].cpu(),
+                   outs[0].cpu(), outs[2].cpu(), saved["final_T"].cpu(), saved["contrib_mask"][:N].cpu()], saved
+    N0, ref, _ = run(None)                                  # first call of a shape: waits for the count (exact buffers)
+    assert N0 > 10000
+    misses = raster.LAST_STATS.get("n_guess_misses", 0)
+    N1, pad, saved = run(N0 + 70000)                         # capacity above the count: padded sort
+    assert N1 == N0 and saved["point_list"].numel() == N0 + 70000 and raster.LAST_STATS.get("n_guess_misses", 0) == misses
+    for a, b in zip(ref[:4], pad[:4]): assert torch.equal(a, b)
+    for a, b in zip(ref[4:7], pad[4:7]): assert torch.equal(a, b)           # same kernels on the same lists: bit-identical images
+    gb = raster.rasterize_backward(saved, torch.ones(3, H, W, device=dev), torch.zeros(7, H, W, device=dev))
+    assert torch.isfinite(gb["means3D"]).all() and float(gb["means3D"].abs().max()) > 0
+    N2, rep, saved2 = run(N0 // 2)                          # capacity below the count: detected, R3-R6 repeated with the exact size
+    assert N2 == N0 and raster.LAST_STATS.get("n_guess_misses", 0) == misses + 1 and saved2["point_list"].numel() == N0
+    for a, b in zip(ref[:7], rep[:7]): assert torch.equal(a, b)
+    assert raster._N_GUESS[key] >= N0                        # and the next call starts from a sufficient capacity
+
+
 def test_full_size_baseline_config_vs_oracle():
     """BASELINE configs[1] at full size: 300 k surfels, 800x800, SH degree 3 -- forward indices bit-exact,
     pixels and gradients within tolerance, plus size-independent properties (sortedness, range partition)."""
