@@ -11,6 +11,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/pmc_insts -o c -- $B --steps 3 --warmup 1 > /dev/null 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_active -o c -- $B --steps 3 --warmup 1 > /dev/null 2>&1
 cd $R
+python profiles/summarize.py r02 > /dev/null 2>&1     # the bench lines below quote the counters of THIS collection (profiles/r02_pmc_envgs.json)
 python bench.py > $O/bench_envgs_final.json 2> $O/bench_envgs_final.err
 python bench.py --caller reference --no-cpu-baseline > $O/bench_envgs_reference_caller_final.json 2> $O/bench_envgs_reference_caller_final.err
 python bench.py --caller twin --no-cpu-baseline > $O/bench_envgs_twin_caller_final.json 2> $O/bench_envgs_twin_caller_final.err

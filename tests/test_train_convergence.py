@@ -43,7 +43,10 @@ def _psnr(a, b):
     return -10.0 * math.log10(float(((a - b) ** 2).mean()) + 1e-12)
 
 
-def test_training_fits_ground_truth_renders():
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_training_fits_ground_truth_renders(storage):
+    """storage = f16: the feature arrays handed to both extensions are half copies of the fp32 parameters (BASELINE configs[4]'s storage variant;
+    fp32 arithmetic and gradients) -- the same fit must be reached."""
     import diff_surfel_rasterization_wet_ch05 as pkg
     import diff_surfel_tracing as tpkg
     dev = torch.device("cuda:0")
@@ -59,6 +62,7 @@ def test_training_fits_ground_truth_renders():
     deg = torch.tensor([2], device=dev)
     tracer = tpkg.SurfelTracer()
     envgs_step.FUSED["on"] = True
+    envgs_step.FEATURE_F16["on"] = storage == "f16"
     try:
         def render(base, env, v):
             return envgs_step.envgs_forward(pkg, tpkg, tracer, cams[v], rays[v], _act(base), _act(env), bg, env_bg, deg)
@@ -107,6 +111,7 @@ def test_training_fits_ground_truth_renders():
         psnr1, env1 = evaluate(), evaluate_env()
     finally:
         envgs_step.FUSED["on"] = False
+        envgs_step.FEATURE_F16["on"] = False
     first, last = sum(losses[:VIEWS * 2]) / (VIEWS * 2), sum(losses[-VIEWS * 2:]) / (VIEWS * 2)
     print("PSNR %.2f -> %.2f dB, loss %.4f -> %.4f" % (psnr0, psnr1, first, last))
     assert all(math.isfinite(l) for l in losses)
