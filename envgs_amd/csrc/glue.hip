@@ -320,6 +320,31 @@ surface_normal_bwd(int H, int W, float ratio, float fx, float fy, const float *_
     dallmap[6 * HW + p] = 0.f;
 }
 
+// get_disks (optix_utils.py:39-69): one lane per surfel, the four corners of its 3-sigma quad (+ the two triangles' indices)
+__global__ void __launch_bounds__(256)
+surfel_quads(int P, const float *__restrict__ means, const float *__restrict__ scales, const float *__restrict__ rots, float *__restrict__ v,
+             int32_t *__restrict__ f)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float r = rots[4 * i], x = rots[4 * i + 1], y = rots[4 * i + 2], z = rots[4 * i + 3];
+    const float inv = 1.0f / sqrtf(r * r + x * x + y * y + z * z);
+    r *= inv; x *= inv; y *= inv; z *= inv;
+    const float su = 3.0f * scales[2 * i], sv = 3.0f * scales[2 * i + 1];
+    const float a[3] = {(1.f - 2.f * (y * y + z * z)) * su, (2.f * (x * y + r * z)) * su, (2.f * (x * z - r * y)) * su};          // rotation column 0
+    const float b[3] = {(2.f * (x * y - r * z)) * sv, (1.f - 2.f * (x * x + z * z)) * sv, (2.f * (y * z + r * x)) * sv};          // rotation column 1
+    float *o = v + (size_t)i * 12;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float m = means[3 * i + c];
+        o[c] = m - a[c] + b[c]; o[3 + c] = m - a[c] - b[c]; o[6 + c] = m + a[c] + b[c]; o[9 + c] = m + a[c] - b[c];
+    }
+    if (f) {
+        int32_t *g = f + (size_t)i * 6;
+        g[0] = 4 * i; g[1] = 4 * i + 1; g[2] = 4 * i + 2; g[3] = 4 * i + 1; g[4] = 4 * i + 2; g[5] = 4 * i + 3;
+    }
+}
+
 }  // namespace envgs
 
 using namespace envgs;
@@ -387,6 +412,15 @@ int envgs_surface_normal_backward(int32_t H, int32_t W, float depth_ratio, float
     const int HW = H * W;
     hipLaunchKernelGGL(surface_normal_bwd, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, H, W, depth_ratio, fx, fy, viewmatrix,
                        allmap, dsurf_depth, dsurf_normal, dallmap);
+    return (int)hipGetLastError();
+}
+
+int envgs_surfel_quads(int32_t P, const float *means3D, const float *scales, const float *rotations, float *vertices, int32_t *faces, void *stream)
+{
+    if (P < 0) return ENVGS_ERR_BAD_ARG;
+    if (P == 0) return 0;
+    if (!means3D || !scales || !rotations || !vertices) return ENVGS_ERR_BAD_ARG;
+    hipLaunchKernelGGL(surfel_quads, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, means3D, scales, rotations, vertices, faces);
     return (int)hipGetLastError();
 }
 

@@ -131,8 +131,13 @@ def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree):
         scale_modifier=1.0, viewmatrix=cam.world_view_transform.contiguous(), projmatrix=cam.full_proj_transform.contiguous(),
         sh_degree=sh_degree, campos=cam.camera_center.contiguous(), prefiltered=False, debug=False, max_trace_depth=int(TRACE["depth"]),
         specular_threshold=float(TRACE["specular_threshold"]))
-    v, f = (synth.get_disks_reference_form if REFERENCE_FORMS["on"] else synth.get_disks)(env["means3D"], env["scales"], env["rotations"])
-    tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
+    if FUSED["on"] and not REFERENCE_FORMS["on"]:
+        from . import fused
+        v, f = fused.surfel_quads(env["means3D"], env["scales"], env["rotations"])          # one launch instead of ~25 torch kernels in front of the trace
+        tracer.build_acceleration_structure(v, f, rebuild=True)
+    else:
+        v, f = (synth.get_disks_reference_form if REFERENCE_FORMS["on"] else synth.get_disks)(env["means3D"], env["scales"], env["rotations"])
+        tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
     grads3D = torch.zeros_like(env["means3D"], requires_grad=True) + 0
     return tracer(ref_o.contiguous(), ref_d.contiguous(), v, means3D=env["means3D"].contiguous(), grads3D=grads3D,
                   shs=(env["shs"].half() if FEATURE_F16["on"] else env["shs"]).contiguous(), colors_precomp=None, others_precomp=env.get("others"), opacities=env["opacities"].contiguous(),

@@ -134,3 +134,28 @@ def surface_normal(allmap, cam, depth_ratio=0.0):
     fx = cam.image_width / (2.0 * math.tan(cam.FoVx / 2.0))
     fy = cam.image_height / (2.0 * math.tan(cam.FoVy / 2.0))
     return _SurfaceNormal.apply(allmap, cam.world_view_transform, fx, fy, depth_ratio)
+
+
+_FACES = {}
+
+
+def surfel_quads(means3D, scales, rotations):
+    """get_disks (optix_utils.py:39-69) in one launch: v (4P,3) f32, f (2P,3) i32.  No gradient flows through the quads (they only seed the
+    acceleration structure); the face table depends on P alone and is cached."""
+    lib = _lib.load()
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("envgs_amd.fused needs tensors on the GPU; there is no CPU path")
+    P = means3D.shape[0]
+    m, s, q = _f32c(means3D.detach()), _f32c(scales.detach()), _f32c(rotations.detach())
+    v = torch.empty(4 * P, 3, dtype=torch.float32, device=dev)
+    f = _FACES.get((dev.index, P))
+    fresh = f is None
+    if fresh:
+        f = _FACES[(dev.index, P)] = torch.empty(2 * P, 3, dtype=torch.int32, device=dev)
+        if len(_FACES) > 8:
+            _FACES.pop(next(iter(_FACES)))
+    p = _lib.ptr
+    _lib.check(lib.envgs_surfel_quads(P, p(m), p(s), p(q), p(v), p(f) if fresh else None, _stream(dev)), "envgs_surfel_quads")
+    return v, f
+

@@ -61,6 +61,15 @@ ENVGS_API int envgs_surface_normal_backward(int32_t H, int32_t W, float depth_ra
                                             const float *viewmatrix, const float *dsurf_depth, const float *dsurf_normal,
                                             float *dallmap, void *stream);
 
+/*
+ * The 3-sigma quads the reference hands to SurfelTracer.build_acceleration_structure (easyvolcap/utils/optix_utils.py:39-69, get_disks):
+ * vertices (4P,3) = mu + 3 (s_u a (-+) + s_v b (+-)) in the corner order (-,+) (-,-) (+,+) (+,-), a / b = columns 0 / 1 of the rotation of the
+ * NORMALISED quaternion; faces (2P,3) int32 = (4i, 4i+1, 4i+2), (4i+1, 4i+2, 4i+3) (may be NULL).  The reference builds them with ~25 torch
+ * kernels (a batched matmul among them) every training step, right in front of the trace; no gradient flows through them.
+ */
+ENVGS_API int envgs_surfel_quads(int32_t P, const float *means3D, const float *scales, const float *rotations, float *vertices, int32_t *faces,
+                                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,3 +108,19 @@ def test_surface_normal_matches_torch(ratio):
         err = (g1[ch][live] - g2[ch][live]).abs().max()
         assert float(err) <= 2e-4 * scale + 1e-6, (ch, float(err), scale)
     assert float(g1[[2, 3, 4, 6]].abs().max()) == 0 and float(g1[:2][:, ~live].abs().max()) == 0
+
+
+def test_surfel_quads_match_get_disks():
+    """fused.surfel_quads == the python get_disks twin (itself pinned against the reference's own output by tests/test_golden.py)."""
+    from envgs_amd import fused, synth
+    dev = torch.device("cuda:0")
+    e = synth.env_gaussians(5000, seed=3, device=dev)
+    q = e["rotations"] * (0.5 + torch.rand(5000, 1, device=dev))           # un-normalised quaternions, as the optimizer leaves them
+    v, f = fused.surfel_quads(e["means3D"], e["scales"], q)
+    v2, f2 = synth.get_disks(e["means3D"], e["scales"], q)
+    assert v.shape == v2.shape and f.shape == f2.shape and f.dtype == f2.dtype
+    assert torch.equal(f, f2)
+    assert float((v - v2).abs().max()) <= 2e-6 * float(v2.abs().max())
+    v3, f3 = fused.surfel_quads(e["means3D"], e["scales"], q)               # the cached face table
+    assert f3 is f and torch.equal(v3, v)
+
