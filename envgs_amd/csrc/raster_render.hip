@@ -100,11 +100,50 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float4 r0, const float4 
     const float mx = 0.05f + 1e-3f * (bx1 - bx0), my = 0.05f + 1e-3f * (by1 - by0);
     bx0 -= mx; bx1 += mx; by0 -= my; by1 += my;
     if (!(bx0 <= bx1 && by0 <= by1)) return 0xFu;       // NaN guard: never cull on garbage
+    // Beyond the box: the ellipse itself.  pp = k x l is LINEAR in the pixel, pp = x a + y b + c with a = Tv x Tw, b = Tw x Tu, so
+    // {rho3d <= tau} = {pp.x^2 + pp.y^2 - tau pp.z^2 <= 0} is a conic whose quadratic part (A00, A01, A11) does not depend on where the origin
+    // is put; with the origin at its centre (pxc, pyc) it reads  A00 x^2 + 2 A01 x y + A11 y^2 <= ex^2 det / A11  (ex = the half extent
+    // found above).  A long thin splat seen at an angle fills a small fraction of its box: most of the quadrants the box touches -- in most
+    // of the tiles the (square) binning radius assigned it to -- never see it.  The quadrant's pixel rect misses the ellipse iff the
+    // minimum of the form over the rect (the origin if inside, else on one of the four edges) exceeds the bound; 5 % and 0.05 px of margin.
+    const float ax = Tvy * Twz - Tvz * Twy, ay = Tvz * Twx - Tvx * Twz, az = Tvx * Twy - Tvy * Twx;
+    const float bxx = Twy * Tuz - Twz * Tuy, bxy = Twz * Tux - Twx * Tuz, bxz = Twx * Tuy - Twy * Tux;
+    const float A00 = ax * ax + ay * ay - tau * az * az, A11 = bxx * bxx + bxy * bxy - tau * bxz * bxz, A01 = ax * bxx + ay * bxy - tau * az * bxz;
+    const float det = A00 * A11 - A01 * A01;
+    // (the same bound follows from either extent, hx A00 = hy A11: a conic whose two closed forms disagree is not trusted, nor is anything NaN)
+    const bool conic = A00 > 0.0f && A11 > 0.0f && det > 1e-6f * A00 * A11 && hx > 0.0f && hy > 0.0f &&
+                       fabsf(hx * A00 - hy * A11) <= 0.02f * (hx * A00 + hy * A11);
+    const float bound = conic ? 1.05f * hx * det / A11 : 0.0f;
+    const float iA00 = conic ? 1.0f / A00 : 0.0f, iA11 = conic ? 1.0f / A11 : 0.0f;
     uint32_t m = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float qx = (float)(tile_px + (q & 1) * 8), qy = (float)(tile_py + (q >> 1) * 8);
-        if (bx0 <= qx + 7.0f && bx1 >= qx && by0 <= qy + 7.0f && by1 >= qy) m |= 1u << q;
+        if (!(bx0 <= qx + 7.0f && bx1 >= qx && by0 <= qy + 7.0f && by1 >= qy)) continue;
+        bool hit = true;
+        if (conic) {
+            // the low-pass disc of radius r2d around (cx, cy)
+            const float ddx = fmaxf(fmaxf(qx - cx, cx - (qx + 7.0f)), 0.0f), ddy = fmaxf(fmaxf(qy - cy, cy - (qy + 7.0f)), 0.0f);
+            const bool disc = ddx * ddx + ddy * ddy <= (r2d + 0.05f) * (r2d + 0.05f);
+            // the ellipse, in coordinates relative to its centre
+            const float x0 = qx - 0.05f - pxc, x1 = qx + 7.05f - pxc, y0 = qy - 0.05f - pyc, y1 = qy + 7.05f - pyc;
+            bool ell = x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f;
+            if (!ell) {
+                float fmin = 3.0e38f;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const float yy = e ? y1 : y0;                                  // horizontal edges: minimise over x
+                    const float xs = fminf(fmaxf(-A01 * yy * iA00, x0), x1);
+                    fmin = fminf(fmin, (A00 * xs + 2.0f * A01 * yy) * xs + A11 * yy * yy);
+                    const float xx = e ? x1 : x0;                                  // vertical edges: minimise over y
+                    const float ys = fminf(fmaxf(-A01 * xx * iA11, y0), y1);
+                    fmin = fminf(fmin, (A11 * ys + 2.0f * A01 * xx) * ys + A00 * xx * xx);
+                }
+                ell = fmin <= bound;
+            }
+            hit = disc || ell || !(bound == bound);
+        }
+        if (hit) m |= 1u << q;
     }
     return m;
 }
@@ -113,7 +152,7 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float4 r0, const float4 
 // AUDIT = true is the parity-audit instantiation of the SAME kernel (envgs_raster_render_audit): it additionally records, per pixel and
 // list entry, whether the entry was blended (contrib[pid][entry] = 1), so that tests can compare contributor SETS with the oracle.
 template <int C, bool AUDIT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 5)
 composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list,
               const float *__restrict__ geom, const Feat colors, const float *__restrict__ bg,
               float *__restrict__ out_color, float *__restrict__ allmap, float *__restrict__ final_T,
@@ -394,7 +433,7 @@ __device__ __forceinline__ void composite_bwd_tile(TileLds<C, BWD_BATCH> &lds, f
 }
 
 template <int C>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list,
               const float *__restrict__ geom, const Feat colors, const float *__restrict__ bg,
               const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
