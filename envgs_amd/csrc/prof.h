@@ -18,4 +18,10 @@ struct ProfScope {
 };
 // Process-global diagnostic switches (envgs_debug_set, include/envgs_raster.h); 0 = production.  The library never reads the environment.
 int debug_switch(int which);
+// Zero up to ZERO_MAX float buffers in ONE launch (the tracer backward clears eleven gradient outputs: as hipMemsetAsync calls that is eleven
+// fill kernels and eleven launch gaps in front of its first kernel).
+constexpr int ZERO_MAX = 12;
+struct ZeroBatch { float *ptr[ZERO_MAX]; unsigned long long n[ZERO_MAX]; int count; };
+int launch_zero_many(const ZeroBatch &b, hipStream_t stream);
+
 }  // namespace envgs

@@ -48,6 +48,20 @@ void prof_end(int id, hipStream_t stream)
     (void)hipEventRecord(g_open[id].back().b, stream);
     g_has_cur[id] = false;
 }
+__global__ void __launch_bounds__(256) zero_many(const ZeroBatch b)
+{
+    float *p = b.ptr[blockIdx.y];
+    const unsigned long long n = b.n[blockIdx.y];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) p[i] = 0.f;
+}
+
+int launch_zero_many(const ZeroBatch &b, hipStream_t stream)
+{
+    if (b.count <= 0) return 0;
+    hipLaunchKernelGGL(zero_many, dim3(512, b.count), dim3(256), 0, stream, b);
+    return (int)hipGetLastError();
+}
+
 }  // namespace envgs
 
 using namespace envgs;

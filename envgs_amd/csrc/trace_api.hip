@@ -80,17 +80,21 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     hipStream_t stream = (hipStream_t)stream_;
     envgs_raster_cfg dbg; dbg.debug = cfg->debug;
     const envgs_raster_cfg *dcfg = &dbg;
-    hipError_t e = hipMemsetAsync(counters, 0, 96 * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return (int)e;
+    hipError_t e;
+    {   // counters, wet, mid and (list path) the per-surfel accumulators: one launch instead of four fills
+        ZeroBatch zb; zb.count = 0;
+        zb.ptr[zb.count] = reinterpret_cast<float *>(counters); zb.n[zb.count++] = 96;
+        if (cfg->P > 0) { zb.ptr[zb.count] = wet; zb.n[zb.count++] = (unsigned long long)cfg->P; }
+        zb.ptr[zb.count] = mid; zb.n[zb.count++] = (unsigned long long)cfg->num_rays * MID * (cfg->max_trace_depth + 1);
+        if (lists_usable(cfg, L)) { zb.ptr[zb.count] = reinterpret_cast<float *>(L->surf_acc); zb.n[zb.count++] = (unsigned long long)cfg->P * NCOPY * 2; }
+        const int rcz = launch_zero_many(zb, stream);
+        if (rcz) return rcz;
+    }
     if (cfg->P > 0) {
-        e = hipMemsetAsync(wet, 0, sizeof(float) * (size_t)cfg->P, stream);
-        if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(make_surfel_records, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, cfg->scale_modifier,
                            means3D, scales, rotations, opacities, srec);
         ENVGS_CHECK_LAUNCH(dcfg, stream);
     }
-    e = hipMemsetAsync(mid, 0, sizeof(float) * (size_t)cfg->num_rays * MID * (cfg->max_trace_depth + 1), stream);
-    if (e != hipSuccess) return (int)e;
     TraceArgs A;
     A = TraceArgs{};
     A.P = cfg->P; A.R = cfg->num_rays; A.D = cfg->sh_degree; A.M = cfg->sh_coeffs; A.ND = cfg->max_trace_depth + 1;
@@ -125,8 +129,6 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             while ((1ll << ib) <= (long long)cfg->num_rays) ib++;
             A.wfrac = 40 - ib > 30 ? 30 : 40 - ib;
         }
-        e = hipMemsetAsync(L->surf_acc, 0, sizeof(unsigned long long) * (size_t)cfg->P * NCOPY, stream);
-        if (e != hipSuccess) return (int)e;
         A.state = (float4 *)L->hit_state; A.entries = (unsigned long long *)L->entries; A.pairs = L->pairs; A.n_entries = L->n_entries;
         if (L->sh_perm && shs && cfg->sh_coeffs == 16) {
             const size_t nw = (size_t)cfg->P * 48;
@@ -242,11 +244,16 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     const envgs_raster_cfg *dcfg = &dbg;
     const size_t P = (size_t)cfg->P, R = (size_t)cfg->num_rays;
     hipError_t e;
-#define ZERO(ptr, n) do { if ((ptr) && (n) > 0) { e = hipMemsetAsync((ptr), 0, sizeof(float) * (n), stream); if (e != hipSuccess) return (int)e; } } while (0)
-    ZERO(geo_rec, P * ENVGS_GEOREC_STRIDE); ZERO(dmeans3D, P * 3); ZERO(dgrads3D, P * 3); ZERO(dscales, P * 2); ZERO(drots, P * 4);
-    ZERO(dopacities, P); ZERO(dothers, P * 2); ZERO(dray_o, R * 3); ZERO(dray_d, R * 3);
-    if (cfg->sh_coeffs > 0) ZERO(dshs, P * cfg->sh_coeffs * 3); else ZERO(dcolors, P * 3);
+    {
+        ZeroBatch zb; zb.count = 0;
+#define ZERO(buf_, nn) do { if ((buf_) && (nn) > 0) { zb.ptr[zb.count] = (buf_); zb.n[zb.count] = (unsigned long long)(nn); zb.count++; } } while (0)
+        ZERO(geo_rec, P * ENVGS_GEOREC_STRIDE); ZERO(dmeans3D, P * 3); ZERO(dgrads3D, P * 3); ZERO(dscales, P * 2); ZERO(drots, P * 4);
+        ZERO(dopacities, P); ZERO(dothers, P * 2); ZERO(dray_o, R * 3); ZERO(dray_d, R * 3);
+        if (cfg->sh_coeffs > 0) ZERO(dshs, P * cfg->sh_coeffs * 3); else ZERO(dcolors, P * 3);
 #undef ZERO
+        const int rcz = launch_zero_many(zb, stream);              // one launch instead of eleven fills
+        if (rcz) return rcz;
+    }
     if (cfg->num_rays == 0 || cfg->P == 0) return 0;
     if (!nodes || !ray_o || !ray_d || !srec || !counters || !rgb || !dpt || !acc || !norm || !aux || !final_T || !dL_drgb || !dL_ddpt ||
         !dL_dacc || !dL_dnorm || !dL_daux || !geo_rec || !dmeans3D || !dscales || !drots || !dopacities || !dray_o || !dray_d || !rotations || !bg)
