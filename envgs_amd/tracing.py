@@ -331,10 +331,12 @@ class SurfelTracer(nn.Module):
             raise RuntimeError("vertices must be (4P,3) in the get_disks layout, got %s" % (tuple(vertices.shape),))
         if vertices.device.type != "cuda":
             raise RuntimeError("envgs_amd tracer needs tensors on the GPU (got %s); there is no CPU path" % vertices.device)
-        if rebuild or (self.nodes is None and self._pending is None):
-            self._pending = vertices.detach()
-            self.nodes = None
-            self.num_surfels = vertices.shape[0] // 4
+        # rebuild=False is OptiX's "update" (refit the boxes of the existing topology to the new vertices).  Hit sets do not depend on the
+        # topology, a full LBVH build is 0.2 ms at 164 k surfels, and a stale structure would be silently wrong -- so an update request
+        # rebuilds as well (the reference itself only ever passes rebuild=True: optix_utils.py:78).
+        self._pending = vertices.detach()
+        self.nodes = None
+        self.num_surfels = vertices.shape[0] // 4
 
     def forward(self, ray_o, ray_d, v=None, *, means3D, grads3D=None, shs=None, colors_precomp=None, others_precomp=None,
                 opacities=None, scales=None, rotations=None, cov3D_precomp=None, tracer_settings=None, start_from_first=True):

@@ -513,6 +513,35 @@ def test_trace_forward_is_independent_of_the_traversal_interleaving():
             assert torch.equal(a, b)
 
 
+def test_trace_update_request_follows_the_new_vertices():
+    """build_acceleration_structure(..., rebuild=False) is OptiX's update: the structure must follow the moved surfels (a stale one would be
+    silently wrong).  The result equals a fresh tracer's."""
+    import diff_surfel_tracing as mod
+    dev = torch.device("cuda:0")
+    P, R = 4000, 2048
+    e = synth.env_gaussians(P, seed=7, device=dev)
+    gen = torch.Generator().manual_seed(3)
+    ro = ((torch.rand(R, 3, generator=gen) * 2 - 1) * 1.3).to(dev)
+    rd = torch.randn(R, 3, generator=gen); rd = (rd / rd.norm(dim=-1, keepdim=True)).to(dev)
+    st = _settings(mod, torch.zeros(3), 3, dev)
+
+    def trace(tracer, means, rebuild):
+        v, f = synth.get_disks(means, e["scales"] * 0.4, e["rotations"])
+        tracer.build_acceleration_structure(v, f, rebuild=rebuild)
+        with torch.no_grad():
+            return tracer(ro, rd, v, means3D=means, grads3D=None, shs=e["shs"], colors_precomp=None, others_precomp=None, opacities=e["opacities"],
+                          scales=e["scales"] * 0.4, rotations=e["rotations"], cov3D_precomp=None, tracer_settings=st, start_from_first=False)
+    m0 = e["means3D"] * 0.1
+    m1 = m0 + 0.5 * torch.randn_like(m0)
+    t = mod.SurfelTracer()
+    a0 = trace(t, m0, True)
+    a1 = trace(t, m1, False)                       # update request with moved surfels
+    b1 = trace(mod.SurfelTracer(), m1, True)
+    assert float(a1[2].mean()) > 0.05 and not torch.equal(a0[0], a1[0])
+    for x, y in zip(a1, b1):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("P,R", [(50, 0), (0, 64), (0, 0), (1, 64)])
 def test_trace_empty_inputs(P, R):
     """No rays, no surfels, neither, and a single surfel: shapes follow the inputs, an empty scene renders the background, backward runs."""
