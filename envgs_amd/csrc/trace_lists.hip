@@ -389,17 +389,14 @@ register_hits(const TraceArgs A)
                     if (old == -1 || old == (int)e[j].y) { ok = true; break; }
                     h = (h + 1) & (RH_TAB - 1);
                 }
-                unsigned x = 0xFFFFFFFFu;
                 if (ok) {
-                    const unsigned rank = (unsigned)(atomicAdd(&acc[h], (wq << 8) | 1ull) & 0xFFull);
-                    x = (h << 8) | rank;                                  // rank < 64: a ray meets a planar surfel once
+                    atomicAdd(&acc[h], (wq << 8) | 1ull);                 // (no return value needed: the pairs get their ranks in the last phase)
                 } else {                                                  // table full around h: an entry of its own
                     const unsigned long long old = atomicAdd(A.surf_acc + (size_t)e[j].y * NCOPY + copy, (wq << 24) | 1ull);
                     const unsigned f = atomicAdd(&nfail, 1u);
                     if (ent) ent[region - 1 - f] = (unsigned long long)e[j].y | ((old & 0xFFFFFFull) << 32);
                     if (prs) prs[region - 1 - f] = ((unsigned)lane << 16) | (unsigned)k;
                 }
-                list[k].x = x;
             }
         }
         __syncthreads();
@@ -429,16 +426,31 @@ register_hits(const TraceArgs A)
         }
         __syncthreads();
         if (prs) {
+            // Every hit finds its surfel's table slot again (the same probe sequence; hits that found no room fail again and were filed in
+            // the first phase) and takes the next free position of that surfel's run of pairs: acc[h] holds the run's offset in its low word
+            // and hands out ranks from its high word.  (Writing slot and rank back into the list in the first phase instead cost a scattered
+            // 4 B store -- a whole 32 B sector of write traffic -- and a second gather per hit: 2 GB per step.)
             constexpr int U2 = 4;                               // independent loads first: one memory round trip per 4 hits, not per hit
             for (int kb = part; kb < n; kb += U2 * RH_W) {
-                unsigned x[U2];
+                unsigned sidv[U2];
 #pragma unroll
-                for (int j = 0; j < U2; j++) { const int k = kb + j * RH_W; x[j] = (k < n) ? list[k].x : 0xFFFFFFFFu; }
+                for (int j = 0; j < U2; j++) { const int k = kb + j * RH_W; sidv[j] = (k < n) ? list[k].y : 0xFFFFFFFFu; }
 #pragma unroll
                 for (int j = 0; j < U2; j++)
-                    if (x[j] != 0xFFFFFFFFu) {
-                        const unsigned idx = (unsigned)acc[x[j] >> 8] + (x[j] & 255u), v = ((unsigned)lane << 16) | (unsigned)(kb + j * RH_W);
-                        if (idx < (unsigned)RH_STAGE) pstage[idx] = v; else prs[idx] = v;
+                    if (sidv[j] != 0xFFFFFFFFu) {
+                        unsigned h = (sidv[j] * 2654435761u) >> 22;
+                        bool ok = false;
+                        for (int t = 0; t < 24; t++) {
+                            const int kk = key[h];
+                            if (kk == (int)sidv[j]) { ok = true; break; }
+                            if (kk == -1) break;
+                            h = (h + 1) & (RH_TAB - 1);
+                        }
+                        if (ok) {
+                            const unsigned long long o = atomicAdd(&acc[h], 1ull << 32);
+                            const unsigned idx = (unsigned)o + (unsigned)(o >> 32), v = ((unsigned)lane << 16) | (unsigned)(kb + j * RH_W);
+                            if (idx < (unsigned)RH_STAGE) pstage[idx] = v; else prs[idx] = v;
+                        }
                     }
             }
             __syncthreads();
