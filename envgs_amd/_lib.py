@@ -69,6 +69,8 @@ SYMBOLS = {
     "envgs_sh_colors_forward": (c_int, [ctypes.c_int32] * 4 + [_P] * 7 + [_P]),
     "envgs_sh_colors_backward": (c_int, [ctypes.c_int32] * 4 + [_P] * 9 + [_P]),
     "envgs_surfel_quads": (c_int, [ctypes.c_int32] + [_P] * 5 + [_P]),
+    "envgs_blend_forward": (c_int, [ctypes.c_int32] * 3 + [_P] * 3 + [_P]),
+    "envgs_blend_backward": (c_int, [ctypes.c_int32] * 3 + [_P] * 5 + [_P]),
     "envgs_reflect_forward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float] + [_P] * 8 + [_P]),
     "envgs_reflect_backward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float] + [_P] * 11 + [_P]),
     "envgs_surface_normal_forward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float] + [_P] * 4 + [_P]),

@@ -345,6 +345,40 @@ surfel_quads(int P, const float *__restrict__ means, const float *__restrict__ s
     }
 }
 
+// rgb = (1 - s) img[:3] + s rgb_env, one lane per pixel (img is channel-major, rgb_env / rgb pixel-major)
+__global__ void __launch_bounds__(256)
+blend_fwd(int HW, int C, const float *__restrict__ img, const float *__restrict__ env, float *__restrict__ rgb)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int S = C - 4;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float s = img[(size_t)(3 + (S == 3 ? c : 0)) * HW + p];
+        rgb[(size_t)p * 3 + c] = (1.0f - s) * img[(size_t)c * HW + p] + s * env[(size_t)p * 3 + c];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+blend_bwd(int HW, int C, const float *__restrict__ img, const float *__restrict__ env, const float *__restrict__ g, float *__restrict__ dimg,
+          float *__restrict__ denv)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int S = C - 4;
+    float ds[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int sc = S == 3 ? c : 0;
+        const float s = img[(size_t)(3 + sc) * HW + p], gc = g[(size_t)p * 3 + c];
+        dimg[(size_t)c * HW + p] = (1.0f - s) * gc;
+        if (denv) denv[(size_t)p * 3 + c] = s * gc;
+        ds[sc] += (env[(size_t)p * 3 + c] - img[(size_t)c * HW + p]) * gc;
+    }
+    for (int sc = 0; sc < S; sc++) dimg[(size_t)(3 + sc) * HW + p] = ds[sc];
+    dimg[(size_t)(C - 1) * HW + p] = 0.f;
+}
+
 }  // namespace envgs
 
 using namespace envgs;
@@ -421,6 +455,23 @@ int envgs_surfel_quads(int32_t P, const float *means3D, const float *scales, con
     if (P == 0) return 0;
     if (!means3D || !scales || !rotations || !vertices) return ENVGS_ERR_BAD_ARG;
     hipLaunchKernelGGL(surfel_quads, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, means3D, scales, rotations, vertices, faces);
+    return (int)hipGetLastError();
+}
+
+int envgs_blend_forward(int32_t H, int32_t W, int32_t channels, const float *img, const float *rgb_env, float *rgb, void *stream)
+{
+    if (H <= 0 || W <= 0 || (channels != 5 && channels != 7) || !img || !rgb_env || !rgb) return ENVGS_ERR_BAD_ARG;
+    const int HW = H * W;
+    hipLaunchKernelGGL(blend_fwd, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, HW, channels, img, rgb_env, rgb);
+    return (int)hipGetLastError();
+}
+
+int envgs_blend_backward(int32_t H, int32_t W, int32_t channels, const float *img, const float *rgb_env, const float *drgb, float *dimg,
+                         float *drgb_env, void *stream)
+{
+    if (H <= 0 || W <= 0 || (channels != 5 && channels != 7) || !img || !rgb_env || !drgb || !dimg) return ENVGS_ERR_BAD_ARG;
+    const int HW = H * W;
+    hipLaunchKernelGGL(blend_bwd, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, HW, channels, img, rgb_env, drgb, dimg, drgb_env);
     return (int)hipGetLastError();
 }
 

@@ -68,7 +68,7 @@ def base_pass(pkg, cam, base, bg, sh_degree, scale_modifier=1.0):
     S = img.shape[0] - 4                         # specular channels: 1 (-ch05) or 3 (-ch07)
     if FUSED["on"]:
         return dict(rgb=img[:3], spec=img[3:3 + S], rough=img[3 + S:4 + S], alpha=allmap[1:2], radii=radii, weight=weight, means2D=means2D,
-                    allmap=allmap)
+                    allmap=allmap, img=img)
     alpha = allmap[1:2]
     # view -> world, the reference's own expression (gaussian2d_utils.py:1123)
     normal = (allmap[2:5].permute(1, 2, 0) @ (cam.world_view_transform[:3, :3].T)).permute(2, 0, 1)
@@ -155,8 +155,7 @@ def envgs_forward(pkg, tpkg, tracer, cam, rays, base, env, bg, env_bg, sh_degree
         nw, dep, ref_o, ref_d = fused.reflect(b["allmap"], ray_o, ray_d, cam.world_view_transform, 0.0)
         b["normal"], b["depth"] = nw, dep
         rgb_env, dpt, acc, norm, dist, aux, mid, wet = env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree)
-        spec = b["spec"].permute(1, 2, 0)
-        rgb = (1 - spec) * b["rgb"].permute(1, 2, 0) + spec * rgb_env
+        rgb = fused.blend(b["img"], rgb_env)          # (1 - spec) * rgb_base + spec * rgb_env without slicing the rasterizer's output
         return dict(rgb=rgb, base=b, rgb_env=rgb_env, env_wet=wet, ref_o=ref_o, ref_d=ref_d)
     if REFERENCE_FORMS["on"]:                                      # render() always builds these (gaussian2d_utils.py:1125-1142); the supervisor consumes them
         b["surf_depth"], b["surf_normal"] = surface_maps(cam, b["allmap"], 0.0)

@@ -159,3 +159,36 @@ def surfel_quads(means3D, scales, rotations):
     _lib.check(lib.envgs_surfel_quads(P, p(m), p(s), p(q), p(v), p(f) if fresh else None, _stream(dev)), "envgs_surfel_quads")
     return v, f
 
+
+class _Blend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, rgb_env):
+        lib = _lib.load()
+        if img.device.type != "cuda":
+            raise RuntimeError("envgs_amd.fused needs tensors on the GPU; there is no CPU path")
+        img, rgb_env = _f32c(img), _f32c(rgb_env)
+        C, H, W = img.shape
+        rgb = torch.empty(H, W, 3, dtype=torch.float32, device=img.device)
+        p = _lib.ptr
+        _lib.check(lib.envgs_blend_forward(H, W, C, p(img), p(rgb_env), p(rgb), _stream(img.device)), "envgs_blend_forward")
+        ctx.save_for_backward(img, rgb_env)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        img, rgb_env = ctx.saved_tensors
+        C, H, W = img.shape
+        g = _f32c(g)
+        dimg = torch.empty_like(img)
+        denv = torch.empty_like(rgb_env) if ctx.needs_input_grad[1] else None
+        p = _lib.ptr
+        _lib.check(lib.envgs_blend_backward(H, W, C, p(img), p(rgb_env), p(g), p(dimg), p(denv), _stream(img.device)), "envgs_blend_backward")
+        return dimg, denv
+
+
+def blend(img, rgb_env):
+    """(1 - s) * img[:3] + s * rgb_env  (H,W,3) from the -ch05 / -ch07 rasterizer output img (C,H,W) = [rgb | specular C-4 | roughness] and the
+    traced colour rgb_env (H,W,3): envgs_sampler.py:474, one launch each way instead of ~20 (include/envgs_glue.h)."""
+    return _Blend.apply(img, rgb_env)
+

@@ -70,6 +70,17 @@ ENVGS_API int envgs_surface_normal_backward(int32_t H, int32_t W, float depth_ra
 ENVGS_API int envgs_surfel_quads(int32_t P, const float *means3D, const float *scales, const float *rotations, float *vertices, int32_t *faces,
                                  void *stream);
 
+/*
+ * The specular blend that closes an EnvGS forward (easyvolcap/models/samplers/envgs_sampler.py:474 with the channel layout of
+ * gaussian2d_utils.py:1119-1144): img (C,H,W) is the -ch05 / -ch07 rasterizer output [rgb 3 | specular S = C-4 | roughness 1], rgb_env (H,W,3)
+ * the traced colour;  rgb (H,W,3) = (1 - s) * img[:3] + s * rgb_env  with s = the specular channel (S = 1: shared by the three colours,
+ * S = 3: per colour).  The torch form is three slices of `img`, four elementwise kernels and, in the backward, the slices' scatter-adds into a
+ * zero image: ~20 launches; here one each way.  dimg (C,H,W) is fully written (zeros in the roughness channel).
+ */
+ENVGS_API int envgs_blend_forward(int32_t H, int32_t W, int32_t channels, const float *img, const float *rgb_env, float *rgb, void *stream);
+ENVGS_API int envgs_blend_backward(int32_t H, int32_t W, int32_t channels, const float *img, const float *rgb_env, const float *drgb,
+                                   float *dimg, float *drgb_env, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,3 +124,25 @@ def test_surfel_quads_match_get_disks():
     v3, f3 = fused.surfel_quads(e["means3D"], e["scales"], q)               # the cached face table
     assert f3 is f and torch.equal(v3, v)
 
+
+@pytest.mark.parametrize("C", [5, 7])
+def test_blend_matches_torch(C):
+    """fused.blend == (1 - spec) * rgb_base + spec * rgb_env on slices of the rasterizer's output, values and both gradients."""
+    from envgs_amd import fused
+    dev = torch.device("cuda:0")
+    H, W, S = 37, 53, C - 4
+    gen = torch.Generator().manual_seed(4)
+    img = torch.rand(C, H, W, generator=gen).to(dev).requires_grad_(True)
+    env = torch.rand(H, W, 3, generator=gen).to(dev).requires_grad_(True)
+    up = torch.randn(H, W, 3, generator=gen).to(dev)
+    out = fused.blend(img, env)
+    (out * up).sum().backward()
+    gi, ge = img.grad.clone(), env.grad.clone()
+    img.grad = None; env.grad = None
+    spec = img[3:3 + S].permute(1, 2, 0)
+    ref = (1 - spec) * img[:3].permute(1, 2, 0) + spec * env
+    (ref * up).sum().backward()
+    assert float((out - ref).abs().max()) <= 1e-6
+    assert float((gi - img.grad).abs().max()) <= 1e-5 * float(img.grad.abs().max()) and float((ge - env.grad).abs().max()) <= 1e-6
+    assert float(gi[C - 1].abs().max()) == 0.0
+
