@@ -1,6 +1,7 @@
 // glue.hip -- fused caller-side glue (include/envgs_glue.h): per-surfel SH -> colour channels and per-pixel reflected-ray
 // construction, forward and backward, one HBM pass each (the reference spends ~125 torch launches on the same expressions).
 #include "common.h"
+#include <cstdint>
 
 #include "../../include/envgs_glue.h"
 
@@ -117,6 +118,104 @@ sh_colors_bwd(int P, int D, int M, int S, const float *__restrict__ means, const
     dmeans[3 * i + 2] = (-dx * dz * ddx - dy * dz * ddy + (sum2 - dz * dz) * ddz) * inv3;
     for (int s = 0; s < S; s++) dspec[(size_t)i * S + s] = g[3 + s];
     drough[i] = g[3 + S];
+}
+
+// The same two kernels for the usual 16-coefficient layout, FOUR LANES PER SURFEL: with one lane per surfel every 4 B access of the 192 B
+// SH / gradient block touches 64 different cache lines per instruction (48 such loads and 48 such stores per lane: 0.9 TB/s measured); here
+// lane q of a quad owns coefficients 4q .. 4q+3 = 48 contiguous bytes (three 16 B accesses), the quad covers the block, and the per-surfel sums
+// are reduced inside the quad with DPP.
+template <int CTRL> __device__ __forceinline__ float quad_xchg(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+__device__ __forceinline__ float quad_sum(float v) { v += quad_xchg<0xB1>(v); v += quad_xchg<0x4E>(v); return v; }
+
+__global__ void __launch_bounds__(256)
+sh_colors_fwd_q16(int P, int D, int S, const float *__restrict__ means, const float *__restrict__ shs, const float *__restrict__ campos,
+                  const float *__restrict__ spec, const float *__restrict__ rough, float *__restrict__ colors, uint8_t *__restrict__ clamped)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, i = t >> 2, q = t & 3;
+    const bool live = i < P;
+    const int ii = live ? i : 0;
+    const int C = 3 + S + 1;
+    const float dx = means[3 * ii] - campos[0], dy = means[3 * ii + 1] - campos[1], dz = means[3 * ii + 2] - campos[2];
+    const float il = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    float b[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) b[k] = 0.f;
+    basis16(D, dx * il, dy * il, dz * il, b);
+    const int nb = (D + 1) * (D + 1);
+    float bq[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const float v = q == 0 ? b[m] : q == 1 ? b[4 + m] : q == 2 ? b[8 + m] : b[12 + m];
+        bq[m] = (4 * q + m) < nb ? v : 0.f;
+    }
+    const float4 *sh4 = reinterpret_cast<const float4 *>(shs + (size_t)ii * 48) + 3 * q;
+    const float4 x0 = sh4[0], x1 = sh4[1], x2 = sh4[2];
+    const float x[12] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
+    float r[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < 12; f++) r[f % 3] += bq[f / 3] * x[f];
+    const float r0 = quad_sum(r[0]) + 0.5f, r1 = quad_sum(r[1]) + 0.5f, r2 = quad_sum(r[2]) + 0.5f;
+    if (live && q == 0) {
+        clamped[3 * i] = r0 < 0.f; clamped[3 * i + 1] = r1 < 0.f; clamped[3 * i + 2] = r2 < 0.f;
+        float *o = colors + (size_t)i * C;
+        o[0] = fmaxf(r0, 0.f); o[1] = fmaxf(r1, 0.f); o[2] = fmaxf(r2, 0.f);
+        for (int s2 = 0; s2 < S; s2++) o[3 + s2] = spec[(size_t)i * S + s2];
+        o[3 + S] = rough[i];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sh_colors_bwd_q16(int P, int D, int S, const float *__restrict__ means, const float *__restrict__ shs, const float *__restrict__ campos,
+                  const uint8_t *__restrict__ clamped, const float *__restrict__ dcolors, float *__restrict__ dmeans, float *__restrict__ dshs,
+                  float *__restrict__ dspec, float *__restrict__ drough)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, i = t >> 2, q = t & 3;
+    const bool live = i < P;
+    const int ii = live ? i : 0;
+    const int C = 3 + S + 1;
+    const float *g = dcolors + (size_t)ii * C;
+    const float g0 = clamped[3 * ii] ? 0.f : g[0], g1 = clamped[3 * ii + 1] ? 0.f : g[1], g2 = clamped[3 * ii + 2] ? 0.f : g[2];
+    const float gc[3] = {g0, g1, g2};
+    const float dx = means[3 * ii] - campos[0], dy = means[3 * ii + 1] - campos[1], dz = means[3 * ii + 2] - campos[2];
+    const float sum2 = dx * dx + dy * dy + dz * dz, il = 1.0f / sqrtf(sum2);
+    const float x = dx * il, y = dy * il, z = dz * il;
+    float b[16], gx[16], gy[16], gz[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) b[k] = 0.f;
+    basis16(D, x, y, z, b);
+    basis16_grad(D, x, y, z, gx, gy, gz);
+    const int nb = (D + 1) * (D + 1);
+    float bq[4], gxq[4], gyq[4], gzq[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const bool in = (4 * q + m) < nb;
+        bq[m] = in ? (q == 0 ? b[m] : q == 1 ? b[4 + m] : q == 2 ? b[8 + m] : b[12 + m]) : 0.f;
+        gxq[m] = in ? (q == 0 ? gx[m] : q == 1 ? gx[4 + m] : q == 2 ? gx[8 + m] : gx[12 + m]) : 0.f;
+        gyq[m] = in ? (q == 0 ? gy[m] : q == 1 ? gy[4 + m] : q == 2 ? gy[8 + m] : gy[12 + m]) : 0.f;
+        gzq[m] = in ? (q == 0 ? gz[m] : q == 1 ? gz[4 + m] : q == 2 ? gz[8 + m] : gz[12 + m]) : 0.f;
+    }
+    const float4 *sh4 = reinterpret_cast<const float4 *>(shs + (size_t)ii * 48) + 3 * q;
+    const float4 x0 = sh4[0], x1 = sh4[1], x2 = sh4[2];
+    const float xs[12] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
+    float o[12], sd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < 12; f++) { o[f] = bq[f / 3] * gc[f % 3]; sd[f / 3] += xs[f] * gc[f % 3]; }
+    if (live) {
+        float4 *d4 = reinterpret_cast<float4 *>(dshs + (size_t)i * 48) + 3 * q;
+        d4[0] = make_float4(o[0], o[1], o[2], o[3]); d4[1] = make_float4(o[4], o[5], o[6], o[7]); d4[2] = make_float4(o[8], o[9], o[10], o[11]);
+    }
+    float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; m++) { ddx += gxq[m] * sd[m]; ddy += gyq[m] * sd[m]; ddz += gzq[m] * sd[m]; }
+    ddx = quad_sum(ddx); ddy = quad_sum(ddy); ddz = quad_sum(ddz);
+    if (live && q == 0) {
+        const float inv3 = il * il * il;
+        dmeans[3 * i] = ((sum2 - dx * dx) * ddx - dy * dx * ddy - dz * dx * ddz) * inv3;
+        dmeans[3 * i + 1] = (-dx * dy * ddx + (sum2 - dy * dy) * ddy - dz * dy * ddz) * inv3;
+        dmeans[3 * i + 2] = (-dx * dz * ddx - dy * dz * ddy + (sum2 - dz * dz) * ddz) * inv3;
+        for (int s2 = 0; s2 < S; s2++) dspec[(size_t)i * S + s2] = g[3 + s2];
+        drough[i] = g[3 + S];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ reflect
@@ -391,8 +490,12 @@ int envgs_sh_colors_forward(int32_t P, int32_t D, int32_t M, int32_t S, const fl
     if (P < 0 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || (S != 1 && S != 3)) return ENVGS_ERR_BAD_ARG;
     if (P == 0) return 0;
     if (!means3D || !shs || !campos || !specular || !roughness || !colors || !clamped) return ENVGS_ERR_BAD_ARG;
-    hipLaunchKernelGGL(sh_colors_fwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, D, M, S, means3D, shs, campos, specular,
-                       roughness, colors, clamped);
+    if (M == 16 && (reinterpret_cast<uintptr_t>(shs) & 15) == 0)
+        hipLaunchKernelGGL(sh_colors_fwd_q16, dim3((4 * (size_t)P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, D, S, means3D, shs, campos, specular,
+                           roughness, colors, clamped);
+    else
+        hipLaunchKernelGGL(sh_colors_fwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, D, M, S, means3D, shs, campos, specular,
+                           roughness, colors, clamped);
     return (int)hipGetLastError();
 }
 
@@ -403,8 +506,12 @@ int envgs_sh_colors_backward(int32_t P, int32_t D, int32_t M, int32_t S, const f
     if (P < 0 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || (S != 1 && S != 3)) return ENVGS_ERR_BAD_ARG;
     if (P == 0) return 0;
     if (!means3D || !shs || !campos || !clamped || !dcolors || !dmeans3D || !dshs || !dspecular || !droughness) return ENVGS_ERR_BAD_ARG;
-    hipLaunchKernelGGL(sh_colors_bwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, D, M, S, means3D, shs, campos, clamped,
-                       dcolors, dmeans3D, dshs, dspecular, droughness);
+    if (M == 16 && ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(dshs)) & 15) == 0)
+        hipLaunchKernelGGL(sh_colors_bwd_q16, dim3((4 * (size_t)P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, D, S, means3D, shs, campos, clamped,
+                           dcolors, dmeans3D, dshs, dspecular, droughness);
+    else
+        hipLaunchKernelGGL(sh_colors_bwd, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, D, M, S, means3D, shs, campos, clamped,
+                           dcolors, dmeans3D, dshs, dspecular, droughness);
     return (int)hipGetLastError();
 }
 

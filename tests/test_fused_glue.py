@@ -8,11 +8,13 @@ from envgs_amd import envgs_step, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("deg,S", [(0, 1), (2, 1), (3, 3)])
-def test_sh_colors_matches_torch(deg, S):
+@pytest.mark.parametrize("deg,S,M", [(0, 1, 16), (2, 1, 16), (3, 3, 16), (2, 1, 9), (1, 3, 4)])
+def test_sh_colors_matches_torch(deg, S, M):
+    """M = 16: the four-lanes-per-surfel kernels; other coefficient counts: the one-lane-per-surfel ones."""
     from envgs_amd import fused
     dev = torch.device("cuda:0")
     g = synth.base_gaussians(5000, seed=deg, device=dev)
+    g["shs"] = g["shs"][:, :M].contiguous()
     cam = synth.orbit_camera(1, device=dev)
     spec = torch.rand(5000, S, device=dev)
     g["shs"][:200, 0] = -3.0                            # strongly negative DC: exercises the clamp and its zero gradient
