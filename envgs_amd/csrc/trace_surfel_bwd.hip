@@ -207,13 +207,19 @@ batch_surfel_bwd(const TraceArgs A)
                 const int sid = (int)(d & 0xFFFFFFull);
                 const unsigned long long rec = d >> 32;
                 const bool act = k1 > 0;
-                // this ray's 16 B-matrix words -- dL/dcolour (3) and the first 13 geometry words -- go straight to the LDS tile (zeros from
-                // rays that did not blend this surfel); the last two geometry words are summed with DPP.  Tile layout: word n of ray j at
-                // n*64 + ((j + 2n) & 63): conflict-free both for these writes (fixed n, 64 rays) and for the MFMA operand reads (16 words
-                // x 4 rays).  One wavefront per workgroup: its LDS operations execute in program order, so no barrier is needed -- and a
-                // barrier's vmcnt(0) would drain the state prefetch that is in flight.
-                float g13 = 0.f, g14 = 0.f;
-#define BT(n) btile[(n)][(lane + 2 * (n)) & 63]
+                // This ray's gradient words.  dL/dcolour (3) goes to the LDS tile of the reduction MFMAs -- columns 3 e5 .. 3 e5 + 2, e5 = the
+                // entry's place in a run of FIVE: all entries of a batch share the A operand (the rays' basis values), so one set of sixteen
+                // MFMAs reduces the colour columns of five entries (the matrix pipe's 16 x 32 cycles per set are not hidden by the other
+                // wavefront: 0.66 of 3.64 ms when every entry had its own set).  The 15 geometry words only ever needed the plain sum over the
+                // rays and take the rasterizer's wavefront transpose-reduce instead.  Tile layout: word n of ray j at n*64 + ((j + 2n) & 63):
+                // conflict-free both for the writes (fixed n, 64 rays) and for the MFMA operand reads (16 words x 4 rays).  One wavefront
+                // per workgroup: its LDS operations execute in program order, so no barrier is needed -- and a barrier's vmcnt(0) would
+                // drain the state prefetch that is in flight.
+                const int e5 = el % 5;
+                float gw[16];
+#pragma unroll
+                for (int n = 0; n < 16; n++) gw[n] = 0.f;
+#define BT(n) btile[3 * e5 + (n)][(lane + 2 * (3 * e5 + (n))) & 63]
                 if (act) {
                     const float4 s0 = sdat[buf][el][0], s1 = sdat[buf][el][1], s2 = sdat[buf][el][2], s3 = sdat[buf][el][3];
                     const SurfHit h = hit_surfel(s0, s1, s2, s3, Box, Boy, Boz, Bdx, Bdy, Bdz);
@@ -261,19 +267,18 @@ batch_surfel_bwd(const TraceArgs A)
                     const float kt = dLt_tot * __builtin_amdgcn_rcpf(h.denom);
                     BT(0) = dc[0]; BT(1) = dc[1]; BT(2) = dc[2];
                     const float e0 = dq0 - kt * s3.x, e1 = dq1 - kt * s3.y, e2 = dq2 - kt * s3.z;
-                    BT(3) = -e0; BT(4) = -e1; BT(5) = -e2;
-                    BT(6) = cu * qx; BT(7) = cu * qy; BT(8) = cu * qz;
-                    BT(9) = cv * qx; BT(10) = cv * qy; BT(11) = cv * qz;
+                    gw[0] = -e0; gw[1] = -e1; gw[2] = -e2;
+                    gw[3] = cu * qx; gw[4] = cu * qy; gw[5] = cu * qz;
+                    gw[6] = cv * qx; gw[7] = cv * qy; gw[8] = cv * qz;
                     const float ws = w * sgn;
-                    BT(12) = ws * gN0 - kt * qx; BT(13) = ws * gN1 - kt * qy; BT(14) = ws * gN2 - kt * qz;
-                    BT(15) = -cu * h.u * A.mod;
-                    g13 = -cv * h.v * A.mod;
-                    g14 = h.G * dLa;
+                    gw[9] = ws * gN0 - kt * qx; gw[10] = ws * gN1 - kt * qy; gw[11] = ws * gN2 - kt * qz;
+                    gw[12] = -cu * h.u * A.mod;
+                    gw[13] = -cv * h.v * A.mod;
+                    gw[14] = h.G * dLa;
                     dO0 += e0; dO1 += e1; dO2 += e2;
                     dD0 += h.t * e0; dD1 += h.t * e1; dD2 += h.t * e2;
                 } else {
-#pragma unroll
-                    for (int n = 0; n < 16; n++) BT(n) = 0.f;
+                    BT(0) = 0.f; BT(1) = 0.f; BT(2) = 0.f;
                 }
 #undef BT
                 if (el + 1 < ne) {                           // next entry's state: in flight during the reduction below
@@ -281,32 +286,39 @@ batch_surfel_bwd(const TraceArgs A)
                     const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) * sstr : A.state;
                     st0 = sp[0]; st1 = sp[1]; if (A.has_others) st2 = sp[2];
                 }
-                // Sum over the 64 rays on the matrix cores: D[16 x 16] = basis^T[16 x 64 rays] . B[64 rays x 16], K = 64 in 16 exact-f32
-                // MFMAs (four independent chains: the dependent latency is 40 cycles).  Columns 0-2 are the (16,3) SH gradient block;
-                // basis_0 is the constant C0 for every ray, so row 0 of the other 13 columns is C0 x (the plain sum of a geometry word).
-                f32x4 acc4 = {0.f, 0.f, 0.f, 0.f}, accB = acc4, accC = acc4, accD = acc4;
+                // geometry: lane r*16 + k (k < 4) receives the sum over the 64 rays of word k + 4 r; record words 48 .. 62
                 {
-                    const int n = lane & 15, j = lane >> 4;
-                    const float *brow = &btile[n][0];
-                    const int rot = 2 * n + j;
-#pragma unroll
-                    for (int sI = 0; sI < 16; sI += 4) {
-                        acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI], brow[(4 * sI + rot) & 63], acc4, 0, 0, 0);
-                        accB = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 1], brow[(4 * sI + 4 + rot) & 63], accB, 0, 0, 0);
-                        accC = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 2], brow[(4 * sI + 8 + rot) & 63], accC, 0, 0, 0);
-                        accD = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 3], brow[(4 * sI + 12 + rot) & 63], accD, 0, 0, 0);
-                    }
+                    const float gsum = wave_transpose_reduce<4>(gw, lane);
+                    const int word = (lane & 15) + 4 * (lane >> 4);
+                    if ((lane & 15) < 4 && word < 15 && rec < A.num_records) A.records[rec * RECW + 48 + word] = gsum;
                 }
-                acc4 = (acc4 + accB) + (accC + accD);
-                const float s13 = wave_sum(g13), s14 = wave_sum(g14);
-                if (rec < A.num_records) {
-                    float *ro = A.records + rec * RECW;
-                    const int n = lane & 15, mrow = (lane >> 4) * 4;
-                    if (A.M > 0) {
-                        if (n < 3) { ro[(mrow + 0) * 3 + n] = acc4[0]; ro[(mrow + 1) * 3 + n] = acc4[1]; ro[(mrow + 2) * 3 + n] = acc4[2]; ro[(mrow + 3) * 3 + n] = acc4[3]; }
-                    } else if (lane < 3) ro[lane] = acc4[0] * (1.0f / kC0);
-                    if (lane >= 3 && lane < 16) ro[48 + lane - 3] = acc4[0] * (1.0f / kC0);
-                    if (lane == 0) { ro[61] = s13; ro[62] = s14; }
+                // colour: after the fifth entry of a run (or the last of the group) D[16 x 16] = basis^T[16 x 64 rays] . B[64 rays x 16], K = 64 in
+                // 16 exact-f32 MFMAs (four independent chains: the dependent latency is 40 cycles); column 3 e + c = colour c of the run's
+                // e-th entry, the 16 rows its (16,3) SH gradient block (row 0 = C0 x the plain sum when there are no SH).
+                if (e5 == 4 || el + 1 == ne) {
+                    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f}, accB = acc4, accC = acc4, accD = acc4;
+                    {
+                        const int n = lane & 15, j = lane >> 4;
+                        const float *brow = &btile[n][0];
+                        const int rot = 2 * n + j;
+#pragma unroll
+                        for (int sI = 0; sI < 16; sI += 4) {
+                            acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI], brow[(4 * sI + rot) & 63], acc4, 0, 0, 0);
+                            accB = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 1], brow[(4 * sI + 4 + rot) & 63], accB, 0, 0, 0);
+                            accC = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 2], brow[(4 * sI + 8 + rot) & 63], accC, 0, 0, 0);
+                            accD = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 3], brow[(4 * sI + 12 + rot) & 63], accD, 0, 0, 0);
+                        }
+                    }
+                    acc4 = (acc4 + accB) + (accC + accD);
+                    const int n = lane & 15, mrow = (lane >> 4) * 4, er = n / 3, cc = n - 3 * er;
+                    if (n < 15 && er <= e5) {                                  // this lane's column belongs to an entry of the run
+                        const unsigned long long rc = sdesc[buf][el - e5 + er] >> 32;
+                        if (rc < A.num_records) {
+                            float *ro = A.records + rc * RECW;
+                            if (A.M > 0) { ro[(mrow + 0) * 3 + cc] = acc4[0]; ro[(mrow + 1) * 3 + cc] = acc4[1]; ro[(mrow + 2) * 3 + cc] = acc4[2]; ro[(mrow + 3) * 3 + cc] = acc4[3]; }
+                            else if (mrow == 0) ro[cc] = acc4[0] * (1.0f / kC0);
+                        }
+                    }
                 }
             }
         }
