@@ -229,7 +229,8 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
         if (A.has_others && use) { const float2 xo = reinterpret_cast<const float2 *>(A.others)[sid]; x0 = xo.x; x1 = xo.y; }      // one 8 B gather
         float S[10] = {w * col[0], w * col[1], w * col[2], w * t, w, sg * w * s3.x, sg * w * s3.y, sg * w * s3.z, w * x0, w * x1};
 #pragma unroll
-        for (int j = 0; j < 10; j++) S[j] = C[j] + wave_scan_add(S[j]);               // inclusive: this hit already added
+        for (int j = 0; j < 8; j++) S[j] = C[j] + wave_scan_add(S[j]);                // inclusive: this hit already added
+        if (A.has_others) { S[8] = C[8] + wave_scan_add(S[8]); S[9] = C[9] + wave_scan_add(S[9]); }      // (the two aux sums: only when there is something to sum)
         if (use) {
             list[i] = make_uint2(__float_as_uint(w), (unsigned)sid);
             if (state) {
@@ -246,7 +247,8 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
         used += nu;
         M1 += wave_bcast(S1, 63); M2 += wave_bcast(S2, 63);
 #pragma unroll
-        for (int j = 0; j < 10; j++) C[j] = wave_bcast(S[j], 63);
+        for (int j = 0; j < 8; j++) C[j] = wave_bcast(S[j], 63);
+        if (A.has_others) { C[8] = wave_bcast(S[8], 63); C[9] = wave_bcast(S[9], 63); }
         if (nu > 0) T = T * wave_bcast(P, nu - 1);
         if (f < 64) break;
     }
