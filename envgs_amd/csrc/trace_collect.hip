@@ -460,6 +460,7 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
 // near the origin.  The bound only ever tightens and a stale (larger) one only collects more, so the collected set is a superset of
 // what the compositing needs whatever the interleaving; the lists are sorted afterwards.
 constexpr int COOP_W = 4;
+constexpr float COOP_REFRESH_OD = 0.5f;   // recompute a ray's bound when its optical depth has grown by this much (the bound cuts at ~9.5)
 constexpr int COOP_NBIN = 32;             // distance bins of the termination bound (LDS: the update is one ds_add_f32 whatever their number)
 constexpr int COOP_STK = 96;
 constexpr int COOP_FRONT = 64;            // stop expanding once a level has this many entered subtrees (the next level holds at most 4x that).  Measured
@@ -527,7 +528,7 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             inv_bin_w = 1.0f / bin_w;
         }
         const float tk_open = valid ? 3.0e38f : -3.0e38f;     // lanes without a ray never pass a slab test
-        float tkill = tk_open;
+        float tkill = tk_open, seen = 0.f;               // seen: the ray's optical depth when its bound was last recomputed
         int pend = 0;
         uint2 *list = A.hits + (size_t)rr * A.cap;
         const f32x2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz}, i2x = {ix, ix}, i2y = {iy, iy}, i2z = {iz, iz};
@@ -577,9 +578,13 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
                     }
                 }
             }
-            if (pend >= 3) {               // refresh the bound every third leaf test (a stale bound only collects a little more)
+            if (pend >= 3) {               // look at the bound every third leaf test (a stale bound only collects a little more) ...
                 pend = 0;
-                if (__builtin_amdgcn_ballot_w64(ENVGS_LDS_READ(L.odtot[lane]) >= KILL_OD) != 0ull) {
+                // ... and recompute it -- 31 LDS reads and ~125 VALU, as much as two leaf tests -- only when some ray that can be cut at all has
+                // gathered noticeably more optical depth than at its last recomputation
+                const float tot = ENVGS_LDS_READ(L.odtot[lane]);
+                if (__builtin_amdgcn_ballot_w64(tot >= KILL_OD && tot > seen + COOP_REFRESH_OD) != 0ull) {
+                    seen = tot;
                     float cum = 0.f; int kb = COOP_NBIN - 1;
 #pragma unroll
                     for (int q = 0; q < COOP_NBIN - 1; q++) { cum += ENVGS_LDS_READ(L.od[q][lane]); kb = (cum >= KILL_OD && kb == COOP_NBIN - 1) ? q : kb; }
