@@ -96,9 +96,12 @@ batch_surfel_bwd(const TraceArgs A)
 #pragma unroll
         for (int sI = 0; sI < 16; sI++) Areg[sI] = btile[lane & 15][(4 * sI + (lane >> 4) + 2 * (lane & 15)) & 63];
         __syncthreads();
-        float Sk[16], dO0 = 0.f, dO1 = 0.f, dO2 = 0.f, dD0 = 0.f, dD1 = 0.f, dD2 = 0.f;
+        // dL/d(SH basis) of the rays, accumulated on the matrix cores in the MFMA output layout: SkM[b][i] of lane l = (ray 16 b + 4 (l >> 4) + i,
+        // basis l & 15); handed to the rays through LDS at the end of the batch
+        f32x4 SkM[4];
 #pragma unroll
-        for (int k = 0; k < 16; k++) Sk[k] = 0.f;
+        for (int k = 0; k < 4; k++) SkM[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float dO0 = 0.f, dO1 = 0.f, dO2 = 0.f, dD0 = 0.f, dD1 = 0.f, dD2 = 0.f;
         const int sstr = A.has_others ? 3 : 2;
         const float4 *state = A.state + (size_t)rr * A.cap * sstr;
         const unsigned long long *ent = A.entries + (size_t)batch * region;
@@ -247,15 +250,6 @@ batch_surfel_bwd(const TraceArgs A)
                                      gN2 * st1.w + gX0 * st2.x + gX1 * st2.y;
                     const float dLa = Tb * gv_ - (Fsum - gS) * inv1m;
                     const float dc[3] = {cl[0] ? 0.f : w * gR0, cl[1] ? 0.f : w * gR1, cl[2] ? 0.f : w * gR2};
-                    if (A.M > 0) {
-#pragma unroll
-                        for (int q4 = 0; q4 < 12; q4++) {
-                            const float4 x = sdat[buf][el][4 + q4];
-                            const float xe[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                            for (int e = 0; e < 4; e++) { const int idx = 4 * q4 + e; Sk[idx / 3] += xe[e] * dc[idx % 3]; }
-                        }
-                    }
                     if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * gX1); }
                     const float dLG = s0.w * dLa;
                     const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
@@ -319,9 +313,31 @@ batch_surfel_bwd(const TraceArgs A)
                             else if (mrow == 0) ro[cc] = acc4[0] * (1.0f / kC0);
                         }
                     }
+                    // the same run's contribution to dL/d(basis):  [64 rays x 15 colour-gradient columns] . [15 x 16]  (row 3 e + c = the SH
+                    // coefficients of colour c of the run's e-th surfel) -- the tile is the A operand as it stands, the B operand comes straight
+                    // from the staged SH blocks: 16 MFMAs per run instead of 48 FMAs and 12 LDS reads per entry and lane
+                    if (A.M > 0) {
+                        const int kk = lane >> 4, nn = lane & 15;
+#pragma unroll
+                        for (int ks = 0; ks < 4; ks++) {
+                            const int col = 4 * ks + kk, ee = col / 3, c2 = col - 3 * ee;
+                            float bval = 0.f;
+                            if (col < 15 && ee <= e5) bval = reinterpret_cast<const float *>(&sdat[buf][el - e5 + ee][4])[nn * 3 + c2];
+                            const float *arow = &btile[col][0];
+#pragma unroll
+                            for (int rb = 0; rb < 4; rb++)
+                                SkM[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[(16 * rb + nn + 2 * col) & 63], bval, SkM[rb], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) btile[lane & 15][16 * rb + 4 * (lane >> 4) + i] = SkM[rb][i];
+        __syncthreads();
         if (valid) {
             BwdRay B;
             bwd_load_ray(A, r, B);
@@ -329,7 +345,7 @@ batch_surfel_bwd(const TraceArgs A)
             bwd_init_acc(acc);
             acc.dO0 = dO0; acc.dO1 = dO1; acc.dO2 = dO2; acc.dD0 = dD0; acc.dD1 = dD1; acc.dD2 = dD2;
 #pragma unroll
-            for (int k = 0; k < 16; k++) acc.Sk[k] = Sk[k];
+            for (int k = 0; k < 16; k++) acc.Sk[k] = btile[k][lane];
             bwd_store_ray(A, r, B, acc);
         }
     }
