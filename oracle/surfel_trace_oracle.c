@@ -320,9 +320,11 @@ static int aent_cmp(const void *a, const void *b)
 static int near_thr(double q32, double q64, double thr) { return fabs(q64 - thr) <= AUD_K * fabs(q32 - q64) + AUD_M0 * fabs(thr); }
 
 void trc_audit(const trc_cfg *cfg, const float *ray_o, const float *ray_d, const float *means, const float *scales,
-               const float *rots, const float *opac, const float *others, float tmin_override, float bounce_thr,
+               const float *rots, const float *opac, const float *others, const float *shs, float tmin_override, float bounce_thr,
                uint8_t *fragile, int32_t *ids, uint32_t *tbits, int lcap, int32_t *nhit)
 {
+    /* shs (optional, with cfg->D / cfg->M): the colour clamp clamp_min(SH + 0.5, 0) is a decision too -- a blended colour channel within its
+     * own fp32 rounding of zero flips the clamp and with it that hit's whole SH gradient; such rays are flagged like the other near-threshold ones. */
     const int P = cfg->P, R = cfg->R;
     surfel_t *S = (surfel_t *)malloc(sizeof(surfel_t) * (P ? P : 1));
     surfel64_t *S64 = (surfel64_t *)malloc(sizeof(surfel64_t) * (P ? P : 1));
@@ -336,6 +338,13 @@ void trc_audit(const trc_cfg *cfg, const float *ray_o, const float *ray_d, const
             const float *o = ray_o + 3 * r, *d = ray_d + 3 * r;
             const double o64[3] = {o[0], o[1], o[2]}, d64[3] = {d[0], d[1], d[2]};
             int frag = 0, n = 0;
+            float basis[16];
+            if (shs && cfg->M > 0) {
+                const float il = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                const float dn[3] = {d[0] * il, d[1] * il, d[2] * il};
+                for (int k = 0; k < 16; k++) basis[k] = 0.f;
+                sh_basis(cfg->D, dn, basis);
+            }
             for (int i = 0; i < P; i++) {
                 rhit_t h;
                 const int ok = hit_surfel(&S[i], o, d, tmin, &h);
@@ -385,6 +394,17 @@ void trc_audit(const trc_cfg *cfg, const float *ray_o, const float *ray_d, const
                 const double w64 = ents[k].alpha64 * T64;
                 acc += w; acc64 += w64;
                 if (others) { aux0 += w * others[2 * ents[k].id]; aux064 += w64 * (double)others[2 * ents[k].id]; }
+                if (shs && cfg->M > 0) {
+                    const float *sh = shs + (size_t)ents[k].id * cfg->M * 3;
+                    const int nbas = (cfg->D + 1) * (cfg->D + 1);
+                    for (int c = 0; c < 3; c++) {
+                        float rr = 0.f, mag = 0.5f;
+                        for (int kk = 0; kk < nbas; kk++) { rr += basis[kk] * sh[kk * 3 + c]; mag += fabsf(basis[kk] * sh[kk * 3 + c]); }
+                        rr += 0.5f;
+                        /* rounding of a (nbas + 1)-term fp32 sum whose terms carry a few ulp themselves (basis polynomials, summation order) */
+                        if (fabsf(rr) <= (float)AUD_K * 8.0f * 1.1920929e-7f * mag) frag = 1;
+                    }
+                }
                 if (nh < lcap) { ids[(size_t)r * lcap + nh] = ents[k].id; union { float f; uint32_t u; } cv; cv.f = ents[k].t; tbits[(size_t)r * lcap + nh] = cv.u; }
                 nh++;
                 T = test_T; T64 = test_T64;

@@ -39,19 +39,20 @@ def trace_forward(ray_o, ray_d, means3D, scales, rotations, opacities, *, shs=No
 
 
 def trace_audit(ray_o, ray_d, means3D, scales, rotations, opacities, *, others=None, start_from_first=True, tmin=None,
-                bounce_thr=None, scale_modifier=1.0, lcap=None):
+                bounce_thr=None, scale_modifier=1.0, lcap=None, shs=None, sh_degree=0):
     """Fragility audit of one trace stage (trc_audit): dict(fragile (R,) bool, ids / tbits (R,lcap) front-to-back composited surfel ids and
     float bits of their hit distance, nhit (R,)).  tmin overrides the start_from_first rule (bounce stages: 1e-3); bounce_thr adds the bounce decisions."""
     L = lib()
     ray_o = _f32(ray_o).reshape(-1, 3); ray_d = _f32(ray_d).reshape(-1, 3)
     means3D = _f32(means3D); scales = _f32(scales); rotations = _f32(rotations); opacities = _f32(opacities).reshape(-1)
-    others = _f32(others)
+    others = _f32(others); shs = _f32(shs)          # shs (P,M,3) + sh_degree: audit the colour clamp as well (see trc_audit)
     P, R = means3D.shape[0], ray_o.shape[0]
-    cfg = _TCfg(P, R, 0, 0, 0, int(bool(start_from_first)), int(others is not None), 3, float(scale_modifier), 0.0)
+    cfg = _TCfg(P, R, int(sh_degree) if shs is not None else 0, int(shs.shape[1]) if shs is not None else 0, 0, int(bool(start_from_first)),
+                int(others is not None), 3, float(scale_modifier), 0.0)
     lcap = int(lcap or max(P, 1))
     fragile = np.zeros(max(R, 1), np.uint8); ids = np.full((max(R, 1), lcap), -1, np.int32); nhit = np.zeros(max(R, 1), np.int32)
     tbits = np.zeros((max(R, 1), lcap), np.uint32)
-    L.trc_audit(ctypes.byref(cfg), _p(ray_o), _p(ray_d), _p(means3D), _p(scales), _p(rotations), _p(opacities), _p(others),
+    L.trc_audit(ctypes.byref(cfg), _p(ray_o), _p(ray_d), _p(means3D), _p(scales), _p(rotations), _p(opacities), _p(others), _p(shs),
                 ctypes.c_float(-1.0 if tmin is None else float(tmin)), ctypes.c_float(-1.0 if bounce_thr is None else float(bounce_thr)),
                 _p(fragile), _p(ids), _p(tbits), ctypes.c_int(lcap), _p(nhit))
     return dict(fragile=fragile[:R].astype(bool), ids=ids[:R], tbits=tbits[:R], nhit=nhit[:R])

@@ -54,11 +54,12 @@ def _np(g, k):
     return g[k].numpy()
 
 
-def _drop_fragile(test, g, ro, rd, sff, others=True, max_frac=0.03):
+def _drop_fragile(test, g, ro, rd, sff, others=True, max_frac=0.05, sh_degree=None):
     """The oracle's audit of the stage: returns the non-fragile rays and their brute-force sorted hit-id lists."""
     from oracle import trace as otr
     a = otr.trace_audit(ro.numpy(), rd.numpy(), _np(g, "means3D"), _np(g, "scales"), _np(g, "rotations"), _np(g, "opacities"),
-                        others=_np(g, "others") if others else None, start_from_first=sff)
+                        others=_np(g, "others") if others else None, start_from_first=sff,
+                        shs=(g["shs"].float().numpy() if sh_degree is not None else None), sh_degree=(sh_degree or 0))
     keep = ~a["fragile"]
     record(test, "fragile_rays", a["fragile"].mean(), "(%d of %d rays)" % (int(a["fragile"].sum()), keep.size))
     assert a["fragile"].mean() <= max_frac, "too many fragile rays for the comparison to mean anything: %g" % a["fragile"].mean()
@@ -96,7 +97,7 @@ def _parity(test, g, ro, rd, bg, deg, use_sh, sff, gr_scale=1.0, seed=9, which=G
     """Audit -> drop fragile rays -> HIP forward + backward -> oracle forward + backward -> index parity + the 1e-4 contract."""
     from oracle import trace as otr
     from envgs_amd import tracing
-    ro, rd, ids_ref, nhit_ref, nfr = _drop_fragile(test, g, ro, rd, sff, others=others)
+    ro, rd, ids_ref, nhit_ref, nfr = _drop_fragile(test, g, ro, rd, sff, others=others, sh_degree=(deg if use_sh else None))
     R = ro.shape[0]
     gen = torch.Generator().manual_seed(seed)
     gr = [torch.randn(R, 3, generator=gen) * gr_scale, torch.randn(R, generator=gen) * gr_scale, torch.randn(R, generator=gen) * gr_scale,
@@ -540,6 +541,22 @@ def test_trace_update_request_follows_the_new_vertices():
     assert float(a1[2].mean()) > 0.05 and not torch.equal(a0[0], a1[0])
     for x, y in zip(a1, b1):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("switch", [2048, 16, 512])
+def test_trace_diagnostic_collection_kernels(switch, request):
+    """The collection kernels kept for A/B measurements behind envgs_debug_set (2048: one wavefront per batch over the 4-wide nodes, 16: over the
+    binary nodes, 512: per-ray traversal) must keep producing the contract's results."""
+    P, R = 2500, 1536
+    e = synth.env_gaussians(P, seed=13)
+    gen = torch.Generator().manual_seed(14)
+    ro = (torch.rand(R, 3, generator=gen) * 2 - 1) * 1.2
+    rd = torch.randn(R, 3, generator=gen); rd = rd / rd.norm(dim=-1, keepdim=True)
+    g = dict(means3D=e["means3D"] * 0.06, scales=e["scales"] * 0.3, rotations=e["rotations"], opacities=e["opacities"], shs=e["shs"],
+             others=torch.rand(P, 2, generator=gen), colors_precomp=torch.rand(P, 3, generator=gen))
+    res = _parity(request.node.name, g, ro, rd, torch.tensor([0.3, 0.2, 0.1]), 3, True, False, seed=15, hip_ctx=_Switch(debug_trace=switch),
+                  which=("dmeans3D", "dopacities", "dcolor", "dray_o", "dray_d"))
+    assert res["cnt"]["hits"] > 20 * res["R"]
 
 
 @pytest.mark.parametrize("P,R", [(50, 0), (0, 64), (0, 0), (1, 64)])
