@@ -160,7 +160,7 @@ int launch_bin(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const
 int launch_render_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                       const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
                       int32_t *n_contrib, float *weight, hipStream_t stream, uint8_t *audit_contrib = nullptr, int audit_lmax = 0, int colors_f16 = 0,
-                      uint8_t *contrib_mask = nullptr);
+                      uint8_t *contrib_mask = nullptr, const uint8_t *audit_skip = nullptr);
 int launch_render_bwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                       const float *colors, const float *bg, const float *final_T, const int32_t *n_contrib,
                       const float *dL_dcolor, const float *dL_dallmap, float *grad_rec, hipStream_t stream, int colors_f16 = 0,

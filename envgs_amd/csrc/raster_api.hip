@@ -73,7 +73,7 @@ int envgs_raster_bin_and_render(const envgs_raster_cfg *cfg, uint32_t N, const f
 
 int envgs_raster_render_audit(const envgs_raster_cfg *cfg, const float *geom, const float *colors, const float *bg,
                               const uint32_t *point_list, const uint32_t *ranges, float *out_color, float *allmap, float *final_T,
-                              int32_t *n_contrib, float *weight, uint8_t *contrib, int32_t lmax, void *stream_)
+                              int32_t *n_contrib, float *weight, uint8_t *contrib, int32_t lmax, const uint8_t *skip_px, void *stream_)
 {
     int rc = check_cfg(cfg);
     if (rc) return rc;
@@ -83,7 +83,7 @@ int envgs_raster_render_audit(const envgs_raster_cfg *cfg, const float *geom, co
     hipError_t e = hipMemsetAsync(contrib, 0, (size_t)cfg->width * cfg->height * (size_t)lmax, stream);
     if (e != hipSuccess) return (int)e;
     return launch_render_fwd(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream, contrib, lmax,
-                             (cfg->feature_f16 && cfg->sh_coeffs == 0) ? 1 : 0);
+                             (cfg->feature_f16 && cfg->sh_coeffs == 0) ? 1 : 0, nullptr, skip_px);
 }
 
 int envgs_raster_backward(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const float *colors, const float *bg,

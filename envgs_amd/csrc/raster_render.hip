@@ -157,7 +157,7 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
               const float *__restrict__ geom, const Feat colors, const float *__restrict__ bg,
               float *__restrict__ out_color, float *__restrict__ allmap, float *__restrict__ final_T,
               int32_t *__restrict__ n_contrib, float *__restrict__ weight, uint8_t *__restrict__ audit_contrib, int audit_lmax,
-              uint8_t *__restrict__ contrib_mask)
+              uint8_t *__restrict__ contrib_mask, const uint8_t *__restrict__ audit_skip)
 {
     __shared__ TileLds<C> lds;
     __shared__ float wacc[256];            // per-splat weight summed over the 4 wavefronts before it leaves the CU
@@ -174,6 +174,9 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
     const float px = (float)pxi, py = (float)pyi;
     const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
 
+    // AUDIT only: pixels the caller marks (the oracle's fragile pixels) are left out of the per-surfel weight sums, so that `weight` can be
+    // compared on EVERY surfel with an oracle weight that leaves out the same pixels
+    const bool wskip = AUDIT && audit_skip && inside && audit_skip[(size_t)pyi * W + pxi] != 0;
     bool done = !inside;
     float T = 1.0f, Cacc[C], N0 = 0.f, N1 = 0.f, N2 = 0.f, D = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f;
     int32_t last = 0, medc = -1;
@@ -234,7 +237,7 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
                 last = contributor;
             }
             if (__builtin_amdgcn_ballot_w64(contrib) != 0) {
-                const float ws = wave_sum(w);
+                const float ws = wave_sum((AUDIT && wskip) ? 0.f : w);
                 if (lane == 0) { atomic_add_f32(&wacc[j], ws); cmk[j][wave] = 1; }         // LDS atomic: ds_add_f32
             }
           }
@@ -468,7 +471,10 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
         m = max(m, __shfl_xor(m, 1)); m = max(m, __shfl_xor(m, 2)); m = max(m, __shfl_xor(m, 4));
         m = max(m, __shfl_xor(m, 8)); m = max(m, __shfl_xor(m, 16)); m = max(m, __shfl_xor(m, 32));
         if (lane == 0) atomicMax(&s_max_last, m);
-        if (lane == 0 && __builtin_amdgcn_ballot_w64(reg) != 0) s_dist = 1;
+        // the ballot is taken by the WHOLE wavefront (inside `lane == 0 && ...` only lane 0 would be active and the mask would reflect one
+        // pixel per quadrant: a distortion gradient that is zero at the four quadrant origins but not elsewhere would be dropped)
+        const bool any_reg = __builtin_amdgcn_ballot_w64(reg) != 0;
+        if (lane == 0 && any_reg) s_dist = 1;
     }
     __syncthreads();
     const int max_last = s_max_last;
@@ -483,7 +489,8 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
 template <int C>
 static int run_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                    const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
-                   int32_t *n_contrib, float *weight, uint8_t *audit_contrib, int audit_lmax, hipStream_t stream, int colors_f16, uint8_t *contrib_mask)
+                   int32_t *n_contrib, float *weight, uint8_t *audit_contrib, int audit_lmax, hipStream_t stream, int colors_f16, uint8_t *contrib_mask,
+                   const uint8_t *audit_skip)
 {
     const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
     ProfScope prof_(K_COMPOSITE_FWD, stream);
@@ -491,26 +498,27 @@ static int run_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const ui
     const Feat colors_{colors, colors_f16 != 0};
     if (audit_contrib)
         hipLaunchKernelGGL((composite_fwd<C, true>), grid, block, 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
-                           point_list, geom, colors_, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, contrib_mask);
+                           point_list, geom, colors_, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, contrib_mask, audit_skip);
     else
         hipLaunchKernelGGL((composite_fwd<C, false>), grid, block, 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
-                           point_list, geom, colors_, bg, out_color, allmap, final_T, n_contrib, weight, (uint8_t *)nullptr, 0, contrib_mask);
+                           point_list, geom, colors_, bg, out_color, allmap, final_T, n_contrib, weight, (uint8_t *)nullptr, 0, contrib_mask, (const uint8_t *)nullptr);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;
 }
 
 int launch_render_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                       const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
-                      int32_t *n_contrib, float *weight, hipStream_t stream, uint8_t *audit_contrib, int audit_lmax, int colors_f16, uint8_t *contrib_mask)
+                      int32_t *n_contrib, float *weight, hipStream_t stream, uint8_t *audit_contrib, int audit_lmax, int colors_f16, uint8_t *contrib_mask,
+                      const uint8_t *audit_skip)
 {
     if (cfg->P > 0) {
         hipError_t e = hipMemsetAsync(weight, 0, sizeof(float) * (size_t)cfg->P, stream);
         if (e != hipSuccess) return (int)e;
     }
     switch (cfg->channels) {
-    case 3: return run_fwd<3>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16, contrib_mask);
-    case 5: return run_fwd<5>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16, contrib_mask);
-    case 7: return run_fwd<7>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16, contrib_mask);
+    case 3: return run_fwd<3>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16, contrib_mask, audit_skip);
+    case 5: return run_fwd<5>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16, contrib_mask, audit_skip);
+    case 7: return run_fwd<7>(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, stream, colors_f16, contrib_mask, audit_skip);
     default: return ENVGS_ERR_BAD_ARG;
     }
 }

@@ -144,6 +144,9 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         int nseg = 2;                                         // measured (round 1): 1 -> 18.3 ms / step, 2 -> 17.5, 4 -> 19.4 (each collection launch lasts at least one batch)
         if (debug_switch(ENVGS_DBG_SEGMENTS) > 0) nseg = debug_switch(ENVGS_DBG_SEGMENTS);
         if (nseg > MAX_SEG) nseg = MAX_SEG;                   // (fetch counters: 8 words per segment from counters[32])
+        // the per-ray collection kernel (diagnostic: exp & 512, or no coherence sort) spills its stacks into a slab that is sized for two
+        // segments (envgs_trace_stack_spill_ints)
+        if (nseg > 2 && !(A.order && !(A.exp & 512))) nseg = 2;
         while (nseg > 1 && nbatch_all / nseg < 256) nseg--;
         if (nseg < 1) nseg = 1;
         hipStream_t aux[MAX_SEG] = {};

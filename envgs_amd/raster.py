@@ -207,9 +207,10 @@ def rasterize_forward(C, means3D, shs, colors_precomp, opacities, scales, rotati
     return (out_color, radii, allmap, weight), saved
 
 
-def render_audit(saved, lmax):
+def render_audit(saved, lmax, skip_px=None, want_weight=False):
     """Parity audit (tests): re-runs the compositing kernel in its AUDIT instantiation on the saved binning state and returns
-    (contrib (H*W, lmax) uint8, n_contrib (2,H,W), out_color) -- see envgs_raster_render_audit."""
+    (contrib (H*W, lmax) uint8, n_contrib (2,H,W), out_color) -- see envgs_raster_render_audit.  skip_px: (H,W) bool / uint8 tensor of pixels
+    to leave out of the per-surfel weight sums; want_weight: additionally return that weight (P,)."""
     lib = _lib.load()
     cfg = saved["cfg"]
     dev = saved["geom"].device
@@ -218,10 +219,15 @@ def render_audit(saved, lmax):
     out_color = torch.empty(C, H, W, **f32); allmap = torch.empty(7, H, W, **f32); final_T = torch.empty(3, H, W, **f32)
     n_contrib = torch.empty(2, H, W, dtype=torch.int32, device=dev); weight = torch.empty(max(P, 1), **f32)
     contrib = torch.empty(H * W, int(lmax), dtype=torch.uint8, device=dev)
+    skip = None if skip_px is None else skip_px.to(device=dev, dtype=torch.uint8).reshape(-1).contiguous()
+    if skip is not None and skip.numel() != H * W:
+        raise RuntimeError("skip_px must have H*W elements")
     p = _lib.ptr
     _lib.check(lib.envgs_raster_render_audit(cfg, p(saved["geom"]), p(saved["colors"]), p(saved["bg"]), p(saved["point_list"]),
                                              p(saved["ranges"]), p(out_color), p(allmap), p(final_T), p(n_contrib), p(weight),
-                                             p(contrib), int(lmax), _stream(dev)), "envgs_raster_render_audit")
+                                             p(contrib), int(lmax), p(skip), _stream(dev)), "envgs_raster_render_audit")
+    if want_weight:
+        return contrib, n_contrib, out_color, weight[:P]
     return contrib, n_contrib, out_color
 
 

@@ -118,11 +118,13 @@ ENVGS_API int envgs_raster_bin_and_render(const envgs_raster_cfg *cfg, uint32_t 
  * contrib (H*W, lmax) uint8, contrib[pixel][k] = 1 when entry k of the pixel's tile list was blended into it -- so the per-pixel
  * contributor SETS can be compared bit-exactly with the oracle's.  Inputs are the outputs of _project / _bin_and_render; the image
  * outputs are written again (to caller-provided scratch).  lmax >= the longest tile list.
+ * skip_px (H*W bytes, optional): pixels marked non-zero are left out of the per-surfel `weight` sums written by this call (and of nothing
+ * else) -- the oracle's fragile pixels, so that `weight` is comparable on every surfel, not only on those that touch no fragile pixel.
  */
 ENVGS_API int envgs_raster_render_audit(const envgs_raster_cfg *cfg, const float *geom, const float *colors, const float *bg,
                               const uint32_t *point_list, const uint32_t *ranges,
                               float *out_color, float *allmap, float *final_T, int32_t *n_contrib, float *weight,
-                              uint8_t *contrib, int32_t lmax, void *stream);
+                              uint8_t *contrib, int32_t lmax, const uint8_t *skip_px, void *stream);
 
 /*
  * Stages R7+R8 (GaussianRasterizer backward): back-to-front gradient of the compositing, reduced per

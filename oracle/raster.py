@@ -106,6 +106,30 @@ def raster_audit(fwd, want_contrib=False):
                 tainted=tainted[:P].astype(bool), contrib=contrib, lmax=max(lmax, 1))
 
 
+def sh_clamp_audit(fwd):
+    """(P,) bool: surfels whose SH colour lies within fp32 rounding of the clamp at 0 in some channel (orc_sh_clamp_audit); None without SH."""
+    inp = fwd["inputs"]
+    if inp["shs"] is None:
+        return None
+    L = lib()
+    frag = np.zeros(max(fwd["P"], 1), np.uint8)
+    L.orc_sh_clamp_audit(ctypes.byref(fwd["cfg"]), _p(inp["means3D"]), _p(inp["campos"]), _p(inp["shs"]), _p(frag))
+    return frag[:fwd["P"]].astype(bool)
+
+
+def raster_weight(fwd, skip_px=None):
+    """Per-surfel weight of the forward `fwd` with the pixels of skip_px ((H,W) bool) left out (orc_render_weight).
+    Returns (weight (P,) float64, unc (P,) float64 = sum over the surfel's pixels of |w_f32 - w_f64|, the float code's own error)."""
+    L = lib()
+    cfg = fwd["cfg"]; P = fwd["P"]
+    pl = fwd["point_list"] if fwd["N"] > 0 else np.zeros(1, np.uint32)
+    skip = None if skip_px is None else np.ascontiguousarray(np.asarray(skip_px, np.uint8).reshape(-1))
+    w = np.zeros(max(P, 1), np.float64); e = np.zeros(max(P, 1), np.float64)
+    L.orc_render_weight(ctypes.byref(cfg), _p(fwd["ranges"]), _p(pl), _p(fwd["transmat"]), _p(fwd["xy"]), _p(fwd["normal_opacity"]),
+                        _p(skip), _p(w), _p(e))
+    return w[:P], e[:P]
+
+
 def raster_backward(fwd, dL_dcolor, dL_dallmap, want_cond=False):
     """Gradients for the forward `fwd` (dict from raster_forward).  Returns dict of float32 arrays + raw records.
     want_cond: additionally `cond` = dict of sum |term| per gradient element (same keys): R7's records accumulated in absolute value and

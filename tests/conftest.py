@@ -18,6 +18,13 @@ def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "boundary_golden.npz"))
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """ENVGS_PARITY_COLLECT turns every parity assertion into a recording (diagnosis runs).  A stray variable must not make the suite pass
+    without checking anything: such a session always ends with a failing exit status."""
+    if os.environ.get("ENVGS_PARITY_COLLECT"):
+        session.exitstatus = 1
+
+
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
     """Measured parity errors of this run (tests/util.py:check_close), so that they are part of the test log the driver records."""
     try:
@@ -27,6 +34,8 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     if not ERROR_TABLE:
         return
     tr = terminalreporter
+    if os.environ.get("ENVGS_PARITY_COLLECT"):
+        tr.write_sep("!", "ENVGS_PARITY_COLLECT is set: parity assertions were NOT evaluated in this run -- exit status forced to 1")
     tr.write_sep("=", "measured parity errors (elementwise |a-b| / (|b| + mean|b|); fragile pixels / rays excluded and counted)")
     worst = {}
     for r in ERROR_TABLE:

@@ -86,10 +86,15 @@ def _compare_forward(test, outs, saved, ref, aud, sh, check_sets, tail=None):
     np.testing.assert_array_equal(nc[0][ok], ref["n_contrib"][0][ok])
     np.testing.assert_array_equal(nc[1][ok], ref["n_contrib"][1][ok])
     if check_sets:
-        contrib, nc_a, col_a = raster.render_audit(saved, aud["lmax"])
+        # the audit instantiation also returns the per-surfel weight with the FRAGILE pixels left out (skip_px); the oracle leaves out the same
+        # pixels (orc_render_weight), so `weight` -- which drives prune_visibility, gaussian2d_utils.py:849-865 -- is compared on EVERY surfel
+        contrib, nc_a, col_a, w_masked = raster.render_audit(saved, aud["lmax"], skip_px=torch.from_numpy(frag), want_weight=True)
         okf = ok.reshape(-1)
         np.testing.assert_array_equal(contrib.cpu().numpy()[okf], aud["contrib"][okf])
         assert torch.equal(nc_a, saved["n_contrib"]) and torch.equal(col_a, outs[0])      # the audit instantiation IS the product kernel
+        from oracle import raster as orc
+        w_ref, w_unc = orc.raster_weight(ref, frag)
+        check_close(test, "weight.all_surfels", w_masked.cpu().numpy().astype(np.float64), w_ref, excluded=0, cond=np.zeros_like(w_ref), unc=w_unc, tail=tail)
     # R6 values
     color, radii, allmap, weight = [o.cpu().numpy() for o in outs]
     check_close(test, "color", color[:, ok], ref["out_color"][:, ok], excluded=nfr, tail=tail)
@@ -101,8 +106,8 @@ def _compare_forward(test, outs, saved, ref, aud, sh, check_sets, tail=None):
     check_close(test, "final_T", saved["final_T"].cpu().numpy()[:, ok], ref["final_T"][:, ok], excluded=nfr)
     clean = ~aud["tainted"]
     check_close(test, "weight", weight[clean, 0], ref["weight"][clean], excluded=int(aud["tainted"].sum()))
-    if aud["tainted"].any():        # surfels that touch a fragile pixel: one flipped splat there moves their weight by O(1) pixel
-        d = np.abs(weight[~clean, 0] - ref["weight"][~clean])
+    if aud["tainted"].any():        # (the product kernel's own weight on surfels that touch a fragile pixel: one flipped splat there moves it by O(1)
+        d = np.abs(weight[~clean, 0] - ref["weight"][~clean])                      #  pixel -- bounded here, COMPARED above with those pixels left out)
         record(test, "weight.tainted", d.max(), "(absolute, %d surfels)" % int((~clean).sum()))
         assert d.max() <= 1.0 * max(1, nfr)
 
@@ -136,15 +141,12 @@ def _masked_upstream(C, H, W, seed, frag):
     return dcol * m, dall * m          # zero upstream gradient at fragile pixels, for BOTH implementations
 
 
-def _sh_clamp_fragile(g, cam, deg):
-    """Per-surfel audit of the colour clamp clamp_min(SH + 0.5, 0) (R1 / R8): a colour channel within its own fp32 rounding of zero flips the
-    clamp, and with it all 48 dL/dSH elements of the surfel.  (P,) bool from a float64 evaluation; such surfels are left out of the dshs comparison."""
-    from envgs_amd import envgs_step
-    m = g["means3D"].double(); sh = g["shs"].double()
-    d = m - cam.camera_center.double()[None]; d = d / d.norm(dim=1, keepdim=True)
-    r = envgs_step.eval_sh(deg, sh.transpose(1, 2), d) + 0.5                                   # (P,3)
-    mag = envgs_step.eval_sh(deg, sh.abs().transpose(1, 2), d.abs()).abs() + 0.5                # a magnitude scale of the sum's terms
-    return (r.abs() <= 16.0 * 8.0 * 1.1920929e-7 * mag).any(dim=1).numpy()
+def _sh_clamp_fragile(ref):
+    """Per-surfel audit of the colour clamp clamp_min(SH + 0.5, 0) (R1 / R8), now part of the oracle (orc_sh_clamp_audit): a colour channel
+    within its own fp32 rounding of zero flips the clamp, and with it all 48 dL/dSH elements of the surfel.  Such surfels are left out of
+    the dshs comparison (and counted)."""
+    from oracle import raster as orc
+    return orc.sh_clamp_audit(ref)
 
 
 GRAD_NAMES = (("means3D", "dmeans3D"), ("scales", "dscales"), ("rotations", "drots"), ("opacities", "dopacities"), ("means2D", "dmeans2D"))
@@ -182,10 +184,45 @@ def test_backward_vs_oracle(case, request):
     test = request.node.name
     nfr = int(aud["fragile"].sum())
     grads = dict(leaves, means2D=means2D)
-    clampfrag = _sh_clamp_fragile(g, cam, case["deg"]) if case["sh"] else None
+    clampfrag = _sh_clamp_fragile(ref) if case["sh"] else None
     for k_hip, k_ref in GRAD_NAMES + ((("shs", "dshs"),) if case["sh"] else (("colors_precomp", "dcolors"),)):
         check_close(test, k_ref, grads[k_hip].grad.cpu().numpy().reshape(rb[k_ref].shape), rb[k_ref], excluded=nfr, cond=rb["cond"][k_ref], unc=rb["unc"][k_ref],
                     keep=(~clampfrag if k_ref == "dshs" else None))
+
+def test_backward_sparse_distortion_gradient():
+    """R7 picks its distortion-free instantiation per TILE from a ballot of `dL/d(dist) != 0`.  The ballot must see all 256
+    pixels: here the distortion map's upstream gradient is non-zero ONLY on pixels that are not the origin of an 8x8 quadrant (and is the
+    only upstream gradient, so a dropped distortion term shows as a zero gradient)."""
+    from oracle import raster as orc
+    import diff_surfel_rasterization_wet_ch05 as mod
+    dev = torch.device("cuda:0")
+    C, H, W = 5, 64, 80
+    g, cam = small_scene(P=500, H=H, W=W, seed=12, C=C, sh=False)
+    bg = torch.tensor([0.2, 0.5, 0.9])
+    st = _settings(mod, cam, bg, 0, dev)
+    ref = _oracle(g, cam, bg, 0, C, False)
+    aud = orc.raster_audit(ref)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    sparse = ((xx % 8 == 3) & (yy % 8 == 5)) & torch.from_numpy(~aud["fragile"])
+    assert int(sparse.sum()) > 30 and not bool(sparse[::8, ::8].any())
+    dcol = torch.zeros(C, H, W)
+    dall = torch.zeros(7, H, W)
+    dall[6] = torch.randn(H, W, generator=torch.Generator().manual_seed(3)) / (H * W) * sparse
+    leaves = {k: g[k].to(dev).requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations", "colors_precomp")}
+    means2D = torch.zeros_like(leaves["means3D"], requires_grad=True) + 0
+    means2D.retain_grad()
+    color, radii, allmap, weight = mod.GaussianRasterizer(raster_settings=st)(
+        means3D=leaves["means3D"], means2D=means2D, shs=None, colors_precomp=leaves["colors_precomp"],
+        opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"], cov3D_precomp=None)
+    ((color * dcol.to(dev)).sum() + (allmap * dall.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    rb = orc.raster_backward(ref, dcol.numpy(), dall.numpy(), want_cond=True)
+    assert float(np.abs(rb["dmeans3D"]).max()) > 0 and float(leaves["means3D"].grad.abs().max()) > 0
+    grads = dict(leaves, means2D=means2D)
+    for k_hip, k_ref in GRAD_NAMES:
+        check_close("sparse_distortion_gradient", k_ref, grads[k_hip].grad.cpu().numpy().reshape(rb[k_ref].shape), rb[k_ref],
+                    excluded=int(aud["fragile"].sum()), cond=rb["cond"][k_ref], unc=rb["unc"][k_ref])
+
 
 def test_precomputed_transmat_path():
     """cov3D_precomp (the python transMat of gaussian2d_utils.py:1050-1061) instead of scales/rotations."""
@@ -372,7 +409,7 @@ def test_full_size_baseline_config_vs_oracle():
     grads = raster.rasterize_backward(saved, dcol.to(dev), dall.to(dev))
     torch.cuda.synchronize()
     rb = orc.raster_backward(ref, dcol.numpy(), dall.numpy(), want_cond=True)
-    clampfrag = _sh_clamp_fragile(g, cam, 3)
+    clampfrag = _sh_clamp_fragile(ref)
     record(test, "sh_clamp_fragile_surfels", float(clampfrag.mean()), "(%d of %d surfels)" % (int(clampfrag.sum()), clampfrag.size))
     for k_hip, k_ref in GRAD_NAMES + (("shs", "dshs"),):
         check_close(test, k_ref, grads[k_hip].cpu().numpy().reshape(rb[k_ref].shape), rb[k_ref], excluded=int(aud["fragile"].sum()), cond=rb["cond"][k_ref], unc=rb["unc"][k_ref],
