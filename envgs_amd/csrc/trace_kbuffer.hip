@@ -91,7 +91,7 @@ trace_fwd(const TraceArgs A, const int ray_h, const int ray_w)
                             const float sg = h.denom < 0.0f ? w : -w;
                             S.nrm[0] += sg * s3.x; S.nrm[1] += sg * s3.y; S.nrm[2] += sg * s3.z;
                             if (A.has_others) { S.aux[0] += w * A.others[2 * sid]; S.aux[1] += w * A.others[2 * sid + 1]; }
-                            if (stage == 0) atomic_add_f32(A.wet + sid, w);
+                            atomic_add_f32(A.wet + sid, w);          // every stage: a surfel blended only by bounce rays is visible too
                             S.T = test_T;
                             st_hits++;
                         }

@@ -68,13 +68,13 @@ def base_pass(pkg, cam, base, bg, sh_degree, scale_modifier=1.0):
     S = img.shape[0] - 4                         # specular channels: 1 (-ch05) or 3 (-ch07)
     if FUSED["on"]:
         return dict(rgb=img[:3], spec=img[3:3 + S], rough=img[3 + S:4 + S], alpha=allmap[1:2], radii=radii, weight=weight, means2D=means2D,
-                    allmap=allmap, img=img)
+                    allmap=allmap, img=img, colors=colors)
     alpha = allmap[1:2]
     # view -> world, the reference's own expression (gaussian2d_utils.py:1123)
     normal = (allmap[2:5].permute(1, 2, 0) @ (cam.world_view_transform[:3, :3].T)).permute(2, 0, 1)
     depth = torch.nan_to_num(allmap[0:1] / alpha, 0, 0)
     return dict(rgb=img[:3], spec=img[3:3 + S], rough=img[3 + S:4 + S], alpha=alpha, normal=normal, depth=depth, radii=radii,
-                weight=weight, means2D=means2D, allmap=allmap)
+                weight=weight, means2D=means2D, allmap=allmap, img=img, colors=colors)
 
 
 def dpt2norm(cam, dpt):

@@ -90,32 +90,44 @@ def _cfg(settings, P, R, shs, others, start_from_first, ray_shape, f16=False):
 
 
 NCOPY = 8                    # must equal NCOPY in csrc/trace_common.h
-HIT_CAP = {"cap": 512}
+HIT_CAP = {}                 # tests only: HIT_CAP["force"] pins the list capacity of every tracer (e.g. tiny, to exercise the overflow hand-off)
 SORT_RAYS = {"on": True}     # coherence-sort the rays (direction, origin) before tracing
 USE_RECORDS = {"on": True}   # atomic-free backward (one record per (batch, surfel) entry, grouped by surfel); False = cooperative atomic flush
 
 
-_ASYNC = {}      # pinned host mirrors of two device counters + the events that say when they are valid
+class CapState:
+    """Adaptive capacity of the per-ray hit lists, per TRACER INSTANCE (and device): 20 % above the longest list of that tracer's previous
+    call, read through a pinned host mirror that was copied asynchronously at the end of that call -- no host sync on the hot path.  Two
+    tracers in one process (camera-ray tracing over the base surfels plus the environment trace, gaussian2d_sampler.py:413-426 next to
+    envgs_sampler.py:548) see very different list lengths; a module-global capacity would make each re-size the other's scratch."""
+
+    def __init__(self, cap=512):
+        self.cap = int(cap)
+        self._mirrors = {}          # device -> dict(host, event, valid)
+
+    def mirror(self, dev):
+        m = self._mirrors.get(dev)
+        if m is None:
+            m = self._mirrors[dev] = dict(host=torch.zeros(1, dtype=torch.int32).pin_memory(), event=torch.cuda.Event(), valid=False)
+        return m
+
+    def next_cap(self, dev):
+        if HIT_CAP.get("force"):                       # tests: pin the capacity (e.g. tiny, to exercise the overflow hand-off)
+            return int(HIT_CAP["force"])
+        m = self.mirror(dev)
+        if m["valid"] and m["event"].query():
+            mx = int(m["host"][0])
+            want = ((int(mx * 1.2) + 8 + 63) // 64) * 64          # 20 % headroom, multiple of 64 entries (512 B)
+            self.cap = max(64, min(want, 1024))
+        return self.cap
+
+    def publish(self, counters, dev):
+        """Queue the asynchronous read-back of this call's longest list (counters[1])."""
+        m = self.mirror(dev)
+        m["host"].copy_(counters[1:2], non_blocking=True); m["event"].record(torch.cuda.current_stream(dev)); m["valid"] = True
 
 
-def _mirror(name, dev):
-    m = _ASYNC.get((name, dev))
-    if m is None:
-        m = _ASYNC[(name, dev)] = dict(host=torch.zeros(1, dtype=torch.int32).pin_memory(), event=torch.cuda.Event(), valid=False)
-    return m
-
-
-def _next_cap(dev):
-    """Capacity of the per-ray hit lists: 20 % above the longest list of the PREVIOUS call, read through a pinned mirror that was
-    copied asynchronously at the end of that call -- no host sync on the hot path."""
-    if HIT_CAP.get("force"):                       # tests: pin the capacity (e.g. tiny, to exercise the overflow hand-off)
-        return int(HIT_CAP["force"])
-    m = _mirror("max_list", dev)
-    if m["valid"] and m["event"].query():
-        mx = int(m["host"][0])
-        want = ((int(mx * 1.2) + 8 + 63) // 64) * 64          # 20 % headroom, multiple of 64 entries (512 B)
-        HIT_CAP["cap"] = max(64, min(want, 1024))
-    return HIT_CAP["cap"]
+_DEFAULT_CAPS = CapState()       # direct callers of trace_forward (tests, diagnostics); every SurfelTracer owns its own
 
 
 def _scratch(shape, dtype, dev):
@@ -142,8 +154,9 @@ KEEP_LISTS = {"on": False}   # tests: keep the last forward's per-ray hit lists 
 
 
 def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_precomp, opacities, scales, rotations, settings,
-                  start_from_first, use_lists=True, need_grad=True):
+                  start_from_first, use_lists=True, need_grad=True, caps=None):
     lib = _lib.load()
+    caps = _DEFAULT_CAPS if caps is None else caps
     dev = means3D.device
     lead = tuple(ray_o.shape[:-1])
     ro = _f32c(ray_o).reshape(-1, 3); rd = _f32c(ray_d).reshape(-1, 3)
@@ -161,7 +174,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     rgb = torch.empty(R, 3, **f32); dpt = torch.empty(R, 1, **f32); acc = torch.empty(R, 1, **f32)
     norm = torch.empty(R, 3, **f32); dist = torch.empty(R, 1, **f32); aux = torch.empty(R, 2, **f32)
     mid = torch.empty(R, 16 * ND, **f32); wet = torch.empty(P, 1, **f32); final_T = torch.empty(R, **f32)
-    cap = _next_cap(dev) if (use_lists and ND == 1 and P > 0 and R > 0) else 0
+    cap = caps.next_cap(dev) if (use_lists and ND == 1 and P > 0 and R > 0) else 0
     lists = None
     keep = {}
     if cap:
@@ -192,12 +205,11 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
                                        p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),
                                        p(norm), p(dist), p(aux), p(mid), p(wet), p(final_T), lists, _stream(dev)), "envgs_trace_forward")
-    LAST_STATS.update(P=P, R=R, counters=counters, n_entries=keep.get("n_entries"), cap=cap,
+    LAST_STATS.update(P=P, R=R, caps=caps, counters=counters, n_entries=keep.get("n_entries"), cap=cap,
                       lists=((keep["hit_lists"], keep["n_used"], keep["hit_cnt"]) if (cap and KEEP_LISTS["on"]) else None))
     if cap:
         # asynchronous read-backs for later: the longest list (sizes the next call's cap) and the number of gradient records
-        m = _mirror("max_list", dev)
-        m["host"].copy_(counters[1:2], non_blocking=True); m["event"].record(torch.cuda.current_stream(dev)); m["valid"] = True
+        caps.publish(counters, dev)
         keep["n_rec_host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
         keep["n_rec_host"].copy_(keep["surf_off"].view(-1)[NCOPY * P - 1:NCOPY * P], non_blocking=True)
         keep["n_rec_event"] = torch.cuda.Event(); keep["n_rec_event"].record(torch.cuda.current_stream(dev))
@@ -293,10 +305,10 @@ def frame_from_transmat(cov3D_precomp, settings):
 class _TraceSurfels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ray_o, ray_d, v, means3D, grads3D, shs, colors_precomp, others_precomp, opacities, scales, rotations,
-                cov3D_precomp, tracer_settings, start_from_first, nodes):
+                cov3D_precomp, tracer_settings, start_from_first, nodes, caps=None):
         none = lambda t: None if (t is None or t.numel() == 0) else t
         outs, saved = trace_forward(nodes, ray_o, ray_d, means3D, none(shs), none(colors_precomp), none(others_precomp), opacities,
-                                    scales, rotations, tracer_settings, start_from_first, need_grad=any(ctx.needs_input_grad))
+                                    scales, rotations, tracer_settings, start_from_first, need_grad=any(ctx.needs_input_grad), caps=caps)
         ctx.saved = saved
         ctx.in_dtypes = tuple(None if t is None else t.dtype for t in (ray_o, ray_d, means3D, grads3D, shs, colors_precomp,
                                                                         others_precomp, opacities, scales, rotations))
@@ -310,7 +322,7 @@ class _TraceSurfels(torch.autograd.Function):
         order = ("ray_o", "ray_d", "means3D", "grads3D", "shs", "colors_precomp", "others_precomp", "opacities", "scales", "rotations")
         vals = [None if (g[k] is None or dt is None) else g[k].to(dt) for k, dt in zip(order, ctx.in_dtypes)]
         ro, rd, m3, g3, sh, col, oth, op, sc, rot = vals
-        return ro, rd, None, m3, g3, sh, col, oth, op, sc, rot, None, None, None, None
+        return ro, rd, None, m3, g3, sh, col, oth, op, sc, rot, None, None, None, None, None
 
 
 class SurfelTracer(nn.Module):
@@ -320,6 +332,7 @@ class SurfelTracer(nn.Module):
         self.nodes = None
         self.num_surfels = 0
         self._pending = None
+        self.caps = CapState()            # this tracer's adaptive hit-list capacity (not shared with other tracers of the process)
 
     def build_acceleration_structure(self, vertices, faces=None, rebuild=True):
         """optix_utils.py:78.  `faces` must be the get_disks layout (2 triangles per 4 consecutive vertices).
@@ -367,8 +380,15 @@ class SurfelTracer(nn.Module):
                 e if others_precomp is None else others_precomp, opacities, scales, rotations, None)
         depth = int(tracer_settings.max_trace_depth)
         if depth == 0 or ray_o.numel() == 0 or means3D.shape[0] == 0:
-            return _TraceSurfels.apply(ray_o, ray_d, *args, tracer_settings._replace(max_trace_depth=0), bool(start_from_first), self.nodes)
+            return _TraceSurfels.apply(ray_o, ray_d, *args, tracer_settings._replace(max_trace_depth=0), bool(start_from_first), self.nodes, self.caps)
         return self._forward_bounces(ray_o, ray_d, args, tracer_settings, bool(start_from_first))
+
+    def bounce_caps(self, k):
+        """Bounce stage k traces a different ray population (fewer, less coherent rays) than stage 0: its own capacity state."""
+        st = self.__dict__.setdefault("_bounce_caps", {})
+        if k not in st:
+            st[k] = CapState(self.caps.cap)
+        return st[k]
 
     def _forward_bounces(self, ray_o, ray_d, args, settings, start_from_first):
         """max_trace_depth > 0 (gaussian2d_sampler.py:413-426, optix_utils.py:117-118): every stage is one bounce-free traced call
@@ -380,7 +400,8 @@ class SurfelTracer(nn.Module):
 
         so the backward IS the derivative of the returned `rgb`: through every stage's colour, through the blend weights s_k (into the
         `others_precomp` channel and the opacities / geometry that composite it), and through the reflected-ray construction into the
-        previous stage's depth, accumulation and normal.  dpt / acc / norm / dist / aux / wet are stage 0's, as in the single-stage call;
+        previous stage's depth, accumulation and normal.  dpt / acc / norm / dist / aux are stage 0's, as in the single-stage call; `wet` is summed
+        over all stages;
         `mid` holds the 16 channels of every stage (non-differentiable)."""
         depth = int(settings.max_trace_depth)
         thr = float(settings.specular_threshold)
@@ -389,7 +410,7 @@ class SurfelTracer(nn.Module):
         o = ray_o.reshape(-1, 3); d = ray_d.reshape(-1, 3)
         R = o.shape[0]
         dev = o.device
-        out0 = _TraceSurfels.apply(o, d, *args, s0, start_from_first, self.nodes)
+        out0 = _TraceSurfels.apply(o, d, *args, s0, start_from_first, self.nodes, self.caps)
         stages = [dict(o=o, d=d, out=out0, idx=torch.arange(R, device=dev), sel=None)]
         for k in range(1, depth + 1):
             p = stages[-1]
@@ -407,7 +428,7 @@ class SurfelTracer(nn.Module):
             tdep = dpt[sel] / acc[sel]
             o2 = po + pd * tdep
             d2 = pd - 2.0 * (pd * nh).sum(-1, keepdim=True) * nh
-            out = _TraceSurfels.apply(o2, d2, *args, s0, 2, self.nodes)
+            out = _TraceSurfels.apply(o2, d2, *args, s0, 2, self.nodes, self.bounce_caps(k))
             stages.append(dict(o=o2, d=d2, out=out, idx=p["idx"][sel], sel=sel))
         col = stages[-1]["out"][0]
         for k in range(len(stages) - 2, -1, -1):
@@ -421,6 +442,12 @@ class SurfelTracer(nn.Module):
                 r_, dp_, ac_, no_, _, au_ = st["out"][:6]
                 mid[st["idx"], 16 * k:16 * k + 16] = torch.cat([st["o"], st["d"], dp_, ac_, no_, au_, r_], dim=1).float()
         rgb0, dpt0, acc0, norm0, dist0, aux0, mid0, wet = out0
+        with torch.no_grad():
+            # wet = the blend weights every surfel received over ALL stages: a surfel that only bounce rays blend contributes to the returned
+            # colour and receives gradients, so the caller's visibility filter (wet > 0, optix_utils.py:203-213), its densification statistics
+            # and the sparse Adam must see it (the OptiX ray-gen loop adds the weight wherever it composites a hit)
+            for st in stages[1:]:
+                wet = wet + st["out"][7]
         return (col.reshape(lead + (3,)), dpt0.reshape(lead + (1,)), acc0.reshape(lead + (1,)), norm0.reshape(lead + (3,)),
                 dist0.reshape(lead + (1,)), aux0.reshape(lead + (2,)), mid.reshape(lead + (16 * (depth + 1),)), wet)
 
@@ -454,4 +481,4 @@ def last_trace_counts():
     w = c.cpu()
     v = w[2:20].view(torch.int64)
     return dict(coop_cycles=dict(expand=int(v[6]), walk=int(v[7]), wait=int(v[8])), hits=int(v[0]), node_visits=int(v[1]), rounds=int(v[2]), found=int(v[3]), packet_nodes=int(v[4]), packet_leaves=int(v[5]),
-                max_list=int(w[1]), cap=HIT_CAP["cap"], rays=LAST_STATS["R"], stack_overflows=int(w[20]))
+                max_list=int(w[1]), cap=LAST_STATS["caps"].cap, rays=LAST_STATS["R"], stack_overflows=int(w[20]))

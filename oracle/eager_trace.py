@@ -88,7 +88,7 @@ def trace_bounces(ray_o, ray_d, means3D, scales, rotations, opacities, *, max_tr
     """max_trace_depth > 0 as ONE differentiable expression (float64 autograd gives the true derivative of the blended colour):
     stage k+1 starts at o + d * dpt_k / acc_k along d - 2 (d.n) n (n = normalised accumulated normal) where aux_k[0] > threshold and
     acc_k > 0.5, t_min = 1e-3; rgb = (1 - s_0) rgb_0 + s_0 ((1 - s_1) rgb_1 + ...), s_k = aux_k[0]  (surfel_trace_oracle.c header;
-    reference call sites gaussian2d_sampler.py:413-426, optix_utils.py:117-118).  Returns (rgb, dpt_0, acc_0, norm_0, aux_0, wet_0, n_stages)."""
+    reference call sites gaussian2d_sampler.py:413-426, optix_utils.py:117-118).  Returns (rgb, dpt_0, acc_0, norm_0, aux_0, wet summed over the stages, n_stages)."""
     first = trace(ray_o, ray_d, means3D, scales, rotations, opacities, **kw)
     stages = [dict(o=ray_o, d=ray_d, out=first, sel=None)]
     kw2 = dict(kw); kw2.pop("start_from_first", None)
@@ -110,4 +110,7 @@ def trace_bounces(ray_o, ray_d, means3D, scales, rotations, opacities, *, max_tr
         s = p["out"][4][c["sel"], 0:1]
         col = p["out"][0].index_put((c["sel"],), (1.0 - s) * p["out"][0][c["sel"]] + s * col)
     rgb0, dpt0, acc0, norm0, aux0, wet0 = first
-    return col, dpt0, acc0, norm0, aux0, wet0, len(stages)
+    wet = wet0
+    for st in stages[1:]:            # wet: blend weights summed over ALL stages (a surfel blended only by bounce rays is visible too)
+        wet = wet + st["out"][5]
+    return col, dpt0, acc0, norm0, aux0, wet, len(stages)

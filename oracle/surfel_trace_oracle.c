@@ -78,6 +78,11 @@ static void make_surfel(const trc_cfg *cfg, int i, const float *means, const flo
 
 typedef struct { float t, u, v, G, alpha, denom; } rhit_t;
 
+/* t_min of a traced call: camera rays skip the near 0.2, reflected rays start at 0; start_from_first == 2 is a bounce stage traced as a call
+ * of its own (the drop-in module composes max_trace_depth > 0 stage by stage): it starts just off the surface it left, 1e-3, like the
+ * in-line bounce stages of trc_forward */
+static float first_tmin(int start_from_first) { return start_from_first == 1 ? NEAR_N : (start_from_first == 2 ? 1.0e-3f : 0.0f); }
+
 /* ray / surfel: returns 1 when the hit counts (inside the 3-sigma quad, alpha >= 1/255, t > tmin) */
 static int hit_surfel(const surfel_t *s, const float *o, const float *d, float tmin, rhit_t *h)
 {
@@ -242,9 +247,9 @@ void trc_forward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, con
             float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
             stage_t st[8];
             int ns = 0;
-            float tmin = cfg->start_from_first ? NEAR_N : 0.0f;
+            float tmin = first_tmin(cfg->start_from_first);
             for (int k = 0; k < ND && k < 8; k++) {
-                trace_stage(cfg, S, shs, colors_precomp, others, bg, o, d, tmin, ents, &st[k], k == 0 ? wet : NULL);
+                trace_stage(cfg, S, shs, colors_precomp, others, bg, o, d, tmin, ents, &st[k], wet);     /* wet: summed over ALL stages (a surfel blended only by bounce rays is visible too) */
                 float *m = mid + ((size_t)r * ND + k) * MID_CH;
                 m[0] = o[0]; m[1] = o[1]; m[2] = o[2]; m[3] = d[0]; m[4] = d[1]; m[5] = d[2];
                 m[6] = st[k].dpt; m[7] = st[k].acc; m[8] = st[k].nrm[0]; m[9] = st[k].nrm[1]; m[10] = st[k].nrm[2];
@@ -329,7 +334,7 @@ void trc_audit(const trc_cfg *cfg, const float *ray_o, const float *ray_d, const
     surfel_t *S = (surfel_t *)malloc(sizeof(surfel_t) * (P ? P : 1));
     surfel64_t *S64 = (surfel64_t *)malloc(sizeof(surfel64_t) * (P ? P : 1));
     for (int i = 0; i < P; i++) { make_surfel(cfg, i, means, scales, rots, opac, &S[i]); make_surfel64(cfg, i, means, scales, rots, opac, &S64[i]); }
-    const float tmin = tmin_override >= 0.0f ? tmin_override : (cfg->start_from_first ? NEAR_N : 0.0f);
+    const float tmin = tmin_override >= 0.0f ? tmin_override : first_tmin(cfg->start_from_first);
 #pragma omp parallel
     {
         aent_t *ents = (aent_t *)malloc(sizeof(aent_t) * (P ? P : 1));
@@ -487,7 +492,7 @@ void trc_backward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, co
         for (int r = 0; r < R; r++) {
             const float o[3] = {ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]};
             const float d[3] = {ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]};
-            const float tmin = cfg->start_from_first ? NEAR_N : 0.0f;
+            const float tmin = first_tmin(cfg->start_from_first);
             stage_t fin;
             trace_stage(cfg, S, shs, colors_precomp, others, bg, o, d, tmin, ents, &fin, NULL);   /* final sums; ents sorted */
             int n = 0;

@@ -22,7 +22,7 @@ def trace_forward(ray_o, ray_d, means3D, scales, rotations, opacities, *, shs=No
     P, R = means3D.shape[0], ray_o.shape[0]
     M = 0 if shs is None else shs.shape[1]
     bg = np.zeros(3, np.float32) if bg is None else _f32(bg).reshape(-1)
-    cfg = _TCfg(P, R, int(sh_degree), M, int(max_trace_depth), int(bool(start_from_first)), int(others is not None),
+    cfg = _TCfg(P, R, int(sh_degree), M, int(max_trace_depth), (2 if start_from_first == 2 else int(bool(start_from_first))), int(others is not None),
                 len(bg), float(scale_modifier), float(specular_threshold))
     ND = max_trace_depth + 1
     rgb = np.zeros((R, 3), np.float32); dpt = np.zeros(R, np.float32); acc = np.zeros(R, np.float32)

@@ -187,17 +187,57 @@ class _Switch:
             elif k == "debug_trace": _lib.load().envgs_debug_set(0, v)
 
 
-# Gradients of the composed stages against float64 autograd: the chain through the reflected-ray construction (o + d dpt/acc, the normalised
-# accumulated normal) multiplies the fp32 rounding of stage 0's sums; no per-element noise scale is available from autograd, so the bound is
-# a plain elementwise one with the floor at the tensor's mean magnitude.  Measured on MI355X: <= 1.5e-3 on 9 of 450 elements, the rest <= 1e-4.
-BOUNCE_GRAD_TOL = 3e-3
+# The bounce chain at the 1e-4 contract, link by link (tests/stagewise.py): every traced call of the HIP chain is compared with the oracle on
+# the chain's OWN fp32 rays and upstream gradients (bit-identical inputs, the oracle's cond / unc noise floors), the torch glue between
+# the calls against the same expressions in float64 on the recorded tensors.  The whole-chain comparison with float64 autograd of the eager
+# twin is kept as a DIAGNOSTIC (recorded in the error table, bounded loosely): there stage k+1 traces rays that differ by the fp32 rounding
+# of stage k, which no per-element noise scale describes (round 2 asserted it at 3e-3; measured <= 1.5e-3).
+BOUNCE_CHAIN_DIAGNOSTIC_BOUND = 1e-2
+
+
+def _bounce_glue_f64(calls, thr, gr):
+    """The glue of SurfelTracer._forward_bounces in float64 on the recorded stage outputs.  Returns (leaves per call, o0, d0, loss):
+    loss = <returned outputs, gr> + sum_k>=1 <o_k, dray_o_k> + <d_k, dray_d_k> with the kernels' recorded ray gradients as upstream."""
+    dd = torch.float64
+    cpu = lambda t: t.detach().cpu()
+    S = []
+    for c in calls:
+        o = c["outs"]
+        S.append(dict(rgb=cpu(o[0]).to(dd).requires_grad_(True), dpt=cpu(o[1]).to(dd).requires_grad_(True), acc=cpu(o[2]).to(dd).requires_grad_(True),
+                      norm=cpu(o[3]).to(dd).requires_grad_(True), aux=cpu(o[5]).to(dd).requires_grad_(True)))
+    o0 = cpu(calls[0]["o_in"]).to(dd).reshape(-1, 3).requires_grad_(True); d0 = cpu(calls[0]["d_in"]).to(dd).reshape(-1, 3).requires_grad_(True)
+    R = o0.shape[0]
+    rays = [(o0, d0)]
+    sels = []
+    for k in range(len(calls) - 1):
+        c = calls[k]["outs"]
+        nl = cpu(c[3]).reshape(-1, 3).norm(dim=-1, keepdim=True)                     # the decisions are taken on the fp32 values, as the module does
+        go = ((cpu(c[5]).reshape(-1, 2)[:, 0:1] > thr) & (cpu(c[2]).reshape(-1, 1) > 0.5) & (nl > 0.0))[:, 0]
+        sel = go.nonzero(as_tuple=False)[:, 0]
+        sels.append(sel)
+        po, pd = rays[k][0][sel], rays[k][1][sel]
+        n = S[k]["norm"].reshape(-1, 3)[sel]
+        nh = n / n.norm(dim=-1, keepdim=True)
+        tdep = S[k]["dpt"].reshape(-1, 1)[sel] / S[k]["acc"].reshape(-1, 1)[sel]
+        rays.append((po + pd * tdep, pd - 2.0 * (pd * nh).sum(-1, keepdim=True) * nh))
+    col = S[-1]["rgb"].reshape(-1, 3)
+    for k in range(len(calls) - 2, -1, -1):
+        prgb = S[k]["rgb"].reshape(-1, 3)
+        s_ = S[k]["aux"].reshape(-1, 2)[sels[k], 0:1]
+        col = prgb.index_put((sels[k],), (1.0 - s_) * prgb[sels[k]] + s_ * col)
+    fin = (col, S[0]["dpt"].reshape(R), S[0]["acc"].reshape(R), S[0]["norm"].reshape(R, 3), S[0]["aux"].reshape(R, 2))
+    loss = sum((x.reshape(R, -1) * y.to(dd).reshape(R, -1)).sum() for x, y in zip(fin, gr))
+    for k in range(1, len(calls)):
+        loss = loss + (rays[k][0] * cpu(calls[k]["o_in"].grad).to(dd)).sum() + (rays[k][1] * cpu(calls[k]["d_in"].grad).to(dd)).sum()
+    return S, rays, sels, o0, d0, loss
 
 
 def test_trace_bounces_true_derivative():
-    """max_trace_depth = 2 through the drop-in module: images, per-stage `mid` records and stage-0 weights against the C oracle's forward;
-    EVERY gradient against float64 autograd of the eager twin composed over the stages (oracle/eager_trace.py:trace_bounces) -- the
-    backward is the derivative of the returned blend: through each stage's colour, the blend weights and the reflected-ray construction."""
+    """max_trace_depth = 2 through the drop-in module: images, per-stage `mid` records and weights against the C oracle's forward; EVERY
+    gradient at the 1e-4 contract link by link (each traced call vs the oracle on the chain's own rays, the glue vs float64), and the whole
+    chain against float64 autograd of the eager twin (oracle/eager_trace.py:trace_bounces) as a recorded diagnostic."""
     from oracle import trace as otr, eager_trace
+    from tests import stagewise
     test = "bounces_depth2"
     g, ro, rd = trace_scene(P=150, R=400, seed=4, camera=True)       # 20x20 camera rays
     bg = torch.tensor([0.0, 0.0, 0.0])
@@ -207,25 +247,28 @@ def test_trace_bounces_true_derivative():
     outs, *_ = _run_hip(g, ro, rd, bg, deg, True, True, depth=depth, thr=thr, shape=(20, 20))
     rgb, dpt, acc, norm, dist, aux, mid, wet = outs
     assert rgb.shape == (20, 20, 3) and dpt.shape == (20, 20, 1) and mid.shape == (20, 20, 48) and wet.shape == (P, 1)
-    # audit every stage: stage-k rays come from the oracle's own `mid`
+    # audit every stage ON THE RAYS THE HIP CHAIN TRACED (its own `mid`): stage-k hit sets, orders and bounce decisions must be determined
     args = (_np(g, "means3D"), _np(g, "scales"), _np(g, "rotations"), _np(g, "opacities"))
-    ref = otr.trace_forward(ro.numpy(), rd.numpy(), *args, shs=_np(g, "shs"), sh_degree=deg, others=_np(g, "others"), bg=bg.numpy(),
-                            max_trace_depth=depth, specular_threshold=thr, start_from_first=True)
-    frag = otr.trace_audit(ro.numpy(), rd.numpy(), *args, others=_np(g, "others"), start_from_first=True, bounce_thr=thr)["fragile"]
+    hmid = mid.detach().cpu().numpy().reshape(-1, 48)
+    frag = otr.trace_audit(ro.numpy(), rd.numpy(), *args, others=_np(g, "others"), start_from_first=True, bounce_thr=thr, shs=_np(g, "shs"), sh_degree=deg)["fragile"]
+    ref_all = otr.trace_forward(ro.numpy(), rd.numpy(), *args, shs=_np(g, "shs"), sh_degree=deg, others=_np(g, "others"), bg=bg.numpy(),
+                                max_trace_depth=depth, specular_threshold=thr, start_from_first=True)
     for k in (1, 2):
-        ran = np.abs(ref["mid"][:, 16 * k + 3:16 * k + 6]).sum(-1) > 0
-        a = otr.trace_audit(ref["mid"][ran, 16 * k:16 * k + 3], ref["mid"][ran, 16 * k + 3:16 * k + 6], *args, others=_np(g, "others"),
-                            start_from_first=False, tmin=1e-3, bounce_thr=(thr if k < depth else None))
-        frag[np.nonzero(ran)[0][a["fragile"]]] = True
+        for m_ in (hmid, ref_all["mid"]):                          # the HIP chain's rays and the oracle chain's rays of the stage
+            ran = np.abs(m_[:, 16 * k + 3:16 * k + 6]).sum(-1) > 0
+            a = otr.trace_audit(m_[ran, 16 * k:16 * k + 3], m_[ran, 16 * k + 3:16 * k + 6], *args, others=_np(g, "others"),
+                                start_from_first=False, tmin=1e-3, bounce_thr=(thr if k < depth else None), shs=_np(g, "shs"), sh_degree=deg)
+            frag[np.nonzero(ran)[0][a["fragile"]]] = True
     keep = torch.from_numpy(~frag)
     record(test, "fragile_rays", frag.mean(), "(%d of %d rays, all stages)" % (int(frag.sum()), frag.size))
-    assert frag.mean() < 0.05
+    assert frag.mean() < 0.06
     ro, rd = ro[keep].contiguous(), rd[keep].contiguous()
     R = ro.shape[0]
     gen = torch.Generator().manual_seed(12)
     gr = [torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, generator=gen), torch.randn(R, 3, generator=gen),
           torch.randn(R, 2, generator=gen)]
-    outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, deg, True, True, grads=gr, depth=depth, thr=thr)
+    with stagewise.TraceTap() as tap:
+        outs, L, o, d, g3 = _run_hip(g, ro, rd, bg, deg, True, True, grads=gr, depth=depth, thr=thr)
     rgb, dpt, acc, norm, dist, aux, mid, wet = [x.detach().cpu().numpy() for x in outs]
     ref = otr.trace_forward(ro.numpy(), rd.numpy(), *args, shs=_np(g, "shs"), sh_degree=deg, others=_np(g, "others"), bg=bg.numpy(),
                             max_trace_depth=depth, specular_threshold=thr, start_from_first=True)
@@ -233,8 +276,28 @@ def test_trace_bounces_true_derivative():
     nfr = int(frag.sum())
     check_close(test, "rgb", rgb, ref["rgb"], excluded=nfr)
     check_close(test, "mid", mid, ref["mid"], excluded=nfr)
-    check_close(test, "wet", wet[:, 0], ref["wet"], excluded=nfr)
-    # true derivative: float64 autograd through the composed stages
+    check_close(test, "wet", wet[:, 0], ref["wet"], excluded=nfr)                           # summed over the three stages on both sides
+    # ---- link by link at 1e-4 --------------------------------------------------------------------------------------------------------
+    assert len(tap.calls) == 3 and [c["sff"] for c in tap.calls] == [True, 2, 2]
+    backs = []
+    for k, c in enumerate(tap.calls):
+        _, rb = stagewise.oracle_trace_call(test, "stage%d" % k, c, g, bg.numpy(), deg, nfr=nfr)
+        backs.append(rb)
+    stagewise.check_summed_param_grads(test, "sum_over_stages", L, backs, nfr=nfr)
+    S, rays, sels, o0, d0, loss = _bounce_glue_f64(tap.calls, thr, gr)
+    for k in (1, 2):                                                                        # the glue's forward: the rays it handed to stage k
+        stagewise.glue_check(test, "glue.o_%d" % k, tap.calls[k]["o_in"], rays[k][0], floor=1.0)
+        stagewise.glue_check(test, "glue.d_%d" % k, tap.calls[k]["d_in"], rays[k][1], floor=1.0)
+    loss.backward()
+    for k, c in enumerate(tap.calls):                                                       # the glue's backward: what it delivers to every stage output
+        for i, nm in ((0, "rgb"), (1, "dpt"), (2, "acc"), (3, "norm"), (5, "aux")):
+            want = S[k][nm].grad if S[k][nm].grad is not None else torch.zeros_like(S[k][nm])
+            got = c["up"][i] if c["up"][i] is not None else torch.zeros_like(c["outs"][i])
+            stagewise.glue_check(test, "glue.up%d.%s" % (k, nm), got, want, floor=float(want.abs().mean()) + 1e-12)
+    # ... and into the original rays: leaf gradient = stage 0's kernel gradient + the glue's
+    stagewise.glue_check(test, "glue.dray_o", o.grad - tap.calls[0]["o_in"].grad, o0.grad, floor=float(o0.grad.abs().mean()) + 1e-12)
+    stagewise.glue_check(test, "glue.dray_d", d.grad - tap.calls[0]["d_in"].grad, d0.grad, floor=float(d0.grad.abs().mean()) + 1e-12)
+    # ---- whole chain vs float64 autograd of the eager twin: diagnostic ------------------------------------------------------------------
     dd = torch.float64
     E = {k: g[k].to(dd).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "others", "shs")}
     o64 = ro.to(dd).requires_grad_(True); d64 = rd.to(dd).requires_grad_(True)
@@ -243,6 +306,7 @@ def test_trace_bounces_true_derivative():
                                                                           sh_degree=deg, bg=bg, start_from_first=True)
     assert nst == 3
     check_close(test, "rgb.vs_f64", rgb, ergb.detach().numpy(), excluded=nfr)
+    check_close(test, "wet.vs_f64", wet[:, 0], ewet.detach().numpy(), excluded=nfr)
     loss = sum((x.reshape(R, -1) * y.to(dd).reshape(R, -1)).sum() for x, y in zip((ergb, edpt, eacc, enorm, eaux), gr))
     loss.backward()
     q = g["rotations"].double()
@@ -250,8 +314,9 @@ def test_trace_bounces_true_derivative():
     for nm, a, b in (("dmeans3D", L["means3D"].grad, E["means3D"].grad), ("grads3D", g3.grad, E["means3D"].grad), ("dscales", L["scales"].grad, E["scales"].grad),
                      ("dopacities", L["opacities"].grad, E["opacities"].grad), ("dothers", L["others"].grad, E["others"].grad), ("dshs", L["shs"].grad, E["shs"].grad),
                      ("dray_o", o.grad, o64.grad), ("dray_d", d.grad, d64.grad)):
-        check_close(test, nm, a.cpu().numpy(), b.numpy(), excluded=nfr, tol=BOUNCE_GRAD_TOL)
-    check_close(test, "drots", proj(L["rotations"].grad.cpu().double()).numpy(), proj(E["rotations"].grad).numpy(), excluded=nfr, tol=BOUNCE_GRAD_TOL)
+        check_close(test, "chain_f64_diagnostic." + nm, a.cpu().numpy(), b.numpy(), excluded=nfr, tol=BOUNCE_CHAIN_DIAGNOSTIC_BOUND)
+    check_close(test, "chain_f64_diagnostic.drots", proj(L["rotations"].grad.cpu().double()).numpy(), proj(E["rotations"].grad).numpy(), excluded=nfr,
+                tol=BOUNCE_CHAIN_DIAGNOSTIC_BOUND)
 
 
 def test_trace_kbuffer_in_kernel_bounces_forward():
