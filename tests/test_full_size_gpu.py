@@ -1,0 +1,283 @@
+"""GPU: the two BASELINE configurations that no small case represents, run as ONE workload each.
+
+configs[2]  full EnvGS at 800x800: the ch05 base pass over 300 k surfels, then its 640 k ACTUAL reflected rays over the 163 840-surfel
+            environment set, forward + backward.  Size-independent properties on the whole run (weight conservation, per-ray list sums,
+            index ranges, finiteness), and a sample of >= 4 096 of those reflected rays against the brute-force oracle: bit-exact sorted hit
+            lists, values within 1e-4, and -- traced again as a filtered (1,S,3) ray tensor, the form envgs_sampler.py:436-447 passes, with
+            the full run's own upstream gradients -- ray and parameter gradients within 1e-4 (oracle cond / unc floors).
+configs[4]  1600x1200, -ch07 raster, fp16 feature storage, two specular bounces WITH gradients: the stated combination in one step; the
+            oracle sees the half-rounded features.  Raster: index work and image against the oracle at full size, gradients against the
+            oracle with the step's own upstream gradients.  Tracer: properties on the whole run, a ray sample link by link (every stage of the
+            bounce chain against the oracle on the chain's own rays: tests/stagewise.py).
+
+The oracle legs are bounded (a few thousand rays brute force; one raster view) so that the file runs in about two minutes of mostly host time."""
+import numpy as np
+import pytest
+import torch
+
+from envgs_amd import envgs_step, synth
+from tests import stagewise
+from tests.util import check_close, record
+
+pytestmark = pytest.mark.gpu
+
+n = lambda t: t.detach().cpu().numpy()
+
+
+def _leaves(d, dev):
+    return {k: v.to(dev).clone().requires_grad_(True) for k, v in d.items()}
+
+
+def _tracer_settings(tpkg, cam, env_bg, deg, dev, depth=0, thr=0.0):
+    return tpkg.SurfelTracingSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=env_bg, scale_modifier=1.0,
+        viewmatrix=cam.world_view_transform.contiguous(), projmatrix=cam.full_proj_transform.contiguous(), sh_degree=torch.tensor([deg], device=dev),
+        campos=cam.camera_center.contiguous(), prefiltered=False, debug=False, max_trace_depth=depth, specular_threshold=thr)
+
+
+def _list_properties(test, tracing, acc, P_env):
+    """Size-independent properties of the sorted, composited per-ray lists of the last forward."""
+    ids, wbits, n_used, hit_cnt = tracing.last_hit_lists()
+    cap = ids.shape[1]
+    listed = hit_cnt <= cap
+    assert bool((n_used[listed] <= hit_cnt[listed]).all()) and int(n_used.min()) >= 0
+    valid = (torch.arange(cap, device=ids.device)[None] < n_used[:, None]) & listed[:, None]
+    assert bool(((ids >= 0) & (ids < P_env))[valid].all())                                     # every composited entry is a surfel
+    w = wbits.view(torch.float32)
+    wv = torch.where(valid, w, torch.zeros_like(w))
+    assert bool((wv[valid] > 0).all()) and bool((wv[valid] <= 0.99 + 1e-6).all())              # blend weights alpha * T: positive, below the alpha cap
+    rs = wv.double().sum(1)
+    a = acc.reshape(-1).double()
+    err = ((rs - a).abs() / (a.abs() + 1e-3))[listed]
+    record(test, "lists.sum_w_vs_acc", float(err.max()), "(%d listed rays, cap %d)" % (int(listed.sum()), cap))
+    assert float(err.max()) < 1e-4                                                              # sum of a ray's list weights = its accumulation
+    return ids, n_used, hit_cnt, listed
+
+
+def test_full_envgs_step_full_size():
+    import diff_surfel_rasterization_wet_ch05 as pkg
+    import diff_surfel_tracing as tpkg
+    from envgs_amd import tracing
+    from oracle import trace as otr
+    test = "config2_full_size"
+    dev = torch.device("cuda:0")
+    P, PE, H, W, deg = 300000, 163840, 800, 800, 3
+    base = _leaves(synth.base_gaussians(P, seed=0), dev)
+    env = _leaves(synth.env_gaussians(PE, seed=1), dev)
+    cam = synth.orbit_camera(3, n_views=8, H=H, W=W, fx=1111.1, device=dev)
+    rays = synth.get_rays(cam)
+    bg = torch.zeros(3, device=dev); env_bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    gen = torch.Generator().manual_seed(1)
+    dcol = (torch.randn(H, W, 3, generator=gen) / (H * W)).to(dev)
+    dall = (torch.randn(7, H, W, generator=gen) / (H * W)).to(dev); dall[5:] = 0
+    envgs_step.FUSED["on"] = True                       # the bench's default caller
+    tracing.KEEP_LISTS["on"] = True
+    try:
+        tracer = tpkg.SurfelTracer()
+        with stagewise.TraceTap() as tap:
+            out = envgs_step.envgs_forward(pkg, tpkg, tracer, cam, rays, base, env, bg, env_bg, torch.tensor([deg], device=dev))
+            ((out["rgb"] * dcol).sum() + (out["base"]["allmap"] * dall).sum()).backward()
+        torch.cuda.synchronize()
+        rec = tap.calls[0]
+        rgb, dpt, acc, norm, dist, aux, mid, wet = rec["outs"]
+        R = H * W
+        cnt = tracing.last_trace_counts()
+        record(test, "composited_hits_per_ray", cnt["hits"] / R, "(found %.1f, max list %d, cap %d)" % (cnt["found"] / R, cnt["max_list"], cnt["cap"]))
+        assert cnt["stack_overflows"] == 0
+        # ---- properties of the whole run ------------------------------------------------------------------------------------------------
+        for t in (rgb, dpt, acc, norm, dist, aux, mid, wet, out["rgb"]):
+            assert bool(torch.isfinite(t).all())
+        for k, v in list(base.items()) + list(env.items()):
+            assert v.grad is not None and bool(torch.isfinite(v.grad).all()), k
+        assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
+        sa, sw = float(acc.double().sum()), float(wet.double().sum())
+        record(test, "conservation.sum_wet_vs_sum_acc", abs(sw - sa) / sa)
+        assert abs(sw - sa) <= 1e-4 * sa                 # every composited weight reached exactly one surfel (fixed-point sums, rounded up per entry)
+        assert torch.equal(mid.reshape(R, 16)[:, 0:3], rec["o_in"].detach().reshape(R, 3)) and torch.equal(mid.reshape(R, 16)[:, 13:16], rgb.reshape(R, 3))
+        ids, n_used, hit_cnt, listed = _list_properties(test, tracing, acc, PE)
+        assert float(listed.float().mean()) > 0.999
+        # the surfels the lists name are exactly the surfels that received weight
+        seen = torch.zeros(PE, dtype=torch.bool, device=dev)
+        valid = torch.arange(ids.shape[1], device=dev)[None] < n_used[:, None]
+        valid &= listed[:, None]
+        seen[ids[valid].long()] = True
+        assert bool((wet[:, 0] > 0)[seen].all())
+        if bool(listed.all()):
+            assert torch.equal(seen, wet[:, 0] > 0)
+        # ---- a sample of the ACTUAL reflected rays against the brute-force oracle ---------------------------------------------------------
+        S = 4096
+        idx = torch.randperm(R, generator=torch.Generator().manual_seed(5))[:S].to(dev)
+        so = rec["o_in"].detach().reshape(R, 3)[idx].contiguous(); sd = rec["d_in"].detach().reshape(R, 3)[idx].contiguous()
+        env_cpu = {k: v.detach().cpu() for k, v in env.items()}
+        LC = 1024
+        a = otr.trace_audit(n(so), n(sd), n(env["means3D"]), n(env["scales"]), n(env["rotations"]), n(env["opacities"]), start_from_first=False,
+                            shs=n(env["shs"]), sh_degree=deg, lcap=LC)
+        assert int(a["nhit"].max()) < LC
+        keep = ~a["fragile"] & n(listed[idx])
+        record(test, "sample.fragile_rays", float(a["fragile"].mean()), "(%d of %d sampled rays)" % (int(a["fragile"].sum()), S))
+        assert keep.mean() > 0.9
+        kt = torch.from_numpy(keep).to(dev)
+        # index parity: the full run's sorted, composited list of every sampled ray == the brute-force list
+        ids_s = n(ids[idx]); nu_s = n(n_used[idx])
+        np.testing.assert_array_equal(nu_s[keep], a["nhit"][keep])
+        w_ = min(ids_s.shape[1], LC)
+        vmask = (np.arange(ids_s.shape[1])[None] < nu_s[:, None])
+        np.testing.assert_array_equal(np.where(vmask, ids_s, -1)[keep][:, :w_], a["ids"][keep][:, :w_])
+        record(test, "sample.hit_lists_bit_exact", 0.0, "(%d rays, %d composited (t, id) pairs compared)" % (int(keep.sum()), int(nu_s[keep].sum())))
+        # the sample traced on its own, as a filtered (1,S,3) ray tensor with the full run's upstream gradients
+        for v in env.values(): v.grad = None
+        so_g = so[kt].reshape(1, -1, 3).clone().requires_grad_(True); sd_g = sd[kt].reshape(1, -1, 3).clone().requires_grad_(True)
+        v_, f_ = synth.get_disks(env["means3D"].detach(), env["scales"].detach(), env["rotations"].detach())
+        tracer2 = tpkg.SurfelTracer(); tracer2.build_acceleration_structure(v_, f_, rebuild=True)
+        with stagewise.TraceTap() as tap2:
+            o2 = tracer2(so_g, sd_g, v_, means3D=env["means3D"], grads3D=None, shs=env["shs"], colors_precomp=None, others_precomp=None,
+                         opacities=env["opacities"], scales=env["scales"], rotations=env["rotations"], cov3D_precomp=None,
+                         tracer_settings=_tracer_settings(tpkg, cam, env_bg, deg, dev), start_from_first=False)
+            sel = idx[kt]
+            ups = [rec["up"][i].reshape(R, -1)[sel] if rec["up"][i] is not None else None for i in (0, 1, 2, 3, 5)]
+            loss = sum((o2[i].reshape(sel.numel(), -1) * u).sum() for i, u in zip((0, 1, 2, 3, 5), ups) if u is not None)
+            loss.backward()
+        torch.cuda.synchronize()
+        assert o2[0].shape == (1, sel.numel(), 3)
+        # a ray's result does not depend on the rays it is traced with: the sample call reproduces the full run bit for bit
+        for i in (0, 1, 2, 3):
+            assert torch.equal(o2[i].reshape(sel.numel(), -1), rec["outs"][i].reshape(R, -1)[sel]), i
+        _, tb = stagewise.oracle_trace_call(test, "sample", tap2.calls[0], env_cpu, n(env_bg), deg, use_sh=True, others=False,
+                                            nfr=int((~keep).sum()))
+        stagewise.check_summed_param_grads(test, "sample", env, [tb], nfr=int((~keep).sum()))
+        # and the full run's ray gradients at the sampled rays (same terms, summed in the order of a different batch)
+        check_close(test, "full_run.dray_o", n(rec["o_in"].grad.reshape(R, 3)[sel]), tb["dray_o"], cond=tb["cond"]["dray_o"], unc=tb["unc"]["dray_o"])
+        check_close(test, "full_run.dray_d", n(rec["d_in"].grad.reshape(R, 3)[sel]), tb["dray_d"], cond=tb["cond"]["dray_d"], unc=tb["unc"]["dray_d"])
+    finally:
+        envgs_step.FUSED["on"] = False
+        tracing.KEEP_LISTS["on"] = False
+        tracing.LAST_STATS["lists"] = None
+
+
+def test_config5_combination_fp16_ch07_two_bounces_with_gradients():
+    import diff_surfel_rasterization_wet_ch07 as pkg
+    import diff_surfel_tracing as tpkg
+    from envgs_amd import tracing
+    from oracle import raster as orc, trace as otr
+    test = "config5_combination"
+    dev = torch.device("cuda:0")
+    P, PE, H, W, deg, depth, thr = 300000, 163840, 1200, 1600, 3, 2, 0.5
+    g = synth.base_gaussians(P, seed=0)
+    g["specular"] = g["specular"].repeat(1, 3).contiguous()                    # -ch07: three specular channels
+    base = _leaves(g, dev)
+    env = _leaves(synth.env_gaussians(PE, seed=1), dev)
+    env["others"] = torch.rand(PE, 2, generator=torch.Generator().manual_seed(3)).to(dev).requires_grad_(True)      # [specular, roughness] of the env set: half of the rays bounce
+    cam = synth.orbit_camera(2, n_views=8, H=H, W=W, fx=1111.1 * W / 800.0, device=dev)
+    rays = synth.get_rays(cam)
+    bg = torch.zeros(3, device=dev); env_bg = torch.zeros(3, device=dev)
+    gen = torch.Generator().manual_seed(1)
+    dcol = (torch.randn(H, W, 3, generator=gen) / (H * W)).to(dev)
+    dall = (torch.randn(7, H, W, generator=gen) / (H * W)).to(dev); dall[5:] = 0
+    R = H * W
+    envgs_step.FUSED["on"] = True
+    envgs_step.FEATURE_F16["on"] = True
+    envgs_step.TRACE.update(depth=depth, specular_threshold=thr)
+    try:
+        tracer = tpkg.SurfelTracer()
+        with stagewise.RasterTap() as rtap, stagewise.TraceTap() as tap:
+            out = envgs_step.envgs_forward(pkg, tpkg, tracer, cam, rays, base, env, bg, env_bg, torch.tensor([deg], device=dev))
+            ((out["rgb"] * dcol).sum() + (out["base"]["allmap"] * dall).sum()).backward()
+        torch.cuda.synchronize()
+        assert out["base"]["colors"].dtype == torch.float16 and out["base"]["img"].shape == (7, H, W)
+        # ---- the whole run: three stages, every one differentiated ------------------------------------------------------------------------
+        assert len(tap.calls) == depth + 1 and [c["sff"] for c in tap.calls] == [False, 2, 2]
+        nr = [c["o_in"].reshape(-1, 3).shape[0] for c in tap.calls]
+        record(test, "rays_per_stage", float(nr[1]) / nr[0], "(%s)" % nr)
+        assert nr[0] == R and 0.05 * R < nr[1] < 0.95 * R and 0 < nr[2] < nr[1]
+        for c in tap.calls:
+            for t in c["outs"]:
+                assert bool(torch.isfinite(t).all())
+            assert c["o_in"].grad is not None and bool(torch.isfinite(c["o_in"].grad).all()) and float(c["o_in"].grad.abs().max()) > 0
+        for k, v in list(base.items()) + list(env.items()):
+            assert v.grad is not None and bool(torch.isfinite(v.grad).all()), k
+            if k != "roughness":                                             # (the roughness channel is rendered but no term of this loss reads it)
+                assert float(v.grad.abs().max()) > 0, k
+        sa = sum(float(c["outs"][2].double().sum()) for c in tap.calls)
+        sw = float(out["env_wet"].double().sum())
+        record(test, "conservation.sum_wet_vs_sum_acc_all_stages", abs(sw - sa) / sa)
+        assert abs(sw - sa) <= 1e-4 * sa                 # `wet` is the weight every surfel received over ALL stages
+        peak = torch.cuda.max_memory_allocated(dev) / 2**30
+        record(test, "peak_allocated_GB", peak)
+        # ---- raster link at full size: -ch07, half-rounded colours -----------------------------------------------------------------------
+        rc = rtap.calls[0]
+        col_h = out["base"]["colors"].detach().float()                      # exactly what the kernels read (half -> float is exact)
+        ref = orc.raster_forward(n(base["means3D"]), n(base["opacities"]), n(cam.world_view_transform), n(cam.full_proj_transform), n(cam.camera_center), W, H,
+                                 scales=n(base["scales"]), rotations=n(base["rotations"]), colors_precomp=n(col_h), bg=np.zeros(3, np.float32))
+        aud = orc.raster_audit(ref)
+        okp = ~aud["fragile"]; nfr = int(aud["fragile"].sum())
+        record(test, "raster.fragile_px", float(aud["fragile"].mean()))
+        assert aud["fragile"].mean() < 2e-2
+        saved = rc["saved"]
+        assert saved["N"] == ref["N"]
+        np.testing.assert_array_equal(n(saved["point_list"]).view(np.uint32)[:ref["N"]], ref["point_list"])
+        np.testing.assert_array_equal(n(saved["ranges"]).view(np.uint32), ref["ranges"])
+        np.testing.assert_array_equal(n(saved["n_contrib"])[0][okp], ref["n_contrib"][0][okp])
+        check_close(test, "raster.img", n(out["base"]["img"])[:, okp], ref["out_color"][:, okp], excluded=nfr, tail=(2e-5, 1e-3))
+        for ch, nm in ((0, "depth"), (1, "alpha"), (2, "normal.x"), (3, "normal.y"), (4, "normal.z")):
+            check_close(test, "raster.allmap." + nm, n(out["base"]["allmap"])[ch][okp], ref["allmap"][ch][okp], excluded=nfr, tail=(2e-5, 1e-3))
+        # gradients with the step's own upstream, zeroed at the fragile pixels on both sides: a second backward of the saved forward state
+        from envgs_amd import raster
+        m = torch.from_numpy(okp).to(dev)
+        dc = rc["dL_dcolor"] * m; da = rc["dL_dallmap"] * m
+        gr = rtap.orig(saved, dc, da)
+        rb = orc.raster_backward(ref, n(dc), n(da), want_cond=True)
+        for k_hip, k_ref in (("means3D", "dmeans3D"), ("scales", "dscales"), ("rotations", "drots"), ("opacities", "dopacities"), ("means2D", "dmeans2D"),
+                             ("colors_precomp", "dcolors")):
+            check_close(test, "raster." + k_ref, n(gr[k_hip]).reshape(rb[k_ref].shape), rb[k_ref], excluded=nfr, cond=rb["cond"][k_ref], unc=rb["unc"][k_ref],
+                        tail=(2e-5, 1e-3))
+        # ---- tracer link: a sample of the reflected rays through the whole bounce chain, every stage against the oracle ---------------------
+        S = 2048
+        idx = torch.randperm(R, generator=torch.Generator().manual_seed(6))[:S].to(dev)
+        c0 = tap.calls[0]
+        so = c0["o_in"].detach().reshape(R, 3)[idx].contiguous(); sd = c0["d_in"].detach().reshape(R, 3)[idx].contiguous()
+        env_cpu = {k: v.detach().cpu() for k, v in env.items()}
+        env_cpu["shs"] = env_cpu["shs"].half().float()                       # what the tracer reads: the half-rounded SH blocks
+        args = (n(env["means3D"]), n(env["scales"]), n(env["rotations"]), n(env["opacities"]))
+        shs_np = env_cpu["shs"].numpy(); oth_np = env_cpu["others"].numpy()
+        # pass 1 (forward only): the chain's own rays of every stage -> audit -> drop the rays any stage calls fragile
+        st = _tracer_settings(tpkg, cam, env_bg, deg, dev, depth, thr)
+        v_, f_ = synth.get_disks(env["means3D"].detach(), env["scales"].detach(), env["rotations"].detach())
+        tracer2 = tpkg.SurfelTracer(); tracer2.build_acceleration_structure(v_, f_, rebuild=True)
+        kw = dict(means3D=env["means3D"], grads3D=None, colors_precomp=None, opacities=env["opacities"], scales=env["scales"], rotations=env["rotations"],
+                  cov3D_precomp=None, tracer_settings=st, start_from_first=False)
+        with torch.no_grad():
+            o1 = tracer2(so, sd, v_, shs=env["shs"].half(), others_precomp=env["others"], **kw)
+        hmid = n(o1[6]).reshape(S, 16 * (depth + 1))
+        LC = 1024
+        frag = otr.trace_audit(n(so), n(sd), *args, others=oth_np, start_from_first=False, bounce_thr=thr, shs=shs_np, sh_degree=deg, lcap=LC)["fragile"]
+        for k in range(1, depth + 1):
+            ran = np.abs(hmid[:, 16 * k + 3:16 * k + 6]).sum(-1) > 0
+            a = otr.trace_audit(hmid[ran, 16 * k:16 * k + 3], hmid[ran, 16 * k + 3:16 * k + 6], *args, others=oth_np, start_from_first=False, tmin=1e-3,
+                                bounce_thr=(thr if k < depth else None), shs=shs_np, sh_degree=deg, lcap=LC)
+            frag[np.nonzero(ran)[0][a["fragile"]]] = True
+        record(test, "sample.fragile_rays", float(frag.mean()), "(%d of %d sampled rays, all stages)" % (int(frag.sum()), S))
+        assert frag.mean() < 0.15
+        kt = torch.from_numpy(~frag).to(dev)
+        nfr_s = int(frag.sum())
+        # pass 2: the determined rays with gradients, tapped
+        for v in env.values(): v.grad = None
+        so_g = so[kt].clone().requires_grad_(True); sd_g = sd[kt].clone().requires_grad_(True)
+        S2 = so_g.shape[0]
+        gen = torch.Generator().manual_seed(12)
+        gr = [torch.randn(S2, c, generator=gen).to(dev) for c in (3, 1, 1, 3, 2)]
+        with stagewise.TraceTap() as tap2:
+            o2 = tracer2(so_g, sd_g, v_, shs=env["shs"].half(), others_precomp=env["others"], **kw)
+            sum((o2[i] * u).sum() for i, u in zip((0, 1, 2, 3, 5), gr)).backward()
+        torch.cuda.synchronize()
+        assert len(tap2.calls) == depth + 1 and tap2.calls[1]["o_in"].shape[0] > 0.05 * S2
+        assert torch.equal(o2[6], o1[6][kt])                                 # the chain is deterministic and ray-independent
+        backs = []
+        for k, c in enumerate(tap2.calls):
+            _, tb = stagewise.oracle_trace_call(test, "stage%d" % k, c, env_cpu, n(env_bg), deg, use_sh=True, others=True, nfr=nfr_s)
+            backs.append(tb)
+        leaves = dict(env)
+        stagewise.check_summed_param_grads(test, "sum_over_stages", leaves, backs, nfr=nfr_s)
+    finally:
+        envgs_step.FUSED["on"] = False
+        envgs_step.FEATURE_F16["on"] = False
+        envgs_step.TRACE.update(depth=0, specular_threshold=0.0)
