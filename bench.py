@@ -195,6 +195,8 @@ def main():
     if envgs and args.trace_depth > 0:
         env_in["others"] = env_others
     half = args.feature_dtype == "f16"
+    import envgs_amd
+    envgs_amd.set_feature_storage("f16" if half else "f32")      # half copies inside the autograd nodes: fp32 parameters in, fp32 gradients out
     if half and envgs:
         from envgs_amd import envgs_step as _es2
         _es2.FEATURE_F16["on"] = True
@@ -242,7 +244,7 @@ def main():
         else:
             means2D = torch.zeros_like(params["means3D"], requires_grad=True)
             color, radii, allmap, weight = pkg.GaussianRasterizer(raster_settings=settings(cam))(
-                means3D=params["means3D"], means2D=means2D, shs=(params["shs"].half() if half else params["shs"]), colors_precomp=None,
+                means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
                 opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"], cov3D_precomp=None)
             loss = (color * dcol).sum() + (allmap * dall).sum()
         n_acc["N"] += raster.LAST_STATS["N"]; n_acc["steps"] += 1

@@ -5,3 +5,14 @@ and the host-side mirrors of the reference's operator interface (raster.py, trac
 import names (diff_surfel_rasterization_wet{,_ch05,_ch07}, diff_surfel_tracing) are thin top-level packages.
 """
 __version__ = "0.1.0"
+
+
+def set_feature_storage(kind="f32"):
+    """"f16": the three raster packages and the tracer keep HALF copies of the per-surfel feature arrays they read (shs, colors_precomp) --
+    BASELINE configs[4]'s storage variant: half the gather bytes, fp32 arithmetic -- while accepting fp32 tensors and returning fp32
+    gradients (the copy is made inside the autograd node; a half INPUT would have its gradient cast to half by autograd, which underflows
+    at training magnitudes).  "f32" (default): the arrays are read as passed.  Process-wide, like the reference's own build-time choice."""
+    if kind not in ("f32", "f16"):
+        raise ValueError("feature storage must be 'f32' or 'f16', got %r" % (kind,))
+    from . import raster
+    raster.FEATURE_STORAGE["f16"] = kind == "f16"

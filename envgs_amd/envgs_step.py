@@ -60,8 +60,7 @@ def base_pass(pkg, cam, base, bg, sh_degree, scale_modifier=1.0):
         dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
         colors = torch.clamp_min(eval_sh(int(sh_degree), shs_view, dir_pp) + 0.5, 0.0)
         colors = torch.cat([colors, base["specular"], base["roughness"]], dim=-1)
-    if FEATURE_F16["on"]:
-        colors = colors.half()
+    _select_storage()
     img, radii, allmap, weight = pkg.GaussianRasterizer(raster_settings=st)(
         means3D=base["means3D"], means2D=means2D, shs=None, colors_precomp=colors, opacities=base["opacities"],
         scales=base["scales"], rotations=base["rotations"], cov3D_precomp=None)
@@ -118,7 +117,15 @@ def visibility_filter(wet, means3D=None, K=None, R=None, T=None, H=None, W=None,
         return vis.detach().clone()
 
 
-FEATURE_F16 = {"on": False}        # bench.py --feature-dtype f16: the feature arrays handed to the extensions are half copies of the fp32 parameters
+FEATURE_F16 = {"on": False}        # bench.py --feature-dtype f16: the extensions keep HALF copies of the feature arrays they read (fp32 parameters in, fp32
+                                   # gradients out: envgs_amd.set_feature_storage -- a caller-side .half() would get its gradient back in fp16)
+
+
+def _select_storage():
+    import envgs_amd
+    envgs_amd.set_feature_storage("f16" if FEATURE_F16["on"] else "f32")
+
+
 REFERENCE_FORMS = {"on": False}    # bench.py --caller reference: the expression forms the unchanged EasyVolcap caller executes (batched-matmul get_disks,
                                    # the regulariser maps of render()'s tail) instead of this module's cheaper equivalents
 TRACE = {"depth": 0, "specular_threshold": 0.0}    # EnvGS hard-codes 0 bounces (envgs_sampler.py:510,548); bench.py --trace-depth overrides
@@ -131,6 +138,7 @@ def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree):
         scale_modifier=1.0, viewmatrix=cam.world_view_transform.contiguous(), projmatrix=cam.full_proj_transform.contiguous(),
         sh_degree=sh_degree, campos=cam.camera_center.contiguous(), prefiltered=False, debug=False, max_trace_depth=int(TRACE["depth"]),
         specular_threshold=float(TRACE["specular_threshold"]))
+    _select_storage()
     if FUSED["on"] and not REFERENCE_FORMS["on"]:
         from . import fused
         v, f = fused.surfel_quads(env["means3D"], env["scales"], env["rotations"])          # one launch instead of ~25 torch kernels in front of the trace
@@ -140,7 +148,7 @@ def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree):
         tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
     grads3D = torch.zeros_like(env["means3D"], requires_grad=True) + 0
     return tracer(ref_o.contiguous(), ref_d.contiguous(), v, means3D=env["means3D"].contiguous(), grads3D=grads3D,
-                  shs=(env["shs"].half() if FEATURE_F16["on"] else env["shs"]).contiguous(), colors_precomp=None, others_precomp=env.get("others"), opacities=env["opacities"].contiguous(),
+                  shs=env["shs"].contiguous(), colors_precomp=None, others_precomp=env.get("others"), opacities=env["opacities"].contiguous(),
                   scales=env["scales"].contiguous(), rotations=env["rotations"].contiguous(), cov3D_precomp=None,
                   tracer_settings=ts, start_from_first=False)
 

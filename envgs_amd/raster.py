@@ -97,6 +97,21 @@ def _n_mirror(dev):
     return m
 
 
+# fp16 FEATURE STORAGE without fp16 GRADIENTS (BASELINE configs[4]).  A caller that passes half shs / colors_precomp gets the gradient back in
+# half -- autograd casts an input's gradient to the input's dtype -- and at training magnitudes (1e-6 and below) that is fp16's subnormal
+# range: whole blocks of dL/dSH flush to zero.  With this switch on, fp32 feature tensors are accepted as usual and the HALF COPY is made
+# inside the autograd node: the kernels read 2 B per value, the gradient leaves the node in fp32.  Shared by the three raster packages and
+# the tracer (envgs_amd.set_feature_storage).
+FEATURE_STORAGE = {"f16": False}
+
+
+def _store(t):
+    """The tensor the kernels read for a feature input: a half copy when fp16 feature storage is selected, else the input itself."""
+    if t is not None and FEATURE_STORAGE["f16"] and t.dtype == torch.float32 and t.numel() > 0:
+        return t.detach().half()
+    return t
+
+
 CONTRIB_MASK = {"on": True}   # forward records which pixel quadrants blended each tile instance; the backward walks exactly those (tests switch it off to cover the geometric fallback)
 
 
@@ -267,7 +282,7 @@ def make_package(C):
         @staticmethod
         def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
             none = lambda t: None if (t is None or t.numel() == 0) else t
-            outs, saved = rasterize_forward(C, means3D, none(sh), none(colors_precomp), opacities, none(scales),
+            outs, saved = rasterize_forward(C, means3D, _store(none(sh)), _store(none(colors_precomp)), opacities, none(scales),
                                             none(rotations), none(cov3Ds_precomp), raster_settings)
             ctx.saved = saved
             ctx.in_dtypes = tuple(None if t is None else t.dtype for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))

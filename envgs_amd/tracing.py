@@ -307,7 +307,8 @@ class _TraceSurfels(torch.autograd.Function):
     def forward(ctx, ray_o, ray_d, v, means3D, grads3D, shs, colors_precomp, others_precomp, opacities, scales, rotations,
                 cov3D_precomp, tracer_settings, start_from_first, nodes, caps=None):
         none = lambda t: None if (t is None or t.numel() == 0) else t
-        outs, saved = trace_forward(nodes, ray_o, ray_d, means3D, none(shs), none(colors_precomp), none(others_precomp), opacities,
+        from .raster import _store                       # fp16 feature storage selected (envgs_amd.set_feature_storage): half copies made HERE, fp32 gradients
+        outs, saved = trace_forward(nodes, ray_o, ray_d, means3D, _store(none(shs)), _store(none(colors_precomp)), none(others_precomp), opacities,
                                     scales, rotations, tracer_settings, start_from_first, need_grad=any(ctx.needs_input_grad), caps=caps)
         ctx.saved = saved
         ctx.in_dtypes = tuple(None if t is None else t.dtype for t in (ray_o, ray_d, means3D, grads3D, shs, colors_precomp,

@@ -42,7 +42,7 @@ class TraceTap:
             rec = dict(o_in=o_in, d_in=d_in, outs=outs, up=[None] * 6, settings=rest[10], sff=rest[11])
             for i in (0, 1, 2, 3, 5):
                 if outs[i].requires_grad:
-                    outs[i].register_hook(lambda g, i=i, rec=rec: rec["up"].__setitem__(i, g.detach().clone()))
+                    outs[i].register_hook(lambda g, i=i, rec=rec: rec["up"].__setitem__(i, None if g is None else g.detach().clone()))
             tap.calls.append(rec)
             return outs
 
@@ -121,7 +121,7 @@ def check_summed_param_grads(test, name, leaves, backs, nfr=0):
         check_close(test, "%s.%s" % (name, k_ref), got, want, excluded=nfr, cond=cond, unc=unc)
 
 
-def glue_check(test, name, got, want, floor=None):
+def glue_check(test, name, got, want, floor=None, cond=None):
     """A glue value / gradient (torch autograd in fp32 on the GPU, or the fused HIP glue) against the same expression in float64 on the same
     recorded tensors.  Elements that are not finite on either side (0/0 where a pixel has no coverage: nan_to_num's backward) are left out and
     counted; everything else must be within 1e-4 elementwise."""
@@ -131,4 +131,7 @@ def glue_check(test, name, got, want, floor=None):
     if not fin.all():
         record(test, name + ".nonfinite", float((~fin).mean()), "(%d elements not finite on one side, left out)" % int((~fin).sum()))
         assert (~fin).mean() < 0.2
-    check_close(test, name, a[fin], b[fin], floor=floor)
+    if cond is not None:        # per-element magnitude of what the element is a (cancelling) sum of: floor 2e-6 * cond, like the kernels' gradients
+        check_close(test, name, a[fin], b[fin], cond=_n(cond).astype(np.float64).reshape(a.shape)[fin])
+    else:
+        check_close(test, name, a[fin], b[fin], floor=floor)

@@ -80,8 +80,9 @@ def _colors_f64(cam, base, deg):
     shs_view = base["shs"].transpose(1, 2)
     dir_pp = base["means3D"] - cam.camera_center.detach().cpu().double()[None]
     dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+    dir_pp.retain_grad()
     raw = envgs_step.eval_sh(deg, shs_view, dir_pp) + 0.5
-    return torch.cat([torch.clamp_min(raw, 0.0), base["specular"], base["roughness"]], dim=-1), raw
+    return torch.cat([torch.clamp_min(raw, 0.0), base["specular"], base["roughness"]], dim=-1), raw, dir_pp
 
 
 @pytest.mark.parametrize("fused_glue", [False, True])
@@ -156,7 +157,7 @@ def test_full_envgs_step_link_by_link(fused_glue):
     stagewise.glue_check(test, "glue.d_rgb_env", tc["up"][0], env64.grad, floor=fl(env64.grad))
     # the SH colours handed to the rasterizer, and their gradient back into the base parameters (upstream = the raster kernels' dcolors)
     B64 = {k: v.detach().cpu().to(dd).requires_grad_(True) for k, v in base.items()}
-    col64, raw = _colors_f64(cam, B64, deg)
+    col64, raw, dir64 = _colors_f64(cam, B64, deg)
     near_clamp = (raw.detach().abs() < 1e-5).any(dim=1).numpy()                      # a colour channel within rounding of the clamp at 0: either branch is right
     record(test, "glue.colors.near_clamp_surfels", float(near_clamp.mean()))
     stagewise.glue_check(test, "glue.colors", out["base"]["colors"].float()[torch.from_numpy(~near_clamp).to(dev)], col64[torch.from_numpy(~near_clamp)], floor=1.0)
@@ -164,7 +165,11 @@ def test_full_envgs_step_link_by_link(fused_glue):
     nc = torch.from_numpy(~near_clamp)
     for k in ("shs", "specular", "roughness"):
         stagewise.glue_check(test, "glue.d_" + k, g_h["base." + k][nc.to(dev)], B64[k].grad[nc], floor=fl(B64[k].grad))
-    stagewise.glue_check(test, "glue.d_means3D", (g_h["base.means3D"] - rc["grads"]["means3D"])[nc.to(dev)], B64["means3D"].grad[nc], floor=fl(B64["means3D"].grad))
+    # d colour / d position goes through the NORMALISED view direction: dL/dp = (I - d d^T) dL/dd / |p - c| subtracts the radial part of
+    # dL/dd, which is most of it -- the element is judged against the magnitude of what is subtracted, as the kernels' gradients are
+    vlen = (B64["means3D"].detach() - cam.camera_center.detach().cpu().double()[None]).norm(dim=1, keepdim=True)
+    cond_p = (dir64.grad.abs().sum(dim=1, keepdim=True) / vlen).expand(-1, 3)
+    stagewise.glue_check(test, "glue.d_means3D", (g_h["base.means3D"] - rc["grads"]["means3D"])[nc.to(dev)], B64["means3D"].grad[nc], cond=cond_p[nc])
     # the leaves received exactly kernel gradient (+ glue): nothing else feeds them
     for k in ("scales", "rotations", "opacities"):
         assert torch.equal(g_h["base." + k].reshape(-1), rc["grads"][k].reshape(-1).to(g_h["base." + k].dtype))

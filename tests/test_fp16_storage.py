@@ -1,4 +1,5 @@
-"""fp16 FEATURE storage (BASELINE configs[4]; cfg.feature_f16): the caller passes shs / colors_precomp as half tensors, the kernels convert on
+"""fp16 FEATURE storage (BASELINE configs[4]; cfg.feature_f16): the kernels read shs / colors_precomp as half -- either because the caller passes half
+tensors (its gradient then comes back in half, autograd's rule) or because envgs_amd.set_feature_storage("f16") is on (fp32 in, fp32 gradients out) -- and convert on
 load, arithmetic / accumulation / gradient buffers stay fp32.  Converting half -> float is exact, so the fp16-storage path must reproduce the
 fp32 path run on the SAME (fp16-rounded) values to fp32 rounding -- a much sharper statement than an "fp16 tolerance" -- and, against the
 original fp32 features, stay within the quantisation error of the features themselves."""
@@ -87,3 +88,46 @@ def test_tracer_fp16_feature_storage(use_sh):
     check_close(t, "dray_d", out["h"][4].cpu().numpy(), out["f"][4].cpu().numpy(), tol=1e-5)
     sel = out["f"][2].abs() > 6.2e-5
     check_close(t, "dfeat(half)", out["h"][2].float()[sel].cpu().numpy(), out["f"][2][sel].cpu().numpy(), tol=1e-3)
+
+
+class _F16Storage:
+    """envgs_amd.set_feature_storage("f16") for the duration of a block: fp32 feature tensors in, half copies inside the nodes, fp32 gradients out."""
+    def __enter__(self):
+        import envgs_amd
+        envgs_amd.set_feature_storage("f16")
+    def __exit__(self, *a):
+        import envgs_amd
+        envgs_amd.set_feature_storage("f32")
+
+
+@pytest.mark.parametrize("C,sh", [(3, True), (7, False)])
+def test_raster_fp16_storage_keeps_fp32_gradients(C, sh):
+    """The storage switch (configs[4]'s training form): the forward is the half-input path bit for bit, and the feature gradient -- which a half
+    INPUT gets back rounded to fp16, i.e. flushed to zero below 6e-8 -- comes back in fp32 and equals the fp32 path's on EVERY element."""
+    from tests.test_raster_parity import _mod_for
+    dev = torch.device("cuda:0")
+    g, cam = small_scene(P=600, H=64, W=80, seed=3, C=C, sh=sh)
+    mod = _mod_for(C)
+    feats = (g["shs"] if sh else g["colors_precomp"]).half().float()              # representable in half: storing them loses nothing
+    c32, a32, g32, f32 = _raster(mod, C, g, cam, 3, feats, dev)
+    ch, ah, gh, fh = _raster(mod, C, g, cam, 3, feats.half(), dev)
+    with _F16Storage():
+        cs, as_, gs, fs = _raster(mod, C, g, cam, 3, feats, dev)
+    t = "fp16_storage_switch_raster_C%d" % C
+    assert fs.dtype == torch.float32 and torch.equal(cs, ch) and torch.equal(as_, ah) and torch.equal(cs, c32)
+    check_close(t, "dfeat", fs.cpu().numpy(), f32.cpu().numpy(), tol=1e-5)        # all elements, whatever their magnitude
+    lost = float(((fh.float() == 0) & (f32 != 0)).float().mean())
+    record(t, "elements_a_half_gradient_flushes_to_zero", lost)
+    for k in g32:
+        check_close(t, "d" + k, gs[k].cpu().numpy(), g32[k].cpu().numpy(), tol=1e-5)
+
+
+def test_tracer_fp16_storage_against_the_oracle_on_the_rounded_features(request):
+    """fp16 SH storage against the ORACLE run on the half-rounded features (not HIP against HIP): hit lists, values, every gradient at 1e-4."""
+    from tests.test_trace_parity import _parity
+    g, ro, rd = trace_scene(P=2000, R=1024, seed=7, camera=False)
+    g["scales"] = g["scales"] * 0.35
+    g["shs"] = g["shs"].half().float()
+    with _F16Storage():
+        res = _parity("fp16_storage_tracer_vs_oracle", g, ro, rd, torch.tensor([0.3, 0.1, 0.7]), 2, True, False)
+    assert res["ref"]["nhits"].mean() > 1

@@ -183,7 +183,8 @@ def test_config5_combination_fp16_ch07_two_bounces_with_gradients():
             out = envgs_step.envgs_forward(pkg, tpkg, tracer, cam, rays, base, env, bg, env_bg, torch.tensor([deg], device=dev))
             ((out["rgb"] * dcol).sum() + (out["base"]["allmap"] * dall).sum()).backward()
         torch.cuda.synchronize()
-        assert out["base"]["colors"].dtype == torch.float16 and out["base"]["img"].shape == (7, H, W)
+        assert out["base"]["colors"].dtype == torch.float32 and out["base"]["img"].shape == (7, H, W)
+        assert rtap.calls[0]["saved"]["colors"].dtype == torch.float16                     # what the kernels read: the half copy made inside the node
         # ---- the whole run: three stages, every one differentiated ------------------------------------------------------------------------
         assert len(tap.calls) == depth + 1 and [c["sff"] for c in tap.calls] == [False, 2, 2]
         nr = [c["o_in"].reshape(-1, 3).shape[0] for c in tap.calls]
@@ -205,7 +206,7 @@ def test_config5_combination_fp16_ch07_two_bounces_with_gradients():
         record(test, "peak_allocated_GB", peak)
         # ---- raster link at full size: -ch07, half-rounded colours -----------------------------------------------------------------------
         rc = rtap.calls[0]
-        col_h = out["base"]["colors"].detach().float()                      # exactly what the kernels read (half -> float is exact)
+        col_h = rtap.calls[0]["saved"]["colors"].float()                   # exactly what the kernels read (half -> float is exact)
         ref = orc.raster_forward(n(base["means3D"]), n(base["opacities"]), n(cam.world_view_transform), n(cam.full_proj_transform), n(cam.camera_center), W, H,
                                  scales=n(base["scales"]), rotations=n(base["rotations"]), colors_precomp=n(col_h), bg=np.zeros(3, np.float32))
         aud = orc.raster_audit(ref)
@@ -246,7 +247,7 @@ def test_config5_combination_fp16_ch07_two_bounces_with_gradients():
         kw = dict(means3D=env["means3D"], grads3D=None, colors_precomp=None, opacities=env["opacities"], scales=env["scales"], rotations=env["rotations"],
                   cov3D_precomp=None, tracer_settings=st, start_from_first=False)
         with torch.no_grad():
-            o1 = tracer2(so, sd, v_, shs=env["shs"].half(), others_precomp=env["others"], **kw)
+            o1 = tracer2(so, sd, v_, shs=env["shs"], others_precomp=env["others"], **kw)
         hmid = n(o1[6]).reshape(S, 16 * (depth + 1))
         LC = 1024
         frag = otr.trace_audit(n(so), n(sd), *args, others=oth_np, start_from_first=False, bounce_thr=thr, shs=shs_np, sh_degree=deg, lcap=LC)["fragile"]
@@ -266,7 +267,7 @@ def test_config5_combination_fp16_ch07_two_bounces_with_gradients():
         gen = torch.Generator().manual_seed(12)
         gr = [torch.randn(S2, c, generator=gen).to(dev) for c in (3, 1, 1, 3, 2)]
         with stagewise.TraceTap() as tap2:
-            o2 = tracer2(so_g, sd_g, v_, shs=env["shs"].half(), others_precomp=env["others"], **kw)
+            o2 = tracer2(so_g, sd_g, v_, shs=env["shs"], others_precomp=env["others"], **kw)
             sum((o2[i] * u).sum() for i, u in zip((0, 1, 2, 3, 5), gr)).backward()
         torch.cuda.synchronize()
         assert len(tap2.calls) == depth + 1 and tap2.calls[1]["o_in"].shape[0] > 0.05 * S2
@@ -281,3 +282,5 @@ def test_config5_combination_fp16_ch07_two_bounces_with_gradients():
         envgs_step.FUSED["on"] = False
         envgs_step.FEATURE_F16["on"] = False
         envgs_step.TRACE.update(depth=0, specular_threshold=0.0)
+        import envgs_amd
+        envgs_amd.set_feature_storage("f32")
