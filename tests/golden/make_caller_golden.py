@@ -79,15 +79,18 @@ def _recording_trace_pkg():
     class SurfelTracer(torch.nn.Module):
         def __init__(self):
             super().__init__()
-            CALLS.append(dict(package="diff_surfel_tracing", what="SurfelTracer()", args=[]))
+            self.tracer_id = sum(1 for c_ in CALLS if c_.get("what") == "SurfelTracer()")      # which live tracer object a record belongs to
+            CALLS.append(dict(package="diff_surfel_tracing", what="SurfelTracer()", args=[], tracer=self.tracer_id))
             self.inner = inner.SurfelTracer()
 
         def build_acceleration_structure(self, *a, **kw):
-            CALLS.append(dict(package="diff_surfel_tracing", what="build_acceleration_structure", args=[_desc(x) for x in a], kwargs={k: _desc(v) for k, v in kw.items()}))
+            CALLS.append(dict(package="diff_surfel_tracing", what="build_acceleration_structure", args=[_desc(x) for x in a], kwargs={k: _desc(v) for k, v in kw.items()},
+                              tracer=self.tracer_id))
             return self.inner.build_acceleration_structure(*a, **kw)
 
         def forward(self, *a, **kw):
-            rec = dict(package="diff_surfel_tracing", what="call", args=[_desc(x) for x in a], kwargs={k: _desc(v) for k, v in kw.items()}, order=list(kw))
+            rec = dict(package="diff_surfel_tracing", what="call", args=[_desc(x) for x in a], kwargs={k: _desc(v) for k, v in kw.items()}, order=list(kw),
+                       tracer=self.tracer_id)
             outs = self.inner(*a, **kw)
             rec["outputs"] = [_desc(o) for o in outs]
             st = kw["tracer_settings"]

@@ -49,7 +49,7 @@ def make_raster_pkg(C):
 def make_trace_pkg():
     class _F(torch.autograd.Function):
         @staticmethod
-        def forward(ctx, ray_o, ray_d, means3D, shs, opacities, scales, rotations, ts, sff):
+        def forward(ctx, ray_o, ray_d, means3D, grads3D, shs, opacities, scales, rotations, ts, sff):
             lead = tuple(ray_o.shape[:-1])
             deg = int(ts.sh_degree.item()) if torch.is_tensor(ts.sh_degree) else int(ts.sh_degree)
             fwd = otr.trace_forward(_np(ray_o), _np(ray_d), _np(means3D), _np(scales), _np(rotations), _np(opacities), shs=_np(shs),
@@ -69,7 +69,8 @@ def make_trace_pkg():
             b = otr.trace_backward(f, z(g_rgb, 3), z(g_dpt, 1)[:, 0], z(g_acc, 1)[:, 0], z(g_norm, 3), z(g_aux, 2))
             t = lambda a: torch.from_numpy(a.astype(np.float32))
             lead = ctx.lead
-            return (t(b["dray_o"]).reshape(lead + (3,)), t(b["dray_d"]).reshape(lead + (3,)), t(b["dmeans3D"]), t(b["dshs"]),
+            # grads3D is the densification sink (optix_utils.py:134-136): it receives dL/dmeans3D, as the HIP package delivers it
+            return (t(b["dray_o"]).reshape(lead + (3,)), t(b["dray_d"]).reshape(lead + (3,)), t(b["dmeans3D"]), t(b["dmeans3D"]), t(b["dshs"]),
                     t(b["dopacities"])[:, None], t(b["dscales"]), t(b["drots"]), None, None)
 
     class SurfelTracer(nn.Module):
@@ -79,6 +80,8 @@ def make_trace_pkg():
         def forward(self, ray_o, ray_d, v=None, *, means3D, grads3D=None, shs=None, colors_precomp=None, others_precomp=None,
                     opacities=None, scales=None, rotations=None, cov3D_precomp=None, tracer_settings=None, start_from_first=True):
             assert colors_precomp is None and others_precomp is None
-            return _F.apply(ray_o, ray_d, means3D, shs, opacities, scales, rotations, tracer_settings, start_from_first)
+            if grads3D is None:
+                grads3D = torch.zeros_like(means3D)
+            return _F.apply(ray_o, ray_d, means3D, grads3D, shs, opacities, scales, rotations, tracer_settings, start_from_first)
 
     return SimpleNamespace(SurfelTracer=SurfelTracer, SurfelTracingSettings=SurfelTracingSettings)

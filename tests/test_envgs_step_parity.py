@@ -168,7 +168,8 @@ def test_full_envgs_step_link_by_link(fused_glue):
     # d colour / d position goes through the NORMALISED view direction: dL/dp = (I - d d^T) dL/dd / |p - c| subtracts the radial part of
     # dL/dd, which is most of it -- the element is judged against the magnitude of what is subtracted, as the kernels' gradients are
     vlen = (B64["means3D"].detach() - cam.camera_center.detach().cpu().double()[None]).norm(dim=1, keepdim=True)
-    cond_p = (dir64.grad.abs().sum(dim=1, keepdim=True) / vlen).expand(-1, 3)
+    # (and the glue part is read off the leaf as leaf - kernel part: that difference carries the rounding of the SUM, an ulp of the larger addend)
+    cond_p = (dir64.grad.abs().sum(dim=1, keepdim=True) / vlen).expand(-1, 3) + rc["grads"]["means3D"].detach().cpu().double().abs()
     stagewise.glue_check(test, "glue.d_means3D", (g_h["base.means3D"] - rc["grads"]["means3D"])[nc.to(dev)], B64["means3D"].grad[nc], cond=cond_p[nc])
     # the leaves received exactly kernel gradient (+ glue): nothing else feeds them
     for k in ("scales", "rotations", "opacities"):
