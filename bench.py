@@ -127,6 +127,7 @@ def main():
                     help="N > 1: direct reduce-scatter + all-gather over the xGMI mesh (all_to_all + local sum + all_gather), or one all_reduce per bucket")
     ap.add_argument("--no-render", action="store_true", help="skip the forward-only render timing (profiling runs: keeps the kernel statistics to the training steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-caller", action="store_true", help="skip the extra few steps that time the unchanged-EasyVolcap-caller form of the step (config.reference_caller_ms_per_step)")
     ap.add_argument("--step-times", type=int, default=0, help="diagnostics: after the timed region, run this many extra steps one by one (synchronised) and print their wall times and the allocator statistics to stderr")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the same view traced by the brute-force CPU oracle (bounded sample)")
@@ -180,8 +181,13 @@ def main():
         pkg = importlib.import_module("diff_surfel_rasterization_wet_ch0%d" % C)
         import diff_surfel_tracing as tpkg
         from envgs_amd import envgs_step
-        envgs_step.FUSED["on"] = args.caller == "fused"
-        envgs_step.REFERENCE_FORMS["on"] = args.caller == "reference"
+        mode = {"caller": args.caller}
+
+        def set_caller(c):
+            mode["caller"] = c
+            envgs_step.FUSED["on"] = c == "fused"
+            envgs_step.REFERENCE_FORMS["on"] = c == "reference"
+        set_caller(args.caller)
         dnorm_hw = (torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)) / HW).to(dev)
         tracer = tpkg.SurfelTracer()
         rays = [synth.get_rays(c) for c in cams]
@@ -239,7 +245,7 @@ def main():
             last_rays[0], last_rays[1] = out["ref_o"].detach(), out["ref_d"].detach()
             allmap = out["base"]["allmap"]
             loss = (out["rgb"] * dcol_hw3).sum() + (allmap * dall).sum()
-            if args.caller == "reference":        # the normal-consistency term consumes render()'s regulariser maps (volumetric_video_supervisor)
+            if mode["caller"] == "reference":     # the normal-consistency term consumes render()'s regulariser maps (volumetric_video_supervisor)
                 loss = loss + (out["base"]["surf_normal"] * dnorm_hw).sum()
         else:
             means2D = torch.zeros_like(params["means3D"], requires_grad=True)
@@ -285,6 +291,29 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # The drop-in number next to the headline: the SAME step with the expression forms the UNCHANGED EasyVolcap caller executes (batched-matmul
+    # get_disks, render()'s regulariser maps + normal term, torch SH / reflection / blend) around the same two extensions -- what a user who only
+    # swaps the packages pays.  A few steps, outside the timed region, reported in config.reference_caller_ms_per_step.
+    ref_caller_ms = None
+    if envgs and args.caller != "reference" and not args.no_reference_caller:
+        set_caller("reference")
+        for it in range(3):
+            step(args.warmup + args.steps + it)
+        sync_all()
+        tr_ = time.perf_counter()
+        nref = max(4, min(args.steps, 10))
+        for it in range(nref):
+            step(args.warmup + args.steps + 3 + it)
+        sync_all()
+        ref_caller_ms = (time.perf_counter() - tr_) / nref * 1e3
+        if world > 1:
+            tt = torch.tensor([ref_caller_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ref_caller_ms = float(tt.item())
+        set_caller(args.caller)
+        step(args.warmup + args.steps + 20)          # (back on the measured caller for the diagnostics below)
+        sync_all()
 
     if args.step_times > 0 and rank == 0:
         ms0 = torch.cuda.memory_stats(dev)
@@ -413,6 +442,8 @@ def main():
                        "optimizer": {"fused": "sparse fused Adam, one launch (envgs_amd.optim)", "torch": "torch.optim.Adam", "none": "none"}[args.optim],
                        "caller_glue": ("n/a (raster only)" if not envgs else {"fused": "fused HIP (envgs_amd.fused)", "twin": "torch expressions (envgs_amd/envgs_step.py)",
                                        "reference": "the unchanged EasyVolcap caller's expression forms (batched-matmul get_disks, render()'s regulariser maps + normal term)"}[args.caller]),
+                       "reference_caller_ms_per_step": (None if ref_caller_ms is None else round(ref_caller_ms, 3)),
+                       "reference_caller_note": "the same step with the UNCHANGED EasyVolcap caller's expression forms around the same extensions (--caller reference), a few steps outside the timed region",
                        "torch_blas": str(torch.backends.cuda.preferred_blas_library()).split(".")[-1],
                        "debug_switches": {"trace": args.debug_trace, "segments": args.debug_segments},
                        "allreduce_bytes_per_step": int(ar_bytes)},
@@ -471,15 +502,20 @@ def cpu_baseline(g, cam, bg, dcol, dall, H, W, reps, C, env=None):
             out["tracer_s_per_iter"] = round(dtt, 1)
             out["tracer_note"] = "BRUTE FORCE: the tracer oracle tests every ray against every surfel (no acceleration structure), %.0f %% of this figure" % (100.0 * dtt / dt)
         out["eager_config1"] = eager_config1()
+        if out["eager_config1"].get("value"):       # (also in `sample`, which every consumer of the line keeps)
+            out["sample"] += "; PyTorch-eager config-1 (2 000 surfels, 256x256, CPU): " + out["eager_config1"]["sample"]
         return out
     except Exception as e:                       # the baseline is a reported figure, never a reason to lose the GPU number
         return {"value": None, "unit": "iters/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
 
 
-def eager_config1(reps=1, warm=0):
+def eager_config1(reps=10, warm=2, budget_s=75.0, threads=None):
     """BASELINE configs[0] / north_star: "PyTorch-eager CPU project + alpha-blend" -- 2 000 surfels, 256x256, forward only, oracle/eager.py
-    (dense per-pixel blend in pixel chunks, fp32), torch.set_num_threads(all host cores); the figure SURVEY.md 8(d) asks for next to the C port."""
+    (dense per-pixel blend in pixel chunks, fp32).  SURVEY.md 8(d): 2 warm-ups, then 10 repetitions, torch.set_num_threads(all host cores);
+    median and minimum reported.  Bounded: the repetitions stop early (never below 3) once `budget_s` seconds are spent, and the count is
+    reported -- the default bench.py run has to finish within minutes."""
     try:
+        import statistics
         from envgs_amd import synth
         from oracle import eager
         P, H, W = 2000, 256, 256
@@ -487,18 +523,24 @@ def eager_config1(reps=1, warm=0):
         g["scales"] = g["scales"] * 2.0
         cam = synth.orbit_camera(0, H=H, W=W, fx=1111.1 * W / 800.0)
         old = torch.get_num_threads()
-        nthreads = min(os.cpu_count() or 1, 16)                 # (dense eager kernels on 2 000 x 8 192 tiles stop scaling -- and oversubscribe -- long before 256 threads)
+        nthreads = threads or (os.cpu_count() or 1)
         torch.set_num_threads(nthreads)
         run = lambda: eager.rasterize(g["means3D"], g["opacities"], cam.world_view_transform, cam.full_proj_transform, cam.camera_center, W, H,
                                       scales=g["scales"], rotations=g["rotations"], shs=g["shs"], sh_degree=3, bg=torch.ones(3), pix_chunk=8192)
+        ts = []
+        t_all = time.perf_counter()
         with torch.no_grad():
             for _ in range(warm): run()
-            t0 = time.perf_counter()
-            for _ in range(reps): run()
-            dt = (time.perf_counter() - t0) / reps
+            for _ in range(reps):
+                t0 = time.perf_counter(); run(); ts.append(time.perf_counter() - t0)
+                if len(ts) >= 3 and time.perf_counter() - t_all > budget_s:
+                    break
         torch.set_num_threads(old)
-        return {"value": round(1.0 / dt, 3), "unit": "renders/s", "mpix_per_s": round(H * W / dt / 1e6, 4), "threads": nthreads, "host_cores": os.cpu_count(),
-                "sample": "%d x forward of 2000 surfels at 256x256 (BASELINE configs[0]), oracle/eager.py, torch eager fp32" % reps}
+        med, mn = statistics.median(ts), min(ts)
+        return {"value": round(1.0 / med, 3), "unit": "renders/s", "best": round(1.0 / mn, 3), "median_s": round(med, 3), "min_s": round(mn, 3),
+                "mpix_per_s": round(H * W / med / 1e6, 4), "threads": nthreads, "host_cores": os.cpu_count(), "warmups": warm, "reps": len(ts),
+                "sample": "%d warm-ups + %d x forward of 2000 surfels at 256x256 (BASELINE configs[0]), oracle/eager.py, torch eager fp32, %d threads: median %.2f s, min %.2f s"
+                          % (warm, len(ts), nthreads, med, mn)}
     except Exception as e:
         return {"value": None, "sample": "failed: %r" % (e,)}
 
