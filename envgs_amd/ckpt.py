@@ -6,7 +6,10 @@ reference's own GaussianModel instances).
 properties  x y z nx ny nz f_dc_0..2 f_rest_0..(3K-4) opacity scale_0..1 rot_0..3  (K = (sh_degree + 1)^2), binary little-endian, features stored
 channel-major (`features.transpose(1, 2).flatten(1)`), raw (pre-activation) opacity / scaling / rotation.  The reader accepts any property order
 and extra properties, as the reference's does (it looks properties up by name).  Host-side I/O: numpy only.
-"PLY layout unpinned": the header text plyfile would write is restated from the PLY specification, not diffed against a file the reference wrote."""
+PLY CONTENT PINNED (tests/golden/ply_golden.npz, tests/golden/make_ply_golden.py): the reference's own save_ply was run and the structured array
+it hands to `plyfile` -- field names, order, dtype, every value -- recorded; its load_ply was run on a file written by `save_ply` below and returned
+the saved parameters.  What stays from the PLY 1.0 specification rather than from a reference-written file is only plyfile's header TEXT
+(`format binary_little_endian 1.0`, one `property float <name>` line per field, no comments): plyfile is not installed here."""
 import numpy as np
 import torch
 

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/gpmc_$2
 rm -rf $O
-rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $O -o c -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-render > $O.log 2>&1
+rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $O -o c -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-render --no-reference-caller > $O.log 2>&1
 python - "$O" <<'PY'
 import csv, glob, re, collections, sys
 acc = collections.defaultdict(list)

@@ -152,3 +152,30 @@ def test_pt_checkpoint_against_the_reference_models_own_state_dict(tmp_path):
         g = gold["model"]["sampler.env." + k]
         assert mine["sampler.env." + k].dtype == g.dtype and mine["sampler.env." + k].shape == g.shape, k
     assert int(mine["sampler.env.active_sh_degree"]) == 3
+
+
+def test_ply_content_is_what_the_reference_hands_to_plyfile(tmp_path):
+    """tests/golden/ply_golden.npz: the reference's own GaussianModel.save_ply was run (gaussian2d_utils.py:935-960) and the structured array it
+    hands to plyfile -- field names, order, dtype, every value -- was recorded; its load_ply (:962-1000) was run on a file written by
+    envgs_amd.ckpt.save_ply and gave back the saved parameters (asserted by the generator).  Here: save_ply writes exactly that table behind a
+    PLY 1.0 binary_little_endian header with one `property float <name>` line per recorded field, and load_ply inverts it."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ply_golden.npz"))
+    raw = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("raw")}
+    path = str(tmp_path / "golden.ply")
+    ckpt.save_ply(path, raw["_xyz"], raw["_features_dc"], raw["_features_rest"], raw["_opacity"], raw["_scaling"], raw["_rotation"])
+    names = [str(n) for n in g["names"]]
+    data = open(path, "rb").read()
+    head, body = data.split(b"end_header\n", 1)
+    lines = head.decode("ascii").splitlines()
+    assert lines[0] == "ply" and lines[1] == "format binary_little_endian 1.0" and lines[2] == "element %s %d" % (str(g["element_name"]), g["table"].shape[0])
+    assert lines[3:] == ["property float %s" % n for n in names]                    # the reference's construct_list_of_attributes, in its order
+    assert body == np.ascontiguousarray(g["table"].astype("<f4")).tobytes()          # the bytes of the recorded structured array (all fields f4: no padding)
+    tab = ckpt.read_vertex_table(path)
+    assert list(tab.dtype.names) == names
+    back = ckpt.load_ply(path, max_sh_degree=3)
+    loaded = {k[6:]: g[k] for k in g.files if k.startswith("loaded")}
+    for ours, ref in (("xyz", "_xyz"), ("features_dc", "_features_dc"), ("features_rest", "_features_rest"), ("opacity", "_opacity"), ("scaling", "_scaling"),
+                      ("rotation", "_rotation")):
+        assert np.array_equal(back[ours].numpy(), loaded[ref]), ours                # what the reference's load_ply made of the same file
+    assert int(g["active_sh_degree_after_load"]) == 3
