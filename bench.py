@@ -315,6 +315,29 @@ def main():
         step(args.warmup + args.steps + 20)          # (back on the measured caller for the diagnostics below)
         sync_all()
 
+    # N > 1: the gradient exchange on its own, both forms, on the step's own flat buffers (after the timed region): the first hardware run with
+    # N > 1 ranks decides between the direct reduce-scatter + all-gather and the library's all_reduce from these fields
+    exch = None
+    if world > 1 and reducer is not None and reducer.buckets:
+        exch = {"bytes_per_step": int(sum(B.flat.numel() * 4 for B in reducer.buckets)), "world": world}
+        for algo in ("direct", "allreduce"):
+            for _ in range(2):
+                for B in reducer.buckets: edist.exchange_flat(B.flat, average=True, algo=algo, recv=B.recv, mine=B.mine)
+            sync_all()
+            te = time.perf_counter()
+            nex = 5
+            for _ in range(nex):
+                for B in reducer.buckets: edist.exchange_flat(B.flat, average=True, algo=algo, recv=B.recv, mine=B.mine)
+            sync_all()
+            ms = (time.perf_counter() - te) / nex * 1e3
+            tt = torch.tensor([ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ms = float(tt.item())
+            S = exch["bytes_per_step"]
+            # bytes that cross ONE link: direct = S/world out + S/world back on each of the world-1 links; a ring all_reduce pushes 2 (world-1)/world S through every link of the ring
+            per_link = (2.0 * S / world) if algo == "direct" else (2.0 * (world - 1) / world * S)
+            exch[algo] = {"ms": round(ms, 4), "algorithm_GBps": round(S / 1e9 / (ms / 1e3), 2), "per_link_GBps_model": round(per_link / 1e9 / (ms / 1e3), 2)}
+
     if args.step_times > 0 and rank == 0:
         ms0 = torch.cuda.memory_stats(dev)
         ts = []
@@ -450,6 +473,7 @@ def main():
             "train_mpix_per_s": round(value * HW / 1e6, 2),
             "render_mpix_per_s": (round(world * HW / render_s / 1e6, 2) if n_render else None),
             "render_ms_per_view": (round(render_s * 1e3, 4) if n_render else None),
+            "exchange": exch,
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "trace_counts": (dict(tcounts, entries=entries) if tcounts else None),
         }
         print(json.dumps(line))

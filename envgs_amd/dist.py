@@ -50,20 +50,70 @@ def shard_views(num_views, rank, world):
 # ------------------------------------------------------------------------------------------------------------------
 # the collective itself
 
-def exchange_flat(flat, average=True, group=None, algo="direct", async_op=False):
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """One communication stream per device: an exchange launched from a backward hook is ordered on it (after the gradient kernels already
+    queued on the compute stream, before nothing of the compute stream), so the rest of backward() keeps running underneath."""
+    s = _SIDE_STREAMS.get(dev)
+    if s is None:
+        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def exchange_flat(flat, average=True, group=None, algo="direct", async_op=False, recv=None, mine=None):
     """Sum (or average) the flat fp32 buffer `flat` over the ranks, in place.  len(flat) must be a multiple of the world size.
 
     algo = "direct": reduce-scatter + all-gather, each ONE step over the full xGMI mesh:
         all_to_all_single (chunk j of every rank -> rank j; 7 concurrent point-to-point transfers per GPU) -> local sum of the world
         received chunks (one torch kernel over S/world floats x world) -> all_gather_into_tensor of the owned chunk back into `flat`.
     algo = "allreduce": one `all_reduce` (the library picks the algorithm; a ring is per-link bound on xGMI).
-    Returns a callable that completes the exchange (waits, finishes the arithmetic); with async_op=False it has already been called."""
+    recv (len(flat)) / mine (len(flat) / world): optional persistent scratch (GradExchange keeps one pair per bucket; allocated here otherwise).
+    Returns a callable that completes the exchange; with async_op=False it has already been called.
+
+    GPU buffers, async_op=True: the WHOLE exchange -- all-to-all, local sum, scale, all-gather -- is queued at launch time on a communication
+    stream that waits for the work already queued on the current stream, so bucket 0 (the environment set, final when the tracer's backward
+    is done) is exchanged completely while the base rasterizer is still differentiating; the returned callable only makes the current stream
+    wait for it.  (Round 2 queued the all-to-all alone and did the sum + all-gather in finish().)  CPU buffers (gloo): the collectives'
+    own async work objects."""
     world = dist.get_world_size(group)
     n = flat.numel()
     assert flat.dtype == torch.float32 and flat.is_contiguous()
+    if algo not in ("direct", "allreduce"):
+        raise ValueError("algo must be 'direct' or 'allreduce', got %r" % (algo,))
     if algo == "direct" and n % world != 0:
         raise ValueError("exchange_flat('direct') needs a buffer length that is a multiple of the world size (%d %% %d != 0)" % (n, world))
     scale = (1.0 / world) if average else 1.0
+    if algo == "direct":
+        if recv is None or recv.numel() != n or recv.device != flat.device:
+            recv = torch.empty_like(flat)
+        if mine is None or mine.numel() != n // world or mine.device != flat.device:
+            mine = torch.empty(n // world, dtype=torch.float32, device=flat.device)
+
+    def whole():
+        if algo == "allreduce":
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            if scale != 1.0:
+                flat.mul_(scale)
+        else:
+            dist.all_to_all_single(recv, flat, group=group)
+            torch.sum(recv.view(world, n // world), dim=0, out=mine)   # chunk `rank` of every peer, summed: this rank's share of the result
+            if scale != 1.0:
+                mine.mul_(scale)
+            dist.all_gather_into_tensor(flat, mine, group=group)
+
+    if not async_op:
+        whole()
+        return lambda: None
+    if flat.is_cuda:
+        cur = torch.cuda.current_stream(flat.device)
+        side = _side_stream(flat.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            whole()
+        return lambda: torch.cuda.current_stream(flat.device).wait_stream(side)
+    # CPU (gloo): asynchronous work objects; the arithmetic between the two collectives runs when the first completes
     if algo == "allreduce":
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
@@ -71,28 +121,20 @@ def exchange_flat(flat, average=True, group=None, algo="direct", async_op=False)
             work.wait()
             if scale != 1.0:
                 flat.mul_(scale)
-    elif algo == "direct":
-        recv = torch.empty_like(flat)
-        w1 = dist.all_to_all_single(recv, flat, group=group, async_op=True)
-        state = {}
+        return done
+    w1 = dist.all_to_all_single(recv, flat, group=group, async_op=True)
 
-        def done():
-            w1.wait()
-            mine = recv.view(world, n // world).sum(0)             # chunk `rank` of every peer, summed: this rank's share of the result
-            if scale != 1.0:
-                mine.mul_(scale)
-            state["mine"] = mine
-            dist.all_gather_into_tensor(flat, mine, group=group)
-    else:
-        raise ValueError("algo must be 'direct' or 'allreduce', got %r" % (algo,))
-    if not async_op:
-        done()
-        return lambda: None
+    def done():
+        w1.wait()
+        torch.sum(recv.view(world, n // world), dim=0, out=mine)
+        if scale != 1.0:
+            mine.mul_(scale)
+        dist.all_gather_into_tensor(flat, mine, group=group)
     return done
 
 
 class _Bucket:
-    __slots__ = ("params", "ids", "flat", "numel", "offsets", "pending", "done", "launched")
+    __slots__ = ("params", "ids", "flat", "recv", "mine", "numel", "offsets", "pending", "done", "launched")
 
 
 class GradExchange:
@@ -141,6 +183,10 @@ class GradExchange:
             pad = (-n) % self.world
             dev = plist[0].device if plist else torch.device("cpu")
             B.flat = torch.zeros(n + pad, dtype=torch.float32, device=dev)
+            # persistent scratch of the direct exchange (round 2 allocated 72 - 162 MB per call): the all-to-all's receive buffer, this rank's reduced chunk
+            direct = self.enabled and self.algo == "direct"
+            B.recv = torch.empty(n + pad, dtype=torch.float32, device=dev) if direct else None
+            B.mine = torch.empty((n + pad) // self.world, dtype=torch.float32, device=dev) if direct else None
             B.offsets, off = [], 0
             for p in plist:
                 if p.dtype != torch.float32:
@@ -208,7 +254,7 @@ class GradExchange:
     def _launch(self, B):
         B.launched = True
         if B.flat.numel():
-            B.done = exchange_flat(B.flat, average=self.average, group=self.group, algo=self.algo, async_op=True)
+            B.done = exchange_flat(B.flat, average=self.average, group=self.group, algo=self.algo, async_op=True, recv=B.recv, mine=B.mine)
 
     def finish(self):
         """Call after the last backward(): launches the remaining buckets in order, completes all of them, returns the bytes exchanged."""
@@ -264,17 +310,32 @@ def allreduce_grads(tensors, average=True, group=None, algo="allreduce"):
     return flat.numel() * 4
 
 
+_STATS_FLAT = {}
+
+
 def allreduce_densify_stats(grad_norm_accum, denom, weight_accum, max_radii, group=None):
     """Make the densification statistics identical on every rank: sums for the accumulators
-    (gaussian2d_utils.py:901-909), max for the screen radii (gaussian2d_sampler.py:330-332)."""
+    (gaussian2d_utils.py:901-909), max for the screen radii (gaussian2d_sampler.py:330-332).  One persistent flat buffer per
+    (device, size) for the three sums (copied in and out by slices: no torch.cat, no per-call allocation); the radii take their own MAX."""
     if not _active(group):
         return
-    flat = torch.cat([grad_norm_accum.reshape(-1).float(), denom.reshape(-1).float(), weight_accum.reshape(-1).float()])
+    parts = (grad_norm_accum, denom, weight_accum)
+    n = sum(p.numel() for p in parts)
+    key = (grad_norm_accum.device, n)
+    flat = _STATS_FLAT.get(key)
+    if flat is None:
+        if len(_STATS_FLAT) > 4:
+            _STATS_FLAT.clear()                                   # P changed (densify / prune): drop the stale sizes
+        flat = _STATS_FLAT[key] = torch.empty(n, dtype=torch.float32, device=grad_norm_accum.device)
+    off = 0
+    for p in parts:
+        flat[off:off + p.numel()].copy_(p.reshape(-1))
+        off += p.numel()
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    n = grad_norm_accum.numel()
-    grad_norm_accum.copy_(flat[:n].view_as(grad_norm_accum))
-    denom.copy_(flat[n:n + denom.numel()].view_as(denom))
-    weight_accum.copy_(flat[n + denom.numel():].view_as(weight_accum))
+    off = 0
+    for p in parts:
+        p.copy_(flat[off:off + p.numel()].view_as(p))
+        off += p.numel()
     r = max_radii.float().contiguous()
     dist.all_reduce(r, op=dist.ReduceOp.MAX, group=group)
     max_radii.copy_(r.to(max_radii.dtype))

@@ -34,3 +34,5 @@ def test_bench_two_ranks_gloo_on_one_gpu(exchange):
     n_params = 20000 * (3 + 48 + 1 + 2 + 4 + 1 + 1) + 8192 * (3 + 48 + 1 + 2 + 4)
     assert d["config"]["allreduce_bytes_per_step"] >= 4 * n_params               # both flat buffers were exchanged (padded to the world size)
     assert exchange in d["config"]["parallelism"]
+    ex = d["exchange"]                                                          # both exchange forms timed on the step's own flat buffers
+    assert ex["world"] == 2 and ex["bytes_per_step"] == d["config"]["allreduce_bytes_per_step"] and ex["direct"]["ms"] > 0 and ex["allreduce"]["ms"] > 0
