@@ -119,6 +119,7 @@ def main():
                          "(fp32 master parameters in the optimizer, a half copy per step for the render path; arithmetic and gradients stay fp32)")
     ap.add_argument("--keep-blas", action="store_true", help="do not let diff_surfel_tracing select rocBLAS for torch's tiny-K batched matmuls (INTEGRATION.md section 5)")
     ap.add_argument("--debug-trace", type=int, default=0, help="ENVGS_DBG_TRACE diagnostic switch mask (include/envgs_raster.h); reported in the JSON line")
+    ap.add_argument("--diag", action="store_true", help="load the diagnostic build (A/B kernels of --debug-trace 8 / 16 / 512 / 2048; the product library rejects those switches)")
     ap.add_argument("--debug-segments", type=int, default=0, help="ENVGS_DBG_SEGMENTS diagnostic switch; reported in the JSON line")
     ap.add_argument("--optim", default="fused", choices=["fused", "torch", "none"],
                     help="optimizer step inside the timed iteration: sparse fused Adam (envgs_amd.optim, SURVEY 8(f).2), torch.optim.Adam, or none")
@@ -146,6 +147,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     dev = torch.device("cuda", local % torch.cuda.device_count())     # (a functional test may run 2 gloo ranks on one GPU)
     torch.cuda.set_device(dev)
+    if args.diag:
+        _lib.select("diag")                        # libenvgs_hip_diag.so: the product kernels + the superseded A/B kernels behind --debug-trace
     lib = _lib.load()
     lib.envgs_debug_set(0, args.debug_trace); lib.envgs_debug_set(1, args.debug_segments)
     import torch.distributed as dist

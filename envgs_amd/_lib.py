@@ -91,21 +91,44 @@ SYMBOLS = {
 }
 
 
-def load():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+LIB_DIAG_PATH = os.path.join(HERE, "libenvgs_hip_diag.so")
+_libs = {}
+_selected = {"kind": "product"}
+
+
+def _open(path):
+    if not os.path.exists(path):
         raise RuntimeError(
             "envgs_amd: %s is missing. Build it with `python -m envgs_amd.build` (hipcc, gfx950). "
-            "There is no CPU fallback for the render-and-trace path." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            "There is no CPU fallback for the render-and-trace path." % path)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    return lib
+
+
+def load():
+    """The library every entry point of the package calls into: the PRODUCT build, unless a test / `bench.py --diag` selected the diagnostic one."""
+    global _lib
+    kind = _selected["kind"]
+    lib = _libs.get(kind)
+    if lib is None:
+        lib = _libs[kind] = _open(LIB_PATH if kind == "product" else LIB_DIAG_PATH)
     _lib = lib
     return lib
+
+
+def select(kind):
+    """"product" (default) or "diag": the diagnostic build carries, behind envgs_debug_set, the superseded A/B kernels the product library was
+    trimmed of (csrc: ENVGS_DIAG).  Both export the same C-ABI; each keeps its own diagnostic switches and timers.  Returns the previous kind."""
+    if kind not in ("product", "diag"):
+        raise ValueError(kind)
+    old = _selected["kind"]
+    _selected["kind"] = kind
+    load()
+    return old
 
 
 def ptr(t):

@@ -12,6 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libenvgs_hip.so")
+# Diagnostic build: the same library plus the superseded A/B kernels (three earlier collection kernels, the per-ray atomic-flush list
+# backward) behind envgs_debug_set -- compiled with -DENVGS_DIAG from the three sources that mention them; tests and `bench.py --diag` load it,
+# the product library does not contain them.
+LIB_DIAG = os.path.join(HERE, "libenvgs_hip_diag.so")
+DIAG_SOURCES = ("trace_collect.hip", "trace_surfel_bwd.hip", "trace_api.hip")
 ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fvisibility=hidden",
           "-Wall", "-Wno-unused-function"]
@@ -34,12 +39,12 @@ def _headers_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
-def _compile(src, force, hdr_m):
-    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+def _compile(src, force, hdr_m, diag=False):
+    obj = os.path.join(OBJ, src.replace(".hip", ".diag.o" if diag else ".o"))
     path = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_m):
         return obj, False
-    cmd = ["hipcc"] + COMMON + EXTRA.get(src, []) + ["-c", path, "-o", obj]
+    cmd = ["hipcc"] + COMMON + EXTRA.get(src, []) + (["-DENVGS_DIAG"] if diag else []) + ["-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr[-4000:]))
@@ -49,16 +54,20 @@ def _compile(src, force, hdr_m):
 def build_library(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hdr_m = _headers_mtime()
+    jobs = [(s, False) for s in _sources()] + [(s, True) for s in DIAG_SOURCES]
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        res = list(ex.map(lambda s: _compile(s, force, hdr_m), _sources()))
-    objs = [o for o, _ in res]
-    if force or any(ch for _, ch in res) or not os.path.exists(LIB):
-        cmd = ["hipcc", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
-        if verbose:
-            print("built", LIB)
+        res = list(ex.map(lambda j: _compile(j[0], force, hdr_m, j[1]), jobs))
+    by = {j: r for j, r in zip(jobs, res)}
+    for lib, diag in ((LIB, False), (LIB_DIAG, True)):
+        objs = [by[(s, diag and s in DIAG_SOURCES)][0] for s in _sources()]
+        changed = any(by[(s, diag and s in DIAG_SOURCES)][1] for s in _sources())
+        if force or changed or not os.path.exists(lib):
+            cmd = ["hipcc", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+            if verbose:
+                print("built", lib)
     return LIB
 
 

@@ -105,6 +105,9 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     A.mod = cfg->scale_modifier;
     A.f16 = cfg->feature_f16;
     A.exp = debug_switch(ENVGS_DBG_TRACE);
+#ifndef ENVGS_DIAG
+    if (A.exp & (8 | 16 | 512 | 2048)) return ENVGS_ERR_BAD_ARG;      // A/B kernels of the diagnostic build (libenvgs_hip_diag.so) were requested
+#endif
     int rh, rw; ray_layout(cfg, &rh, &rw);
     const bool lists = lists_usable(cfg, L);
     if (L && L->cap > SORT_MAX) return ENVGS_ERR_BAD_ARG;
@@ -188,6 +191,12 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             const int rays_seg = (S.batch1 - S.batch0) * 64;
             {
                 ProfScope p1(K_TRACE_COLLECT, st);
+#ifndef ENVGS_DIAG
+                // product library: the cooperative collection is the only collection kernel (without a coherence sort its batches are the
+                // rays in the order given: correct, slower)
+                hipLaunchKernelGGL(collect_hits_coop, dim3(persistent_grid(rays_seg, 8)), dim3(256), 0, st, S, S.nodes,
+                                   S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4, S.srec);
+#else
                 if (S.order && !(S.exp & 512) && !(S.exp & 16) && !(S.exp & 2048))
                     hipLaunchKernelGGL(collect_hits_coop, dim3(persistent_grid(rays_seg, 8)), dim3(256), 0, st, S, S.nodes,
                                        S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4, S.srec);
@@ -198,6 +207,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
                     hipLaunchKernelGGL(collect_hits_packet, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S, S.nodes, S.srec);
                 else
                     hipLaunchKernelGGL(collect_hits, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S);
+#endif
             }
             ENVGS_CHECK_LAUNCH(dcfg, st);
             {
@@ -274,6 +284,9 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     A.g_rgb = dL_drgb; A.g_dpt = dL_ddpt; A.g_acc = dL_dacc; A.g_norm = dL_dnorm; A.g_aux = dL_daux;
     A.geo_rec = geo_rec; A.dshs = dshs; A.dcolors = dcolors;
     A.exp = debug_switch(ENVGS_DBG_TRACE);
+#ifndef ENVGS_DIAG
+    if (A.exp & (8 | 16 | 512 | 2048)) return ENVGS_ERR_BAD_ARG;
+#endif
     A.f16 = cfg->feature_f16;
     A.dothers = dothers; A.dray_o = dray_o; A.dray_d = dray_d; A.mod = cfg->scale_modifier;
     int rh, rw; ray_layout(cfg, &rh, &rw);
@@ -289,8 +302,15 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
                 { ProfScope p5(K_TRACE_LIST_BWD, stream); hipLaunchKernelGGL(batch_surfel_bwd, dim3(stride_grid((cfg->num_rays + 63) / 64, 1)), dim3(64), 0, stream, A); }
                 { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, stream, A); }
             } else {
+#ifdef ENVGS_DIAG
                 ProfScope p5(K_TRACE_LIST_BWD, stream);
                 hipLaunchKernelGGL(composite_lists_bwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A);
+#else
+                // product library: the record backward is the only list backward.  No records = the forward composited nothing on the list
+                // path (num_records is its device-side count) -- anything else is a caller error, not a reason to differentiate nothing silently
+                if (!(L->surf_cnt && L->surf_off && L->hit_state && L->entries && L->pairs && L->n_entries) || (L->records == nullptr && L->num_records > 0))
+                    return ENVGS_ERR_BAD_ARG;
+#endif
             }
             A.only_overflow = 1;
         }

@@ -38,6 +38,7 @@ make_ray_keys(int R, const float *__restrict__ ray_o, const float *__restrict__ 
     vals[r] = (unsigned)r;
 }
 
+#ifdef ENVGS_DIAG   // superseded collection kernel: A/B measurements and tests only (libenvgs_hip_diag.so), not in the product library
 __global__ void __launch_bounds__(64)
 collect_hits(const TraceArgs A)
 {
@@ -155,6 +156,7 @@ collect_hits(const TraceArgs A)
         if (lane == 0) { atomicAdd(A.stats + 1, (unsigned long long)fv); atomicAdd(A.stats + 3, (unsigned long long)ff); }
     }
 }
+#endif  // ENVGS_DIAG
 
 // Packet form of collect_hits for coherence-sorted rays.  The 64 rays of a batch mostly walk the SAME nodes (measured on the bench
 // scene: the union of the surfels a batch finds is 2.4x what one of its rays finds), so the wavefront walks the tree ONCE with a single,
@@ -165,6 +167,7 @@ collect_hits(const TraceArgs A)
 // (8 waves per SIMD: with two segments in flight ~10 k wavefronts want a slot; the (n - o) * (1/d) slab form is kept on purpose -- the
 //  one-fma form n*(1/d) - o/d needs an error margin proportional to |o/d|, and in a packet ONE ray with a tiny direction component then
 //  drags the whole wavefront through nodes nobody hits: measured +0.6 ms)
+#ifdef ENVGS_DIAG   // superseded collection kernel: A/B measurements and tests only (libenvgs_hip_diag.so), not in the product library
 __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(64)
 collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ srec)
 {
@@ -297,12 +300,14 @@ collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const f
         if (lane == 0) { atomicAdd(A.stats + 1, (unsigned long long)visits); atomicAdd(A.stats + 3, (unsigned long long)ff); }
     }
 }
+#endif  // ENVGS_DIAG
 
 // The same traversal over the 4-wide nodes (trace_bvh.hip: node4[i] = the grandchildren of binary node i): half the steps, and each step is
 // one scalar-load round trip plus the stack / mask bookkeeping of the scalar unit, which is what the binary walk spends most of its time on.
 // Children that any ray hits are entered nearest first, ordered by the entry distance of each child's first hitting lane (the rays of a
 // batch are coherent; the order only affects how early the termination bounds tighten).  `visits` counts 64 B units (two per wide node).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifdef ENVGS_DIAG   // superseded collection kernel: A/B measurements and tests only (libenvgs_hip_diag.so), not in the product library
 __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(64)
 collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec)
 {
@@ -448,6 +453,7 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
         }
     }
 }
+#endif  // ENVGS_DIAG
 
 // Cooperative packet traversal: COOP_W wavefronts share one 64-ray batch.  With one wavefront per batch the kernel lasts as long as its
 // longest batch (a chain of ~2000 dependent node steps against a mean of ~830) while most of the chip has already drained; here every

@@ -584,11 +584,14 @@ __global__ void __launch_bounds__(64) trace_fwd(const TraceArgs A, const int ray
 __global__ void __launch_bounds__(64) trace_bwd(const TraceArgs A, const int ray_h, const int ray_w);
 __global__ void __launch_bounds__(256) make_ray_keys(int R, const float *__restrict__ ray_o, const float *__restrict__ ray_d,
                                                      const float4 *__restrict__ nodes, int P, unsigned *__restrict__ keys, unsigned *__restrict__ vals);
+#ifdef ENVGS_DIAG
 __global__ void __launch_bounds__(64) collect_hits(const TraceArgs A);
 __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(64)
 collect_hits_packet(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ srec);
 __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(64)
 collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec);
+__global__ void __launch_bounds__(64) composite_lists_bwd(const TraceArgs A);
+#endif
 __global__ void __launch_bounds__(256, 8)
 collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec);
 __global__ void __launch_bounds__(256) permute_sh(int P, int nb, int f16, const void *__restrict__ shs, void *__restrict__ shp);
@@ -602,7 +605,6 @@ extern template __global__ void __launch_bounds__(256) sort_composite_fwd<16, tr
 __global__ void __launch_bounds__(64 * RH_W) register_hits(const TraceArgs A);
 __global__ void __launch_bounds__(256) unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, unsigned *__restrict__ cnt,
                                                          float *__restrict__ wet);
-__global__ void __launch_bounds__(64) composite_lists_bwd(const TraceArgs A);
 __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd(const TraceArgs A);
 __global__ void __launch_bounds__(256) reduce_surfel_records(const TraceArgs A);
 __global__ void __launch_bounds__(256) finish_surfel_grads(int P, const float *__restrict__ rots, const float *__restrict__ geo_rec,

@@ -4,6 +4,7 @@
 
 namespace envgs {
 
+#ifdef ENVGS_DIAG   // per-ray atomic-flush backward of the list path: superseded by the record backward, kept for A/B measurements and tests
 __global__ void __launch_bounds__(64)
 composite_lists_bwd(const TraceArgs A)
 {
@@ -42,6 +43,7 @@ composite_lists_bwd(const TraceArgs A)
         if (valid) bwd_store_ray(A, r, B, acc);
     }
 }
+#endif  // ENVGS_DIAG
 
 // Backward of the list path, SURFEL-MAJOR per batch (the tracer's counterpart of the rasterizer's tile backward): one wavefront owns a
 // batch of 64 coherence-sorted rays, LANE = RAY.  It walks the batch's entries (distinct surfels); the surfel's record and SH block are

@@ -84,7 +84,27 @@ def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch):
     with pytest.raises(RuntimeError, match="no CPU path"):
         tpkg.SurfelTracer().build_acceleration_structure(torch.zeros(16, 3), torch.zeros(8, 3, dtype=torch.int32))
     # missing library -> loud failure at first use
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libenvgs_hip.so")
     with pytest.raises(RuntimeError, match="is missing"):
         _lib.load()
+
+
+def test_product_library_is_trimmed_of_the_diagnostic_kernels():
+    """the superseded A/B kernels (three earlier collection kernels, the per-ray atomic-flush list backward) are compiled only with
+    -DENVGS_DIAG into libenvgs_hip_diag.so, which tests and `bench.py --diag` select explicitly; the product library does not contain them
+    (and rejects the debug switches that would ask for them).  Both builds export the whole C-ABI."""
+    from envgs_amd import _lib, build
+    prod = open(build.LIB, "rb").read(); diag = open(build.LIB_DIAG, "rb").read()
+    for name in (b"collect_hits_packet4", b"collect_hits_packet", b"composite_lists_bwd"):
+        assert name not in prod and name in diag, name
+    for name in (b"collect_hits_coop", b"sort_composite_fwd", b"batch_surfel_bwd", b"composite_bwd"):
+        assert name in prod and name in diag, name
+    old = _lib.select("diag")
+    try:
+        lib = _lib.load()
+        for sym in _lib.SYMBOLS:
+            assert hasattr(lib, sym)
+    finally:
+        _lib.select(old)
+    assert _lib.load() is not lib or old == "diag"

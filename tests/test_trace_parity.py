@@ -165,6 +165,8 @@ class _Switch:
     def __enter__(self):
         from envgs_amd import tracing, _lib
         self.old = {}
+        # the A/B kernels these switches select live in the DIAGNOSTIC build only (libenvgs_hip_diag.so; the product library was trimmed of them)
+        self.lib_kind = _lib.select("diag") if any(k in self.kw for k in ("records", "sort_rays", "debug_trace")) else None
         for k, v in self.kw.items():
             if k == "force_cap":
                 self.old[k] = dict(tracing.HIT_CAP)
@@ -185,6 +187,8 @@ class _Switch:
             elif k == "records": tracing.USE_RECORDS["on"] = v
             elif k == "sort_rays": tracing.SORT_RAYS["on"] = v
             elif k == "debug_trace": _lib.load().envgs_debug_set(0, v)
+        if self.lib_kind is not None:
+            _lib.select(self.lib_kind)
 
 
 # The bounce chain at the 1e-4 contract, link by link (tests/stagewise.py): every traced call of the HIP chain is compared with the oracle on
