@@ -133,6 +133,9 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             A.wfrac = 40 - ib > 30 ? 30 : 40 - ib;
         }
         A.state = (float4 *)L->hit_state; A.entries = (unsigned long long *)L->entries; A.pairs = L->pairs; A.n_entries = L->n_entries;
+        const bool compact = L->compact_rows > 0 && L->row_off && L->batch_rows && L->row_blk && L->hit_state;
+        if (L->compact_rows > 0 && !compact) return ENVGS_ERR_BAD_ARG;
+        if (compact) { A.row_off = L->row_off; A.batch_rows = (const uint2 *)L->batch_rows; }
         if (L->sh_perm && shs && cfg->sh_coeffs == 16) {
             const size_t nw = (size_t)cfg->P * 48;
             hipLaunchKernelGGL(permute_sh, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, cfg->P, (cfg->sh_degree + 1) * (cfg->sh_degree + 1),
@@ -210,6 +213,18 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
 #endif
             }
             ENVGS_CHECK_LAUNCH(dcfg, st);
+            if (compact) {
+                // row offsets of the compact per-hit buffers: scan of this segment's hit counts in sorted order; the segment owns the share of
+                // the rows that corresponds to its share of the batches
+                const int nblk = (rays_seg + 255) / 256;
+                unsigned *blk = L->row_blk + (size_t)S.batch0 / 4 + 2 * sg;       // (batch0 * 64 / 256 blocks precede this segment; + slack)
+                const unsigned long long base = (unsigned long long)((long double)L->compact_rows * S.batch0 / nbatch_all);
+                const unsigned long long limit = (unsigned long long)((long double)L->compact_rows * S.batch1 / nbatch_all);
+                hipLaunchKernelGGL(row_count, dim3(nblk), dim3(256), 0, st, S, blk);
+                hipLaunchKernelGGL(row_scan_blocks, dim3(1), dim3(1024), 0, st, blk, nblk);
+                hipLaunchKernelGGL(row_offsets, dim3(nblk), dim3(256), 0, st, S, blk, L->row_off, (uint2 *)L->batch_rows, base, limit);
+                ENVGS_CHECK_LAUNCH(dcfg, st);
+            }
             {
                 ProfScope p2(K_TRACE_SORT, st);
                 const dim3 g(stride_grid(rays_seg, 4)), b(256);
@@ -299,6 +314,10 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
                 // atomic-free: one record per (batch, surfel) entry, grouped by surfel; then each surfel's records are summed
                 A.surf_cnt = L->surf_cnt; A.surf_off = L->surf_off; A.records = L->records; A.num_records = L->num_records;
                 A.state = (float4 *)L->hit_state; A.entries = (unsigned long long *)L->entries; A.pairs = L->pairs; A.n_entries = L->n_entries;
+                if (L->compact_rows > 0) {
+                    if (!L->row_off || !L->batch_rows) return ENVGS_ERR_BAD_ARG;
+                    A.row_off = L->row_off; A.batch_rows = (const uint2 *)L->batch_rows;
+                }
                 { ProfScope p5(K_TRACE_LIST_BWD, stream); hipLaunchKernelGGL(batch_surfel_bwd, dim3(stride_grid((cfg->num_rays + 63) / 64, 1)), dim3(64), 0, stream, A); }
                 { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, stream, A); }
             } else {

@@ -158,6 +158,9 @@ struct TraceArgs {
     int *n_entries;               // (batches, 2) table entries, single entries
     unsigned *long_list; // (R) scratch: slots of the rays whose lists exceed 256 hits, appended by the main sort pass (counter[24 + seg] = how many)
     float4 *state;      // (R, cap, 2 | 3) x 16 B per composited hit: transmittance before it and the prefix sums after it (for the backward)
+    // compact per-hit buffers (envgs_trace.h: compact_rows): nullptr = the (R, cap) layouts
+    const unsigned *row_off;      // (R) by sorted slot: the ray's first row of hit_state
+    const uint2 *batch_rows;      // (batches) {first row, rows} of the batch in entries / pairs
     const void *shp;    // (P, 48) quad-permuted copy of the SH blocks (permute_sh), same storage type as shs; nullptr = per-lane gathers from shs
 };
 
@@ -561,6 +564,18 @@ __device__ __forceinline__ int fetch_batch(unsigned *ctr /*8 counters*/, int nba
     return __builtin_amdgcn_readfirstlane(b);
 }
 
+// Where a ray's per-hit state rows start, and a batch's region of entries / pairs: compact (row offsets from the scan of the hit counts in
+// sorted order) or the (R, cap) / (batches, 64 cap) layouts.
+__device__ __forceinline__ size_t state_row0(const TraceArgs &A, const int slot, const int r)
+{
+    return A.row_off ? (size_t)A.row_off[slot] : (size_t)r * A.cap;
+}
+__device__ __forceinline__ void batch_region(const TraceArgs &A, const int batch, size_t &start, size_t &size)
+{
+    if (A.batch_rows) { const uint2 br = A.batch_rows[batch]; start = br.x; size = br.y; }
+    else { size = (size_t)64 * A.cap; start = (size_t)batch * size; }
+}
+
 // Conservative termination bound for the unordered collection.  The ray's accepted hits are binned by distance into 16
 // linear bins over its chord through the scene box (16 registers of optical depth -ln(1-alpha)); as soon as the bins up to edge e hold more optical depth than
 // the compositing can survive (T < 1e-4), every hit beyond e is provably after the terminating hit: it is dropped and BVH nodes
@@ -603,6 +618,10 @@ extern template __global__ void __launch_bounds__(256) sort_composite_fwd<4, fal
 extern template __global__ void __launch_bounds__(256) sort_composite_fwd<8, true, true>(const TraceArgs A);
 extern template __global__ void __launch_bounds__(256) sort_composite_fwd<16, true, true>(const TraceArgs A);
 __global__ void __launch_bounds__(64 * RH_W) register_hits(const TraceArgs A);
+__global__ void __launch_bounds__(256) row_count(const TraceArgs A, unsigned *__restrict__ blk);
+__global__ void __launch_bounds__(1024) row_scan_blocks(unsigned *__restrict__ blk, int n);
+__global__ void __launch_bounds__(256) row_offsets(const TraceArgs A, const unsigned *__restrict__ blk, unsigned *__restrict__ row_off, uint2 *__restrict__ batch_rows,
+                                                   unsigned long long base, unsigned long long limit);
 __global__ void __launch_bounds__(256) unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, unsigned *__restrict__ cnt,
                                                          float *__restrict__ wet);
 __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd(const TraceArgs A);

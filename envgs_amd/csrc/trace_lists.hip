@@ -154,7 +154,7 @@ __device__ __forceinline__ void quad_sh_color(const void *shp, const int sid, co
 // so the sorted chunk c is simply register c: no LDS, no barriers, no bank conflicts.  The sorted list is written back only up to the
 // terminating hit.
 template <int E, bool QSH>
-__device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int r, const int n, const int lane, unsigned &st_hits)
+__device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int slot, const int r, const int n, const int lane, unsigned &st_hits)
 {
     uint2 *list = A.hits + (size_t)r * A.cap;
     unsigned long long kreg[E];
@@ -190,7 +190,7 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
     float dist = 0.f;                                   // per-lane partial sum
     int used = 0;
     const int sstr = A.has_others ? 3 : 2;              // per-hit state row: 32 B, or 48 B when the two `others` sums are needed too
-    float4 *state = A.state ? A.state + (size_t)r * A.cap * sstr : nullptr;
+    float4 *state = A.state ? A.state + state_row0(A, slot, r) * sstr : nullptr;
 #pragma unroll
     for (int ce = 0; ce < E; ce++) {
         const int cb = ce * 64;
@@ -290,10 +290,10 @@ sort_composite_fwd(const TraceArgs A)
                 if (A.long_list && lane == 0) A.long_list[A.batch0 * 64 + atomicAdd(A.counter + 24 + A.seg, 1u)] = (unsigned)slot;
                 continue;
             }
-            if (n <= 64) sort_composite_ray<1, QSH>(A, r, n, lane, st_hits);
-            else if (n <= 128) sort_composite_ray<2, QSH>(A, r, n, lane, st_hits);
-            else if (n <= 192) sort_composite_ray<3, QSH>(A, r, n, lane, st_hits);       // (a third of the rays of the bench scene)
-            else sort_composite_ray<4, QSH>(A, r, n, lane, st_hits);
+            if (n <= 64) sort_composite_ray<1, QSH>(A, slot, r, n, lane, st_hits);
+            else if (n <= 128) sort_composite_ray<2, QSH>(A, slot, r, n, lane, st_hits);
+            else if (n <= 192) sort_composite_ray<3, QSH>(A, slot, r, n, lane, st_hits);       // (a third of the rays of the bench scene)
+            else sort_composite_ray<4, QSH>(A, slot, r, n, lane, st_hits);
         }
     } else {
         // the longest list so far (this segment's collection has finished, so its own maximum is in): nothing to do in the usual case
@@ -305,8 +305,8 @@ sort_composite_fwd(const TraceArgs A)
             for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < nl; i += gridDim.x * 4) {
                 const int slot = (int)A.long_list[A.batch0 * 64 + i];
                 const int rr = ray_of(A, slot), nn = A.hit_cnt[rr];
-                if (EMAX == 8 || nn <= 512) sort_composite_ray<8, QSH>(A, rr, nn, lane, st_hits);
-                else if constexpr (EMAX >= 16) sort_composite_ray<16, QSH>(A, rr, nn, lane, st_hits);
+                if (EMAX == 8 || nn <= 512) sort_composite_ray<8, QSH>(A, slot, rr, nn, lane, st_hits);
+                else if constexpr (EMAX >= 16) sort_composite_ray<16, QSH>(A, slot, rr, nn, lane, st_hits);
             }
             if (A.stats && lane == 0 && st_hits) atomicAdd(A.stats + 0, (unsigned long long)st_hits);
             return;
@@ -320,8 +320,8 @@ sort_composite_fwd(const TraceArgs A)
                 const int l = (int)__builtin_ctzll(todo);
                 todo &= todo - 1;
                 const int rr = __shfl(r, l), nn = __shfl(n, l);
-                if (EMAX == 8 || nn <= 512) sort_composite_ray<8, QSH>(A, rr, nn, lane, st_hits);
-                else if constexpr (EMAX >= 16) sort_composite_ray<16, QSH>(A, rr, nn, lane, st_hits);
+                if (EMAX == 8 || nn <= 512) sort_composite_ray<8, QSH>(A, base + l, rr, nn, lane, st_hits);
+                else if constexpr (EMAX >= 16) sort_composite_ray<16, QSH>(A, base + l, rr, nn, lane, st_hits);
             }
         }
     }
@@ -352,12 +352,13 @@ register_hits(const TraceArgs A)
     __shared__ unsigned ptotal;
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const float wscale = __builtin_ldexpf(1.0f, A.wfrac);
-    const size_t region = (size_t)64 * A.cap;
     for (int base = (A.batch0 + (int)blockIdx.x) * 64; base < min(A.R, A.batch1 * 64); base += gridDim.x * 64) {
         const int batch = base >> 6;
         const int copy = batch & (NCOPY - 1);
-        unsigned long long *ent = A.entries ? A.entries + (size_t)batch * region : nullptr;
-        unsigned *prs = A.pairs ? A.pairs + (size_t)batch * region : nullptr;
+        size_t rstart, region;
+        batch_region(A, batch, rstart, region);
+        unsigned long long *ent = A.entries ? A.entries + rstart : nullptr;
+        unsigned *prs = A.pairs ? A.pairs + rstart : nullptr;
         __syncthreads();
         for (int i = threadIdx.x; i < RH_TAB; i += 64 * RH_W) { key[i] = -1; acc[i] = 0ull; }
         if (threadIdx.x == 0) { nfail = 0u; ndense = 0u; }
@@ -459,6 +460,81 @@ register_hits(const TraceArgs A)
             const unsigned T = min(ptotal, (unsigned)RH_STAGE);
             for (unsigned i = threadIdx.x; i < T; i += 64 * RH_W) prs[i] = pstage[i];
         }
+    }
+}
+
+// Row offsets of the compact per-hit buffers (envgs_trace.h: compact_rows).  Runs per forward segment between the collection and the sort:
+// rows of a ray = min(hits found, cap) (none for a ray whose list overflowed), scanned over the segment's slots in coherence-sorted order --
+// three small launches: per-block sums (256 slots = 4 batches per block), one workgroup scanning the block sums, per-block offsets.
+__device__ __forceinline__ unsigned rows_of_slot(const TraceArgs &A, const int slot, const int slot_end)
+{
+    if (slot >= slot_end) return 0u;
+    const int r = ray_of(A, slot);
+    const int n = A.hit_cnt[r];
+    return n > A.cap ? 0u : (unsigned)n;
+}
+
+__global__ void __launch_bounds__(256)
+row_count(const TraceArgs A, unsigned *__restrict__ blk)
+{
+    __shared__ unsigned wsum[4];
+    const int slot_end = min(A.R, A.batch1 * 64);
+    const int slot = A.batch0 * 64 + (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const float s = wave_sum((float)rows_of_slot(A, slot, slot_end));            // exact: <= 64 * 1024
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (unsigned)s;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ void __launch_bounds__(1024)
+row_scan_blocks(unsigned *__restrict__ blk, int n)
+{
+    // exclusive scan in place, one workgroup: each thread owns a contiguous run (n <= a few thousand blocks)
+    __shared__ unsigned part[1024];
+    const int per = (n + 1023) / 1024, lo = (int)threadIdx.x * per, hi = min(n, lo + per);
+    unsigned s = 0u;
+    for (int i = lo; i < hi; i++) s += blk[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned run = part[threadIdx.x] - s;
+    for (int i = lo; i < hi; i++) { const unsigned v = blk[i]; blk[i] = run; run += v; }
+}
+
+__global__ void __launch_bounds__(256)
+row_offsets(const TraceArgs A, const unsigned *__restrict__ blk, unsigned *__restrict__ row_off, uint2 *__restrict__ batch_rows,
+            unsigned long long base, unsigned long long limit)
+{
+    __shared__ unsigned wsum[4];
+    const int slot_end = min(A.R, A.batch1 * 64);
+    const int slot = A.batch0 * 64 + (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned cnt = rows_of_slot(A, slot, slot_end);
+    const float incl = wave_scan_add((float)cnt);
+    if (lane == 63) wsum[wave] = (unsigned)incl;
+    __syncthreads();
+    unsigned before = 0u;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    const unsigned long long row = base + (unsigned long long)blk[blockIdx.x] + before + (unsigned long long)((unsigned)incl - cnt);
+    const bool fits = row + cnt <= limit;
+    if (slot < slot_end) {
+        row_off[slot] = (unsigned)(fits ? row : 0ull);
+        if (!fits && cnt > 0u) {                                     // the segment's share of the rows is used up: this ray (and every later one
+            A.hit_cnt[ray_of(A, slot)] = A.cap + 1;                 // of the segment) takes the K-buffer kernels, like a ray whose list overflowed
+            atomicAdd(A.counter + 21, 1u);
+        }
+    }
+    // the batch (= this wavefront's 64 slots): first row and rows, clipped to the segment's share (rays that do not fit are a suffix)
+    const unsigned long long row0 = __shfl(row, 0);
+    const unsigned tot = wsum[wave];
+    if (lane == 0 && slot < slot_end) {
+        const unsigned long long end = row0 + tot < limit ? row0 + tot : limit;
+        batch_rows[slot >> 6] = make_uint2((unsigned)(row0 < limit ? row0 : limit), (unsigned)(end > row0 ? end - row0 : 0ull));
     }
 }
 

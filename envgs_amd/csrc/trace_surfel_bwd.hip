@@ -66,7 +66,6 @@ batch_surfel_bwd(const TraceArgs A)
     __shared__ float btile[16][64];                        // B operand of the reduction MFMAs: 16 words per ray, swizzled (see below)
     const int lane = threadIdx.x;
     const int nb = (A.D + 1) * (A.D + 1);
-    const size_t region = (size_t)64 * A.cap;
     const int nbatch = (A.R + 63) >> 6;
     for (int batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
         const int base = batch << 6;
@@ -105,9 +104,11 @@ batch_surfel_bwd(const TraceArgs A)
         for (int k = 0; k < 4; k++) SkM[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         float dO0 = 0.f, dO1 = 0.f, dO2 = 0.f, dD0 = 0.f, dD1 = 0.f, dD2 = 0.f;
         const int sstr = A.has_others ? 3 : 2;
-        const float4 *state = A.state + (size_t)rr * A.cap * sstr;
-        const unsigned long long *ent = A.entries + (size_t)batch * region;
-        const unsigned *prs = A.pairs + (size_t)batch * region;
+        const float4 *state = A.state + state_row0(A, min(base + lane, A.R - 1), rr) * sstr;
+        size_t rstart, region;
+        batch_region(A, batch, rstart, region);
+        const unsigned long long *ent = A.entries + rstart;
+        const unsigned *prs = A.pairs + rstart;
         const int D = A.n_entries[2 * batch], NE = D + A.n_entries[2 * batch + 1];
         unsigned poff = 0u;                                  // pairs of the table entries staged so far
         // Stage one group of entries, a whole group ahead of its use: 4 lanes per entry fetch the surfel record and SH block, then the

@@ -90,6 +90,8 @@ def _cfg(settings, P, R, shs, others, start_from_first, ray_shape, f16=False):
 
 
 NCOPY = 8                    # must equal NCOPY in csrc/trace_common.h
+ROW_CAP = {}                 # tests only: ROW_CAP["force_per_ray"] pins the rows per ray of the compact per-hit buffers; COMPACT["on"] = False keeps the (R, cap) layouts
+COMPACT = {"on": True}
 HIT_CAP = {}                 # tests only: HIT_CAP["force"] pins the list capacity of every tracer (e.g. tiny, to exercise the overflow hand-off)
 SORT_RAYS = {"on": True}     # coherence-sort the rays (direction, origin) before tracing
 USE_RECORDS = {"on": True}   # atomic-free backward (one record per (batch, surfel) entry, grouped by surfel); False = cooperative atomic flush
@@ -103,12 +105,13 @@ class CapState:
 
     def __init__(self, cap=512):
         self.cap = int(cap)
+        self.found_per_ray = None   # hits found per ray in the previous call: sizes the COMPACT per-hit buffers (rows) of the next one
         self._mirrors = {}          # device -> dict(host, event, valid)
 
     def mirror(self, dev):
         m = self._mirrors.get(dev)
         if m is None:
-            m = self._mirrors[dev] = dict(host=torch.zeros(1, dtype=torch.int32).pin_memory(), event=torch.cuda.Event(), valid=False)
+            m = self._mirrors[dev] = dict(host=torch.zeros(4, dtype=torch.int32).pin_memory(), event=torch.cuda.Event(), valid=False, rays=1)
         return m
 
     def next_cap(self, dev):
@@ -119,12 +122,25 @@ class CapState:
             mx = int(m["host"][0])
             want = ((int(mx * 1.2) + 8 + 63) // 64) * 64          # 20 % headroom, multiple of 64 entries (512 B)
             self.cap = max(64, min(want, 1024))
+            found = (int(m["host"][2]) & 0xFFFFFFFF) | ((int(m["host"][3]) & 0xFFFFFFFF) << 32)
+            self.found_per_ray = found / max(1, m["rays"])
         return self.cap
 
-    def publish(self, counters, dev):
-        """Queue the asynchronous read-back of this call's longest list (counters[1])."""
+    def next_rows(self, R, cap):
+        """Rows of the compact per-hit buffers (hit_state / entries / pairs; include/envgs_trace.h: compact_rows) for a call with R rays:
+        30 % above the previous call's hits found per ray (a first call assumes 192 per ray), never more than the (R, cap) layout would take.
+        Rays that do not fit fall back to the K-buffer kernels -- slower, never wrong -- and the next call has the right size."""
+        if ROW_CAP.get("force_per_ray") is not None:                   # tests: pin the rows per ray (tight: exercises the fall-back)
+            per = float(ROW_CAP["force_per_ray"])
+        else:
+            per = 192.0 if self.found_per_ray is None else 1.3 * self.found_per_ray + 4.0
+        return int(min(R * cap, max(int(per * R) + 4096, 4096)))
+
+    def publish(self, counters, dev, rays=1):
+        """Queue the asynchronous read-back of this call's longest list (counters[1]) and of its total of hits found (counters[8:10])."""
         m = self.mirror(dev)
-        m["host"].copy_(counters[1:2], non_blocking=True); m["event"].record(torch.cuda.current_stream(dev)); m["valid"] = True
+        m["host"][0:1].copy_(counters[1:2], non_blocking=True); m["host"][2:4].copy_(counters[8:10], non_blocking=True)
+        m["event"].record(torch.cuda.current_stream(dev)); m["valid"] = True; m["rays"] = int(rays)
 
 
 _DEFAULT_CAPS = CapState()       # direct callers of trace_forward (tests, diagnostics); every SurfelTracer owns its own
@@ -191,25 +207,36 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
         srt = SORT_RAYS["on"]
         if shs is not None and shs.shape[1] == 16 and QUAD_SH["on"]:
             keep["sh_perm"] = torch.empty(P, 48, dtype=shs.dtype, device=dev)      # quad-permuted SH copy (envgs_trace.h: sh_perm)
+        rows = 0
         if need_grad and USE_RECORDS["on"]:
-            # what the record backward needs from the forward: per-hit state, and the (batch, surfel) entries with their (lane, k) pairs
+            # what the record backward needs from the forward: per-hit state, and the (batch, surfel) entries with their (lane, k) pairs.
+            # COMPACT: rows follow the hits the rays actually have (a prefix sum of the hit counts, taken on the device between the collection
+            # and the sort) instead of rays x capacity -- a ray uses a third of its capacity (42 -> 19 GB for a 1.92 M-ray stage)
             nbatch = (R + 63) // 64
-            keep.update(hit_state=_scratch((R, cap, 12 if others_precomp is not None else 8), torch.float32, dev), entries=_scratch((nbatch, 64 * cap), torch.int64, dev),
-                        pairs=_scratch((nbatch, 64 * cap), torch.int32, dev), n_entries=torch.empty(nbatch, 2, **i32))
+            sw = 12 if others_precomp is not None else 8
+            if COMPACT["on"] and srt:
+                rows = caps.next_rows(R, cap)
+                keep.update(hit_state=_scratch((rows, sw), torch.float32, dev), entries=_scratch((rows,), torch.int64, dev), pairs=_scratch((rows,), torch.int32, dev),
+                            n_entries=torch.empty(nbatch, 2, **i32), row_off=torch.empty(R, **i32), batch_rows=torch.empty(nbatch, 2, **i32),
+                            row_blk=torch.empty((R + 255) // 256 + 16, **i32))
+            else:
+                keep.update(hit_state=_scratch((R, cap, sw), torch.float32, dev), entries=_scratch((nbatch, 64 * cap), torch.int64, dev),
+                            pairs=_scratch((nbatch, 64 * cap), torch.int32, dev), n_entries=torch.empty(nbatch, 2, **i32))
         lists = _lib.TraceLists(keep["hit_lists"].data_ptr(), keep["hit_cnt"].data_ptr(), keep["n_used"].data_ptr(), cap,
                                 keep["spill"].data_ptr(), keep["surf_acc"].data_ptr(), keep["surf_cnt"].data_ptr(), keep["surf_off"].data_ptr(),
                                 keep["scan_temp"].data_ptr(), sb, keep["ray_keys"].data_ptr() if srt else None,
                                 keep["ray_order"].data_ptr() if srt else None, keep["ray_sort_temp"].data_ptr() if srt else None, rb, None, 0,
-                                *[(keep[k].data_ptr() if k in keep else None) for k in ("hit_state", "entries", "pairs", "n_entries", "sh_perm")])
+                                *[(keep[k].data_ptr() if k in keep else None) for k in ("hit_state", "entries", "pairs", "n_entries")], rows,
+                                *[(keep[k].data_ptr() if k in keep else None) for k in ("row_off", "batch_rows", "row_blk", "sh_perm")])
     p = _lib.ptr
     _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
                                        p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),
                                        p(norm), p(dist), p(aux), p(mid), p(wet), p(final_T), lists, _stream(dev)), "envgs_trace_forward")
-    LAST_STATS.update(P=P, R=R, caps=caps, counters=counters, n_entries=keep.get("n_entries"), cap=cap,
+    LAST_STATS.update(P=P, R=R, caps=caps, rows=rows, counters=counters, n_entries=keep.get("n_entries"), cap=cap,
                       lists=((keep["hit_lists"], keep["n_used"], keep["hit_cnt"]) if (cap and KEEP_LISTS["on"]) else None))
     if cap:
         # asynchronous read-backs for later: the longest list (sizes the next call's cap) and the number of gradient records
-        caps.publish(counters, dev)
+        caps.publish(counters, dev, rays=R)
         keep["n_rec_host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
         keep["n_rec_host"].copy_(keep["surf_off"].view(-1)[NCOPY * P - 1:NCOPY * P], non_blocking=True)
         keep["n_rec_event"] = torch.cuda.Event(); keep["n_rec_event"].record(torch.cuda.current_stream(dev))
@@ -482,4 +509,4 @@ def last_trace_counts():
     w = c.cpu()
     v = w[2:20].view(torch.int64)
     return dict(coop_cycles=dict(expand=int(v[6]), walk=int(v[7]), wait=int(v[8])), hits=int(v[0]), node_visits=int(v[1]), rounds=int(v[2]), found=int(v[3]), packet_nodes=int(v[4]), packet_leaves=int(v[5]),
-                max_list=int(w[1]), cap=LAST_STATS["caps"].cap, rays=LAST_STATS["R"], stack_overflows=int(w[20]))
+                max_list=int(w[1]), cap=LAST_STATS["caps"].cap, compact_rows=LAST_STATS.get("rows", 0), rays_without_rows=int(w[21]), rays=LAST_STATS["R"], stack_overflows=int(w[20]))

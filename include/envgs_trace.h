@@ -94,6 +94,18 @@ typedef struct envgs_trace_lists {
     uint64_t *entries;       /* (ceil(R/64), 64*cap) distinct surfels of every batch, packed id | hits-1 << 24 | slot << 32 */
     uint32_t *pairs;         /* (ceil(R/64), 64*cap) (lane << 16 | list position) of every composited hit, grouped by entry */
     int32_t *n_entries;      /* (ceil(R/64), 2) entries merged in the batch's table, single entries filed from the top */
+    /* COMPACT per-hit buffers (optional; compact_rows == 0 selects the (R, cap) layouts documented above).  A ray uses a third of its list
+     * capacity on average, so hit_state / entries / pairs are addressed through per-ray ROW offsets instead: after the collection the rays'
+     * hit counts are scanned in coherence-sorted order (a batch's rows are contiguous), ray at sorted slot s owns rows
+     * [row_off[s], row_off[s] + min(hit_cnt, cap)) of hit_state (compact_rows x 8|12 floats), and batch b owns the same row range
+     * batch_rows[b] = {first row, rows} of entries / pairs (compact_rows elements each).  Each forward segment is given the share of the
+     * rows that corresponds to its share of the rays; rays that do not fit are handed to the K-buffer kernels like rays whose list overflowed
+     * (hit_cnt := cap + 1, counters[21] counts them) -- slower, never wrong.  The caller sizes compact_rows from the previous call's
+     * total of hits found (counters[8..9]). */
+    uint64_t compact_rows;   /* rows of hit_state / elements of entries and pairs; 0 = (R, cap) layouts */
+    uint32_t *row_off;       /* (R) by sorted slot */
+    uint32_t *batch_rows;    /* (ceil(R/64), 2) */
+    uint32_t *row_blk;       /* (ceil(R/256) + 8) scratch of the row scan */
     void *sh_perm;           /* optional scratch, (P, 48) elements of the shs storage type (used when sh_coeffs == 16): a quad-permuted copy of the SH
                                 blocks, rebuilt by every forward, that lets four lanes fetch one surfel's block as contiguous 64 B runs; NULL = each
                                 lane gathers its own block from shs */

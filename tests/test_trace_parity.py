@@ -176,6 +176,8 @@ class _Switch:
                 orig = tracing.trace_forward
                 tracing.trace_forward = lambda *a, **kk: orig(*a, **{**kk, "use_lists": False})
             elif k == "records": self.old[k] = tracing.USE_RECORDS["on"]; tracing.USE_RECORDS["on"] = v
+            elif k == "rows_per_ray": self.old[k] = dict(tracing.ROW_CAP); tracing.ROW_CAP["force_per_ray"] = v
+            elif k == "compact": self.old[k] = tracing.COMPACT["on"]; tracing.COMPACT["on"] = v
             elif k == "sort_rays": self.old[k] = tracing.SORT_RAYS["on"]; tracing.SORT_RAYS["on"] = v
             elif k == "debug_trace":
                 lib = _lib.load(); self.old[k] = lib.envgs_debug_get(0); lib.envgs_debug_set(0, v)
@@ -185,6 +187,8 @@ class _Switch:
             if k == "force_cap": tracing.HIT_CAP.clear(); tracing.HIT_CAP.update(v)
             elif k == "no_lists": tracing.trace_forward = v
             elif k == "records": tracing.USE_RECORDS["on"] = v
+            elif k == "rows_per_ray": tracing.ROW_CAP.clear(); tracing.ROW_CAP.update(v)
+            elif k == "compact": tracing.COMPACT["on"] = v
             elif k == "sort_rays": tracing.SORT_RAYS["on"] = v
             elif k == "debug_trace": _lib.load().envgs_debug_set(0, v)
         if self.lib_kind is not None:
@@ -662,3 +666,22 @@ def test_trace_empty_inputs(P, R):
                             start_from_first=False)
         ok = ~a["fragile"]
         check_close("single_surfel", "rgb", rgb.detach().cpu().numpy()[ok], ref["rgb"][ok], excluded=int((~ok).sum()))
+
+
+@pytest.mark.parametrize("mode", ["generous", "tight", "legacy"])
+def test_trace_compact_per_hit_buffers(mode, request):
+    """hit_state / entries / pairs are addressed through row offsets taken from a scan of the hit counts (envgs_trace.h: compact_rows).
+    generous: every ray has its rows; tight: the rows run out part-way through each segment and the remaining rays are handed to the K-buffer
+    kernels (slower, never wrong); legacy: the (R, cap) layouts.  All three must meet the same contract."""
+    from envgs_amd import tracing
+    g, ro, rd = trace_scene(P=2000, R=1024, seed=7, camera=False)
+    g["scales"] = g["scales"] * 0.35
+    sw = {"generous": _Switch(rows_per_ray=400.0), "tight": _Switch(rows_per_ray=6.0), "legacy": _Switch(compact=False)}[mode]
+    res = _parity(request.node.name, g, ro, rd, torch.tensor([0.3, 0.1, 0.7]), 2, True, False, hip_ctx=sw, require_lists=(mode != "tight"))
+    cnt = res["cnt"]
+    if mode == "generous":
+        assert cnt["compact_rows"] > 0 and cnt["rays_without_rows"] == 0 and res["n_listed"] == res["R"]
+    elif mode == "tight":
+        assert cnt["compact_rows"] > 0 and cnt["rays_without_rows"] > 50 and 0 < res["n_listed"] < res["R"]
+    else:
+        assert cnt["compact_rows"] == 0 and res["n_listed"] == res["R"]
