@@ -29,8 +29,10 @@ trace_fwd(const TraceArgs A, const int ray_h, const int ray_w)
 {
     __shared__ int stk[STACK][64];
     const int lane = threadIdx.x;
-    // overflow pass after the list path: counter[1] holds the longest list of this call -- nothing overflowed, nothing to do
-    if (A.only_overflow && (int)__hip_atomic_load(A.counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= A.cap) return;
+    // overflow pass after the list path: counter[1] holds the longest list of this call, counter[21] the rays that found no room in the compact
+    // per-hit buffers -- nothing overflowed, nothing to do
+    if (A.only_overflow && (int)__hip_atomic_load(A.counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= A.cap &&
+        __hip_atomic_load(A.counter + 21, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;      // ([21]: rays the compact row scan handed over)
     while (true) {
         int base = 0;
         if (lane == 0) base = (int)atomicAdd(A.counter, 64u);
@@ -155,7 +157,8 @@ trace_bwd(const TraceArgs A, const int ray_h, const int ray_w)
     __shared__ int stk[STACK][64];
     __shared__ float fld[NFLD][65];                 // row stride 65: lanes 48..62 read 15 different rows of one column conflict-free
     const int lane = threadIdx.x;
-    if (A.only_overflow && (int)__hip_atomic_load(A.counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= A.cap) return;
+    if (A.only_overflow && (int)__hip_atomic_load(A.counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= A.cap &&
+        __hip_atomic_load(A.counter + 21, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;      // ([21]: rays the compact row scan handed over)
     const FlushRole role = flush_role(A, lane);
     const int nb = (A.D + 1) * (A.D + 1);
     while (true) {

@@ -191,6 +191,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     norm = torch.empty(R, 3, **f32); dist = torch.empty(R, 1, **f32); aux = torch.empty(R, 2, **f32)
     mid = torch.empty(R, 16 * ND, **f32); wet = torch.empty(P, 1, **f32); final_T = torch.empty(R, **f32)
     cap = caps.next_cap(dev) if (use_lists and ND == 1 and P > 0 and R > 0) else 0
+    rows = 0
     lists = None
     keep = {}
     if cap:
@@ -207,7 +208,6 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
         srt = SORT_RAYS["on"]
         if shs is not None and shs.shape[1] == 16 and QUAD_SH["on"]:
             keep["sh_perm"] = torch.empty(P, 48, dtype=shs.dtype, device=dev)      # quad-permuted SH copy (envgs_trace.h: sh_perm)
-        rows = 0
         if need_grad and USE_RECORDS["on"]:
             # what the record backward needs from the forward: per-hit state, and the (batch, surfel) entries with their (lane, k) pairs.
             # COMPACT: rows follow the hits the rays actually have (a prefix sum of the hit counts, taken on the device between the collection

@@ -583,7 +583,8 @@ def test_trace_forward_is_independent_of_the_traversal_interleaving():
     # (list capacity pinned above the longest list, ~630 hits here: a ray whose FOUND count -- which does depend on timing -- straddles the
     #  capacity of a fresh tracer (512) is composited by the K-buffer kernels in one run and by the list kernels in the other: the same terms
     #  summed in a different order, 1e-7 apart; scratch/determinism_probe.py)
-    with _Switch(force_cap=1024):
+    # (same for the rows of the compact per-hit buffers: a fresh tracer assumes 192 hits per ray, this scene has more)
+    with _Switch(force_cap=1024, rows_per_ray=1024.0):
         runs = [[x.detach().clone() for x in _run_hip(g, ro, rd, torch.tensor([0.2, 0.3, 0.4]), 3, True, False)[0]] for _ in range(3)]
     assert float(runs[0][2].mean()) > 0.3                       # the rays blend plenty
     for other in runs[1:]:
@@ -611,7 +612,7 @@ def test_trace_update_request_follows_the_new_vertices():
                           scales=e["scales"] * 0.4, rotations=e["rotations"], cov3D_precomp=None, tracer_settings=st, start_from_first=False)
     m0 = e["means3D"] * 0.1
     m1 = m0 + 0.5 * torch.randn_like(m0)
-    with _Switch(force_cap=1024):                  # (one capacity for both tracers: the second call of `t` would otherwise run with a capacity adapted
+    with _Switch(force_cap=1024, rows_per_ray=1024.0):   # (one capacity for both tracers: the second call of `t` would otherwise run with a capacity adapted
         t = mod.SurfelTracer()                     #  to its first call, the fresh tracer with the default, and a ray near either takes a different kernel path)
         a0 = trace(t, m0, True)
         a1 = trace(t, m1, False)                   # update request with moved surfels
