@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--exchange", default="direct", choices=["direct", "allreduce"],
                     help="N > 1: direct reduce-scatter + all-gather over the xGMI mesh (all_to_all + local sum + all_gather), or one all_reduce per bucket")
     ap.add_argument("--no-render", action="store_true", help="skip the forward-only render timing (profiling runs: keeps the kernel statistics to the training steps)")
+    ap.add_argument("--no-prebuild", action="store_true", help="fused caller: build the environment structure inside the traced call (as the reference caller does) instead of ahead, under the base pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-caller", action="store_true", help="skip the extra few steps that time the unchanged-EasyVolcap-caller form of the step (config.reference_caller_ms_per_step)")
     ap.add_argument("--step-times", type=int, default=0, help="diagnostics: after the timed region, run this many extra steps one by one (synchronised) and print their wall times and the allocator statistics to stderr")
@@ -191,6 +192,7 @@ def main():
             envgs_step.FUSED["on"] = c == "fused"
             envgs_step.REFERENCE_FORMS["on"] = c == "reference"
         set_caller(args.caller)
+        envgs_step.PREBUILD["on"] = not args.no_prebuild
         dnorm_hw = (torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)) / HW).to(dev)
         tracer = tpkg.SurfelTracer()
         rays = [synth.get_rays(c) for c in cams]

@@ -128,10 +128,21 @@ def _select_storage():
 
 REFERENCE_FORMS = {"on": False}    # bench.py --caller reference: the expression forms the unchanged EasyVolcap caller executes (batched-matmul get_disks,
                                    # the regulariser maps of render()'s tail) instead of this module's cheaper equivalents
+PREBUILD = {"on": True}            # fused caller: start the environment structure build before the base pass (SurfelTracer.prepare)
 TRACE = {"depth": 0, "specular_threshold": 0.0}    # EnvGS hard-codes 0 bounces (envgs_sampler.py:510,548); bench.py --trace-depth overrides
 
 
-def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree):
+def env_prepare(tracer, env):
+    """Fused caller only: the environment set's 3-sigma quads and the request + START of the structure build, issued BEFORE the base pass so
+    that the build (its own stream, SurfelTracer.prepare) runs under the rasterizer's forward.  Returns the vertex buffer for env_pass."""
+    from . import fused
+    v, f = fused.surfel_quads(env["means3D"], env["scales"], env["rotations"])
+    tracer.build_acceleration_structure(v, f, rebuild=True)
+    tracer.prepare(env["opacities"])
+    return v
+
+
+def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree, prepared_v=None):
     """HardwareRendering.render_gaussians of optix_utils.py with start_from_first=False, max_trace_depth=0."""
     ts = tpkg.SurfelTracingSettings(
         image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=env_bg,
@@ -139,7 +150,9 @@ def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree):
         sh_degree=sh_degree, campos=cam.camera_center.contiguous(), prefiltered=False, debug=False, max_trace_depth=int(TRACE["depth"]),
         specular_threshold=float(TRACE["specular_threshold"]))
     _select_storage()
-    if FUSED["on"] and not REFERENCE_FORMS["on"]:
+    if prepared_v is not None:
+        v = prepared_v                                                 # quads computed and the build started before the base pass (env_prepare)
+    elif FUSED["on"] and not REFERENCE_FORMS["on"]:
         from . import fused
         v, f = fused.surfel_quads(env["means3D"], env["scales"], env["rotations"])          # one launch instead of ~25 torch kernels in front of the trace
         tracer.build_acceleration_structure(v, f, rebuild=True)
@@ -156,13 +169,14 @@ def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree):
 def envgs_forward(pkg, tpkg, tracer, cam, rays, base, env, bg, env_bg, sh_degree):
     """One EnvGS forward: base raster -> reflect -> env trace -> blend.  Returns dict of (H,W,*) maps."""
     H, W = cam.image_height, cam.image_width
+    prepared_v = env_prepare(tracer, env) if (FUSED["on"] and not REFERENCE_FORMS["on"] and PREBUILD["on"] and hasattr(tracer, "prepare")) else None
     b = base_pass(pkg, cam, base, bg, sh_degree)
     ray_o, ray_d = rays
     if FUSED["on"]:
         from . import fused
         nw, dep, ref_o, ref_d = fused.reflect(b["allmap"], ray_o, ray_d, cam.world_view_transform, 0.0)
         b["normal"], b["depth"] = nw, dep
-        rgb_env, dpt, acc, norm, dist, aux, mid, wet = env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree)
+        rgb_env, dpt, acc, norm, dist, aux, mid, wet = env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree, prepared_v)
         rgb = fused.blend(b["img"], rgb_env)          # (1 - spec) * rgb_base + spec * rgb_env without slicing the rasterizer's output
         return dict(rgb=rgb, base=b, rgb_env=rgb_env, env_wet=wet, ref_o=ref_o, ref_d=ref_d)
     if REFERENCE_FORMS["on"]:                                      # render() always builds these (gaussian2d_utils.py:1125-1142); the supervisor consumes them

@@ -329,6 +329,16 @@ def frame_from_transmat(cov3D_precomp, settings):
     return torch.cat([su, sv], dim=-1) / mod, q
 
 
+_BUILD_STREAMS = {}
+
+
+def _build_stream(dev):
+    s = _BUILD_STREAMS.get(dev)
+    if s is None:
+        s = _BUILD_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
 class _TraceSurfels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ray_o, ray_d, v, means3D, grads3D, shs, colors_precomp, others_precomp, opacities, scales, rotations,
@@ -376,8 +386,29 @@ class SurfelTracer(nn.Module):
         # topology, a full LBVH build is 0.2 ms at 164 k surfels, and a stale structure would be silently wrong -- so an update request
         # rebuilds as well (the reference itself only ever passes rebuild=True: optix_utils.py:78).
         self._pending = vertices.detach()
+        self.__dict__.pop("_build_event", None)
         self.nodes = None
         self.num_surfels = vertices.shape[0] // 4
+
+    def prepare(self, opacities=None):
+        """OPTIONAL, not part of the reference interface: start the structure build requested by build_acceleration_structure() NOW, on a side
+        stream, instead of inside the next traced call.  A caller that knows the environment set before it renders the base pass (the fused
+        caller of envgs_amd/envgs_step.py) overlaps the 0.2 ms build with the rasterizer's forward; the traced call waits for it.  The
+        unchanged EasyVolcap caller never calls this and builds at trace time, as before."""
+        if self._pending is None or self.nodes is not None:
+            return
+        dev = self._pending.device
+        side = _build_stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))           # the vertex buffer is produced on the caller's stream
+        self._pending.record_stream(side)
+        if opacities is not None:
+            opacities = opacities.detach()
+            opacities.record_stream(side)
+        with torch.cuda.stream(side):
+            self.nodes, self.num_surfels = build_bvh(self._pending, opacities)
+        self._build_event = torch.cuda.Event()
+        self._build_event.record(side)
+        self._pending = None
 
     def forward(self, ray_o, ray_d, v=None, *, means3D, grads3D=None, shs=None, colors_precomp=None, others_precomp=None,
                 opacities=None, scales=None, rotations=None, cov3D_precomp=None, tracer_settings=None, start_from_first=True):
@@ -401,6 +432,11 @@ class SurfelTracer(nn.Module):
                 raise RuntimeError("SurfelTracer: acceleration structure was requested for %d surfels, call has %d" % (self._pending.shape[0] // 4, means3D.shape[0]))
             self.nodes, self.num_surfels = build_bvh(self._pending, opacities)
             self._pending = None
+        ev = self.__dict__.pop("_build_event", None)
+        if ev is not None:                                             # built ahead on the side stream (prepare()): order this stream behind it
+            cur = torch.cuda.current_stream(self.nodes.device)
+            cur.wait_event(ev)
+            self.nodes.record_stream(cur)
         if grads3D is None:
             grads3D = torch.zeros_like(means3D)
         e = torch.Tensor([])
