@@ -91,7 +91,7 @@ def trace_per_ray_model_bytes(kernel, tc, R):
 VALU_PEAK_GINST = 256 * 2 * 2.4
 VALU_MEASURED_GINST = 898.0     # what the chip sustains: independent v_fma_f32 / mixed VALU, 8 waves per SIMD (scratch/valu_peak.hip -> profiles/r02_valu_peak.txt)
 SALU_PEAK_GINST = 256 * 1 * 2.4
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_envgs.json")
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_envgs.json")
 
 
 def main():

@@ -2,7 +2,7 @@
 import collections, csv, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def short(n):
@@ -84,7 +84,7 @@ def pmc():
 stats('envgs', 24, 'full EnvGS step: 300k base surfels ch05 raster + 163840 env surfels LBVH trace, 800x800; python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-render (the tracer forward runs as two batch segments on two streams: 2 launches per step, overlapping, so the kernel times sum to more than the step)')
 stats('raster', 34, 'raster only: 300k surfels, SH deg 3 in-kernel, 800x800; python bench.py --workload raster --steps 30 --warmup 4 --no-cpu-baseline --no-render')
 pmc()
-for n in ('envgs', 'envgs_reference_caller', 'envgs_twin_caller', 'envgs_f16', 'raster', 'env700k', 'config5'):
+for n in ('envgs', 'envgs_reference_caller', 'envgs_twin_caller', 'envgs_f16', 'raster', 'env700k', 'caps', 'config5'):
     src = os.path.join(ROOT, 'gpurun_out', 'bench_%s_final.json' % n)
     if os.path.exists(src) and os.path.getsize(src) > 10:
         open(os.path.join(ROOT, 'profiles', '%s_bench_%s.json' % (TAG, n)), 'w').write(open(src).read())
