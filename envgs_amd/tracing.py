@@ -126,6 +126,14 @@ class CapState:
             self.found_per_ray = found / max(1, m["rays"])
         return self.cap
 
+    def pinned_word(self):
+        """One pinned int32 of a ring of 32 (the record count of a forward is read at its backward: at most a few forwards are outstanding)."""
+        ring = self.__dict__.setdefault("_ring", [None, 0])
+        if ring[0] is None:
+            ring[0] = torch.zeros(32, dtype=torch.int32).pin_memory()
+        ring[1] = (ring[1] + 1) % 32
+        return ring[0][ring[1]:ring[1] + 1]
+
     def next_rows(self, R, cap):
         """Rows of the compact per-hit buffers (hit_state / entries / pairs; include/envgs_trace.h: compact_rows) for a call with R rays:
         30 % above the previous call's hits found per ray (a first call assumes 192 per ray), never more than the (R, cap) layout would take.
@@ -165,6 +173,18 @@ def _scratch(shape, dtype, dev):
     raise AssertionError
 
 
+def _carve_i32(dev, sizes):
+    """One int32 allocation carved into named views (each starting on a 256 B boundary)."""
+    offs, total = {}, 0
+    for k, n in sizes.items():
+        offs[k] = total
+        total += ((int(n) + 63) // 64) * 64
+    buf = torch.empty(max(total, 64), dtype=torch.int32, device=dev)
+    out = {k: buf[o:o + int(sizes[k])] for k, o in offs.items()}
+    out["_i32_block"] = buf
+    return out
+
+
 QUAD_SH = {"on": True}       # list path: four lanes share the fetch of a surfel's SH block (tests switch it off to cover the per-lane gathers)
 KEEP_LISTS = {"on": False}   # tests: keep the last forward's per-ray hit lists reachable through last_hit_lists()
 
@@ -196,15 +216,16 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     keep = {}
     if cap:
         i32 = dict(dtype=torch.int32, device=dev)
-        keep = dict(hit_lists=_scratch((R, cap, 2), torch.int32, dev), hit_cnt=torch.empty(R, **i32), n_used=torch.empty(R, **i32),
-                    spill=torch.empty(lib.envgs_trace_stack_spill_ints(R), **i32), surf_acc=torch.empty(P, NCOPY, dtype=torch.int64, device=dev),
-                    surf_cnt=torch.empty(P, NCOPY, **i32),
-                    surf_off=torch.empty(P, NCOPY, **i32))
         sb = lib.envgs_raster_scan_temp_bytes(NCOPY * P)
-        keep["scan_temp"] = torch.empty(max(sb, 1), dtype=torch.uint8, device=dev)
         rb = lib.envgs_trace_ray_sort_temp_bytes(R)
-        keep.update(ray_keys=torch.empty(2 * R, **i32), ray_order=torch.empty(2 * R, **i32),
-                    ray_sort_temp=torch.empty(max(rb, 1), dtype=torch.uint8, device=dev))
+        nbatch = (R + 63) // 64
+        # the small int32 scratch of a call comes out of ONE allocation (a dozen torch.empty calls are ~0.1 ms of host time, and this code runs
+        # right behind the rasterizer's one host sync, where the GPU has nothing queued)
+        keep = _carve_i32(dev, dict(hit_cnt=R, n_used=R, spill=lib.envgs_trace_stack_spill_ints(R), surf_acc=2 * P * NCOPY, surf_cnt=P * NCOPY,
+                                    surf_off=P * NCOPY, scan_temp=(max(sb, 1) + 3) // 4, ray_keys=2 * R, ray_order=2 * R, ray_sort_temp=(max(rb, 1) + 3) // 4,
+                                    n_entries=2 * nbatch, row_off=R, batch_rows=2 * nbatch, row_blk=(R + 255) // 256 + 16))
+        keep["n_entries"] = keep["n_entries"].view(nbatch, 2)
+        keep["hit_lists"] = _scratch((R, cap, 2), torch.int32, dev)
         srt = SORT_RAYS["on"]
         if shs is not None and shs.shape[1] == 16 and QUAD_SH["on"]:
             keep["sh_perm"] = torch.empty(P, 48, dtype=shs.dtype, device=dev)      # quad-permuted SH copy (envgs_trace.h: sh_perm)
@@ -212,34 +233,34 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
             # what the record backward needs from the forward: per-hit state, and the (batch, surfel) entries with their (lane, k) pairs.
             # COMPACT: rows follow the hits the rays actually have (a prefix sum of the hit counts, taken on the device between the collection
             # and the sort) instead of rays x capacity -- a ray uses a third of its capacity (42 -> 19 GB for a 1.92 M-ray stage)
-            nbatch = (R + 63) // 64
             sw = 12 if others_precomp is not None else 8
             if COMPACT["on"] and srt:
                 rows = caps.next_rows(R, cap)
-                keep.update(hit_state=_scratch((rows, sw), torch.float32, dev), entries=_scratch((rows,), torch.int64, dev), pairs=_scratch((rows,), torch.int32, dev),
-                            n_entries=torch.empty(nbatch, 2, **i32), row_off=torch.empty(R, **i32), batch_rows=torch.empty(nbatch, 2, **i32),
-                            row_blk=torch.empty((R + 255) // 256 + 16, **i32))
+                keep.update(hit_state=_scratch((rows, sw), torch.float32, dev), entries=_scratch((rows,), torch.int64, dev), pairs=_scratch((rows,), torch.int32, dev))
             else:
                 keep.update(hit_state=_scratch((R, cap, sw), torch.float32, dev), entries=_scratch((nbatch, 64 * cap), torch.int64, dev),
-                            pairs=_scratch((nbatch, 64 * cap), torch.int32, dev), n_entries=torch.empty(nbatch, 2, **i32))
+                            pairs=_scratch((nbatch, 64 * cap), torch.int32, dev))
         lists = _lib.TraceLists(keep["hit_lists"].data_ptr(), keep["hit_cnt"].data_ptr(), keep["n_used"].data_ptr(), cap,
                                 keep["spill"].data_ptr(), keep["surf_acc"].data_ptr(), keep["surf_cnt"].data_ptr(), keep["surf_off"].data_ptr(),
                                 keep["scan_temp"].data_ptr(), sb, keep["ray_keys"].data_ptr() if srt else None,
                                 keep["ray_order"].data_ptr() if srt else None, keep["ray_sort_temp"].data_ptr() if srt else None, rb, None, 0,
-                                *[(keep[k].data_ptr() if k in keep else None) for k in ("hit_state", "entries", "pairs", "n_entries")], rows,
-                                *[(keep[k].data_ptr() if k in keep else None) for k in ("row_off", "batch_rows", "row_blk", "sh_perm")])
+                                *[(keep[k].data_ptr() if k in keep else None) for k in ("hit_state", "entries", "pairs")],
+                                keep["n_entries"].data_ptr() if "hit_state" in keep else None, rows,
+                                *[(keep[k].data_ptr() if (k in keep and rows) else None) for k in ("row_off", "batch_rows", "row_blk")],
+                                keep["sh_perm"].data_ptr() if "sh_perm" in keep else None)
     p = _lib.ptr
     _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
                                        p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),
                                        p(norm), p(dist), p(aux), p(mid), p(wet), p(final_T), lists, _stream(dev)), "envgs_trace_forward")
-    LAST_STATS.update(P=P, R=R, caps=caps, rows=rows, counters=counters, n_entries=keep.get("n_entries"), cap=cap,
+    LAST_STATS.update(P=P, R=R, caps=caps, rows=rows, counters=counters, n_entries=(keep.get("n_entries") if "hit_state" in keep else None), cap=cap,
                       lists=((keep["hit_lists"], keep["n_used"], keep["hit_cnt"]) if (cap and KEEP_LISTS["on"]) else None))
     if cap:
         # asynchronous read-backs for later: the longest list (sizes the next call's cap) and the number of gradient records
         caps.publish(counters, dev, rays=R)
-        keep["n_rec_host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
-        keep["n_rec_host"].copy_(keep["surf_off"].view(-1)[NCOPY * P - 1:NCOPY * P], non_blocking=True)
-        keep["n_rec_event"] = torch.cuda.Event(); keep["n_rec_event"].record(torch.cuda.current_stream(dev))
+        if "hit_state" in keep:                                   # (a pinned word from the tracer's ring: pinning host memory per call is ~0.1 ms)
+            keep["n_rec_host"] = caps.pinned_word()
+            keep["n_rec_host"].copy_(keep["surf_off"].view(-1)[NCOPY * P - 1:NCOPY * P], non_blocking=True)
+            keep["n_rec_event"] = torch.cuda.Event(); keep["n_rec_event"].record(torch.cuda.current_stream(dev))
     saved = dict(cfg=cfg, nodes=nodes, ro=ro, rd=rd, means3D=means3D, scales=scales, rotations=rotations, opacities=opacities,
                  shs=shs, colors_precomp=colors_precomp, others=others_precomp, bg=bg, srec=srec, counters=counters,
                  rgb=(rgb if ND == 1 else mid[:, 13:16].contiguous()),      # (C-ABI in-kernel bounces, forward use only: stage 0's own colour)
