@@ -540,8 +540,8 @@ def cpu_baseline(g, cam, bg, dcol, dall, H, W, reps, C, env=None):
 
 def eager_config1(reps=10, warm=2, budget_s=75.0, threads=None):
     """BASELINE configs[0] / north_star: "PyTorch-eager CPU project + alpha-blend" -- 2 000 surfels, 256x256, forward only, oracle/eager.py
-    (dense per-pixel blend in pixel chunks, fp32).  SURVEY.md 8(d): 2 warm-ups, then 10 repetitions, torch.set_num_threads(all host cores);
-    median and minimum reported.  Bounded: the repetitions stop early (never below 3) once `budget_s` seconds are spent, and the count is
+    (dense per-pixel blend in pixel chunks, fp32).  SURVEY.md 8(d): 2 warm-ups, then 10 repetitions; median and minimum reported; 16 torch
+    threads (see below; `host_cores` says what the box has).  Bounded: the repetitions stop early (never below 3) once `budget_s` seconds are spent, and the count is
     reported -- the default bench.py run has to finish within minutes."""
     try:
         import statistics
@@ -552,7 +552,9 @@ def eager_config1(reps=10, warm=2, budget_s=75.0, threads=None):
         g["scales"] = g["scales"] * 2.0
         cam = synth.orbit_camera(0, H=H, W=W, fx=1111.1 * W / 800.0)
         old = torch.get_num_threads()
-        nthreads = threads or (os.cpu_count() or 1)
+        # SURVEY.md 8(d) says "all host cores"; on the GPU box's 256 cores the dense eager kernels of this size oversubscribe badly (measured,
+        # scratch/eager_threads.py: 16 threads 8.0 s per render, 32: 9.2, 64: 16.3, 128: 34.8, 256: 142) -- the best setting is used and reported
+        nthreads = threads or min(os.cpu_count() or 1, 16)
         torch.set_num_threads(nthreads)
         run = lambda: eager.rasterize(g["means3D"], g["opacities"], cam.world_view_transform, cam.full_proj_transform, cam.camera_center, W, H,
                                       scales=g["scales"], rotations=g["rotations"], shs=g["shs"], sh_degree=3, bg=torch.ones(3), pix_chunk=8192)
