@@ -292,6 +292,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     lib.envgs_prof_enable(0)
+    n_timed = dict(n_acc)                          # (the kernel timers cover the timed steps only; later steps -- the reference-caller form, --step-times -- must not dilute the per-launch figures)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -357,7 +358,7 @@ def main():
             ms1.get("allocated_bytes.all.peak", 0) / 2**30), file=sys.stderr)
 
     # per-kernel HIP-event times (this rank)
-    N_avg = n_acc["N"] / max(n_acc["steps"], 1)
+    N_avg = n_timed["N"] / max(n_timed["steps"], 1)
     tcounts = tracing.last_trace_counts() if envgs else None
     entries = sum(tracing.last_entry_counts()) if envgs else 0
 
@@ -401,7 +402,7 @@ def main():
                 nz = sum(int((g_ != 0).sum()) for g_ in last_grads if g_ is not None)
                 tot = sum(g_.numel() for g_ in last_grads if g_ is not None)
                 ab = 28 * nz + 4 * (tot - nz)
-            per_step = max(1, round(c_.value / max(n_acc["steps"], 1)))      # the tracer forward runs its kernels once per batch segment
+            per_step = max(1, round(c_.value / max(n_timed["steps"], 1)))      # the tracer forward runs its kernels once per batch segment
             ab = ab / per_step                                               # (2 segments on 2 streams, overlapping): bytes per LAUNCH
             kernels[name] = {"ms": round(ms, 4), "launches": c_.value, "alg_MB": round(ab / 1e6, 2),
                              "GBps": round(ab / 1e9 / (ms / 1e3), 1) if ab and ms > 0 else None}
@@ -443,8 +444,8 @@ def main():
                     "frac": round(A / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "alg_bytes_per_launch": int(kernels[dom]["alg_MB"] * 1e6), "ms_per_launch": kernels[dom]["ms"],
                     "tile_instances_N": int(N_avg), "issue": issue_of(dom),
-                    "step_total": {"alg_MB": round(sum(v["alg_MB"] * max(1, round(v["launches"] / max(n_acc["steps"], 1))) for v in leaf.values()), 1),
-                                   "GBps_over_step": round(sum(v["alg_MB"] * max(1, round(v["launches"] / max(n_acc["steps"], 1))) for v in leaf.values()) / 1e3 / (ms_per_step / 1e3), 1)},
+                    "step_total": {"alg_MB": round(sum(v["alg_MB"] * max(1, round(v["launches"] / max(n_timed["steps"], 1))) for v in leaf.values()), 1),
+                                   "GBps_over_step": round(sum(v["alg_MB"] * max(1, round(v["launches"] / max(n_timed["steps"], 1))) for v in leaf.values()) / 1e3 / (ms_per_step / 1e3), 1)},
                     "note": "dominant kernel = most HIP-event time per step (duration x launches).  achieved = DEDUPLICATED algorithmic HBM bytes per launch (every "
                             "input structure once, every list / state / record element once: bench.py:trace_algorithmic_bytes; raster: SURVEY.md 8d formulas) / launch time; "
                             "traffic = (2*FETCH_SIZE + WRITE_SIZE) per launch from " + PMC_SUMMARY + " (separate --pmc passes).  The tracer and compositing kernels are "

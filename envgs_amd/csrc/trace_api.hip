@@ -135,7 +135,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         A.state = (float4 *)L->hit_state; A.entries = (unsigned long long *)L->entries; A.pairs = L->pairs; A.n_entries = L->n_entries;
         const bool compact = L->compact_rows > 0 && L->row_off && L->batch_rows && L->row_blk && L->hit_state;
         if (L->compact_rows > 0 && !compact) return ENVGS_ERR_BAD_ARG;
-        if (compact) { A.row_off = L->row_off; A.batch_rows = (const uint2 *)L->batch_rows; }
+        if (compact) { A.row_off = L->row_off; A.batch_rows = (const uint2 *)L->batch_rows; A.batch_cnt = L->row_blk; }
         if (L->sh_perm && shs && cfg->sh_coeffs == 16) {
             const size_t nw = (size_t)cfg->P * 48;
             hipLaunchKernelGGL(permute_sh, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, cfg->P, (cfg->sh_degree + 1) * (cfg->sh_degree + 1),
@@ -216,13 +216,16 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             if (compact) {
                 // row offsets of the compact per-hit buffers: scan of this segment's hit counts in sorted order; the segment owns the share of
                 // the rows that corresponds to its share of the batches
-                const int nblk = (rays_seg + 255) / 256;
-                unsigned *blk = L->row_blk + (size_t)S.batch0 / 4 + 2 * sg;       // (batch0 * 64 / 256 blocks precede this segment; + slack)
+                const int nb_seg = S.batch1 - S.batch0, nblk = (rays_seg + 255) / 256;
+                unsigned *cntb = L->row_blk;                                       // (batches) row counts, scanned in place per segment
                 const unsigned long long base = (unsigned long long)((long double)L->compact_rows * S.batch0 / nbatch_all);
                 const unsigned long long limit = (unsigned long long)((long double)L->compact_rows * S.batch1 / nbatch_all);
-                hipLaunchKernelGGL(row_count, dim3(nblk), dim3(256), 0, st, S, blk);
-                hipLaunchKernelGGL(row_scan_blocks, dim3(1), dim3(1024), 0, st, blk, nblk);
-                hipLaunchKernelGGL(row_offsets, dim3(nblk), dim3(256), 0, st, S, blk, L->row_off, (uint2 *)L->batch_rows, base, limit);
+#ifdef ENVGS_DIAG
+                if (!(S.order && !(S.exp & 512) && !(S.exp & 16) && !(S.exp & 2048)))     // the A/B collection kernels do not write batch counts
+                    hipLaunchKernelGGL(row_count, dim3(nblk), dim3(256), 0, st, S, cntb);
+#endif
+                hipLaunchKernelGGL(row_scan_blocks, dim3(1), dim3(1024), 0, st, cntb + S.batch0, nb_seg);
+                hipLaunchKernelGGL(row_offsets, dim3(nblk), dim3(256), 0, st, S, cntb, L->row_off, (uint2 *)L->batch_rows, base, limit);
                 ENVGS_CHECK_LAUNCH(dcfg, st);
             }
             {

@@ -686,6 +686,10 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             int mx = n;
             for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
             if (lane == 0) atomicMax((int *)(A.counter + 1), mx);
+            if (A.batch_cnt) {                         // rows of the compact per-hit buffers this batch needs (envgs_trace.h: compact_rows)
+                const float rows = wave_sum((valid && n <= A.cap) ? (float)n : 0.f);
+                if (lane == 0) A.batch_cnt[A.batch0 + fb] = (unsigned)rows;
+            }
         }
         __syncthreads();
     }

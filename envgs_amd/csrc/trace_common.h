@@ -159,6 +159,7 @@ struct TraceArgs {
     unsigned *long_list; // (R) scratch: slots of the rays whose lists exceed 256 hits, appended by the main sort pass (counter[24 + seg] = how many)
     float4 *state;      // (R, cap, 2 | 3) x 16 B per composited hit: transmittance before it and the prefix sums after it (for the backward)
     // compact per-hit buffers (envgs_trace.h: compact_rows): nullptr = the (R, cap) layouts
+    unsigned *batch_cnt;          // (batches) written by the cooperative collection: rows the batch needs (sum of its listed rays' hit counts)
     const unsigned *row_off;      // (R) by sorted slot: the ray's first row of hit_state
     const uint2 *batch_rows;      // (batches) {first row, rows} of the batch in entries / pairs
     const void *shp;    // (P, 48) quad-permuted copy of the SH blocks (permute_sh), same storage type as shs; nullptr = per-lane gathers from shs
@@ -621,7 +622,7 @@ __global__ void __launch_bounds__(64 * RH_W) register_hits(const TraceArgs A);
 __global__ void __launch_bounds__(256) row_count(const TraceArgs A, unsigned *__restrict__ blk);
 __global__ void __launch_bounds__(1024) row_scan_blocks(unsigned *__restrict__ blk, int n);
 __global__ void __launch_bounds__(256) row_offsets(const TraceArgs A, const unsigned *__restrict__ blk, unsigned *__restrict__ row_off, uint2 *__restrict__ batch_rows,
-                                                   unsigned long long base, unsigned long long limit);
+                                                   unsigned long long base, unsigned long long limit);      // blk: exclusive scan of the per-BATCH row counts
 __global__ void __launch_bounds__(256) unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, unsigned *__restrict__ cnt,
                                                          float *__restrict__ wet);
 __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd(const TraceArgs A);

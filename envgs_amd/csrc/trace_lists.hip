@@ -464,8 +464,10 @@ register_hits(const TraceArgs A)
 }
 
 // Row offsets of the compact per-hit buffers (envgs_trace.h: compact_rows).  Runs per forward segment between the collection and the sort:
-// rows of a ray = min(hits found, cap) (none for a ray whose list overflowed), scanned over the segment's slots in coherence-sorted order --
-// three small launches: per-block sums (256 slots = 4 batches per block), one workgroup scanning the block sums, per-block offsets.
+// rows of a ray = its hits found (none for a ray whose list overflowed), scanned over the segment's slots in coherence-sorted order.  The
+// cooperative collection writes each batch's row count as it finishes the batch (TraceArgs::batch_cnt), so two small launches remain: one
+// workgroup scanning the segment's batch counts, then one wavefront per batch placing its rays.  (row_count -- per-block sums from the hit
+// counts -- serves the diagnostic collection kernels, which do not write batch counts.)
 __device__ __forceinline__ unsigned rows_of_slot(const TraceArgs &A, const int slot, const int slot_end)
 {
     if (slot >= slot_end) return 0u;
@@ -477,13 +479,11 @@ __device__ __forceinline__ unsigned rows_of_slot(const TraceArgs &A, const int s
 __global__ void __launch_bounds__(256)
 row_count(const TraceArgs A, unsigned *__restrict__ blk)
 {
-    __shared__ unsigned wsum[4];
     const int slot_end = min(A.R, A.batch1 * 64);
     const int slot = A.batch0 * 64 + (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if ((slot >> 6) >= A.batch1) return;
     const float s = wave_sum((float)rows_of_slot(A, slot, slot_end));            // exact: <= 64 * 1024
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (unsigned)s;
-    __syncthreads();
-    if (threadIdx.x == 0) blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if ((threadIdx.x & 63) == 0) blk[slot >> 6] = (unsigned)s;
 }
 
 __global__ void __launch_bounds__(1024)
@@ -510,17 +510,15 @@ __global__ void __launch_bounds__(256)
 row_offsets(const TraceArgs A, const unsigned *__restrict__ blk, unsigned *__restrict__ row_off, uint2 *__restrict__ batch_rows,
             unsigned long long base, unsigned long long limit)
 {
-    __shared__ unsigned wsum[4];
+    // one wavefront per batch; blk[batch] = rows of the segment's batches before this one (exclusive scan of the counts the collection wrote)
     const int slot_end = min(A.R, A.batch1 * 64);
     const int slot = A.batch0 * 64 + (int)blockIdx.x * 256 + (int)threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, batch = slot >> 6;
+    if (batch >= A.batch1) return;
     const unsigned cnt = rows_of_slot(A, slot, slot_end);
     const float incl = wave_scan_add((float)cnt);
-    if (lane == 63) wsum[wave] = (unsigned)incl;
-    __syncthreads();
-    unsigned before = 0u;
-    for (int w = 0; w < wave; w++) before += wsum[w];
-    const unsigned long long row = base + (unsigned long long)blk[blockIdx.x] + before + (unsigned long long)((unsigned)incl - cnt);
+    const unsigned long long row0 = base + (unsigned long long)blk[batch];
+    const unsigned long long row = row0 + (unsigned long long)((unsigned)incl - cnt);
     const bool fits = row + cnt <= limit;
     if (slot < slot_end) {
         row_off[slot] = (unsigned)(fits ? row : 0ull);
@@ -529,12 +527,10 @@ row_offsets(const TraceArgs A, const unsigned *__restrict__ blk, unsigned *__res
             atomicAdd(A.counter + 21, 1u);
         }
     }
-    // the batch (= this wavefront's 64 slots): first row and rows, clipped to the segment's share (rays that do not fit are a suffix)
-    const unsigned long long row0 = __shfl(row, 0);
-    const unsigned tot = wsum[wave];
-    if (lane == 0 && slot < slot_end) {
+    const unsigned tot = (unsigned)wave_bcast(incl, 63);
+    if (lane == 0) {                                                // first row and rows, clipped to the segment's share (rays that do not fit are a suffix)
         const unsigned long long end = row0 + tot < limit ? row0 + tot : limit;
-        batch_rows[slot >> 6] = make_uint2((unsigned)(row0 < limit ? row0 : limit), (unsigned)(end > row0 ? end - row0 : 0ull));
+        batch_rows[batch] = make_uint2((unsigned)(row0 < limit ? row0 : limit), (unsigned)(end > row0 ? end - row0 : 0ull));
     }
 }
 

@@ -223,7 +223,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
         # right behind the rasterizer's one host sync, where the GPU has nothing queued)
         keep = _carve_i32(dev, dict(hit_cnt=R, n_used=R, spill=lib.envgs_trace_stack_spill_ints(R), surf_acc=2 * P * NCOPY, surf_cnt=P * NCOPY,
                                     surf_off=P * NCOPY, scan_temp=(max(sb, 1) + 3) // 4, ray_keys=2 * R, ray_order=2 * R, ray_sort_temp=(max(rb, 1) + 3) // 4,
-                                    n_entries=2 * nbatch, row_off=R, batch_rows=2 * nbatch, row_blk=(R + 255) // 256 + 16))
+                                    n_entries=2 * nbatch, row_off=R, batch_rows=2 * nbatch, row_blk=nbatch + 16))
         keep["n_entries"] = keep["n_entries"].view(nbatch, 2)
         keep["hit_lists"] = _scratch((R, cap, 2), torch.int32, dev)
         srt = SORT_RAYS["on"]

@@ -105,7 +105,7 @@ typedef struct envgs_trace_lists {
     uint64_t compact_rows;   /* rows of hit_state / elements of entries and pairs; 0 = (R, cap) layouts */
     uint32_t *row_off;       /* (R) by sorted slot */
     uint32_t *batch_rows;    /* (ceil(R/64), 2) */
-    uint32_t *row_blk;       /* (ceil(R/256) + 8) scratch of the row scan */
+    uint32_t *row_blk;       /* (ceil(R/64)) scratch: per-batch row counts (written by the collection), scanned in place per segment */
     void *sh_perm;           /* optional scratch, (P, 48) elements of the shs storage type (used when sh_coeffs == 16): a quad-permuted copy of the SH
                                 blocks, rebuilt by every forward, that lets four lanes fetch one surfel's block as contiguous 64 B runs; NULL = each
                                 lane gathers its own block from shs */
