@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--keep-blas", action="store_true", help="do not let diff_surfel_tracing select rocBLAS for torch's tiny-K batched matmuls (INTEGRATION.md section 5)")
     ap.add_argument("--debug-trace", type=int, default=0, help="ENVGS_DBG_TRACE diagnostic switch mask (include/envgs_raster.h); reported in the JSON line")
     ap.add_argument("--diag", action="store_true", help="load the diagnostic build (A/B kernels of --debug-trace 8 / 16 / 512 / 2048; the product library rejects those switches)")
+    ap.add_argument("--debug-collect-wgs", type=int, default=0, help="ENVGS_DBG_COLLECT_WGS diagnostic switch: workgroups per CU of the collection's persistent grid (default 8)")
     ap.add_argument("--debug-segments", type=int, default=0, help="ENVGS_DBG_SEGMENTS diagnostic switch; reported in the JSON line")
     ap.add_argument("--optim", default="fused", choices=["fused", "torch", "none"],
                     help="optimizer step inside the timed iteration: sparse fused Adam (envgs_amd.optim, SURVEY 8(f).2), torch.optim.Adam, or none")
@@ -151,7 +152,7 @@ def main():
     if args.diag:
         _lib.select("diag")                        # libenvgs_hip_diag.so: the product kernels + the superseded A/B kernels behind --debug-trace
     lib = _lib.load()
-    lib.envgs_debug_set(0, args.debug_trace); lib.envgs_debug_set(1, args.debug_segments)
+    lib.envgs_debug_set(0, args.debug_trace); lib.envgs_debug_set(1, args.debug_segments); lib.envgs_debug_set(2, args.debug_collect_wgs)
     import torch.distributed as dist
 
     P, H, W = args.gaussians, (args.height or args.res), (args.width or args.res)
@@ -474,7 +475,7 @@ def main():
                        "reference_caller_ms_per_step": (None if ref_caller_ms is None else round(ref_caller_ms, 3)),
                        "reference_caller_note": "the same step with the UNCHANGED EasyVolcap caller's expression forms around the same extensions (--caller reference), a few steps outside the timed region",
                        "torch_blas": str(torch.backends.cuda.preferred_blas_library()).split(".")[-1],
-                       "debug_switches": {"trace": args.debug_trace, "segments": args.debug_segments},
+                       "debug_switches": {"trace": args.debug_trace, "segments": args.debug_segments, "collect_wgs": args.debug_collect_wgs},
                        "allreduce_bytes_per_step": int(ar_bytes)},
             "train_mpix_per_s": round(value * HW / 1e6, 2),
             "render_mpix_per_s": (round(world * HW / render_s / 1e6, 2) if n_render else None),

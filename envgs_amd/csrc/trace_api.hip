@@ -184,6 +184,13 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
                 }
             }
         }
+        // Workgroups per CU of the collection's persistent grid.  8 fill the CU -- and then nothing else gets a wavefront slot until the
+        // collection drains: with two segments in flight the other segment's sort / register kernels could only move into the CUs a finishing
+        // collection leaves.  With HALF the slots (4 workgroups = 16 of 32 waves per CU) the collection itself is slower (1.73 -> 1.89 ms per
+        // launch) but the two segments really run side by side: tracer forward 4.80 -> 4.62 ms, step 10.08 -> 9.90 ms (2 / 3 / 4 / 5 / 6 / 7 / 8
+        // workgroups: 10.48 / 10.03 / 9.89 / 10.06 / 10.05 / 10.04 / 10.09 ms).  A single segment has nobody to share with: 8.
+        const int coop_wgs = (debug_switch(ENVGS_DBG_COLLECT_WGS) > 0 && debug_switch(ENVGS_DBG_COLLECT_WGS) <= 8) ? debug_switch(ENVGS_DBG_COLLECT_WGS)
+                                                                                                                  : (nseg > 1 ? 4 : 8);
         for (int sg = 0; sg < nseg; sg++) {                   // segment 0 on the caller's stream, the others on auxiliary streams
             hipStream_t st = sg ? aux[sg] : stream;
             TraceArgs S = A;
@@ -197,11 +204,11 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
 #ifndef ENVGS_DIAG
                 // product library: the cooperative collection is the only collection kernel (without a coherence sort its batches are the
                 // rays in the order given: correct, slower)
-                hipLaunchKernelGGL(collect_hits_coop, dim3(persistent_grid(rays_seg, 8)), dim3(256), 0, st, S, S.nodes,
+                hipLaunchKernelGGL(collect_hits_coop, dim3(persistent_grid(rays_seg, coop_wgs)), dim3(256), 0, st, S, S.nodes,
                                    S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4, S.srec);
 #else
                 if (S.order && !(S.exp & 512) && !(S.exp & 16) && !(S.exp & 2048))
-                    hipLaunchKernelGGL(collect_hits_coop, dim3(persistent_grid(rays_seg, 8)), dim3(256), 0, st, S, S.nodes,
+                    hipLaunchKernelGGL(collect_hits_coop, dim3(persistent_grid(rays_seg, coop_wgs)), dim3(256), 0, st, S, S.nodes,
                                        S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4, S.srec);
                 else if (S.order && !(S.exp & 512) && !(S.exp & 16))
                     hipLaunchKernelGGL(collect_hits_packet4, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S, S.nodes,
