@@ -452,6 +452,12 @@ def main():
                             "traffic = (2*FETCH_SIZE + WRITE_SIZE) per launch from " + PMC_SUMMARY + " (separate --pmc passes).  The tracer and compositing kernels are "
                             "instruction-issue bound, not HBM bound: `issue` carries their VALU / SALU issue rates against the issue peaks (2 VALU + 1 SALU "
                             "wave-instructions per cycle per CU, 256 CUs, 2.4 GHz)"}
+            # the next kernels by time per step, the same way (the dominant one can change from round to round -- in round 3 the collection
+            # overtook the sort / composite pass, which got 20 % faster while the collection gave up half of its wavefront slots to it)
+            order = sorted(leaf, key=lambda k: -leaf[k]["ms"] * leaf[k]["launches"])
+            roof["next_kernels"] = [{"kernel": k, "ms_per_launch": kernels[k]["ms"], "launches_per_step": max(1, round(kernels[k]["launches"] / max(n_timed["steps"], 1))),
+                                     "achieved": kernels[k]["GBps"], "frac": round(kernels[k]["GBps"] / HBM_PEAK_GBS, 5), "traffic": pm.get(k, {}).get("hbm_bytes"),
+                                     "valu_util_measured_peak": (issue_of(k) or {}).get("valu_util_measured_peak")} for k in order[1:4]]
             rb = kernels.get("composite_bwd")
             if rb and rb["GBps"]:
                 roof["raster_composite_bwd"] = {"achieved": rb["GBps"], "frac": round(rb["GBps"] / HBM_PEAK_GBS, 5), "ms_per_launch": rb["ms"],
