@@ -4,6 +4,11 @@ operator raises."""
 import ctypes
 import os
 
+# torch FIRST: PyTorch-ROCm wheels carry their own libamdhip64, and whichever HIP runtime is loaded first serves every later library with
+# the same SONAME.  If this library (linked against /opt/rocm) were opened before torch, torch would run on a runtime it was not built with
+# and the stream handles it passes here would belong to a different runtime instance ("hipErrorNoDevice" at the first launch).
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libenvgs_hip.so")
 _lib = None
