@@ -39,8 +39,10 @@ def algorithmic_bytes(kernel, P, N, HW, C, sh_in_kernel):
     """BASELINE.md section 4 / SURVEY.md section 8(d): per-launch algorithmic HBM bytes (fp32)."""
     if kernel == "project_surfels":
         return P * (112 + (204 if sh_in_kernel else 4 * C))
-    if kernel in ("emit_tile_keys", "radix_sort_pairs", "find_tile_ranges"):
-        return {"emit_tile_keys": 12, "radix_sort_pairs": 144, "find_tile_ranges": 8}[kernel] * N
+    if kernel == "bin_tile_pairs":        # two walks over (centre, radius, depth) of every surfel, one 8 B pair written per tile instance
+        return 2 * 16 * P + 8 * N
+    if kernel == "sort_tile_lists":       # pair read, surfel id written (SURVEY's 164 B x N is the reference's device-wide radix sort: not done here)
+        return (8 + 4) * N
     if kernel == "composite_fwd":
         return N * (64 + 4 * C) + HW * (48 + 4 * C) + 4 * P
     if kernel == "composite_bwd":

@@ -62,7 +62,7 @@ SYMBOLS = {
     "envgs_raster_scan_temp_bytes": (c_size_t, [ctypes.c_int32]),
     "envgs_raster_sort_temp_bytes": (c_size_t, [c_uint32, ctypes.c_int32, ctypes.c_int32]),
     "envgs_raster_project": (c_int, [ctypes.POINTER(RasterCfg)] + [_P] * 15 + [_P, c_size_t, ctypes.POINTER(c_uint32), _P]),
-    "envgs_raster_bin_and_render": (c_int, [ctypes.POINTER(RasterCfg), c_uint32] + [_P] * 9 + [_P, c_size_t] + [_P] * 8 + [_P]),
+    "envgs_raster_bin_and_render": (c_int, [ctypes.POINTER(RasterCfg), c_uint32] + [_P] * 7 + [_P, c_size_t] + [_P] * 7 + [_P]),
     "envgs_raster_render_audit": (c_int, [ctypes.POINTER(RasterCfg)] + [_P] * 11 + [ctypes.c_int32, _P, _P]),
     "envgs_raster_backward": (c_int, [ctypes.POINTER(RasterCfg), c_uint32] + [_P] * 29 + [_P]),
     "envgs_bvh_temp_bytes": (c_size_t, [ctypes.c_int32]),

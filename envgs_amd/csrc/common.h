@@ -153,10 +153,9 @@ int launch_project(const envgs_raster_cfg *cfg, const float *means3D, const floa
                    int32_t *radii, uint32_t *tiles_touched, hipStream_t stream);
 int launch_scan(const uint32_t *in, uint32_t *out, int n, void *temp, size_t temp_bytes, hipStream_t stream);
 size_t scan_temp_bytes(int n);
-size_t sort_temp_bytes(uint32_t n, int end_bit);
-int launch_bin(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const int32_t *radii, const uint32_t *offsets,
-               uint64_t *keys_unsorted, uint32_t *vals_unsorted, uint64_t *keys_sorted, uint32_t *point_list,
-               void *sort_temp, size_t sort_temp_bytes, uint32_t *ranges, hipStream_t stream, const uint32_t *n_dev = nullptr);
+size_t sort_temp_bytes(uint32_t n, int width, int height);
+int launch_bin(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const int32_t *radii, uint64_t *tile_pairs,
+               uint64_t *keys_sorted, uint32_t *point_list, void *bin_temp, size_t bin_temp_bytes, uint32_t *ranges, hipStream_t stream);
 int launch_render_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                       const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
                       int32_t *n_contrib, float *weight, hipStream_t stream, uint8_t *audit_contrib = nullptr, int audit_lmax = 0, int colors_f16 = 0,

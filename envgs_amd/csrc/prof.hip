@@ -101,8 +101,8 @@ int32_t envgs_debug_get(int32_t which) { return debug_switch(which); }
 
 const char *envgs_prof_kernel_name(int kernel_id)
 {
-    static const char *names[K_COUNT] = {"project_surfels", "scan_tiles_touched", "emit_tile_keys", "radix_sort_pairs",
-                                         "find_tile_ranges", "composite_fwd", "composite_bwd", "project_surfels_bwd",
+    static const char *names[K_COUNT] = {"project_surfels", "scan_tiles_touched", "bin_tile_pairs", "sort_tile_lists",
+                                         "find_tile_ranges(unused)", "composite_fwd", "composite_bwd", "project_surfels_bwd",
                                          "bvh_build", "trace_fwd", "trace_bwd", "trace.collect_hits", "trace.sort_composite_fwd",
                                          "trace.composite_lists_fwd(unused)", "trace.kbuffer_fwd", "trace.batch_surfel_bwd", "trace.kbuffer_bwd", "trace.reduce_surfel_records", "trace.register_hits", "fused_adam_multi", "l1_ssim_fwd", "l1_ssim_bwd"};
     return (kernel_id >= 0 && kernel_id < K_COUNT) ? names[kernel_id] : "";

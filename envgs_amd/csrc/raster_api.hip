@@ -10,7 +10,7 @@ size_t envgs_raster_scan_temp_bytes(int32_t P) { return scan_temp_bytes(P); }
 
 size_t envgs_raster_sort_temp_bytes(uint32_t N, int32_t width, int32_t height)
 {
-    return sort_temp_bytes(N, 32 + tile_bits(width, height) + 1);      // (+1: the padded sort of a speculative capacity uses one more key bit)
+    return sort_temp_bytes(N, width, height);
 }
 
 static int check_cfg(const envgs_raster_cfg *cfg)
@@ -50,21 +50,17 @@ int envgs_raster_project(const envgs_raster_cfg *cfg, const float *means3D, cons
 }
 
 int envgs_raster_bin_and_render(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const int32_t *radii,
-                                const uint32_t *offsets, const float *colors, const float *bg, uint64_t *keys_unsorted,
-                                uint32_t *vals_unsorted, uint64_t *keys_sorted, uint32_t *point_list, void *sort_temp,
-                                size_t sort_temp_bytes_, uint32_t *ranges, float *out_color, float *allmap,
-                                float *final_T, int32_t *n_contrib, float *weight, uint8_t *contrib_mask, const uint32_t *num_rendered_dev,
-                                void *stream_)
+                                const float *colors, const float *bg, uint64_t *tile_pairs, uint64_t *keys_sorted, uint32_t *point_list,
+                                void *bin_temp, size_t bin_temp_bytes_, uint32_t *ranges, float *out_color, float *allmap,
+                                float *final_T, int32_t *n_contrib, float *weight, uint8_t *contrib_mask, void *stream_)
 {
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (!ranges || !out_color || !allmap || !final_T || !n_contrib || !bg) return ENVGS_ERR_BAD_ARG;
-    if (cfg->P > 0 && (!geom || !radii || !offsets || !colors || !weight)) return ENVGS_ERR_BAD_ARG;
-    if (N > 0 && (!keys_unsorted || !vals_unsorted || !keys_sorted || !point_list)) return ENVGS_ERR_BAD_ARG;
-    if (N > 0 && sort_temp_bytes_ < sort_temp_bytes(N, 32 + tile_bits(cfg->width, cfg->height) + 1)) return ENVGS_ERR_TEMP_TOO_SMALL;
+    if (cfg->P > 0 && (!geom || !radii || !colors || !weight)) return ENVGS_ERR_BAD_ARG;
+    if (N > 0 && (!tile_pairs || !point_list || !bin_temp)) return ENVGS_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
-    rc = launch_bin(cfg, N, geom, radii, offsets, keys_unsorted, vals_unsorted, keys_sorted, point_list, sort_temp,
-                    sort_temp_bytes_, ranges, stream, num_rendered_dev);
+    rc = launch_bin(cfg, N, geom, radii, tile_pairs, keys_sorted, point_list, bin_temp, bin_temp_bytes_, ranges, stream);
     if (rc) return rc;
     // `colors` is the caller's (possibly half) colors_precomp only when no SH were given; the SH -> RGB result of _project is fp32
     return launch_render_fwd(cfg, ranges, point_list, geom, colors, bg, out_color, allmap, final_T, n_contrib, weight, stream, nullptr, 0,

@@ -1,115 +1,392 @@
-// raster_bin.hip -- R2..R5: prefix sum of tiles_touched, (tile id << 32 | depth bits) key emit,
-// stable LSD radix sort of (key, surfel id) pairs, per-tile [start, end) ranges.
-// All integer work: results are bit-exact against the oracle (tests/test_raster_parity.py).
-// Scan and pair sort use rocPRIM's device-wide primitives (the vendor library plays the role CUB plays
-// upstream); emit / ranges are hand-written.  HBM-bound: N * ~164 B.
+// raster_bin.hip -- R2..R5, hand-written for gfx950: prefix sum of tiles_touched, and the per-tile depth-ordered surfel lists.
+//
+// The reference's extension bins with CUB: scan -> emit (tile id << 32 | depth bits, surfel id) -> device-wide stable radix sort of the
+// N pairs over 32 + log2(tiles) key bits -> range detection.  The RESULT that contract fixes is: per tile, the surfels whose 3-sigma
+// rectangle covers it, ordered by (depth bits, emission order) -- and emission order within one tile is surfel-index order.  So the list
+// of tile t is exactly "its instances sorted by the 64-bit value (depth bits << 32 | surfel id)", and that is what is built here,
+// without a device-wide sort (N = millions of 12 B pairs through ~6 radix passes = 144 B per instance):
+//
+//   bin_pass<count>     each workgroup histograms ITS slice of the surfels over the tiles in LDS (LDS atomics only) and stores the
+//                       histogram row                                   hist[w][t]           (no global atomics anywhere)
+//   bin_column_scan     per tile, exclusive scan down the rows          hist[w][t] -> first slot of workgroup w inside tile t's segment
+//   bin_tile_scan       exclusive scan over the tile totals             tile_start[t], ranges[t] = [start, start + count)   (= R5)
+//   bin_pass<scatter>   the same walk again; an LDS cursor per tile (tile_start + row prefix) hands out slots: pair -> its tile's segment
+//   sort_tile_lists     one workgroup per tile: the segment is sorted in LDS by a bitonic network whose compare-exchange steps run four at
+//                       a time in registers (tile_sort.h), and written out as point_list (ids) + keys_sorted (tile id << 32 | depth);
+//                       the LDS array (2048 / 4096 / 8192 entries) is picked from the average list length, longer segments go to
+//                       sort_long_lists (16 384 entries in LDS, beyond that an all-ascending network on the segment in HBM)
+//
+// Per instance that is 8 B written + 8 B read + 12 B written.  All integer work: point_list / keys_sorted / ranges are bit-exact against
+// the oracle's stable sort (tests/test_raster_parity.py).
 #include "common.h"
-
-#include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
+#include "tile_sort.h"
 
 namespace envgs {
 
-size_t scan_temp_bytes(int n)
+// ---- wave64 integer scan / sum (DPP, same lane patterns as common.h's float versions) ------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_fill_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {
+    v += dpp_fill_u32<0x111>(v); v += dpp_fill_u32<0x112>(v); v += dpp_fill_u32<0x114>(v); v += dpp_fill_u32<0x118>(v);
+    v += dpp_fill_u32<0x142, 0xa>(v);
+    v += dpp_fill_u32<0x143, 0xc>(v);
+    return v;
+}
+
+// Exclusive prefix of `v` over the workgroup's NW wavefronts (thread order), and the workgroup total.  s_w: NW + 1 words of LDS.
+template <int NW>
+__device__ __forceinline__ uint32_t block_exclusive_u32(uint32_t v, uint32_t *s_w, uint32_t &total)
 {
-    size_t bytes = 0;
-    (void)rocprim::inclusive_scan(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)(n > 0 ? n : 1),
-                            rocprim::plus<uint32_t>());
-    return bytes;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_scan_add_u32(v);
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) { const uint32_t t = s_w[k]; all += t; before += (k < wave) ? t : 0u; }
+    total = all;
+    __syncthreads();
+    return before + inc - v;
+}
+
+// ---- R2: inclusive prefix sum over n uint32 counters (two launches: block sums, then apply) ------
+constexpr int SCAN_ITEMS = 1024;                 // per workgroup: 256 lanes x 4 consecutive counters
+
+size_t scan_temp_bytes(int n) { return sizeof(uint32_t) * (size_t)(((n > 0 ? n : 1) + SCAN_ITEMS - 1) / SCAN_ITEMS) + 64; }
+
+__global__ void __launch_bounds__(256)
+scan_block_sums(const uint32_t *__restrict__ in, uint32_t *__restrict__ sums, int n)
+{
+    __shared__ uint32_t s_w[5];
+    const int base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) s += (base + k < n) ? in[base + k] : 0u;
+    uint32_t total;
+    (void)block_exclusive_u32<4>(s, s_w, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256)
+scan_apply(const uint32_t *in, uint32_t *out, const uint32_t *__restrict__ sums, int n)       // in == out allowed (each lane loads its counters before it stores)
+{
+    __shared__ uint32_t s_w[5];
+    uint32_t pre = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += 256) pre += sums[k];
+    uint32_t before;
+    (void)block_exclusive_u32<4>(pre, s_w, before);                                            // `before` = sum of all earlier workgroups
+    const int base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+    uint32_t a[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) a[k] = (base + k < n) ? in[base + k] : 0u;
+    a[1] += a[0]; a[2] += a[1]; a[3] += a[2];
+    uint32_t total;
+    const uint32_t ex = block_exclusive_u32<4>(a[3], s_w, total) + before;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (base + k < n) out[base + k] = ex + a[k];
 }
 
 int launch_scan(const uint32_t *in, uint32_t *out, int n, void *temp, size_t temp_bytes, hipStream_t stream)
 {
     if (n <= 0) return 0;
+    if (temp_bytes < scan_temp_bytes(n)) return ENVGS_ERR_TEMP_TOO_SMALL;
     ProfScope prof_(K_SCAN, stream);
-    hipError_t e = rocprim::inclusive_scan(temp, temp_bytes, in, out, (size_t)n, rocprim::plus<uint32_t>(), stream);
-    return (int)e;
+    const int nb = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, stream, in, (uint32_t *)temp, n);
+    hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(256), 0, stream, in, out, (const uint32_t *)temp, n);
+    return (int)hipGetLastError();
 }
 
-size_t sort_temp_bytes(uint32_t n, int end_bit)
+// ---- R3..R5 ---------------------------------------------------------------------------------------
+constexpr int BIN_ROWS_MAX = 512;                // histogram rows (= workgroups of bin_pass) at most
+constexpr int BIN_SLICE_MIN = 1024;              // surfels per workgroup at least
+constexpr int BIN_BAND = 16384;                  // tiles per LDS histogram (64 KB); larger images are walked band by band
+constexpr int BIG_RECT = 32;                     // rectangles above this many tiles are walked by the whole wavefront
+constexpr int SORT_LONG_N = 16384;               // sort_long_lists: 132 KB of LDS
+constexpr int SORT_LONG_WGS = 256;               // one per CU
+
+struct BinPlan { int rows, slice, ntiles; };
+static BinPlan bin_plan(int P, int W, int H)
 {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr,
-                              (uint32_t *)nullptr, (size_t)(n > 0 ? n : 1), 0u, (unsigned)end_bit);
-    return bytes;
+    BinPlan p;
+    p.ntiles = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    int rows = (P + BIN_SLICE_MIN - 1) / BIN_SLICE_MIN;
+    rows = rows < 1 ? 1 : (rows > BIN_ROWS_MAX ? BIN_ROWS_MAX : rows);
+    p.slice = (((P + rows - 1) / rows + 255) / 256) * 256;
+    p.rows = p.slice > 0 ? (P + p.slice - 1) / p.slice : 1;
+    if (p.rows < 1) p.rows = 1;
+    return p;
 }
 
-// One lane per surfel; each visible surfel writes its tiles_touched instances at offsets[i-1].
-// The tile rect is recomputed from the stored centre and INTEGER radius exactly as R1 did.
-__global__ void __launch_bounds__(256)
-emit_tile_keys(int P, int W, int H, const float *__restrict__ geom, const int32_t *__restrict__ radii,
-               const uint32_t *__restrict__ offsets, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t cap)
+// Scratch of one binning call, carved from the caller's temp buffer (uint32 words):
+//   hist (BIN_ROWS_MAX x ntiles) | tile_count (ntiles) | tile_start (ntiles + 1) | long_list (ntiles) | hdr (4: total, long count, -, -)
+size_t sort_temp_bytes(uint32_t, int width, int height)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    const size_t ntiles = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+    return sizeof(uint32_t) * ((size_t)BIN_ROWS_MAX * ntiles + 3 * ntiles + 1 + 4) + 256;
+}
+
+// The tile rectangle of surfel i, recomputed from the stored centre and INTEGER radius exactly as R1 did.
+__device__ __forceinline__ bool tile_rect(int i, int W, int H, const float *__restrict__ geom, const int32_t *__restrict__ radii,
+                                          int &x0, int &y0, int &x1, int &y1, uint32_t &dbits)
+{
     const int rad = radii[i];
-    if (rad <= 0) return;
-    uint32_t off = (i == 0) ? 0u : offsets[i - 1];
+    if (rad <= 0) return false;
     const float cx = geom[(size_t)i * GEOM + 9], cy = geom[(size_t)i * GEOM + 10];
-    const uint32_t dbits = __float_as_uint(geom[(size_t)i * GEOM + 15]);
+    dbits = __float_as_uint(geom[(size_t)i * GEOM + 15]);
     const float radius = (float)rad;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    int x0 = (int)((cx - radius) / (float)TILE); x0 = x0 < 0 ? 0 : (x0 > gx ? gx : x0);
-    int y0 = (int)((cy - radius) / (float)TILE); y0 = y0 < 0 ? 0 : (y0 > gy ? gy : y0);
-    int x1 = (int)((cx + radius + (float)(TILE - 1)) / (float)TILE); x1 = x1 < 0 ? 0 : (x1 > gx ? gx : x1);
-    int y1 = (int)((cy + radius + (float)(TILE - 1)) / (float)TILE); y1 = y1 < 0 ? 0 : (y1 > gy ? gy : y1);
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            const uint64_t key = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
-            if (off < cap) { keys[off] = key; vals[off] = (uint32_t)i; }      // (cap < N only when a speculative capacity was too small: the caller repeats the call)
-            off++;
+    x0 = (int)((cx - radius) / (float)TILE); x0 = x0 < 0 ? 0 : (x0 > gx ? gx : x0);
+    y0 = (int)((cy - radius) / (float)TILE); y0 = y0 < 0 ? 0 : (y0 > gy ? gy : y0);
+    x1 = (int)((cx + radius + (float)(TILE - 1)) / (float)TILE); x1 = x1 < 0 ? 0 : (x1 > gx ? gx : x1);
+    y1 = (int)((cy + radius + (float)(TILE - 1)) / (float)TILE); y1 = y1 < 0 ? 0 : (y1 > gy ? gy : y1);
+    return x1 > x0 && y1 > y0;
+}
+
+// One workgroup per slice of `slice` surfels.  SCATTER == false: hist[w][t] = instances of this slice in tile t.  SCATTER == true: the
+// LDS counters start at the slice's first slot inside each tile's segment and every instance takes the next one.
+struct SurfelRect { int x0, y0, x1, y1; uint32_t dbits; bool vis; };
+__device__ __forceinline__ SurfelRect load_rect(int i, int g1, int W, int H, const float *__restrict__ geom, const int32_t *__restrict__ radii)
+{
+    SurfelRect r;
+    r.x0 = r.y0 = r.x1 = r.y1 = 0; r.dbits = 0;
+    r.vis = i < g1 && tile_rect(i, W, H, geom, radii, r.x0, r.y0, r.x1, r.y1, r.dbits);
+    return r;
+}
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(256)
+bin_pass(int P, int W, int H, int slice, int ntiles, const float *__restrict__ geom, const int32_t *__restrict__ radii,
+         uint32_t *hist, const uint32_t *__restrict__ tile_start, uint64_t *__restrict__ pairs, uint32_t cap)
+{
+    extern __shared__ uint32_t s_bin[];
+    const int gx = (W + TILE - 1) / TILE;
+    const int g0 = blockIdx.x * slice, g1 = min(P, g0 + slice);
+    uint32_t *row = hist + (size_t)blockIdx.x * ntiles;
+    const int lane = lane_id();
+    for (int band0 = 0; band0 < ntiles; band0 += BIN_BAND) {
+        const int bn = min(BIN_BAND, ntiles - band0);
+        SurfelRect cur = load_rect(g0 + (int)threadIdx.x, g1, W, H, geom, radii);          // (in flight while the counters are set up)
+        for (int t = threadIdx.x; t < bn; t += 256) s_bin[t] = SCATTER ? tile_start[band0 + t] + row[band0 + t] : 0u;
+        __syncthreads();
+        auto visit = [&](int t, uint64_t pair) {
+            t -= band0;
+            if ((unsigned)t >= (unsigned)bn) return;
+            const uint32_t slot = atomicAdd(&s_bin[t], 1u);
+            if (SCATTER && slot < cap) pairs[slot] = pair;           // (cap below the instance count: the caller repeats the call; nothing out of bounds)
+        };
+        for (int ib = g0; ib < g1; ib += 256) {
+            const int i = ib + (int)threadIdx.x;
+            const SurfelRect c = cur;
+            cur = load_rect(i + 256, g1, W, H, geom, radii);          // the next surfel's record is fetched before this one's tiles are walked
+            const int x0 = c.x0, y0 = c.y0, x1 = c.x1, y1 = c.y1;
+            const uint32_t dbits = c.dbits;
+            const bool vis = c.vis;
+            const uint64_t pair = ((uint64_t)dbits << 32) | (uint32_t)i;
+            const bool big = vis && (x1 - x0) * (y1 - y0) > BIG_RECT;
+            if (vis && !big)
+                for (int y = y0; y < y1; y++)
+                    for (int x = x0; x < x1; x++) visit(y * gx + x, pair);
+            uint64_t m = __builtin_amdgcn_ballot_w64(big);
+            while (m) {                                               // a large splat would stall its 63 neighbours: all lanes share its tiles
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
+                const int bw = __builtin_amdgcn_readlane(x1, l) - bx0, bh = __builtin_amdgcn_readlane(y1, l) - by0;
+                const uint64_t bp = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dbits, l) << 32) | (uint32_t)__builtin_amdgcn_readlane(i, l);
+                for (int k = lane; k < bw * bh; k += 64) visit((by0 + k / bw) * gx + bx0 + k % bw, bp);
+            }
+        }
+        __syncthreads();
+        if (!SCATTER)
+            for (int t = threadIdx.x; t < bn; t += 256) row[band0 + t] = s_bin[t];
+        __syncthreads();
+    }
+}
+
+// 16 tiles x 16 row segments per workgroup: hist[w][t] becomes the number of instances of tile t in the slices before w.  Every lane keeps
+// its (at most 32) rows in registers: one read of the matrix, all loads in flight before the first store.
+constexpr int CS_SEG = 16, CS_ROWS = BIN_ROWS_MAX / CS_SEG;
+__global__ void __launch_bounds__(256)
+bin_column_scan(int rows, int ntiles, uint32_t *hist, uint32_t *__restrict__ tile_count)
+{
+    __shared__ uint32_t s_seg[CS_SEG][16];
+    const int tl = threadIdx.x & 15, seg = threadIdx.x >> 4;
+    const int t = blockIdx.x * 16 + tl;
+    const int per = (rows + CS_SEG - 1) / CS_SEG, r0 = seg * per;
+    uint32_t v[CS_ROWS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < CS_ROWS; k++) {
+        const int r = r0 + k;
+        v[k] = (t < ntiles && k < per && r < rows) ? hist[(size_t)r * ntiles + t] : 0u;
+        s += v[k];
+    }
+    s_seg[seg][tl] = s;
+    __syncthreads();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < CS_SEG; k++) acc += (k < seg) ? s_seg[k][tl] : 0u;
+    if (t >= ntiles) return;
+#pragma unroll
+    for (int k = 0; k < CS_ROWS; k++) {
+        const int r = r0 + k;
+        if (k < per && r < rows) hist[(size_t)r * ntiles + t] = acc;
+        acc += v[k];
+    }
+    if (seg == CS_SEG - 1) tile_count[t] = acc;
+}
+
+// One workgroup: exclusive scan of the tile totals -> tile_start, ranges (R5; empty tiles read [0,0) like the reference's zeroed buffer).
+__global__ void __launch_bounds__(1024)
+bin_tile_scan(int ntiles, const uint32_t *__restrict__ tile_count, uint32_t *__restrict__ tile_start, uint32_t *__restrict__ ranges,
+              uint32_t cap, uint32_t *__restrict__ hdr)
+{
+    __shared__ uint32_t s_w[17];
+    const int per = (ntiles + 1023) / 1024, b = min(ntiles, (int)threadIdx.x * per), e = min(ntiles, b + per);
+    uint32_t s = 0;
+    for (int k = b; k < e; k++) s += tile_count[k];
+    uint32_t total;
+    uint32_t run = block_exclusive_u32<16>(s, s_w, total);
+    const bool ok = total <= cap;                      // otherwise the caller repeats the call with the exact size: leave nothing to composite
+    for (int k = b; k < e; k++) {
+        const uint32_t c = tile_count[k];
+        tile_start[k] = run;
+        ranges[2 * k] = (c && ok) ? run : 0u;
+        ranges[2 * k + 1] = (c && ok) ? run + c : 0u;
+        run += c;
+    }
+    if (threadIdx.x == 0) { tile_start[ntiles] = total; hdr[0] = total; hdr[1] = 0u; }
+}
+
+// Sort the power-of-two padded LDS array of 1 << lp entries (tile_sort.h: register-blocked bitonic network, one barrier per 4 steps;
+// entry i lives in slot ts_slot(i)).
+template <int NT>
+__device__ __forceinline__ void sort_padded_lds(uint64_t *s, int lp, int tid)
+{
+    const int npad = 1 << lp;
+    for (int g = tid; g < (npad >> TS_S); g += NT) bitonic_first(s, g, lp);
+    __syncthreads();
+    for (int lk = TS_S + 1; lk <= lp; lk++)
+        for (int a = lk - 1; a >= 0;) {
+            const int S = ts_chunk(a);
+            if (S == 4) { for (int g = tid; g < (npad >> 4); g += NT) bitonic_group<4>(s, g, lk, a, lp); }
+            else if (S == 3) { for (int g = tid; g < (npad >> 3); g += NT) bitonic_group<3>(s, g, lk, a, lp); }
+            else if (S == 2) { for (int g = tid; g < (npad >> 2); g += NT) bitonic_group<2>(s, g, lk, a, lp); }
+            else { for (int g = tid; g < (npad >> 1); g += NT) bitonic_group<1>(s, g, lk, a, lp); }
+            __syncthreads();
+            a -= S;
         }
 }
 
-// Speculative capacity (launch_bin): the slots [N, cap) of the key buffer sort behind every real key.
-__global__ void __launch_bounds__(256)
-pad_tile_keys(uint32_t cap, const uint32_t *__restrict__ n_dev, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
-{
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < cap && j >= *n_dev) { keys[j] = ~0ull; vals[j] = 0u; }
-}
+constexpr int lds_slots(int lp_cap) { return (1 << lp_cap) + (1 << (lp_cap - 5)); }
 
-__global__ void __launch_bounds__(256)
-find_tile_ranges(uint32_t N, const uint32_t *__restrict__ n_dev, const uint64_t *__restrict__ keys_sorted, uint32_t *__restrict__ ranges)
+template <int NT>
+__device__ __forceinline__ void load_sort_write(uint64_t *s, const uint64_t *__restrict__ pairs, int n, uint32_t tile, uint32_t b,
+                                                uint64_t *__restrict__ keys_sorted, uint32_t *__restrict__ point_list, int tid)
 {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n_dev) N = min(N, *n_dev);
-    if (j >= N) return;
-    const uint32_t t = (uint32_t)(keys_sorted[j] >> 32);
-    if (j == 0 || t != (uint32_t)(keys_sorted[j - 1] >> 32)) ranges[2 * t] = j;
-    if (j == N - 1 || t != (uint32_t)(keys_sorted[j + 1] >> 32)) ranges[2 * t + 1] = j + 1;
-}
-
-int launch_bin(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const int32_t *radii, const uint32_t *offsets,
-               uint64_t *keys_unsorted, uint32_t *vals_unsorted, uint64_t *keys_sorted, uint32_t *point_list,
-               void *sort_temp, size_t sort_temp_bytes, uint32_t *ranges, hipStream_t stream, const uint32_t *n_dev)
-{
-    // n_dev == nullptr: N is the exact number of tile instances.  Otherwise N is a CAPACITY chosen before the count was known on the host
-    // (no host sync between projection and binning) and *n_dev the count: the tail [count, N) is padded with keys that sort last (one more
-    // key bit makes them larger than any tile id), and the ranges are built from the first `count` sorted entries only.
-    const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
-    hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)gx * gy, stream);
-    if (e != hipSuccess) return (int)e;
-    if (N == 0 || cfg->P <= 0) return 0;
-    prof_begin(K_EMIT_KEYS, stream);
-    hipLaunchKernelGGL(emit_tile_keys, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, cfg->width, cfg->height,
-                       geom, radii, offsets, keys_unsorted, vals_unsorted, N);
-    ENVGS_CHECK_LAUNCH(cfg, stream);
-    if (n_dev) {
-        hipLaunchKernelGGL(pad_tile_keys, dim3((N + 255) / 256), dim3(256), 0, stream, N, n_dev, keys_unsorted, vals_unsorted);
-        ENVGS_CHECK_LAUNCH(cfg, stream);
+    const int lp = ts_log2_padded(n);
+    for (int i = tid; i < (1 << lp); i += NT) s[ts_slot(i)] = i < n ? pairs[b + i] : ~0ull;       // (a real pair is below 2^63: view depths are positive floats)
+    __syncthreads();
+    sort_padded_lds<NT>(s, lp, tid);
+    for (int i = tid; i < n; i += NT) {
+        const uint64_t v = s[ts_slot(i)];
+        point_list[b + i] = (uint32_t)v;
+        if (keys_sorted) keys_sorted[b + i] = ((uint64_t)tile << 32) | (v >> 32);
     }
+}
+
+// One workgroup per tile; lists longer than the LDS array of this instantiation are handed to sort_long_lists.
+template <int LP_CAP, int NT>
+__global__ void __launch_bounds__(NT)
+sort_tile_lists(const uint32_t *__restrict__ ranges, const uint64_t *__restrict__ pairs, uint64_t *__restrict__ keys_sorted,
+                uint32_t *__restrict__ point_list, uint32_t *__restrict__ hdr, uint32_t *__restrict__ long_list)
+{
+    __shared__ uint64_t s_k[lds_slots(LP_CAP)];
+    const uint32_t t = blockIdx.x, b = ranges[2 * t];
+    const int n = (int)(ranges[2 * t + 1] - b);
+    if (n == 0) return;
+    if (n > (1 << LP_CAP)) {
+        if (threadIdx.x == 0) long_list[atomicAdd(&hdr[1], 1u)] = t;
+        return;
+    }
+    load_sort_write<NT>(s_k, pairs, n, t, b, keys_sorted, point_list, (int)threadIdx.x);
+}
+
+// One workgroup per CU walks the long lists: up to 16 384 entries in LDS, beyond that the all-ascending network on the segment in HBM.
+__global__ void __launch_bounds__(1024)
+sort_long_lists(const uint32_t *__restrict__ ranges, uint64_t *pairs, uint64_t *__restrict__ keys_sorted, uint32_t *__restrict__ point_list,
+                const uint32_t *__restrict__ hdr, const uint32_t *__restrict__ long_list)
+{
+    __shared__ uint64_t s_long[lds_slots(14)];
+    const uint32_t count = hdr[1];
+    const int tid = (int)threadIdx.x;
+    for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
+        const uint32_t t = long_list[w], b = ranges[2 * t];
+        const int n = (int)(ranges[2 * t + 1] - b);
+        if (n <= SORT_LONG_N) {
+            load_sort_write<1024>(s_long, pairs, n, t, b, keys_sorted, point_list, tid);
+        } else {
+            uint64_t *seg = pairs + b;                                     // (workgroup barriers order the accesses to the segment)
+            int lp = 1;
+            while ((1 << lp) < n) lp++;
+            for (int lk = 1; lk <= lp; lk++)
+                for (int q = 0; q < lk; q++) {
+                    for (int idx = tid; idx < (1 << (lp - 1)); idx += 1024) ascending_step(seg, n, lk, q, idx);
+                    __syncthreads();
+                }
+            for (int i = tid; i < n; i += 1024) {
+                const uint64_t v = seg[i];
+                point_list[b + i] = (uint32_t)v;
+                if (keys_sorted) keys_sorted[b + i] = ((uint64_t)t << 32) | (v >> 32);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_bin(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const int32_t *radii, uint64_t *tile_pairs,
+               uint64_t *keys_sorted, uint32_t *point_list, void *bin_temp, size_t bin_temp_bytes, uint32_t *ranges, hipStream_t stream)
+{
+    // N is the CAPACITY of the N-sized buffers: the exact instance count when the caller waited for it, or a guess made before the count was
+    // known on the host (no host sync between projection and binning).  The count itself is re-derived here (sum of the tile totals); a
+    // capacity below it leaves every range empty and writes nothing out of bounds.
+    const BinPlan pl = bin_plan(cfg->P, cfg->width, cfg->height);
+    if (N == 0 || cfg->P <= 0) return (int)hipMemsetAsync(ranges, 0, sizeof(uint32_t) * 2 * (size_t)pl.ntiles, stream);
+    if (bin_temp_bytes < sort_temp_bytes(N, cfg->width, cfg->height)) return ENVGS_ERR_TEMP_TOO_SMALL;
+    uint32_t *hist = (uint32_t *)bin_temp;
+    uint32_t *tile_count = hist + (size_t)BIN_ROWS_MAX * pl.ntiles;
+    uint32_t *tile_start = tile_count + pl.ntiles;
+    uint32_t *long_list = tile_start + pl.ntiles + 1;
+    uint32_t *hdr = long_list + pl.ntiles;
+    const size_t lds = sizeof(uint32_t) * (size_t)(pl.ntiles < BIN_BAND ? pl.ntiles : BIN_BAND);
+    prof_begin(K_EMIT_KEYS, stream);
+    hipLaunchKernelGGL(bin_pass<false>, dim3(pl.rows), dim3(256), lds, stream, cfg->P, cfg->width, cfg->height, pl.slice, pl.ntiles,
+                       geom, radii, hist, (const uint32_t *)nullptr, (uint64_t *)nullptr, 0u);
+    ENVGS_CHECK_LAUNCH(cfg, stream);
+    hipLaunchKernelGGL(bin_column_scan, dim3((pl.ntiles + 15) / 16), dim3(256), 0, stream, pl.rows, pl.ntiles, hist, tile_count);
+    ENVGS_CHECK_LAUNCH(cfg, stream);
+    hipLaunchKernelGGL(bin_tile_scan, dim3(1), dim3(1024), 0, stream, pl.ntiles, tile_count, tile_start, ranges, N, hdr);
+    ENVGS_CHECK_LAUNCH(cfg, stream);
+    hipLaunchKernelGGL(bin_pass<true>, dim3(pl.rows), dim3(256), lds, stream, cfg->P, cfg->width, cfg->height, pl.slice, pl.ntiles,
+                       geom, radii, hist, tile_start, tile_pairs, N);
+    ENVGS_CHECK_LAUNCH(cfg, stream);
     prof_end(K_EMIT_KEYS, stream);
-    const int end_bit = 32 + tile_bits(cfg->width, cfg->height) + (n_dev ? 1 : 0);
-    prof_begin(K_SORT, stream);
-    size_t need = sort_temp_bytes;
-    e = rocprim::radix_sort_pairs(sort_temp, need, keys_unsorted, keys_sorted, vals_unsorted, point_list, (size_t)N, 0u,
-                                  (unsigned)end_bit, stream);
-    prof_end(K_SORT, stream);
-    if (e != hipSuccess) return (int)e;
-    ProfScope prof_(K_RANGES, stream);
-    hipLaunchKernelGGL(find_tile_ranges, dim3((N + 255) / 256), dim3(256), 0, stream, N, n_dev, keys_sorted, ranges);
+    ProfScope prof_(K_SORT, stream);
+    // LDS array per tile: room for 1.6x the average list length the capacity N allows, 16.5 / 33 / 66 KB (the smaller the array, the more
+    // tiles are in flight per CU: 46 us vs 53 us for the 300 k / 800 x 800 lists); what does not fit is a long list
+    const uint64_t want = (uint64_t)N * 8 / ((uint64_t)pl.ntiles * 5);
+    if (want <= 2048)
+        hipLaunchKernelGGL((sort_tile_lists<11, 128>), dim3(pl.ntiles), dim3(128), 0, stream, ranges, tile_pairs, keys_sorted, point_list, hdr, long_list);
+    else if (want <= 4096)
+        hipLaunchKernelGGL((sort_tile_lists<12, 256>), dim3(pl.ntiles), dim3(256), 0, stream, ranges, tile_pairs, keys_sorted, point_list, hdr, long_list);
+    else
+        hipLaunchKernelGGL((sort_tile_lists<13, 512>), dim3(pl.ntiles), dim3(512), 0, stream, ranges, tile_pairs, keys_sorted, point_list, hdr, long_list);
+    ENVGS_CHECK_LAUNCH(cfg, stream);
+    hipLaunchKernelGGL(sort_long_lists, dim3(SORT_LONG_WGS), dim3(1024), 0, stream, ranges, tile_pairs,
+                       keys_sorted, point_list, hdr, long_list);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;
 }

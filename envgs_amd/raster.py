@@ -166,21 +166,20 @@ def rasterize_forward(C, means3D, shs, colors_precomp, opacities, scales, rotati
     weight = torch.empty(P, 1, **f32)
     ranges = torch.empty(tiles_n, 2, **i32)
 
-    def bin_and_render(cap, n_dev):
-        """R3-R6 with N-sized buffers of `cap` entries; n_dev = device pointer to the instance count when cap is a guess."""
-        keys_u = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
-        keys_s = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
-        vals_u = torch.empty(max(cap, 1), **i32)
+    def bin_and_render(cap):
+        """R3-R6 with N-sized buffers of `cap` entries (the instance count, or a guess: the kernels re-derive the count themselves)."""
+        pairs = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+        keys_s = torch.empty(max(cap, 1), dtype=torch.int64, device=dev) if keep_binning else None
         point_list = torch.empty(max(cap, 1), **i32)
-        sort_bytes = lib.envgs_raster_sort_temp_bytes(max(cap, 1), W, H)
-        sort_temp = torch.empty(max(sort_bytes, 1), dtype=torch.uint8, device=dev)
+        bin_bytes = lib.envgs_raster_sort_temp_bytes(max(cap, 1), W, H)
+        bin_temp = torch.empty(max(bin_bytes, 1), dtype=torch.uint8, device=dev)
         # per tile instance: the pixel quadrants that blended it (the backward walks exactly those)
         cmask = torch.empty(max(cap, 1), dtype=torch.uint8, device=dev) if CONTRIB_MASK["on"] else None
-        _lib.check(lib.envgs_raster_bin_and_render(cfg, cap, p(geom), p(radii), p(offsets), p(colors), p(bg), p(keys_u), p(vals_u),
-                                                   p(keys_s), p(point_list), p(sort_temp), sort_bytes, p(ranges), p(out_color),
-                                                   p(allmap), p(final_T), p(n_contrib), p(weight), p(cmask), n_dev, stream),
+        _lib.check(lib.envgs_raster_bin_and_render(cfg, cap, p(geom), p(radii), p(colors), p(bg), p(pairs), p(keys_s), p(point_list),
+                                                   p(bin_temp), bin_bytes, p(ranges), p(out_color), p(allmap), p(final_T),
+                                                   p(n_contrib), p(weight), p(cmask), stream),
                    "envgs_raster_bin_and_render")
-        return keys_u, keys_s, vals_u, point_list, cmask
+        return pairs, keys_s, point_list, cmask
 
     # The number of tile instances N sizes the binning buffers, and it is known only after the projection.  Waiting for it drains the
     # GPU's queue at the start of every step (and every launch after it is exposed until the host is ahead again: ~0.5 ms of idle GPU per
@@ -196,7 +195,7 @@ def rasterize_forward(C, means3D, shs, colors_precomp, opacities, scales, rotati
                                             p(view), p(proj), p(campos), p(geom), p(rgb), p(clamped), p(radii), p(tiles),
                                             p(offsets), p(scan_temp), scan_bytes, n_host, stream), "envgs_raster_project")
         N = int(n_host.value)
-        bufs = bin_and_render(N, None)
+        bufs = bin_and_render(N)
     else:
         _lib.check(lib.envgs_raster_project(cfg, p(means3D), p(scales), p(rotations), p(opacities), p(shs), p(cov3D_precomp),
                                             p(view), p(proj), p(campos), p(geom), p(rgb), p(clamped), p(radii), p(tiles),
@@ -204,13 +203,13 @@ def rasterize_forward(C, means3D, shs, colors_precomp, opacities, scales, rotati
         mirror["host"].copy_(offsets[P - 1:P], non_blocking=True)
         mirror["event"].record(torch.cuda.current_stream(dev))
         cap = guess
-        bufs = bin_and_render(cap, _lib.c_void_p(offsets[P - 1:P].data_ptr()))
+        bufs = bin_and_render(cap)
         mirror["event"].synchronize()                        # (the copy was queued BEFORE R3-R6: this does not wait for them)
         N = int(mirror["host"][0]) & 0xFFFFFFFF
         if N > cap:
             LAST_STATS["n_guess_misses"] = LAST_STATS.get("n_guess_misses", 0) + 1
-            bufs = bin_and_render(N, None)
-    keys_u, keys_s, vals_u, point_list, cmask = bufs
+            bufs = bin_and_render(N)
+    pairs, keys_s, point_list, cmask = bufs
     # next capacity: 15 % above this count (64 k granularity), and not below 97 % of the previous capacity -- views alternate, scenes change slowly
     _N_GUESS[key] = max(((max(int(N * 1.15), N + 4096) + 65535) // 65536) * 65536, int(0.97 * (guess or 0)))
     LAST_STATS.update(N=N, P=P, H=H, W=W, C=C)
@@ -218,7 +217,7 @@ def rasterize_forward(C, means3D, shs, colors_precomp, opacities, scales, rotati
                  n_contrib=n_contrib, contrib_mask=cmask, means3D=means3D, scales=scales, rotations=rotations, shs=shs, clamped=clamped,
                  cov3D_precomp=cov3D_precomp, radii=radii, view=view, proj=proj, campos=campos)
     if keep_binning:
-        saved.update(tiles_touched=tiles, offsets=offsets, keys_unsorted=keys_u, vals_unsorted=vals_u, keys_sorted=keys_s)
+        saved.update(tiles_touched=tiles, offsets=offsets, tile_pairs=pairs, keys_sorted=keys_s)
     return (out_color, radii, allmap, weight), saved
 
 

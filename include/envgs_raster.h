@@ -69,7 +69,8 @@ typedef struct envgs_raster_cfg {
                                variant of BASELINE configs[4]; the reference has no counterpart. */
 } envgs_raster_cfg;
 
-/* Bytes of scratch the prefix sum over P counters and the pair sort over N tile instances need. */
+/* Bytes of scratch the prefix sum over P counters needs, and the binning of one width x height image (N is not used any more: the scratch
+ * is per-tile histograms, see _bin_and_render). */
 ENVGS_API size_t envgs_raster_scan_temp_bytes(int32_t P);
 ENVGS_API size_t envgs_raster_sort_temp_bytes(uint32_t N, int32_t width, int32_t height);
 
@@ -92,26 +93,27 @@ ENVGS_API int envgs_raster_project(const envgs_raster_cfg *cfg,
                          uint32_t *num_rendered_host, void *stream);
 
 /*
- * Stages R3-R6 (GaussianRasterizer.forward, second half): key emit (tile id << 32 | depth bits),
- * stable radix sort, per-tile ranges, front-to-back compositing of `channels` colours + the 7 allmap
- * channels + the per-surfel accumulated weight (the "-wet" output, gaussian2d_utils.py:1090,1114).
- * keys_sorted / point_list / ranges are outputs the backward pass (and the parity tests) read.
- * num_rendered_dev (optional): when the caller did not wait for the instance count of _project (num_rendered_host == NULL there), N is a
- * CAPACITY it chose for the N-sized buffers and num_rendered_dev = offsets + P - 1 points at the count on the device: the sort runs over N
- * slots padded with keys that sort last, ranges are built from the real entries.  If the count turns out larger than N the outputs are
- * invalid (nothing is written out of bounds) and the caller repeats the call with the exact size.  NULL: N is exact.
+ * Stages R3-R6 (GaussianRasterizer.forward, second half).  The reference emits (tile id << 32 | depth bits, surfel id) pairs, radix-sorts
+ * all N of them (stable) and detects the per-tile ranges; what that fixes is, per tile, its instances in (depth bits, surfel id) order.
+ * Here the instances are counted per tile in LDS histograms, scattered into their tile's segment (tile_pairs: depth bits << 32 | id) and
+ * each segment is sorted by one workgroup in LDS -- no device-wide sort (csrc/raster_bin.hip).  Then front-to-back compositing of
+ * `channels` colours + the 7 allmap channels + the per-surfel accumulated weight (the "-wet" output, gaussian2d_utils.py:1090,1114).
+ * point_list / ranges are outputs the backward pass reads; keys_sorted (tile id << 32 | depth bits per list entry, what the reference's
+ * sorted key buffer holds) is written only when non-NULL (parity tests).
+ * N is the CAPACITY of the N-sized buffers (tile_pairs, keys_sorted, point_list, contrib_mask): the instance count envgs_raster_project
+ * returned, or -- when the caller did not wait for it (num_rendered_host == NULL there) -- a guess.  The count is re-derived on the device;
+ * if it exceeds N every range is left empty (nothing is written out of bounds) and the caller repeats the call with the exact size.
  * contrib_mask (N bytes, optional): for every tile instance (= entry of point_list) the set of 8x8 pixel quadrants of its tile in which
  * some pixel blended it (bit q = quadrant q; row-major 2x2).  Passed to envgs_raster_backward it lets the backward visit exactly the
  * (quadrant, entry) pairs the forward blended instead of re-deriving them geometrically (most candidates fail the alpha test everywhere).
  */
 ENVGS_API int envgs_raster_bin_and_render(const envgs_raster_cfg *cfg, uint32_t N,
-                                const float *geom, const int32_t *radii, const uint32_t *offsets,
+                                const float *geom, const int32_t *radii,
                                 const float *colors, const float *bg,
-                                uint64_t *keys_unsorted, uint32_t *vals_unsorted,
-                                uint64_t *keys_sorted, uint32_t *point_list,
-                                void *sort_temp, size_t sort_temp_bytes, uint32_t *ranges,
+                                uint64_t *tile_pairs, uint64_t *keys_sorted /* may be NULL */, uint32_t *point_list,
+                                void *bin_temp, size_t bin_temp_bytes, uint32_t *ranges,
                                 float *out_color, float *allmap, float *final_T, int32_t *n_contrib,
-                                float *weight, uint8_t *contrib_mask, const uint32_t *num_rendered_dev, void *stream);
+                                float *weight, uint8_t *contrib_mask, void *stream);
 
 /*
  * Parity audit of stage R6 (tests only; no reference counterpart): the SAME compositing kernel, instantiated with one extra store --
@@ -150,7 +152,7 @@ ENVGS_API int envgs_raster_backward(const envgs_raster_cfg *cfg, uint32_t N,
 /*
  * Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg; the
  * reference's counterpart is its `timer.record` sections, easyvolcap/utils/console_utils.py:615-693).
- * kernel_id: 0 project_surfels, 1 scan, 2 emit_tile_keys, 3 radix_sort_pairs, 4 find_tile_ranges,
+ * kernel_id: 0 project_surfels, 1 scan, 2 bin_tile_pairs (histograms + scans + scatter), 3 sort_tile_lists, 4 (unused),
  *            5 composite_fwd, 6 composite_bwd, 7 project_surfels_bwd, 8 bvh_build, 9 trace_fwd (whole forward), 10 trace_bwd
  *            (whole backward), 11 collect_hits, 12 sort_composite_fwd, 13 (unused), 14 K-buffer forward, 15 batch_surfel_bwd,
  *            16 K-buffer backward, 17 reduce_surfel_records, 18 register_hits, 19 fused_adam_multi, 20 l1_ssim_fwd, 21 l1_ssim_bwd.  envgs_prof_kernel_name(id) returns "" past the last id.

@@ -36,7 +36,7 @@ def pmc():
     f = load(os.path.join(ROOT, 'gpurun_out/pmc_fetch/f_counter_collection.csv'), 'FETCH_SIZE')
     w = load(os.path.join(ROOT, 'gpurun_out/pmc_write/w_counter_collection.csv'), 'WRITE_SIZE')
     names = {'envgs::composite_fwd': 'composite_fwd', 'envgs::composite_bwd': 'composite_bwd', 'envgs::project_surfels': 'project_surfels',
-             'envgs::project_surfels_bwd': 'project_surfels_bwd', 'envgs::emit_tile_keys': 'emit_tile_keys', 'envgs::find_tile_ranges': 'find_tile_ranges',
+             'envgs::project_surfels_bwd': 'project_surfels_bwd', 'envgs::bin_pass': 'bin_tile_pairs', 'envgs::sort_tile_lists': 'sort_tile_lists',
              'envgs::collect_hits_coop': 'trace.collect_hits', 'envgs::collect_hits_packet4': 'trace.collect_hits(one wavefront per batch)', 'envgs::collect_hits_packet': 'trace.collect_hits(binary)', 'envgs::collect_hits': 'trace.collect_hits(per-ray)', 'envgs::sort_composite_fwd<4, false, true>': 'trace.sort_composite_fwd', 'envgs::sort_composite_fwd<4, false, false>': 'trace.sort_composite_fwd(per-lane SH gathers)',
              'envgs::register_hits': 'trace.register_hits', 'envgs::batch_surfel_bwd': 'trace.batch_surfel_bwd',
              'envgs::reduce_surfel_records': 'trace.reduce_surfel_records'}
