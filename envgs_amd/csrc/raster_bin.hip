@@ -14,7 +14,7 @@
 //   sort_tile_lists     one workgroup per tile: the segment is sorted in LDS by a bitonic network whose compare-exchange steps run four at
 //                       a time in registers (tile_sort.h), and written out as point_list (ids) + keys_sorted (tile id << 32 | depth);
 //                       the LDS array (2048 / 4096 / 8192 entries) is picked from the average list length, longer segments go to
-//                       sort_long_lists (16 384 entries in LDS, beyond that an all-ascending network on the segment in HBM)
+//                       sort_long_lists (16 384 entries in LDS; beyond that chunks go through LDS and only the wide merge steps run in HBM)
 //
 // Per instance that is 8 B written + 8 B read + 12 B written.  All integer work: point_list / keys_sorted / ranges are bit-exact against
 // the oracle's stable sort (tests/test_raster_parity.py).
@@ -281,6 +281,22 @@ __device__ __forceinline__ void sort_padded_lds(uint64_t *s, int lp, int tid)
         }
 }
 
+// The ascending merge of a padded LDS array whose two halves are each sorted after a mirror step further up: distances 2^(lc-1) .. 1.
+template <int NT>
+__device__ __forceinline__ void merge_padded_lds(uint64_t *s, int lc, int tid)
+{
+    const int npad = 1 << lc;
+    for (int a = lc - 1; a >= 0;) {
+        const int S = ts_chunk(a);
+        if (S == 4) { for (int g = tid; g < (npad >> 4); g += NT) bitonic_group<4>(s, g, lc, a, lc); }
+        else if (S == 3) { for (int g = tid; g < (npad >> 3); g += NT) bitonic_group<3>(s, g, lc, a, lc); }
+        else if (S == 2) { for (int g = tid; g < (npad >> 2); g += NT) bitonic_group<2>(s, g, lc, a, lc); }
+        else { for (int g = tid; g < (npad >> 1); g += NT) bitonic_group<1>(s, g, lc, a, lc); }
+        __syncthreads();
+        a -= S;
+    }
+}
+
 constexpr int lds_slots(int lp_cap) { return (1 << lp_cap) + (1 << (lp_cap - 5)); }
 
 template <int NT>
@@ -315,7 +331,7 @@ sort_tile_lists(const uint32_t *__restrict__ ranges, const uint64_t *__restrict_
     load_sort_write<NT>(s_k, pairs, n, t, b, keys_sorted, point_list, (int)threadIdx.x);
 }
 
-// One workgroup per CU walks the long lists: up to 16 384 entries in LDS, beyond that the all-ascending network on the segment in HBM.
+// One workgroup per CU walks the long lists: up to 16 384 entries in LDS, beyond that chunk by chunk through LDS with the wide steps in HBM.
 __global__ void __launch_bounds__(1024)
 sort_long_lists(const uint32_t *__restrict__ ranges, uint64_t *pairs, uint64_t *__restrict__ keys_sorted, uint32_t *__restrict__ point_list,
                 const uint32_t *__restrict__ hdr, const uint32_t *__restrict__ long_list)
@@ -329,14 +345,30 @@ sort_long_lists(const uint32_t *__restrict__ ranges, uint64_t *pairs, uint64_t *
         if (n <= SORT_LONG_N) {
             load_sort_write<1024>(s_long, pairs, n, t, b, keys_sorted, point_list, tid);
         } else {
-            uint64_t *seg = pairs + b;                                     // (workgroup barriers order the accesses to the segment)
-            int lp = 1;
+            // Too long for LDS: chunks of 16 384 entries are sorted in LDS, and of every later merge stage only the steps whose distance is
+            // at least a chunk touch the segment in HBM (all-ascending network: entries beyond n never move, so nothing is padded in
+            // memory); the rest of the stage is an ascending merge of each chunk in LDS again (tile_sort.h: ts_sort_hybrid).
+            uint64_t *seg = pairs + b;
+            constexpr int LC = 14, C = 1 << LC;
+            int lp = LC;
             while ((1 << lp) < n) lp++;
-            for (int lk = 1; lk <= lp; lk++)
-                for (int q = 0; q < lk; q++) {
-                    for (int idx = tid; idx < (1 << (lp - 1)); idx += 1024) ascending_step(seg, n, lk, q, idx);
+            const int nchunks = (n + C - 1) / C;
+            for (int lk = LC; lk <= lp; lk++) {
+                if (lk > LC)
+                    for (int q = 0; q <= lk - LC - 1; q++) {
+                        for (int idx = tid; idx < (1 << (lp - 1)); idx += 1024) ascending_step(seg, n, lk, q, idx);
+                        __syncthreads();
+                    }
+                for (int c = 0; c < nchunks; c++) {
+                    for (int i = tid; i < C; i += 1024) s_long[ts_slot(i)] = (c * C + i) < n ? seg[c * C + i] : ~0ull;
+                    __syncthreads();
+                    if (lk == LC) sort_padded_lds<1024>(s_long, LC, tid);
+                    else merge_padded_lds<1024>(s_long, LC, tid);
+                    for (int i = tid; i < C; i += 1024)
+                        if (c * C + i < n) seg[c * C + i] = s_long[ts_slot(i)];
                     __syncthreads();
                 }
+            }
             for (int i = tid; i < n; i += 1024) {
                 const uint64_t v = seg[i];
                 point_list[b + i] = (uint32_t)v;

@@ -7,8 +7,9 @@
 //    and one workgroup barrier per S steps).  Stage k = 2^lk merges runs of k/2; step 2^a compares elements whose indices differ in bit a; the
 //    run direction is bit lk of the index (the last stage, lk = log2(length), is ascending everywhere).
 //  * ascending_step: the same sorter with every comparator ascending (each merge stage starts by comparing element i of the lower run
-//    with its MIRROR in the upper run), so entries at or beyond n never take part: no padding, any n.  One step per barrier; used on
-//    segments that are sorted in place in HBM.
+//    with its MIRROR in the upper run), so entries at or beyond n never take part: no padding, any n.  Used on segments too long for LDS,
+//    as a hybrid: chunks of 2^lc entries are sorted in LDS; of every later stage only the steps whose distance is at least a chunk run
+//    on the segment in HBM, the rest of the stage is an ascending merge of each chunk in LDS again (ts_sort_hybrid below is the schedule).
 #pragma once
 #include <stdint.h>
 
@@ -127,6 +128,36 @@ void ts_sort_blocked(uint64_t *s, int n, uint64_t *pad)
             a -= S;
         }
     for (int i = 0; i < n; i++) s[i] = pad[ts_slot(i)];
+}
+// the hybrid schedule of sort_long_lists' HBM branch with chunks of 2^lc entries (the kernel uses lc = 14); pad = scratch of ts_slot(2^lc)
+void ts_sort_hybrid(uint64_t *s, int n, uint64_t *pad, int lc)
+{
+    using namespace envgs;
+    const int C = 1 << lc;
+    int lp = lc;
+    while ((1 << lp) < n) lp++;
+    auto load = [&](int c) { for (int i = 0; i < C; i++) pad[ts_slot(i)] = (c * C + i) < n ? s[c * C + i] : ~0ull; };
+    auto store = [&](int c) { for (int i = 0; i < C; i++) if (c * C + i < n) s[c * C + i] = pad[ts_slot(i)]; };
+    auto lds_steps = [&](bool full) {          // the chunk in LDS: sorted in full, or (later stages) only the ascending merge of its distances below a chunk
+        if (full) {
+            for (int g = 0; g < (C >> TS_S); g++) bitonic_first(pad, g, lc);
+            for (int lk = TS_S + 1; lk <= lc; lk++)
+                for (int a = lk - 1; a >= 0;) { const int S = ts_chunk(a);
+                    for (int g = 0; g < (C >> S); g++) { if (S == 4) bitonic_group<4>(pad, g, lk, a, lc); else if (S == 3) bitonic_group<3>(pad, g, lk, a, lc); else if (S == 2) bitonic_group<2>(pad, g, lk, a, lc); else bitonic_group<1>(pad, g, lk, a, lc); }
+                    a -= S; }
+        } else {
+            for (int a = lc - 1; a >= 0;) { const int S = ts_chunk(a);
+                for (int g = 0; g < (C >> S); g++) { if (S == 4) bitonic_group<4>(pad, g, lc, a, lc); else if (S == 3) bitonic_group<3>(pad, g, lc, a, lc); else if (S == 2) bitonic_group<2>(pad, g, lc, a, lc); else bitonic_group<1>(pad, g, lc, a, lc); }
+                a -= S; }
+        }
+    };
+    const int nchunks = (n + C - 1) / C;
+    for (int c = 0; c < nchunks; c++) { load(c); lds_steps(true); store(c); }
+    for (int lk = lc + 1; lk <= lp; lk++) {
+        for (int q = 0; q <= lk - lc - 1; q++)
+            for (int idx = 0; idx < (1 << (lp - 1)); idx++) ascending_step(s, n, lk, q, idx);
+        for (int c = 0; c < nchunks; c++) { load(c); lds_steps(false); store(c); }
+    }
 }
 void ts_sort_ascending(uint64_t *s, int n)
 {

@@ -43,10 +43,10 @@ def _assert_lists_equal(saved, ref):
     np.testing.assert_array_equal(saved["point_list"].cpu().numpy().view(np.uint32)[:N], ref["point_list"])
 
 
-@pytest.mark.parametrize("P, lo, hi", [(1500, 0, 4096), (6000, 4096, 8192), (12000, 8192, 16384), (30000, 16384, 1 << 30)])
+@pytest.mark.parametrize("P, lo, hi", [(1500, 0, 4096), (6000, 4096, 8192), (12000, 8192, 16384), (30000, 16384, 32768), (150000, 131072, 1 << 30)])
 def test_long_tile_lists(P, lo, hi):
     """Four tiles, every surfel large: lists of ~P/1.1 entries per tile -- one per-tile LDS sort (4096 / 8192 entries), the 16 384-entry
-    LDS sort of the long-list kernel, and a segment sorted in place in HBM."""
+    LDS sort of the long-list kernel, and segments sorted chunk by chunk (2 chunks / 9 chunks, four merge stages wider than a chunk)."""
     H = W = 32
     g, cam = small_scene(P=P, H=H, W=W, seed=5, C=3, sh=False, scale_mul=40.0)
     outs, saved, ref = _run(g, cam, H, W)

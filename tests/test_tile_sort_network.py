@@ -25,6 +25,7 @@ def net():
     p64 = ctypes.POINTER(ctypes.c_uint64)
     lib.ts_sort_blocked.argtypes = [p64, ctypes.c_int, p64]
     lib.ts_sort_ascending.argtypes = [p64, ctypes.c_int]
+    lib.ts_sort_hybrid.argtypes = [p64, ctypes.c_int, p64, ctypes.c_int]
     return lib
 
 
@@ -52,3 +53,20 @@ def test_both_networks_sort_every_length(net, kind):
         b = k.copy()
         net.ts_sort_ascending(b.ctypes.data_as(p64), n)
         np.testing.assert_array_equal(b, want, err_msg="all-ascending network, n=%d" % n)
+
+
+@pytest.mark.parametrize("lc", [4, 5, 7, 14])
+def test_hybrid_schedule_for_lists_beyond_one_lds_array(net, lc):
+    """sort_long_lists' schedule for segments longer than its LDS array (chunks of 2^lc entries sorted / merged in LDS, only the steps
+    whose distance is at least a chunk run on the whole segment) -- with small chunks, so that many stages are 'wide', and at the kernel's
+    own chunk size."""
+    rng = np.random.default_rng(lc)
+    p64 = ctypes.POINTER(ctypes.c_uint64)
+    lengths = [1, 2, 15, 16, 17, 31, 33, 100, 255, 256, 257, 777, 1024, 1500, 4097] if lc < 14 else [16385, 40000, 100000]
+    for n in lengths:
+        for kind in ("random", "ties"):
+            k = _keys(n, kind, rng)
+            a = k.copy()
+            pad = np.zeros((1 << lc) + (1 << lc) // 32 + 64, dtype=np.uint64)
+            net.ts_sort_hybrid(a.ctypes.data_as(p64), n, pad.ctypes.data_as(p64), lc)
+            np.testing.assert_array_equal(a, np.sort(k), err_msg="hybrid schedule, chunk 2^%d, n=%d" % (lc, n))
