@@ -43,7 +43,9 @@ def pmc():
     out = {"_how": "rocprofv3 --pmc FETCH_SIZE --kernel-trace / rocprofv3 --pmc WRITE_SIZE --kernel-trace (two separate passes, no other trace domains) -- "
                    "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-render on MI355X; per-launch averages. Units per MI355X_MICROARCH.md: counters are KB; on gfx950 "
                    "FETCH_SIZE reports 1/2 of the bytes of 16 B/lane reads, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024. WRITE_SIZE is uncalibrated "
-                   "(scattered 4-8 B stores are counted at 32 B granularity).", "kernels": {}}
+                   "(scattered 4-8 B stores are counted at 32 B granularity). Calibrated in round 3 (profiles/r03_fetch_calibration.txt): FETCH_SIZE = read requests x 64 B -- a coalesced "
+                   "stream issues 128 B requests (hence the x2), a scattered 16 / 32 B gather ONE request per lane-access, so for the gather-dominated tracer kernels "
+                   "(sort_composite_fwd, register_hits, batch_surfel_bwd) hbm_bytes over-states the reads by up to 2x; fetch_requests = FETCH_SIZE*1024/64 is exact for every kernel.", "kernels": {}}
     def pick(d, k):                         # exact name, or any template instantiation of it (kernel<...>), launches pooled
         vals = []
         for name, v in d.items():
@@ -54,7 +56,7 @@ def pmc():
         fv_, wv_ = pick(f, k), pick(w, k)
         if fv_:
             fv = sum(fv_) / len(fv_); wv = sum(wv_) / len(wv_) if wv_ else 0
-            out["kernels"][v] = {"FETCH_SIZE_KB": round(fv, 1), "WRITE_SIZE_KB": round(wv, 1), "hbm_bytes": int((2 * fv + wv) * 1024)}
+            out["kernels"][v] = {"FETCH_SIZE_KB": round(fv, 1), "WRITE_SIZE_KB": round(wv, 1), "hbm_bytes": int((2 * fv + wv) * 1024), "fetch_requests": int(fv * 1024 / 64)}
     # every other counter pass (gpurun_out/pmc_<anything>/**/*counter_collection.csv): per-launch averages per kernel
     import glob
     other = collections.defaultdict(lambda: collections.defaultdict(list))
