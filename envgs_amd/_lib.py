@@ -70,6 +70,7 @@ SYMBOLS = {
     "envgs_bvh_build": (c_int, [ctypes.c_int32, _P, _P, _P, _P, c_size_t, ctypes.c_int32, _P]),
     "envgs_trace_stack_spill_ints": (c_size_t, [ctypes.c_int32]),
     "envgs_trace_ray_sort_temp_bytes": (c_size_t, [ctypes.c_int32]),
+    "envgs_trace_ray_order": (c_int, [ctypes.c_int32, _P, _P, _P, ctypes.c_int32, _P, _P, _P, c_size_t, _P]),
     "envgs_trace_forward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 22 + [ctypes.POINTER(TraceLists), _P]),
     "envgs_trace_backward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 35 + [ctypes.POINTER(TraceLists), _P]),
     "envgs_sh_colors_forward": (c_int, [ctypes.c_int32] * 4 + [_P] * 7 + [_P]),

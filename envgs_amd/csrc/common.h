@@ -156,6 +156,11 @@ size_t scan_temp_bytes(int n);
 size_t sort_temp_bytes(uint32_t n, int width, int height);
 int launch_bin(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const int32_t *radii, uint64_t *tile_pairs,
                uint64_t *keys_sorted, uint32_t *point_list, void *bin_temp, size_t bin_temp_bytes, uint32_t *ranges, hipStream_t stream);
+size_t key_sort_temp_bytes(int n);
+int launch_key_sort(int n, const uint64_t *keys_in, uint64_t *keys_out, int top_bit, void *temp, size_t temp_bytes, hipStream_t stream);
+size_t ray_sort_temp_bytes(int R);
+int launch_ray_sort(int R, const float *ray_o, const float *ray_d, const float4 *nodes, int P, uint64_t *pairs, uint32_t *order, void *temp,
+                    size_t temp_bytes, hipStream_t stream);
 int launch_render_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const uint32_t *point_list, const float *geom,
                       const float *colors, const float *bg, float *out_color, float *allmap, float *final_T,
                       int32_t *n_contrib, float *weight, hipStream_t stream, uint8_t *audit_contrib = nullptr, int audit_lmax = 0, int colors_f16 = 0,

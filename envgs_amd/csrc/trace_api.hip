@@ -4,7 +4,6 @@
 
 #include <mutex>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace envgs {
 
@@ -53,12 +52,15 @@ static void ray_layout(const envgs_trace_cfg *cfg, int *rh, int *rw)
 
 extern "C" {
 
-size_t envgs_trace_ray_sort_temp_bytes(int32_t num_rays)
+size_t envgs_trace_ray_sort_temp_bytes(int32_t num_rays) { return ray_sort_temp_bytes(num_rays); }
+
+int envgs_trace_ray_order(int32_t num_rays, const float *ray_o, const float *ray_d, const float *nodes, int32_t P, uint64_t *pairs,
+                          uint32_t *order, void *temp, size_t temp_bytes, void *stream)
 {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned *)nullptr, (unsigned *)nullptr, (const unsigned *)nullptr, (unsigned *)nullptr,
-                                    (size_t)(num_rays > 0 ? num_rays : 1), 0u, 31u);
-    return bytes;
+    if (num_rays < 0 || P < 0) return ENVGS_ERR_BAD_ARG;
+    if (num_rays == 0) return 0;
+    if (!ray_o || !ray_d || !pairs || !order || !temp || (P > 0 && !nodes)) return ENVGS_ERR_BAD_ARG;
+    return launch_ray_sort(num_rays, ray_o, ray_d, (const float4 *)nodes, P, pairs, order, temp, temp_bytes, (hipStream_t)stream);
 }
 
 // one slab per persistent wavefront of the collection kernels, for each of the (at most two) batch segments that run concurrently
@@ -117,15 +119,15 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         A.hits = (uint2 *)L->hit_lists; A.hit_cnt = L->hit_cnt; A.n_used = L->n_used; A.cap = L->cap; A.stack_spill = L->stack_spill;
         A.surf_cnt = L->surf_cnt; A.surf_off = L->surf_off; A.surf_acc = (unsigned long long *)L->surf_acc;
         if (L->ray_keys && L->ray_order && L->ray_sort_temp && !(A.exp & 64)) {
-            // coherence sort of the rays (keys / values double-buffered in ray_keys / ray_order: 2R words each)
+            // coherence sort of the rays: (key, ray id) pairs bucketed and sorted per bucket (raster_bin.hip: launch_ray_sort); the pairs use
+            // ray_keys (2R words = R pairs), the order lands in the second half of ray_order
             const int R = cfg->num_rays;
-            hipLaunchKernelGGL(make_ray_keys, dim3((R + 255) / 256), dim3(256), 0, stream, R, ray_o, ray_d, A.nodes, cfg->P, L->ray_keys, L->ray_order);
+            const int rc = launch_ray_sort(R, ray_o, ray_d, A.nodes, cfg->P, (uint64_t *)L->ray_keys, L->ray_order + R, L->ray_sort_temp,
+                                           L->ray_sort_temp_bytes, stream);
+            if (rc) return rc;
             ENVGS_CHECK_LAUNCH(dcfg, stream);
-            size_t tb = L->ray_sort_temp_bytes;
-            e = rocprim::radix_sort_pairs(L->ray_sort_temp, tb, L->ray_keys, L->ray_keys + R, L->ray_order, L->ray_order + R, (size_t)R, 0u, 31u, stream);
-            if (e != hipSuccess) return (int)e;
             A.order = L->ray_order + R;
-            A.long_list = L->ray_keys;                        // the unsorted keys are dead now: scratch for the queue of long rays
+            A.long_list = L->ray_keys;                        // the pairs are dead now: scratch for the queue of long rays
         }
         {   // 40-bit fixed-point weight: enough integer bits that even a surfel seen with w = 1 by every ray cannot overflow
             int ib = 1;

@@ -12,7 +12,6 @@
 #include "common.h"
 
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "../../include/envgs_trace.h"
 
@@ -39,8 +38,7 @@ static BvhTemp carve(int P, void *base)
     BvhTemp t;
     const int n = P > 0 ? P : 1;
     const int nblocks = (n + 255) / 256;
-    size_t sort_bytes = 0;
-    (void)rocprim::radix_sort_keys(nullptr, sort_bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)n, 0u, 62u);
+    const size_t sort_bytes = key_sort_temp_bytes(n);
     char *p = (char *)base;
     size_t off = 0;
     auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align_up(bytes); return (void *)r; };
@@ -351,9 +349,10 @@ int envgs_bvh_build(int32_t P, const float *vertices, const float *opacities, fl
     ENVGS_CHECK_LAUNCH(cfg, stream);
     hipLaunchKernelGGL(morton_keys, dim3(nblocks), dim3(256), 0, stream, P, t.leaf_box, t.bounds, t.keys_in);
     ENVGS_CHECK_LAUNCH(cfg, stream);
-    size_t sb = t.sort_bytes;
-    hipError_t e = rocprim::radix_sort_keys(t.sort_temp, sb, t.keys_in, t.keys_out, (size_t)P, 0u, 62u, stream);
-    if (e != hipSuccess) return (int)e;
+    // Morton code << 32 | surfel id, ascending: buckets by the code's top bits, one LDS sort per bucket (raster_bin.hip: launch_key_sort)
+    const int rc_sort = launch_key_sort(P, t.keys_in, t.keys_out, 62, t.sort_temp, t.sort_bytes, stream);
+    if (rc_sort) return rc_sort;
+    ENVGS_CHECK_LAUNCH(cfg, stream);
     hipLaunchKernelGGL(st_level0, dim3(nblocks), dim3(256), 0, stream, P, t.keys_out, t.leaf_box, t.st);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     for (int k = 0; k + 1 < t.levels; k += 2) {

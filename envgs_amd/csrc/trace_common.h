@@ -598,8 +598,6 @@ __global__ void __launch_bounds__(256) make_surfel_records(int P, float mod, con
                                                            const float *__restrict__ rots, const float *__restrict__ opac, float *__restrict__ srec);
 __global__ void __launch_bounds__(64) trace_fwd(const TraceArgs A, const int ray_h, const int ray_w);
 __global__ void __launch_bounds__(64) trace_bwd(const TraceArgs A, const int ray_h, const int ray_w);
-__global__ void __launch_bounds__(256) make_ray_keys(int R, const float *__restrict__ ray_o, const float *__restrict__ ray_d,
-                                                     const float4 *__restrict__ nodes, int P, unsigned *__restrict__ keys, unsigned *__restrict__ vals);
 #ifdef ENVGS_DIAG
 __global__ void __launch_bounds__(64) collect_hits(const TraceArgs A);
 __global__ void __attribute__((amdgpu_waves_per_eu(8, 8))) __launch_bounds__(64)

@@ -83,8 +83,8 @@ typedef struct envgs_trace_lists {
     uint32_t *surf_off;      /* (P,8) inclusive prefix sum of surf_cnt; the last entry = number of gradient records */
     void *scan_temp;         /* envgs_raster_scan_temp_bytes(8*P) bytes */
     size_t scan_temp_bytes;
-    uint32_t *ray_keys;      /* (2R) scratch of the ray coherence sort (keys, double buffered); NULL disables the sort */
-    uint32_t *ray_order;     /* (2R) ray permutation (double buffered); the second half holds the order the kernels use */
+    uint32_t *ray_keys;      /* (2R words, 8 B aligned) scratch of the ray coherence sort: R (key << 32 | ray) pairs; NULL disables the sort */
+    uint32_t *ray_order;     /* (2R) the second half receives the ray permutation the kernels use (the first half is spare) */
     void *ray_sort_temp;     /* envgs_trace_ray_sort_temp_bytes(R) bytes */
     size_t ray_sort_temp_bytes;
     float *records;          /* backward only: (num_records, 64) one 256 B gradient record per (batch, surfel) entry, grouped by surfel */
@@ -144,6 +144,11 @@ ENVGS_API int envgs_bvh_build(int32_t P, const float *vertices, const float *opa
  */
 ENVGS_API size_t envgs_trace_stack_spill_ints(int32_t num_rays);
 ENVGS_API size_t envgs_trace_ray_sort_temp_bytes(int32_t num_rays);
+/* The coherence order envgs_trace_forward forms its 64-ray batches in, on its own (parity tests; a caller that wants to reuse one order
+ * for several traces): pairs (num_rays x uint64, scratch) ends up holding every ray's (key << 32 | ray id), order (num_rays) the ray ids
+ * sorted by (key, id).  nodes / P: the acceleration structure whose root box normalises the origins (P == 0: the unit box). */
+ENVGS_API int envgs_trace_ray_order(int32_t num_rays, const float *ray_o, const float *ray_d, const float *nodes, int32_t P,
+                                    uint64_t *pairs, uint32_t *order, void *temp, size_t temp_bytes, void *stream);
 ENVGS_API int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes,
                                   const float *ray_o, const float *ray_d,
                                   const float *means3D, const float *scales, const float *rotations, const float *opacities,

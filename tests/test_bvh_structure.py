@@ -30,7 +30,8 @@ def _build(P, seed, clustered=False):
     return nodes.cpu().numpy(), v.numpy()
 
 
-@pytest.mark.parametrize("P,clustered", [(1, False), (2, False), (3, False), (5, False), (64, False), (1000, False), (777, True)])
+@pytest.mark.parametrize("P,clustered", [(1, False), (2, False), (3, False), (5, False), (64, False), (1000, False), (777, True),
+                                         (12000, True), (40000, True)])      # half of the surfels on ONE Morton code: a 6 000- / 20 000-entry bucket of the key sort (LDS / chunked)
 def test_binary_and_wide_nodes(P, clustered):
     flat, v = _build(P, 11 + P, clustered)
     ni = max(P - 1, 1)
