@@ -295,8 +295,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
         if (rcz) return rcz;
     }
     if (cfg->num_rays == 0 || cfg->P == 0) return 0;
-    if (!nodes || !ray_o || !ray_d || !srec || !counters || !rgb || !dpt || !acc || !norm || !aux || !final_T || !dL_drgb || !dL_ddpt ||
-        !dL_dacc || !dL_dnorm || !dL_daux || !geo_rec || !dmeans3D || !dscales || !drots || !dopacities || !dray_o || !dray_d || !rotations || !bg)
+    if (!nodes || !ray_o || !ray_d || !srec || !counters || !rgb || !dpt || !acc || !norm || !aux || !final_T || !geo_rec || !dmeans3D || !dscales || !drots || !dopacities || !dray_o || !dray_d || !rotations || !bg)
         return ENVGS_ERR_BAD_ARG;
     if (cfg->sh_coeffs > 0 ? (!shs || !dshs) : (!colors_precomp || !dcolors)) return ENVGS_ERR_BAD_ARG;
     e = hipMemsetAsync(counters, 0, sizeof(uint32_t), stream);      // only the ray-fetch counter: [1] (largest list) and the stats stay readable

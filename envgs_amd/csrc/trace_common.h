@@ -365,10 +365,13 @@ __device__ __forceinline__ void bwd_load_ray(const TraceArgs &A, int r, BwdRay &
 {
     B.ox = A.ray_o[3 * r]; B.oy = A.ray_o[3 * r + 1]; B.oz = A.ray_o[3 * r + 2];
     B.dx = A.ray_d[3 * r]; B.dy = A.ray_d[3 * r + 1]; B.dz = A.ray_d[3 * r + 2];
-    B.gR0 = A.g_rgb[3 * r]; B.gR1 = A.g_rgb[3 * r + 1]; B.gR2 = A.g_rgb[3 * r + 2];
-    B.gD = A.g_dpt[r]; B.gA = A.g_acc[r];
-    B.gN0 = A.g_norm[3 * r]; B.gN1 = A.g_norm[3 * r + 1]; B.gN2 = A.g_norm[3 * r + 2];
-    B.gX0 = A.g_aux[2 * r]; B.gX1 = A.g_aux[2 * r + 1];
+    // an upstream gradient the caller did not pass (NULL) is zero: no buffer of zeros has to be made for outputs the loss does not use
+    B.gR0 = B.gR1 = B.gR2 = B.gD = B.gA = B.gN0 = B.gN1 = B.gN2 = B.gX0 = B.gX1 = 0.f;
+    if (A.g_rgb) { B.gR0 = A.g_rgb[3 * r]; B.gR1 = A.g_rgb[3 * r + 1]; B.gR2 = A.g_rgb[3 * r + 2]; }
+    if (A.g_dpt) B.gD = A.g_dpt[r];
+    if (A.g_acc) B.gA = A.g_acc[r];
+    if (A.g_norm) { B.gN0 = A.g_norm[3 * r]; B.gN1 = A.g_norm[3 * r + 1]; B.gN2 = A.g_norm[3 * r + 2]; }
+    if (A.g_aux) { B.gX0 = A.g_aux[2 * r]; B.gX1 = A.g_aux[2 * r + 1]; }
     B.fT = A.f_T[r];
     const float bg0 = 0 < A.bg_len ? A.bg[0] : 0.f, bg1 = 1 < A.bg_len ? A.bg[1] : 0.f, bg2 = 2 < A.bg_len ? A.bg[2] : 0.f;
     B.bgdot = bg0 * B.gR0 + bg1 * B.gR1 + bg2 * B.gR2;

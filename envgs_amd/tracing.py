@@ -276,7 +276,7 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
     P, R = cfg.P, cfg.num_rays
     dev = saved["ro"].device
     f32 = dict(dtype=torch.float32, device=dev)
-    z = lambda g, c: torch.zeros(R, c, **f32) if g is None else _f32c(g).reshape(R, c)
+    z = lambda g, c: None if g is None else _f32c(g).reshape(R, c)          # an output the loss does not use: NULL = zero upstream gradient
     g_rgb, g_dpt, g_acc, g_norm, g_aux = z(g_rgb, 3), z(g_dpt, 1), z(g_acc, 1), z(g_norm, 3), z(g_aux, 2)
     shs, others = saved["shs"], saved["others"]
     geo_rec = torch.empty(max(P, 1), 16, **f32)

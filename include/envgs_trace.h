@@ -162,6 +162,7 @@ ENVGS_API int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes
  * differentiable: easyvolcap/models/samplers/envgs_sampler.py:454-455).  Bounce stages are detached.
  * Outputs are zeroed here.  dshs (P,sh_coeffs,3) or dcolors (P,3); dothers may be NULL; dgrads3D (P,3) receives the
  * densification signal (= dL/dmeans3D; consumer: envgs_sampler.py:357-361).
+ * Any of the five upstream gradients dL_drgb .. dL_daux may be NULL: an output the loss does not use has a zero gradient.
  */
 ENVGS_API int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes,
                                    const float *ray_o, const float *ray_d,
