@@ -175,6 +175,9 @@ int launch_project_bwd(const envgs_raster_cfg *cfg, const float *geom, const flo
                        const float *grad_rec, float *dmeans3D, float *dmeans2D, float *dscales, float *drots, float *dshs,
                        float *dcolors, float *dopacities, float *dtransmat_precomp, hipStream_t stream);
 
+int launch_sh_record_bwd(int P, int D, const float *means3D, const float *shs, const float *campos, const uint8_t *clamped, const int32_t *radii,
+                         const float *grad_rec, float *dmeans3D, float *dshs, hipStream_t stream);
+
 __host__ __device__ inline int tile_bits(int width, int height) {
     int tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
     int b = 0;

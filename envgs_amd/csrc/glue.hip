@@ -218,6 +218,70 @@ sh_colors_bwd_q16(int P, int D, int S, const float *__restrict__ means, const fl
     }
 }
 
+// The rasterizer's in-kernel SH colours (csrc/raster_project.hip) differentiated the same way: dL/dcolour comes out of the per-surfel gradient
+// record R7 accumulated (words 15..17), surfels that were not rendered get zeros; dshs is written, the view-direction term is ADDED to the
+// position gradient project_surfels_bwd has just written.  (One lane per surfel inside project_surfels_bwd: 185 us for 300 k surfels, every
+// 4 B access of the 192 B blocks on its own cache line; this kernel + the SH-free project_surfels_bwd: see DESIGN.md section 4.)
+__global__ void __launch_bounds__(256)
+sh_record_bwd_q16(int P, int D, const float *__restrict__ means, const float *__restrict__ shs, const float *__restrict__ campos,
+                  const uint8_t *__restrict__ clamped, const int32_t *__restrict__ radii, const float *__restrict__ grad_rec,
+                  float *__restrict__ dmeans, float *__restrict__ dshs)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, i = t >> 2, q = t & 3;
+    const bool live = i < P;
+    const int ii = live ? i : 0;
+    const bool vis = radii[ii] > 0;
+    const float *g = grad_rec + (size_t)ii * GREC + 15;
+    const float gc[3] = {(vis && !clamped[3 * ii]) ? g[0] : 0.f, (vis && !clamped[3 * ii + 1]) ? g[1] : 0.f, (vis && !clamped[3 * ii + 2]) ? g[2] : 0.f};
+    const float dx = means[3 * ii] - campos[0], dy = means[3 * ii + 1] - campos[1], dz = means[3 * ii + 2] - campos[2];
+    const float sum2 = dx * dx + dy * dy + dz * dz, il = 1.0f / sqrtf(sum2);
+    const float x = dx * il, y = dy * il, z = dz * il;
+    float b[16], gx[16], gy[16], gz[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) b[k] = 0.f;
+    basis16(D, x, y, z, b);
+    basis16_grad(D, x, y, z, gx, gy, gz);
+    const int nb = (D + 1) * (D + 1);
+    float bq[4], gxq[4], gyq[4], gzq[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const bool in = (4 * q + m) < nb;
+        bq[m] = in ? (q == 0 ? b[m] : q == 1 ? b[4 + m] : q == 2 ? b[8 + m] : b[12 + m]) : 0.f;
+        gxq[m] = in ? (q == 0 ? gx[m] : q == 1 ? gx[4 + m] : q == 2 ? gx[8 + m] : gx[12 + m]) : 0.f;
+        gyq[m] = in ? (q == 0 ? gy[m] : q == 1 ? gy[4 + m] : q == 2 ? gy[8 + m] : gy[12 + m]) : 0.f;
+        gzq[m] = in ? (q == 0 ? gz[m] : q == 1 ? gz[4 + m] : q == 2 ? gz[8 + m] : gz[12 + m]) : 0.f;
+    }
+    const float4 *sh4 = reinterpret_cast<const float4 *>(shs + (size_t)ii * 48) + 3 * q;
+    const float4 x0 = sh4[0], x1 = sh4[1], x2 = sh4[2];
+    const float xs[12] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
+    float o[12], sd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < 12; f++) { o[f] = bq[f / 3] * gc[f % 3]; sd[f / 3] += xs[f] * gc[f % 3]; }
+    if (live) {
+        float4 *d4 = reinterpret_cast<float4 *>(dshs + (size_t)i * 48) + 3 * q;
+        d4[0] = make_float4(o[0], o[1], o[2], o[3]); d4[1] = make_float4(o[4], o[5], o[6], o[7]); d4[2] = make_float4(o[8], o[9], o[10], o[11]);
+    }
+    float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; m++) { ddx += gxq[m] * sd[m]; ddy += gyq[m] * sd[m]; ddz += gzq[m] * sd[m]; }
+    ddx = quad_sum(ddx); ddy = quad_sum(ddy); ddz = quad_sum(ddz);
+    if (live && q == 0 && vis) {
+        const float inv3 = il * il * il;
+        dmeans[3 * i] += ((sum2 - dx * dx) * ddx - dy * dx * ddy - dz * dx * ddz) * inv3;
+        dmeans[3 * i + 1] += (-dx * dy * ddx + (sum2 - dy * dy) * ddy - dz * dy * ddz) * inv3;
+        dmeans[3 * i + 2] += (-dx * dz * ddx - dy * dz * ddy + (sum2 - dz * dz) * ddz) * inv3;
+    }
+}
+
+int launch_sh_record_bwd(int P, int D, const float *means3D, const float *shs, const float *campos, const uint8_t *clamped, const int32_t *radii,
+                         const float *grad_rec, float *dmeans3D, float *dshs, hipStream_t stream)
+{
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(sh_record_bwd_q16, dim3((4 * (size_t)P + 255) / 256), dim3(256), 0, stream, P, D, means3D, shs, campos, clamped, radii, grad_rec,
+                       dmeans3D, dshs);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ reflect
 __global__ void __launch_bounds__(256)
 reflect_fwd(int HW, float ratio, const float *__restrict__ allmap, const float *__restrict__ ray_o, const float *__restrict__ ray_d,

@@ -26,7 +26,7 @@ project_surfels_bwd(int P, int D, int M, int f16, int C, int W, int H, float mod
                     const float *__restrict__ campos, const float *__restrict__ grad_rec,
                     float *__restrict__ dmeans3D, float *__restrict__ dmeans2D, float *__restrict__ dscales,
                     float *__restrict__ drots, float *__restrict__ dshs, float *__restrict__ dcolors,
-                    float *__restrict__ dopacities, float *__restrict__ dtransmat_precomp)
+                    float *__restrict__ dopacities, float *__restrict__ dtransmat_precomp, int sh_split)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
@@ -120,7 +120,7 @@ project_surfels_bwd(int P, int D, int M, int f16, int C, int W, int H, float mod
 #undef VR
         }
 
-        if (shs) {
+        if (shs && !sh_split) {       // (sh_split: the SH part runs four lanes per surfel in sh_record_bwd_q16, right after this kernel)
             const float p0 = means3D[3 * i], p1 = means3D[3 * i + 1], p2 = means3D[3 * i + 2];
             const Feat sh = Feat{shs, f16 != 0}.at((size_t)i * M * 3);          // fp32 or fp16 storage, converted on load
             float *dsh = dshs + (size_t)i * M * 3;
@@ -174,7 +174,7 @@ project_surfels_bwd(int P, int D, int M, int f16, int C, int W, int H, float mod
         const float depth = T[8];
         dm2x = hack_x * depth * 0.5f * (float)W;
         dm2y = hack_y * depth * 0.5f * (float)H;
-    } else if (shs) {
+    } else if (shs && !sh_split) {
         float *dsh = dshs + (size_t)i * M * 3;
         for (int k = 0; k < M * 3; k++) dsh[k] = 0.f;
     }
@@ -203,11 +203,18 @@ int launch_project_bwd(const envgs_raster_cfg *cfg, const float *geom, const flo
     const int P = cfg->P;
     if (P <= 0) return 0;
     ProfScope prof_(K_PROJECT_BWD, stream);
+    // 16 fp32 SH coefficients per surfel (the usual layout): the SH part is split off into a kernel with four lanes per surfel
+    const int sh_split = (shs && cfg->sh_coeffs == 16 && !cfg->feature_f16 && dmeans3D && dshs && clamped && campos) ? 1 : 0;
     hipLaunchKernelGGL(project_surfels_bwd, dim3((P + 255) / 256), dim3(256), 0, stream, P, cfg->sh_degree, cfg->sh_coeffs, cfg->feature_f16,
                        cfg->channels, cfg->width, cfg->height, cfg->scale_modifier, geom, means3D, scales, rotations, shs,
                        clamped, transmat_precomp, radii, viewmatrix, projmatrix, campos, grad_rec, dmeans3D, dmeans2D,
-                       dscales, drots, dshs, dcolors, dopacities, dtransmat_precomp);
+                       dscales, drots, dshs, dcolors, dopacities, dtransmat_precomp, sh_split);
     ENVGS_CHECK_LAUNCH(cfg, stream);
+    if (sh_split) {
+        const int rc = launch_sh_record_bwd(P, cfg->sh_degree, means3D, shs, campos, clamped, radii, grad_rec, dmeans3D, dshs, stream);
+        if (rc) return rc;
+        ENVGS_CHECK_LAUNCH(cfg, stream);
+    }
     return 0;
 }
 
