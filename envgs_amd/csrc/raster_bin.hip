@@ -17,7 +17,11 @@
 //                       sort_long_lists (16 384 entries in LDS; beyond that chunks go through LDS and only the wide merge steps run in HBM)
 //
 // Per instance that is 8 B written + 8 B read + 12 B written.  All integer work: point_list / keys_sorted / ranges are bit-exact against
-// the oracle's stable sort (tests/test_raster_parity.py).
+// the oracle's stable sort (tests/test_raster_parity.py, tests/test_tile_binning.py).
+//
+// The same machinery (histogram rows -> column scan -> bucket scan -> scatter -> per-bucket LDS sort) also orders the tracer's rays
+// (launch_ray_sort: buckets = top bits of the coherence key) and the LBVH's Morton keys (launch_key_sort), at the end of this file: the
+// library contains no other scan or sort.
 #include "common.h"
 #include "ray_key.h"
 #include "tile_sort.h"
