@@ -59,6 +59,7 @@ def sh_colors(means3D, shs, campos, sh_degree, specular, roughness):
 class _Reflect(torch.autograd.Function):
     @staticmethod
     def forward(ctx, allmap, ray_o, ray_d, viewmatrix, depth_ratio):
+        ctx.set_materialize_grads(False)          # outputs the loss does not use arrive as None (= NULL upstream pointer), not as buffers of zeros
         lib = _lib.load()
         if allmap.device.type != "cuda":
             raise RuntimeError("envgs_amd.fused needs tensors on the GPU; there is no CPU path")
@@ -98,6 +99,7 @@ def reflect(allmap, ray_o, ray_d, viewmatrix, depth_ratio=0.0):
 class _SurfaceNormal(torch.autograd.Function):
     @staticmethod
     def forward(ctx, allmap, viewmatrix, fx, fy, depth_ratio):
+        ctx.set_materialize_grads(False)          # outputs the loss does not use arrive as None (= NULL upstream pointer), not as buffers of zeros
         lib = _lib.load()
         if allmap.device.type != "cuda":
             raise RuntimeError("envgs_amd.fused needs tensors on the GPU; there is no CPU path")

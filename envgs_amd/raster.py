@@ -280,6 +280,7 @@ def make_package(C):
     class _RasterizeGaussians(torch.autograd.Function):
         @staticmethod
         def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+            ctx.set_materialize_grads(False)          # outputs the loss does not use arrive as None (= NULL upstream pointer), not as buffers of zeros
             none = lambda t: None if (t is None or t.numel() == 0) else t
             outs, saved = rasterize_forward(C, means3D, _store(none(sh)), _store(none(colors_precomp)), opacities, none(scales),
                                             none(rotations), none(cov3Ds_precomp), raster_settings)

@@ -364,6 +364,7 @@ class _TraceSurfels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ray_o, ray_d, v, means3D, grads3D, shs, colors_precomp, others_precomp, opacities, scales, rotations,
                 cov3D_precomp, tracer_settings, start_from_first, nodes, caps=None):
+        ctx.set_materialize_grads(False)          # outputs the loss does not use arrive as None (= NULL upstream pointer), not as buffers of zeros
         none = lambda t: None if (t is None or t.numel() == 0) else t
         from .raster import _store                       # fp16 feature storage selected (envgs_amd.set_feature_storage): half copies made HERE, fp32 gradients
         outs, saved = trace_forward(nodes, ray_o, ray_d, means3D, _store(none(shs)), _store(none(colors_precomp)), none(others_precomp), opacities,
