@@ -201,16 +201,19 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             S.batch0 = (int)((long long)nbatch_all * sg / nseg);
             S.batch1 = (int)((long long)nbatch_all * (sg + 1) / nseg);
             const int rays_seg = (S.batch1 - S.batch0) * 64;
+            // (the later segment's collection runs beside the first one's sort pass for most of its life: one more workgroup per CU for it --
+            //  4+4 / 4+5 / 4+6 / 3+5 / 5+4 workgroups: 9.54 / 9.48 / 9.57 / 9.62 / 9.59 ms per step)
+            const int seg_wgs = (nseg > 1 && sg > 0 && debug_switch(ENVGS_DBG_COLLECT_WGS) <= 0) ? coop_wgs + 1 : coop_wgs;
             {
                 ProfScope p1(K_TRACE_COLLECT, st);
 #ifndef ENVGS_DIAG
                 // product library: the cooperative collection is the only collection kernel (without a coherence sort its batches are the
                 // rays in the order given: correct, slower)
-                hipLaunchKernelGGL(collect_hits_coop, dim3(persistent_grid(rays_seg, coop_wgs)), dim3(256), 0, st, S, S.nodes,
+                hipLaunchKernelGGL(collect_hits_coop, dim3(persistent_grid(rays_seg, seg_wgs)), dim3(256), 0, st, S, S.nodes,
                                    S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4, S.srec);
 #else
                 if (S.order && !(S.exp & 512) && !(S.exp & 16) && !(S.exp & 2048))
-                    hipLaunchKernelGGL(collect_hits_coop, dim3(persistent_grid(rays_seg, coop_wgs)), dim3(256), 0, st, S, S.nodes,
+                    hipLaunchKernelGGL(collect_hits_coop, dim3(persistent_grid(rays_seg, seg_wgs)), dim3(256), 0, st, S, S.nodes,
                                        S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4, S.srec);
                 else if (S.order && !(S.exp & 512) && !(S.exp & 16))
                     hipLaunchKernelGGL(collect_hits_packet4, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S, S.nodes,

@@ -174,7 +174,7 @@ ENVGS_API const char *envgs_prof_kernel_name(int kernel_id);
  */
 #define ENVGS_DBG_TRACE 0
 #define ENVGS_DBG_SEGMENTS 1
-#define ENVGS_DBG_COLLECT_WGS 2      /* workgroups per CU of the cooperative collection's persistent grid (0 = default: 4 with two segments in flight, 8 for a single one) */
+#define ENVGS_DBG_COLLECT_WGS 2      /* workgroups per CU of the cooperative collection's persistent grid (0 = default: 4 for the first and 5 for the second of two segments in flight, 8 for a single one) */
 #define ENVGS_DBG_COUNT 3
 ENVGS_API void envgs_debug_set(int32_t which, int32_t value);
 ENVGS_API int32_t envgs_debug_get(int32_t which);
