@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--feature-dtype", default="f32", choices=["f32", "f16"],
                     help="storage of the per-surfel feature arrays the extensions read (base colours / SH, env SH): f16 = BASELINE configs[4]'s storage variant "
                          "(fp32 master parameters in the optimizer, a half copy per step for the render path; arithmetic and gradients stay fp32)")
-    ap.add_argument("--keep-blas", action="store_true", help="do not let diff_surfel_tracing select rocBLAS for torch's tiny-K batched matmuls (INTEGRATION.md section 5)")
+    ap.add_argument("--prefer-rocblas", action="store_true", help="opt in to envgs_amd.prefer_rocblas() for the whole run (torch's tiny-K batched matmuls of the unchanged caller's get_disks, INTEGRATION.md section 5); the default run leaves torch's BLAS choice alone and times the reference-caller form under BOTH settings")
     ap.add_argument("--debug-trace", type=int, default=0, help="ENVGS_DBG_TRACE diagnostic switch mask (include/envgs_raster.h); reported in the JSON line")
     ap.add_argument("--diag", action="store_true", help="load the diagnostic build (A/B kernels of --debug-trace 8 / 16 / 512 / 2048; the product library rejects those switches)")
     ap.add_argument("--debug-collect-wgs", type=int, default=0, help="ENVGS_DBG_COLLECT_WGS diagnostic switch: workgroups per CU of the collection's persistent grid (default 8)")
@@ -140,8 +140,9 @@ def main():
 
     if args.torch_glue and args.caller == "fused":
         args.caller = "twin"
-    if args.keep_blas:
-        os.environ["ENVGS_KEEP_BLAS"] = "1"
+    if args.prefer_rocblas:
+        import envgs_amd as _ea
+        _ea.prefer_rocblas()
     from envgs_amd import dist as edist, synth, raster, tracing, _lib
     rank, world, local = edist.init_from_env()
     if world != args.gpus:
@@ -194,6 +195,9 @@ def main():
             mode["caller"] = c
             envgs_step.FUSED["on"] = c == "fused"
             envgs_step.REFERENCE_FORMS["on"] = c == "reference"
+            if c == "reference":
+                from tests import reference_caller          # the unchanged caller's expression forms: measurement material, kept outside the package
+                reference_caller.install()
         set_caller(args.caller)
         envgs_step.PREBUILD["on"] = not args.no_prebuild
         dnorm_hw = (torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)) / HW).to(dev)
@@ -211,9 +215,6 @@ def main():
     half = args.feature_dtype == "f16"
     import envgs_amd
     envgs_amd.set_feature_storage("f16" if half else "f32")      # half copies inside the autograd nodes: fp32 parameters in, fp32 gradients out
-    if half and envgs:
-        from envgs_amd import envgs_step as _es2
-        _es2.FEATURE_F16["on"] = True
 
     def settings(cam):
         return pkg.GaussianRasterizationSettings(
@@ -305,21 +306,40 @@ def main():
     # get_disks, render()'s regulariser maps + normal term, torch SH / reflection / blend) around the same two extensions -- what a user who only
     # swaps the packages pays.  A few steps, outside the timed region, reported in config.reference_caller_ms_per_step.
     ref_caller_ms = None
+    ref_caller_by_blas = None
     if envgs and args.caller != "reference" and not args.no_reference_caller:
         set_caller("reference")
-        for it in range(3):
-            step(args.warmup + args.steps + it)
-        sync_all()
-        tr_ = time.perf_counter()
-        nref = max(4, min(args.steps, 10))
-        for it in range(nref):
-            step(args.warmup + args.steps + 3 + it)
-        sync_all()
-        ref_caller_ms = (time.perf_counter() - tr_) / nref * 1e3
-        if world > 1:
-            tt = torch.tensor([ref_caller_ms], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            ref_caller_ms = float(tt.item())
+
+        def time_reference_form(base_it):
+            for it in range(3):
+                step(base_it + it)
+            sync_all()
+            tr_ = time.perf_counter()
+            nref = max(4, min(args.steps, 10))
+            for it in range(nref):
+                step(base_it + 3 + it)
+            sync_all()
+            ms = (time.perf_counter() - tr_) / nref * 1e3
+            if world > 1:
+                tt = torch.tensor([ms], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ms = float(tt.item())
+            return ms
+        blas_name = lambda: str(torch.backends.cuda.preferred_blas_library()).split(".")[-1].lower()
+        # importing the packages no longer touches torch's BLAS choice: the number a user who ONLY swaps the packages
+        # sees is the one under torch's own setting; the other one is what the one-line pin of INTEGRATION.md section 5 buys
+        ref_caller_by_blas = {}
+        first = blas_name()
+        ref_caller_ms = time_reference_form(args.warmup + args.steps)
+        ref_caller_by_blas[first] = round(ref_caller_ms, 3)
+        try:
+            other = "cublas" if "lt" in first or first == "default" else "cublaslt"
+            before = torch.backends.cuda.preferred_blas_library()
+            torch.backends.cuda.preferred_blas_library(other)
+            ref_caller_by_blas[blas_name()] = round(time_reference_form(args.warmup + args.steps + 40), 3)
+            torch.backends.cuda.preferred_blas_library(before)
+        except Exception as e:                                       # a torch build without the switch
+            ref_caller_by_blas["error"] = str(e)[:80]
         set_caller(args.caller)
         step(args.warmup + args.steps + 20)          # (back on the measured caller for the diagnostics below)
         sync_all()
@@ -481,8 +501,10 @@ def main():
                        "caller_glue": ("n/a (raster only)" if not envgs else {"fused": "fused HIP (envgs_amd.fused)", "twin": "torch expressions (envgs_amd/envgs_step.py)",
                                        "reference": "the unchanged EasyVolcap caller's expression forms (batched-matmul get_disks, render()'s regulariser maps + normal term)"}[args.caller]),
                        "reference_caller_ms_per_step": (None if ref_caller_ms is None else round(ref_caller_ms, 3)),
-                       "reference_caller_note": "the same step with the UNCHANGED EasyVolcap caller's expression forms around the same extensions (--caller reference), a few steps outside the timed region",
+                       "reference_caller_ms_by_torch_blas": ref_caller_by_blas,
+                       "reference_caller_note": "the same step with the UNCHANGED EasyVolcap caller's expression forms around the same extensions (--caller reference), a few steps outside the timed region; reference_caller_ms_per_step is under torch's OWN BLAS choice (importing the packages changes nothing process-wide), reference_caller_ms_by_torch_blas has it under both (cublas = rocBLAS, cublaslt = hipBLASLt; the one-line pin of INTEGRATION.md section 5)",
                        "torch_blas": str(torch.backends.cuda.preferred_blas_library()).split(".")[-1],
+                       "dist_backend": (dist.get_backend() if world > 1 else None),
                        "debug_switches": {"trace": args.debug_trace, "segments": args.debug_segments, "collect_wgs": args.debug_collect_wgs},
                        "allreduce_bytes_per_step": int(ar_bytes)},
             "train_mpix_per_s": round(value * HW / 1e6, 2),

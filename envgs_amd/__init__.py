@@ -16,3 +16,22 @@ def set_feature_storage(kind="f32"):
         raise ValueError("feature storage must be 'f32' or 'f16', got %r" % (kind,))
     from . import raster
     raster.FEATURE_STORAGE["f16"] = kind == "f16"
+
+
+def prefer_rocblas():
+    """OPT-IN (never called on import): select rocBLAS instead of hipBLASLt for torch's own matmuls in this process, announced once on the
+    `envgs_amd` logger.  Only the unchanged EasyVolcap caller's get_disks batched matmul cares (optix_utils.py:59: 8.7 -> 1.0 ms per step on
+    MI355X); the extensions contain no BLAS call.  Returns the previous setting (None if torch has no such switch / no ROCm device)."""
+    import logging
+    import torch
+    if not (torch.cuda.is_available() and getattr(torch.version, "hip", None)):
+        return None
+    log = logging.getLogger("envgs_amd")
+    try:
+        before = torch.backends.cuda.preferred_blas_library()
+        torch.backends.cuda.preferred_blas_library("cublas")          # "cublas" IS rocBLAS on ROCm builds ("cublaslt" = hipBLASLt)
+    except (RuntimeError, AttributeError, ValueError) as e:
+        log.warning("envgs_amd.prefer_rocblas: could not select rocBLAS for torch matmuls (%s)", e)
+        return None
+    log.warning("envgs_amd.prefer_rocblas: torch.backends.cuda.preferred_blas_library %s -> rocBLAS for this process", before)
+    return before

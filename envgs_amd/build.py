@@ -16,15 +16,17 @@ LIB = os.path.join(HERE, "libenvgs_hip.so")
 # backward) behind envgs_debug_set -- compiled with -DENVGS_DIAG from the three sources that mention them; tests and `bench.py --diag` load it,
 # the product library does not contain them.
 LIB_DIAG = os.path.join(HERE, "libenvgs_hip_diag.so")
-DIAG_SOURCES = ("trace_collect.hip", "trace_surfel_bwd.hip", "trace_api.hip")
+DIAG_SOURCES = ("trace_collect.hip", "trace_surfel_bwd.hip", "trace_api.hip", "raster_render.hip")
 ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fvisibility=hidden",
           "-Wall", "-Wno-unused-function"]
-# per-file extra flags; raster_project.hip feeds bit-exact integer keys -> no FMA contraction there
+# per-file extra flags; raster_project.hip feeds bit-exact integer keys -> no FMA contraction there; raster_project_bwd.hip (R8, HBM-bound,
+# one lane per surfel) follows the oracle's operation order statement by statement, so without contraction its 3-term dot products against the
+# pixel-scale projection matrix round exactly as the oracle's do
 # tracer kernels: the SLP vectoriser pairs scalar fp32 ops into v_pk_* and then spends two v_mov per packed op assembling register pairs
 # (batch_surfel_bwd: 89 v_mov per entry, 255 VGPRs; without it 17 and 221)
 _NO_SLP = ["-fno-slp-vectorize"]
-EXTRA = {"raster_project.hip": ["-ffp-contract=off"], "trace_kbuffer.hip": _NO_SLP, "trace_collect.hip": _NO_SLP, "trace_lists.hip": _NO_SLP,
+EXTRA = {"raster_project.hip": ["-ffp-contract=off"], "raster_project_bwd.hip": ["-ffp-contract=off"], "trace_kbuffer.hip": _NO_SLP, "trace_collect.hip": _NO_SLP, "trace_lists.hip": _NO_SLP,
          "trace_surfel_bwd.hip": _NO_SLP, "trace_api.hip": _NO_SLP}
 
 

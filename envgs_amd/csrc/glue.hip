@@ -234,7 +234,11 @@ sh_record_bwd_q16(int P, int D, const float *__restrict__ means, const float *__
     const float *g = grad_rec + (size_t)ii * GREC + 15;
     const float gc[3] = {(vis && !clamped[3 * ii]) ? g[0] : 0.f, (vis && !clamped[3 * ii + 1]) ? g[1] : 0.f, (vis && !clamped[3 * ii + 2]) ? g[2] : 0.f};
     const float dx = means[3 * ii] - campos[0], dy = means[3 * ii + 1] - campos[1], dz = means[3 * ii + 2] - campos[2];
-    const float sum2 = dx * dx + dy * dy + dz * dz, il = 1.0f / sqrtf(sum2);
+    const float sum2 = dx * dx + dy * dy + dz * dz;
+    // a surfel that was not rendered -- or one sitting exactly on the camera centre (0 * inf) -- gets plain zeros, not basis * 0 (a NaN
+    // written into dshs of a culled surfel would poison its Adam moments for good)
+    const bool dead = !vis || !(sum2 > 0.0f);
+    const float il = dead ? 0.0f : 1.0f / sqrtf(sum2);
     const float x = dx * il, y = dy * il, z = dz * il;
     float b[16], gx[16], gy[16], gz[16];
 #pragma unroll

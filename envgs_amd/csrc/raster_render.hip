@@ -17,32 +17,59 @@
 namespace envgs {
 
 struct Hit {
-    float sx, sy, pz, kx, ky, kz, lx, ly, lz, rho3d, rho2d, dx, dy, depth, G, alpha;
+    float sx, sy, inv, kx, ky, kz, lx, ly, lz, rho3d, rho2d, dx, dy, depth, G, alpha;
     bool ok;
 };
 
+// ---- the CANONICAL per-(pixel, splat) arithmetic ------------------------------------------------------------------------------------
+// The ray/splat intersection is ill-conditioned: k = px*Tw - Tu loses ~2 digits at 800 px, p = k x l -> 0 for a splat seen edge-on, and the
+// gradient chain (dk = l x dp, dTw = px dk + py dl + ...) mirrors the same cancellations.  Two fp32 evaluations that round these steps
+// differently (FMA contraction or not, association) disagree by 1e-5 .. 1e-3 RELATIVE in alpha and in every gradient term ~ 1/p.z -- which
+// is what rounds 1-3 measured against the oracle and covered with an uncertainty floor plus a tail allowance.  So the
+// operation order of exactly these steps is FIXED, written with explicit fused multiply-adds, and oracle/surfel_raster_oracle.c:eval_splat /
+// orc_render_bwd execute the same sequence: the amplified rounding is then common to both and what remains between them is a few ulp of
+// well-conditioned arithmetic (the reciprocal, the exponential, the blend recurrences, summation order).
+//   k = fma(px, Tw, -Tu)      l = fma(py, Tw, -Tv)      p = k x l with each component fma(a, b, -(c * d))
+//   inv = 1 / p.z             s = p.xy * inv            rho3d = fma(sx, sx, sy * sy)     rho2d = 2 * fma(dx, dx, dy * dy)
+//   depth = fma(sx, Tw.x, fma(sy, Tw.y, Tw.z))
+// 1 / p.z is v_rcp_f32 + one Newton step (2 FMA: within half an ulp of the correctly rounded quotient in all but a vanishing fraction of the
+// cases; an IEEE division is ~10 instructions in a VALU-bound kernel); exp is v_exp_f32 on the argument scaled by log2 e.
+// EXACT (diagnostic library only, envgs_debug_set(ENVGS_DBG_RASTER_EXACT, 1)): IEEE divisions and the library expf instead -- the attribution run
+// of tests/test_raster_parity.py::test_exact_math_attribution.
+template <bool EXACT>
+__device__ __forceinline__ float recip(float x)
+{
+    if (EXACT) return 1.0f / x;
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+template <bool EXACT>
+__device__ __forceinline__ float recip1(float x) { return EXACT ? 1.0f / x : __builtin_amdgcn_rcpf(x); }     // well-conditioned uses: 1 ulp is enough
+template <bool EXACT>
+__device__ __forceinline__ float expneg(float x) { return EXACT ? expf(x) : __expf(x); }
+
 // Ray / splat evaluation for pixel (px,py).  rec = the 16-float geom record (wave-uniform).
+template <bool EXACT = false>
 __device__ __forceinline__ Hit eval_splat(const float4 r0, const float4 r1, const float4 r2, const float4 r3, float px, float py)
 {
     Hit h;
     const float Tux = r0.x, Tuy = r0.y, Tuz = r0.z, Tvx = r0.w, Tvy = r1.x, Tvz = r1.y, Twx = r1.z, Twy = r1.w, Twz = r2.x;
     const float cx = r2.y, cy = r2.z, opa = r3.z;
-    h.kx = px * Twx - Tux; h.ky = px * Twy - Tuy; h.kz = px * Twz - Tuz;
-    h.lx = py * Twx - Tvx; h.ly = py * Twy - Tvy; h.lz = py * Twz - Tvz;
-    const float ppx = h.ky * h.lz - h.kz * h.ly;
-    const float ppy = h.kz * h.lx - h.kx * h.lz;
-    const float ppz = h.kx * h.ly - h.ky * h.lx;
-    h.pz = ppz;
-    const float inv = __builtin_amdgcn_rcpf(ppz);
-    h.sx = ppx * inv; h.sy = ppy * inv;
-    h.rho3d = h.sx * h.sx + h.sy * h.sy;
+    h.kx = __builtin_fmaf(px, Twx, -Tux); h.ky = __builtin_fmaf(px, Twy, -Tuy); h.kz = __builtin_fmaf(px, Twz, -Tuz);
+    h.lx = __builtin_fmaf(py, Twx, -Tvx); h.ly = __builtin_fmaf(py, Twy, -Tvy); h.lz = __builtin_fmaf(py, Twz, -Tvz);
+    const float ppx = __builtin_fmaf(h.ky, h.lz, -(h.kz * h.ly));
+    const float ppy = __builtin_fmaf(h.kz, h.lx, -(h.kx * h.lz));
+    const float ppz = __builtin_fmaf(h.kx, h.ly, -(h.ky * h.lx));
+    h.inv = recip<EXACT>(ppz);
+    h.sx = ppx * h.inv; h.sy = ppy * h.inv;
+    h.rho3d = __builtin_fmaf(h.sx, h.sx, h.sy * h.sy);
     h.dx = cx - px; h.dy = cy - py;
-    h.rho2d = FILTER_INV_SQ * (h.dx * h.dx + h.dy * h.dy);
+    h.rho2d = FILTER_INV_SQ * __builtin_fmaf(h.dx, h.dx, h.dy * h.dy);
     const bool use3d = h.rho3d <= h.rho2d;
     const float rho = use3d ? h.rho3d : h.rho2d;
-    h.depth = use3d ? (h.sx * Twx + h.sy * Twy) + Twz : Twz;
+    h.depth = use3d ? __builtin_fmaf(h.sx, Twx, __builtin_fmaf(h.sy, Twy, Twz)) : Twz;
     const float power = -0.5f * rho;
-    h.G = __expf(power);
+    h.G = expneg<EXACT>(power);
     const float a = opa * h.G;
     h.alpha = a < ALPHA_CAP ? a : ALPHA_CAP;
     h.ok = (ppz != 0.0f) && (h.depth >= NEAR_N) && (power <= 0.0f) && (h.alpha >= ALPHA_MIN);
@@ -151,7 +178,7 @@ __device__ __forceinline__ uint32_t quadrant_mask(const float4 r0, const float4 
 // ------------------------------------------------------------------------------------------ R6 ---
 // AUDIT = true is the parity-audit instantiation of the SAME kernel (envgs_raster_render_audit): it additionally records, per pixel and
 // list entry, whether the entry was blended (contrib[pid][entry] = 1), so that tests can compare contributor SETS with the oracle.
-template <int C, bool AUDIT>
+template <int C, bool AUDIT, bool EXACT = false>
 __global__ void __launch_bounds__(256, 5)
 composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list,
               const float *__restrict__ geom, const Feat colors, const float *__restrict__ bg,
@@ -211,7 +238,7 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
             const int j = ck * 64 + (int)__builtin_ctzll(todo);
             todo &= todo - 1ull;
             if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
-            const Hit h = eval_splat(lds.rec[0][j], lds.rec[1][j], lds.rec[2][j], lds.rec[3][j], px, py);
+            const Hit h = eval_splat<EXACT>(lds.rec[0][j], lds.rec[1][j], lds.rec[2][j], lds.rec[3][j], px, py);
             bool contrib = !done && h.ok;
             const float test_T = T * (1.0f - h.alpha);
             const bool stop = contrib && test_T < T_EPS;
@@ -276,10 +303,11 @@ composite_fwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
 //     acc_j = alpha_{j+1} * value_{j+1} + (1 - alpha_{j+1}) * acc_{j+1},
 // so the dot product with the upstream gradients is taken FIRST (X_j = sum_ch value_j[ch] * dL/dch) and a single scalar accX is carried:
 // dL/dalpha_j = T_j * (X_j - accX_j) - T_final / (1 - alpha_j) * <bg, dL/dpix>.   (10 + C recurrences of the textbook form -> 1.)
-// 1 / (1 - alpha), 1 / p.z and 1 / depth are v_rcp_f32 (1 ulp): the kernel is VALU-issue bound, and an IEEE division is ~12 instructions.
+// 1 / (1 - alpha) and 1 / depth are v_rcp_f32 (1 ulp; well-conditioned uses), 1 / p.z is the forward's Newton-refined reciprocal (eval_splat):
+// the kernel is VALU-issue bound, and an IEEE division is ~12 instructions.
 // DIST = the distortion map carries an upstream gradient somewhere in this tile (decided per tile at run time; the shipped EnvGS
 // configuration trains with lambda_dist = 0, configs/models/envgs.yaml:73, and then skips the m_d terms altogether).
-template <int C, bool DIST>
+template <int C, bool DIST, bool EXACT>
 __device__ __forceinline__ void composite_bwd_tile(TileLds<C, BWD_BATCH> &lds, float (*gacc)[15 + C], const int W, const int H, const int bg_len,
                                                    const uint32_t *__restrict__ point_list, const float *__restrict__ geom,
                                                    const Feat colors, const float *__restrict__ bg,
@@ -305,16 +333,16 @@ __device__ __forceinline__ void composite_bwd_tile(TileLds<C, BWD_BATCH> &lds, f
     float bg_dot = 0.f;
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        dpix[c] = inside ? dL_dcolor[c * HW + pid] : 0.f;
+        dpix[c] = (inside && dL_dcolor) ? dL_dcolor[c * HW + pid] : 0.f;          // a NULL upstream pointer = that output has no gradient
         bg_dot += (c < bg_len ? bg[c] : 0.0f) * dpix[c];
     }
-    const float dL_ddepth = inside ? dL_dallmap[0 * HW + pid] : 0.f;
-    const float dL_daccum = inside ? dL_dallmap[1 * HW + pid] : 0.f;
-    const float dL_dn0 = inside ? dL_dallmap[2 * HW + pid] : 0.f;
-    const float dL_dn1 = inside ? dL_dallmap[3 * HW + pid] : 0.f;
-    const float dL_dn2 = inside ? dL_dallmap[4 * HW + pid] : 0.f;
-    const float dL_dmed = inside ? dL_dallmap[5 * HW + pid] : 0.f;
-    const float dL_dreg = (DIST && inside) ? dL_dallmap[6 * HW + pid] : 0.f;
+    const float dL_ddepth = (inside && dL_dallmap) ? dL_dallmap[0 * HW + pid] : 0.f;
+    const float dL_daccum = (inside && dL_dallmap) ? dL_dallmap[1 * HW + pid] : 0.f;
+    const float dL_dn0 = (inside && dL_dallmap) ? dL_dallmap[2 * HW + pid] : 0.f;
+    const float dL_dn1 = (inside && dL_dallmap) ? dL_dallmap[3 * HW + pid] : 0.f;
+    const float dL_dn2 = (inside && dL_dallmap) ? dL_dallmap[4 * HW + pid] : 0.f;
+    const float dL_dmed = (inside && dL_dallmap) ? dL_dallmap[5 * HW + pid] : 0.f;
+    const float dL_dreg = (DIST && inside && dL_dallmap) ? dL_dallmap[6 * HW + pid] : 0.f;
     const float final_D = (DIST && inside) ? final_T[HW + pid] : 0.f;
     const float final_D2 = (DIST && inside) ? final_T[2 * HW + pid] : 0.f;
     const float final_A = 1.0f - T_final;
@@ -364,7 +392,7 @@ __device__ __forceinline__ void composite_bwd_tile(TileLds<C, BWD_BATCH> &lds, f
             const bool cand = ci < last;
             if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
             const float4 q0 = lds.rec[0][j], q1 = lds.rec[1][j], q2 = lds.rec[2][j], q3 = lds.rec[3][j];
-            const Hit h = eval_splat(q0, q1, q2, q3, px, py);
+            const Hit h = eval_splat<EXACT>(q0, q1, q2, q3, px, py);
             const bool act = cand && h.ok;
             if (__builtin_amdgcn_ballot_w64(act) == 0) continue;
 
@@ -375,7 +403,7 @@ __device__ __forceinline__ void composite_bwd_tile(TileLds<C, BWD_BATCH> &lds, f
                 const float Twx = q1.z, Twy = q1.w, opa = q3.z;
                 const float nrm0 = q2.w, nrm1 = q3.x, nrm2 = q3.y;
                 const float alpha = h.alpha, G = h.G;
-                const float r1 = __builtin_amdgcn_rcpf(1.0f - alpha);
+                const float r1 = recip1<EXACT>(1.0f - alpha);
                 T = T * r1;                                    // transmittance in front of this splat
                 const float w = alpha * T;
                 // X_j: this splat's blended values dotted with their upstream gradients
@@ -389,7 +417,7 @@ __device__ __forceinline__ void composite_bwd_tile(TileLds<C, BWD_BATCH> &lds, f
                 float dL_dz = w * dL_ddepth;
                 if (ci == medc - 1) dL_dz += dL_dmed;
                 if (DIST) {
-                    const float idep = __builtin_amdgcn_rcpf(h.depth);
+                    const float idep = recip1<EXACT>(h.depth);
                     const float m_d = MD_A * (1.0f - NEAR_N * idep);
                     X += (final_D2 + m_d * m_d * final_A - 2.0f * m_d * final_D) * dL_dreg;           // the distortion weight joins the recurrence
                     dL_dz += 2.0f * w * (m_d * final_A - final_D) * dL_dreg * (MD_B * idep * idep);
@@ -402,17 +430,18 @@ __device__ __forceinline__ void composite_bwd_tile(TileLds<C, BWD_BATCH> &lds, f
                 gv[12] = G * dL_dalpha;
                 const float nGd = -(opa * dL_dalpha) * G;        // dL/dG * dG/d(rho/2-ish): -G * dL/dG
                 if (h.rho3d <= h.rho2d) {
-                    const float dsx = nGd * h.sx + dL_dz * Twx;
-                    const float dsy = nGd * h.sy + dL_dz * Twy;
-                    const float ipz = __builtin_amdgcn_rcpf(h.pz);
-                    const float dpx = dsx * ipz, dpy = dsy * ipz, dpz = -(dpx * h.sx + dpy * h.sy);
-                    const float dkx = h.ly * dpz - h.lz * dpy, dky = h.lz * dpx - h.lx * dpz, dkz = h.lx * dpy - h.ly * dpx;
-                    const float dlx = dpy * h.kz - dpz * h.ky, dly = dpz * h.kx - dpx * h.kz, dlz = dpx * h.ky - dpy * h.kx;
+                    // the canonical gradient chain of the intersection (same operation sequence as oracle/surfel_raster_oracle.c:orc_render_bwd)
+                    const float dsx = __builtin_fmaf(nGd, h.sx, dL_dz * Twx);
+                    const float dsy = __builtin_fmaf(nGd, h.sy, dL_dz * Twy);
+                    const float dpx = dsx * h.inv, dpy = dsy * h.inv;
+                    const float dpz = -__builtin_fmaf(dpx, h.sx, dpy * h.sy);
+                    const float dkx = __builtin_fmaf(h.ly, dpz, -(h.lz * dpy)), dky = __builtin_fmaf(h.lz, dpx, -(h.lx * dpz)), dkz = __builtin_fmaf(h.lx, dpy, -(h.ly * dpx));
+                    const float dlx = __builtin_fmaf(dpy, h.kz, -(dpz * h.ky)), dly = __builtin_fmaf(dpz, h.kx, -(dpx * h.kz)), dlz = __builtin_fmaf(dpx, h.ky, -(dpy * h.kx));
                     gv[0] = -dkx; gv[1] = -dky; gv[2] = -dkz;
                     gv[3] = -dlx; gv[4] = -dly; gv[5] = -dlz;
-                    gv[6] = px * dkx + py * dlx + dL_dz * h.sx;
-                    gv[7] = px * dky + py * dly + dL_dz * h.sy;
-                    gv[8] = px * dkz + py * dlz + dL_dz;
+                    gv[6] = __builtin_fmaf(px, dkx, __builtin_fmaf(py, dlx, dL_dz * h.sx));
+                    gv[7] = __builtin_fmaf(px, dky, __builtin_fmaf(py, dly, dL_dz * h.sy));
+                    gv[8] = __builtin_fmaf(px, dkz, __builtin_fmaf(py, dlz, dL_dz));
                 } else {
                     gv[13] = nGd * (FILTER_INV_SQ * h.dx);
                     gv[14] = nGd * (FILTER_INV_SQ * h.dy);
@@ -435,7 +464,7 @@ __device__ __forceinline__ void composite_bwd_tile(TileLds<C, BWD_BATCH> &lds, f
     }
 }
 
-template <int C>
+template <int C, bool EXACT = false>
 __global__ void __launch_bounds__(256, 4)
 composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, const uint32_t *__restrict__ point_list,
               const float *__restrict__ geom, const Feat colors, const float *__restrict__ bg,
@@ -460,7 +489,7 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
     const bool inside = pxi < W && pyi < H;
     const size_t HW = (size_t)H * W, pid = (size_t)(inside ? pyi : 0) * W + (inside ? pxi : 0);
     const int32_t last = inside ? n_contrib[pid] : 0;
-    const bool reg = inside && dL_dallmap[6 * HW + pid] != 0.0f;
+    const bool reg = inside && dL_dallmap && dL_dallmap[6 * HW + pid] != 0.0f;
 
     // Entries behind the deepest last-contributor of this tile were never blended by any pixel: skip them.
     if (tid == 0) { s_max_last = 0; s_dist = 0; }
@@ -480,9 +509,9 @@ composite_bwd(int W, int H, int bg_len, const uint32_t *__restrict__ ranges, con
     const int max_last = s_max_last;
     const uint32_t r0 = ranges[2 * tile];
     if (s_dist)
-        composite_bwd_tile<C, true>(lds, gacc, W, H, bg_len, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, r0, tx, ty, max_last, contrib_mask);
+        composite_bwd_tile<C, true, EXACT>(lds, gacc, W, H, bg_len, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, r0, tx, ty, max_last, contrib_mask);
     else
-        composite_bwd_tile<C, false>(lds, gacc, W, H, bg_len, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, r0, tx, ty, max_last, contrib_mask);
+        composite_bwd_tile<C, false, EXACT>(lds, gacc, W, H, bg_len, point_list, geom, colors, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, r0, tx, ty, max_last, contrib_mask);
 }
 
 // ------------------------------------------------------------------------------------ launchers ---
@@ -496,6 +525,18 @@ static int run_fwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const ui
     ProfScope prof_(K_COMPOSITE_FWD, stream);
     const dim3 grid(8 * ((gx * gy + 7) / 8)), block(256);
     const Feat colors_{colors, colors_f16 != 0};
+#ifdef ENVGS_DIAG
+    if (debug_switch(ENVGS_DBG_RASTER_EXACT)) {       // diagnostic library only: IEEE divisions + library expf (the attribution run)
+        if (audit_contrib)
+            hipLaunchKernelGGL((composite_fwd<C, true, true>), grid, block, 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
+                               point_list, geom, colors_, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, contrib_mask, audit_skip);
+        else
+            hipLaunchKernelGGL((composite_fwd<C, false, true>), grid, block, 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
+                               point_list, geom, colors_, bg, out_color, allmap, final_T, n_contrib, weight, (uint8_t *)nullptr, 0, contrib_mask, (const uint8_t *)nullptr);
+        ENVGS_CHECK_LAUNCH(cfg, stream);
+        return 0;
+    }
+#endif
     if (audit_contrib)
         hipLaunchKernelGGL((composite_fwd<C, true>), grid, block, 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
                            point_list, geom, colors_, bg, out_color, allmap, final_T, n_contrib, weight, audit_contrib, audit_lmax, contrib_mask, audit_skip);
@@ -530,7 +571,15 @@ static int run_bwd(const envgs_raster_cfg *cfg, const uint32_t *ranges, const ui
 {
     const int gx = (cfg->width + TILE - 1) / TILE, gy = (cfg->height + TILE - 1) / TILE;
     ProfScope prof_(K_COMPOSITE_BWD, stream);
-    hipLaunchKernelGGL(composite_bwd<C>, dim3(8 * ((gx * gy + 7) / 8)), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
+#ifdef ENVGS_DIAG
+    if (debug_switch(ENVGS_DBG_RASTER_EXACT)) {
+        hipLaunchKernelGGL((composite_bwd<C, true>), dim3(8 * ((gx * gy + 7) / 8)), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
+                           point_list, geom, Feat{colors, colors_f16 != 0}, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, contrib_mask);
+        ENVGS_CHECK_LAUNCH(cfg, stream);
+        return 0;
+    }
+#endif
+    hipLaunchKernelGGL((composite_bwd<C, false>), dim3(8 * ((gx * gy + 7) / 8)), dim3(256), 0, stream, cfg->width, cfg->height, cfg->bg_len, ranges,
                        point_list, geom, Feat{colors, colors_f16 != 0}, bg, final_T, n_contrib, dL_dcolor, dL_dallmap, grad_rec, contrib_mask);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;

@@ -1,7 +1,8 @@
 // trace_bvh.hip -- T1: LBVH over the surfel proxies (replaces the OptiX GAS build of the reference).
 //
 //   quad AABBs + scene bounds -> 30-bit Morton code of the centroid || surfel id (unique 62-bit keys)
-//   -> radix sort (rocPRIM) -> Karras-2012 hierarchy (one lane per internal node, clz on key pairs)
+//   -> bucket sort on the rasterizer's binning machinery (launch_key_sort, raster_bin.hip: LDS histograms + one LDS bitonic sort per bucket;
+//      no library sort is left in the library) -> Karras-2012 hierarchy (one lane per internal node, clz on key pairs)
 //   -> sparse table of box unions over the SORTED leaves (st[k][i] = union of leaves [i, i + 2^k)): an LBVH node covers a contiguous
 //      run of sorted leaves, so each internal node reads both child boxes as two overlapping power-of-two windows -- fully parallel,
 //      no bottom-up walk, no atomics (the bottom-up fit was 1 ms of dependent device-scope round trips; the whole build is now 0.14 ms)

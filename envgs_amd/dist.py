@@ -112,7 +112,16 @@ def exchange_flat(flat, average=True, group=None, algo="direct", async_op=False,
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             whole()
-        return lambda: torch.cuda.current_stream(flat.device).wait_stream(side)
+        # scratch allocated HERE (direct API use; GradExchange passes persistent buffers) was allocated on the compute stream and is used on
+        # the side stream: tell the caching allocator, and keep the tensors alive until the caller has waited
+        for t in (recv, mine) if algo == "direct" else ():
+            t.record_stream(side)
+        flat.record_stream(side)
+        held = (recv, mine) if algo == "direct" else ()
+
+        def done(_held=held):
+            torch.cuda.current_stream(flat.device).wait_stream(side)
+        return done
     # CPU (gloo): asynchronous work objects; the arithmetic between the two collectives runs when the first completes
     if algo == "allreduce":
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)

@@ -9,8 +9,6 @@ Followed call sequence (all paths relative to /root/reference):
   easyvolcap/utils/optix_utils.py:71-85,87-267              build_bvh (get_disks + rebuild) and render_gaussians (env pass)
   easyvolcap/models/samplers/envgs_sampler.py:474           rgb = (1 - spec) * rgb_base + spec * rgb_env
 """
-import math
-
 import torch
 
 from . import synth
@@ -76,35 +74,6 @@ def base_pass(pkg, cam, base, bg, sh_degree, scale_modifier=1.0):
                 weight=weight, means2D=means2D, allmap=allmap, img=img, colors=colors)
 
 
-def dpt2norm(cam, dpt):
-    """dpt2xyz + dpt2norm of gaussian2d_utils.py:1158-1206 (torch, any device): depth (1,H,W) -> pseudo surface normals (H,W,3), zero border."""
-    dev = dpt.device
-    c2w = torch.linalg.inv(cam.world_view_transform.T)
-    W, H = cam.image_width, cam.image_height
-    fx = W / (2 * math.tan(cam.FoVx / 2.)); fy = H / (2 * math.tan(cam.FoVy / 2.))
-    K = torch.tensor([[fx, 0., W / 2.], [0., fy, H / 2.], [0., 0., 1.0]], dtype=torch.float32, device=dev)
-    u, v = torch.meshgrid(torch.arange(W, dtype=torch.float32, device=dev), torch.arange(H, dtype=torch.float32, device=dev), indexing='xy')
-    pix = torch.stack([u, v, torch.ones_like(u)], dim=-1).reshape(-1, 3)
-    ray_d = pix @ torch.linalg.inv(K).mT @ c2w[:3, :3].mT
-    xyz = (dpt.reshape(-1, 1) * ray_d + c2w[:3, 3]).reshape(H, W, 3)
-    out = torch.zeros_like(xyz)
-    dx = xyz[2:, 1:-1] - xyz[:-2, 1:-1]
-    dy = xyz[1:-1, 2:] - xyz[1:-1, :-2]
-    out[1:-1, 1:-1, :] = torch.nn.functional.normalize(torch.cross(dx, dy, dim=-1), dim=-1)
-    return out
-
-
-def surface_maps(cam, allmap, depth_ratio=0.0):
-    """surf_depth (1,H,W), surf_normal (3,H,W): the regulariser maps of render()'s tail (gaussian2d_utils.py:1125-1142), torch expressions
-    (envgs_amd.fused.surface_normal is the one-kernel form)."""
-    alpha = allmap[1:2]
-    median = torch.nan_to_num(allmap[5:6], 0, 0)
-    expect = torch.nan_to_num(allmap[0:1] / alpha, 0, 0)
-    depth = expect * (1 - depth_ratio) + median * depth_ratio
-    normal = dpt2norm(cam, depth).permute(2, 0, 1) * alpha.detach()
-    return depth, normal
-
-
 def visibility_filter(wet, means3D=None, K=None, R=None, T=None, H=None, W=None, start_from_first=False):
     """Post-trace visibility of optix_utils.py:203-213: a surfel is visible if any ray blended it (`wet > 0`), or -- only when the trace
     starts at the camera (`start_from_first`) -- if it projects inside the image at depth >= 0.2.  (P,) bool, detached."""
@@ -117,17 +86,22 @@ def visibility_filter(wet, means3D=None, K=None, R=None, T=None, H=None, W=None,
         return vis.detach().clone()
 
 
-FEATURE_F16 = {"on": False}        # bench.py --feature-dtype f16: the extensions keep HALF copies of the feature arrays they read (fp32 parameters in, fp32
-                                   # gradients out: envgs_amd.set_feature_storage -- a caller-side .half() would get its gradient back in fp16)
+FEATURE_F16 = {"on": None}         # tri-state.  None (default): leave the process-wide choice of envgs_amd.set_feature_storage alone -- a caller that
+                                   # selected "f16" through the public API keeps it.  True / False: bench.py --feature-dtype and the tests
+                                   # pin the storage for the passes of this module (half copies of the feature arrays, fp32 parameters in, fp32 gradients out)
 
 
 def _select_storage():
+    if FEATURE_F16["on"] is None:
+        return
     import envgs_amd
     envgs_amd.set_feature_storage("f16" if FEATURE_F16["on"] else "f32")
 
 
-REFERENCE_FORMS = {"on": False}    # bench.py --caller reference: the expression forms the unchanged EasyVolcap caller executes (batched-matmul get_disks,
-                                   # the regulariser maps of render()'s tail) instead of this module's cheaper equivalents
+REFERENCE_FORMS = {"on": False, "get_disks": None, "surface_maps": None}
+# bench.py --caller reference: the expression forms the unchanged EasyVolcap caller executes (batched-matmul get_disks, the regulariser maps
+# of render()'s tail) instead of this module's cheaper equivalents.  Those restatements are measurement / test material and live in
+# tests/reference_caller.py, whose install() puts the two callables here; nothing in the shipped package contains them.
 PREBUILD = {"on": True}            # fused caller: start the environment structure build before the base pass (SurfelTracer.prepare)
 TRACE = {"depth": 0, "specular_threshold": 0.0}    # EnvGS hard-codes 0 bounces (envgs_sampler.py:510,548); bench.py --trace-depth overrides
 
@@ -157,7 +131,7 @@ def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree, prepared_v
         v, f = fused.surfel_quads(env["means3D"], env["scales"], env["rotations"])          # one launch instead of ~25 torch kernels in front of the trace
         tracer.build_acceleration_structure(v, f, rebuild=True)
     else:
-        v, f = (synth.get_disks_reference_form if REFERENCE_FORMS["on"] else synth.get_disks)(env["means3D"], env["scales"], env["rotations"])
+        v, f = (REFERENCE_FORMS["get_disks"] if REFERENCE_FORMS["on"] else synth.get_disks)(env["means3D"], env["scales"], env["rotations"])
         tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
     grads3D = torch.zeros_like(env["means3D"], requires_grad=True) + 0
     return tracer(ref_o.contiguous(), ref_d.contiguous(), v, means3D=env["means3D"].contiguous(), grads3D=grads3D,
@@ -180,7 +154,7 @@ def envgs_forward(pkg, tpkg, tracer, cam, rays, base, env, bg, env_bg, sh_degree
         rgb = fused.blend(b["img"], rgb_env)          # (1 - spec) * rgb_base + spec * rgb_env without slicing the rasterizer's output
         return dict(rgb=rgb, base=b, rgb_env=rgb_env, env_wet=wet, ref_o=ref_o, ref_d=ref_d)
     if REFERENCE_FORMS["on"]:                                      # render() always builds these (gaussian2d_utils.py:1125-1142); the supervisor consumes them
-        b["surf_depth"], b["surf_normal"] = surface_maps(cam, b["allmap"], 0.0)
+        b["surf_depth"], b["surf_normal"] = REFERENCE_FORMS["surface_maps"](cam, b["allmap"], 0.0)
     nrm = b["normal"].permute(1, 2, 0)
     nrm = nrm / (nrm.norm(dim=-1, keepdim=True) + 1e-8)            # easyvolcap/utils/math_utils.py:6-8
     ref_d = ray_d - 2 * (ray_d * nrm).sum(-1, keepdim=True) * nrm

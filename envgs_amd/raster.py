@@ -252,7 +252,7 @@ def rasterize_backward(saved, dL_dcolor, dL_dallmap):
     P, C = cfg.P, cfg.channels
     dev = saved["geom"].device
     f32 = dict(dtype=torch.float32, device=dev)
-    dL_dcolor = _f32c(dL_dcolor); dL_dallmap = _f32c(dL_dallmap)
+    dL_dcolor = _f32c(dL_dcolor); dL_dallmap = _f32c(dL_dallmap)          # None = that output has no upstream gradient (NULL in the C-ABI)
     shs, cov = saved["shs"], saved["cov3D_precomp"]
     grad_rec = torch.empty(P, 32, **f32)
     dmeans3D = torch.empty(P, 3, **f32)
@@ -295,8 +295,6 @@ def make_package(C):
             saved = ctx.saved
             cfg = saved["cfg"]
             dev = saved["geom"].device
-            if grad_color is None: grad_color = torch.zeros(cfg.channels, cfg.height, cfg.width, device=dev)
-            if grad_allmap is None: grad_allmap = torch.zeros(7, cfg.height, cfg.width, device=dev)
             g = rasterize_backward(saved, grad_color, grad_allmap)
             outs = (g["means3D"] if saved["cov3D_precomp"] is None or saved["shs"] is not None else None, g["means2D"],
                     g["shs"], g["colors_precomp"], g["opacities"], g["scales"], g["rotations"], g["cov3D_precomp"])

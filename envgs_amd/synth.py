@@ -144,22 +144,6 @@ def get_disks(means3D, scales, rotations):
     return v.contiguous(), f.contiguous()
 
 
-def get_disks_reference_form(means3D, scales, rotations):
-    """The SAME quads in the reference's own expression form (optix_utils.py:39-69): splat2world^T with the normal column zeroed, applied to
-    the four 3-sigma uv corners as a (4P,4,4) @ (4P,4,1) batched matmul.  Only bench.py --caller reference uses it: it is what the unchanged
-    EasyVolcap caller executes every training step before it calls the tracer (8.7 ms through hipBLASLt, 1.0 ms through rocBLAS on MI355X)."""
-    T = splat2world(means3D, scales, rotations).permute(0, 2, 1).clone()
-    T[..., 2] = 0
-    P = T.shape[0]
-    sigma3 = torch.as_tensor([[-1., 1.], [-1., -1.], [1., 1.], [1., -1.]], device=T.device) * 3
-    sigma3 = torch.cat([sigma3, torch.ones_like(sigma3)], dim=-1)[None].repeat(P, 1, 1)
-    v = T[:, None].expand(-1, 4, -1, -1).reshape(-1, 4, 4) @ sigma3.reshape(-1, 4, 1)
-    v = v[..., :3, 0]
-    idx = torch.arange(0, v.shape[0], device=T.device).reshape(P, 4)
-    f = torch.stack([idx[:, :3], idx[:, 1:]], dim=1).reshape(-1, 3).int()
-    return v.contiguous(), f.contiguous()
-
-
 def get_rays(cam):
     """Camera rays (H,W,3): origin = camera centre, direction with camera-z = 1 (z_depth), pixel centre +0.5."""
     H, W = cam.image_height, cam.image_width

@@ -127,12 +127,17 @@ class CapState:
         return self.cap
 
     def pinned_word(self):
-        """One pinned int32 of a ring of 32 (the record count of a forward is read at its backward: at most a few forwards are outstanding)."""
-        ring = self.__dict__.setdefault("_ring", [None, 0])
+        """One pinned int32 of a ring of 32 (the record count of a forward is read at its backward: normally a few forwards are outstanding)
+        plus a TOKEN that identifies the claim: a forward whose slot was handed out again before its backward ran (more than 32 grad-enabled
+        traced calls in between: eval renders without no_grad, many-view accumulation with retained graphs) finds a different token in the
+        slot and reads its count from the device instead (trace_backward)."""
+        ring = self.__dict__.setdefault("_ring", [None, 0, [None] * 32])
         if ring[0] is None:
             ring[0] = torch.zeros(32, dtype=torch.int32).pin_memory()
         ring[1] = (ring[1] + 1) % 32
-        return ring[0][ring[1]:ring[1] + 1]
+        token = object()
+        ring[2][ring[1]] = token
+        return ring[0][ring[1]:ring[1] + 1], (ring[2], ring[1], token)
 
     def next_rows(self, R, cap):
         """Rows of the compact per-hit buffers (hit_state / entries / pairs; include/envgs_trace.h: compact_rows) for a call with R rays:
@@ -258,7 +263,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
         # asynchronous read-backs for later: the longest list (sizes the next call's cap) and the number of gradient records
         caps.publish(counters, dev, rays=R)
         if "hit_state" in keep:                                   # (a pinned word from the tracer's ring: pinning host memory per call is ~0.1 ms)
-            keep["n_rec_host"] = caps.pinned_word()
+            keep["n_rec_host"], keep["n_rec_claim"] = caps.pinned_word()
             keep["n_rec_host"].copy_(keep["surf_off"].view(-1)[NCOPY * P - 1:NCOPY * P], non_blocking=True)
             keep["n_rec_event"] = torch.cuda.Event(); keep["n_rec_event"].record(torch.cuda.current_stream(dev))
     saved = dict(cfg=cfg, nodes=nodes, ro=ro, rd=rd, means3D=means3D, scales=scales, rotations=rotations, opacities=opacities,
@@ -294,7 +299,11 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
         # atomic-free backward: one 256 B record per (batch, surfel) entry, grouped by surfel.  The count is known on the device
         # (inclusive scan of the per-surfel entry counts, done at the end of the forward); reading it is the one host sync here.
         s["keep"]["n_rec_event"].synchronize()         # copied at the end of the forward; long since complete
-        n_rec = int(s["keep"]["n_rec_host"][0]) & 0xFFFFFFFF if P > 0 else 0
+        slots, slot, token = s["keep"]["n_rec_claim"]
+        if slots[slot] is token:
+            n_rec = int(s["keep"]["n_rec_host"][0]) & 0xFFFFFFFF if P > 0 else 0
+        else:                                           # the pinned slot was re-used by a later forward: synchronous read of this forward's own scan
+            n_rec = int(s["keep"]["surf_off"].view(-1)[NCOPY * P - 1].item()) & 0xFFFFFFFF if P > 0 else 0
         if n_rec > 0:
             records = _scratch((n_rec, 64), torch.float32, dev)
             lists.records = records.data_ptr()

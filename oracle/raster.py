@@ -90,9 +90,12 @@ def raster_forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, *, 
     return out
 
 
-def raster_audit(fwd, want_contrib=False):
-    """Fragility audit of the forward `fwd` (orc_render_audit): returns dict(fragile (H,W) bool = flips | illcond, tainted (P,) bool,
-    contrib (H*W, lmax) uint8 or None, lmax).  See the C comment for the definitions."""
+def raster_audit(fwd, want_contrib=False, canonical=True):
+    """Fragility audit of the forward `fwd` (orc_render_audit).  canonical=True (round 4): `fragile` (H,W) bool = the pixels where a decision of
+    the float code lies within the A-PRIORI few-ulp band that still separates two implementations of the canonical operation sequence;
+    `legacy_fragile` = the round-1..3 definition (K x the float code's own distance from a double shadow, plus ill-conditioned pixels), reported
+    only.  canonical=False: `fragile` is the legacy definition (attribution runs).  Also: illcond / relbad statistics, tainted (P,) bool,
+    contrib (H*W, lmax) uint8 or None, lmax.  See the C comment for the definitions."""
     L = lib()
     cfg = fwd["cfg"]; H, W, P = fwd["H"], fwd["W"], fwd["P"]
     pl = fwd["point_list"] if fwd["N"] > 0 else np.zeros(1, np.uint32)
@@ -101,9 +104,12 @@ def raster_audit(fwd, want_contrib=False):
     fragile = np.zeros(H * W, np.uint8); tainted = np.zeros(max(P, 1), np.uint8)
     contrib = np.zeros((H * W, max(lmax, 1)), np.uint8) if want_contrib else None
     L.orc_render_audit(ctypes.byref(cfg), _p(fwd["ranges"]), _p(pl), _p(fwd["transmat"]), _p(fwd["xy"]), _p(fwd["normal_opacity"]),
-                       _p(fragile), _p(contrib), ctypes.c_int(max(lmax, 1)), _p(tainted))
-    return dict(fragile=(fragile != 0).reshape(H, W), flips=((fragile & 1) != 0).reshape(H, W), illcond=((fragile & 2) != 0).reshape(H, W), relbad=((fragile & 4) != 0).reshape(H, W),
-                tainted=tainted[:P].astype(bool), contrib=contrib, lmax=max(lmax, 1))
+                       _p(fragile), _p(contrib), ctypes.c_int(max(lmax, 1)), _p(tainted), ctypes.c_int(1 if canonical else 0))
+    legacy = ((fragile & 16) != 0).reshape(H, W)
+    flips = ((fragile & 1) != 0).reshape(H, W)
+    illcond = ((fragile & 2) != 0).reshape(H, W)
+    return dict(fragile=(flips if canonical else legacy), flips=flips, illcond=illcond, relbad=((fragile & 4) != 0).reshape(H, W),
+                legacy_fragile=legacy, canonical=bool(canonical), tainted=tainted[:P].astype(bool), contrib=contrib, lmax=max(lmax, 1))
 
 
 def sh_clamp_audit(fwd):

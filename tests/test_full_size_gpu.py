@@ -211,16 +211,16 @@ def test_config5_combination_fp16_ch07_two_bounces_with_gradients():
                                  scales=n(base["scales"]), rotations=n(base["rotations"]), colors_precomp=n(col_h), bg=np.zeros(3, np.float32))
         aud = orc.raster_audit(ref)
         okp = ~aud["fragile"]; nfr = int(aud["fragile"].sum())
-        record(test, "raster.fragile_px", float(aud["fragile"].mean()))
+        record(test, "raster.fragile_px", float(aud["fragile"].mean()), "(%d of %d pixels; by the round-1..3 definition: %d)" % (int(aud["fragile"].sum()), aud["fragile"].size, int(aud["legacy_fragile"].sum())))
         assert aud["fragile"].mean() < 2e-2
         saved = rc["saved"]
         assert saved["N"] == ref["N"]
         np.testing.assert_array_equal(n(saved["point_list"]).view(np.uint32)[:ref["N"]], ref["point_list"])
         np.testing.assert_array_equal(n(saved["ranges"]).view(np.uint32), ref["ranges"])
         np.testing.assert_array_equal(n(saved["n_contrib"])[0][okp], ref["n_contrib"][0][okp])
-        check_close(test, "raster.img", n(out["base"]["img"])[:, okp], ref["out_color"][:, okp], excluded=nfr, tail=(2e-5, 1e-3))
+        check_close(test, "raster.img", n(out["base"]["img"])[:, okp], ref["out_color"][:, okp], excluded=nfr)
         for ch, nm in ((0, "depth"), (1, "alpha"), (2, "normal.x"), (3, "normal.y"), (4, "normal.z")):
-            check_close(test, "raster.allmap." + nm, n(out["base"]["allmap"])[ch][okp], ref["allmap"][ch][okp], excluded=nfr, tail=(2e-5, 1e-3))
+            check_close(test, "raster.allmap." + nm, n(out["base"]["allmap"])[ch][okp], ref["allmap"][ch][okp], excluded=nfr)
         # gradients with the step's own upstream, zeroed at the fragile pixels on both sides: a second backward of the saved forward state
         from envgs_amd import raster
         m = torch.from_numpy(okp).to(dev)
@@ -229,8 +229,7 @@ def test_config5_combination_fp16_ch07_two_bounces_with_gradients():
         rb = orc.raster_backward(ref, n(dc), n(da), want_cond=True)
         for k_hip, k_ref in (("means3D", "dmeans3D"), ("scales", "dscales"), ("rotations", "drots"), ("opacities", "dopacities"), ("means2D", "dmeans2D"),
                              ("colors_precomp", "dcolors")):
-            check_close(test, "raster." + k_ref, n(gr[k_hip]).reshape(rb[k_ref].shape), rb[k_ref], excluded=nfr, cond=rb["cond"][k_ref], unc=rb["unc"][k_ref],
-                        tail=(2e-5, 1e-3))
+            check_close(test, "raster." + k_ref, n(gr[k_hip]).reshape(rb[k_ref].shape), rb[k_ref], excluded=nfr, cond=rb["cond"][k_ref], unc=rb["unc"][k_ref])
         # ---- tracer link: a sample of the reflected rays through the whole bounce chain, every stage against the oracle ---------------------
         S = 2048
         idx = torch.randperm(R, generator=torch.Generator().manual_seed(6))[:S].to(dev)
@@ -280,7 +279,7 @@ def test_config5_combination_fp16_ch07_two_bounces_with_gradients():
         stagewise.check_summed_param_grads(test, "sum_over_stages", leaves, backs, nfr=nfr_s)
     finally:
         envgs_step.FUSED["on"] = False
-        envgs_step.FEATURE_F16["on"] = False
+        envgs_step.FEATURE_F16["on"] = None
         envgs_step.TRACE.update(depth=0, specular_threshold=0.0)
         import envgs_amd
         envgs_amd.set_feature_storage("f32")

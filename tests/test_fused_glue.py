@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from envgs_amd import envgs_step, synth
+from tests import reference_caller
 
 pytestmark = pytest.mark.gpu
 
@@ -77,7 +78,7 @@ def test_reflect_matches_torch(ratio):
 @pytest.mark.parametrize("ratio", [0.0, 0.4])
 def test_surface_normal_matches_torch(ratio):
     """fused.surface_normal (depth select + dpt2norm + alpha scaling, one kernel each way) vs the torch expressions of render()'s tail
-    (envgs_step.surface_maps; its dpt2norm is pinned against the reference's by tests/test_golden.py)."""
+    (tests/reference_caller.py: surface_maps; its dpt2norm is pinned against the reference's by tests/test_golden.py)."""
     from envgs_amd import fused
     dev = torch.device("cuda:0")
     H, W = 44, 60
@@ -93,7 +94,7 @@ def test_surface_normal_matches_torch(ratio):
     a1 = allmap.clone().requires_grad_(True)
     sd, sn = fused.surface_normal(a1, cam, ratio)
     a2 = allmap.clone().requires_grad_(True)
-    sd2, sn2 = envgs_step.surface_maps(cam, a2, ratio)
+    sd2, sn2 = reference_caller.surface_maps(cam, a2, ratio)
     assert sd.shape == (1, H, W) and sn.shape == (3, H, W)
     torch.testing.assert_close(sd, sd2, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(sn, sn2, rtol=2e-4, atol=2e-5)

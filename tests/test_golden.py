@@ -5,6 +5,7 @@ import torch
 
 from envgs_amd import synth
 from oracle import raster as orc
+from tests import reference_caller
 
 
 def _cam(g):
@@ -87,10 +88,10 @@ def test_get_rays(golden):
 
 
 def test_dpt2norm_twin(golden):
-    """envgs_step.dpt2norm (the torch re-derivation the fused surface_normal kernel is tested against) vs the reference's own dpt2norm."""
+    """tests/reference_caller.dpt2norm (the torch re-derivation the fused surface_normal kernel is tested against) vs the reference's own dpt2norm."""
     from envgs_amd import envgs_step
     cam = _cam(golden)
-    out = envgs_step.dpt2norm(cam, torch.tensor(golden["dpt"])[None])
+    out = reference_caller.dpt2norm(cam, torch.tensor(golden["dpt"])[None])
     ref = golden["dpt2norm"]
     assert out.shape == ref.shape and float(np.abs(ref[1:-1, 1:-1]).sum()) > 0 and float(np.abs(ref[0]).sum()) == 0
     np.testing.assert_allclose(out.numpy(), ref, rtol=1e-4, atol=2e-5)

@@ -50,14 +50,14 @@ def _mod_for(C):
     return importlib.import_module({3: "diff_surfel_rasterization_wet", 5: "diff_surfel_rasterization_wet_ch05", 7: "diff_surfel_rasterization_wet_ch07"}[C])
 
 
-def _compare_forward(test, outs, saved, ref, aud, sh, check_sets, tail=None):
+def _compare_forward(test, outs, saved, ref, aud, sh, check_sets):
     """Index work bit-exact; contributor sets / n_contrib bit-exact and values within 1e-4 on every non-fragile pixel."""
     from envgs_amd import raster
     N = ref["N"]
     assert saved["N"] == N and N > 0
     frag = aud["fragile"]; ok = ~frag
     nfr = int(frag.sum())
-    record(test, "fragile_px", frag.mean(), "(%d of %d pixels)" % (nfr, frag.size))
+    record(test, "fragile_px", frag.mean(), "(%d of %d pixels; by the round-1..3 definition: %d)" % (nfr, frag.size, int(aud["legacy_fragile"].sum())))
     assert frag.mean() < 2e-2, "too many fragile pixels for the comparison to mean anything: %g" % frag.mean()
 
     # R1: integer outputs bit-exact, geom bit-exact (same op order, no FMA)
@@ -103,12 +103,12 @@ def _compare_forward(test, outs, saved, ref, aud, sh, check_sets, tail=None):
         assert torch.equal(nc_a, saved["n_contrib"]) and torch.equal(col_a, outs[0])      # the audit instantiation IS the product kernel
         from oracle import raster as orc
         w_ref, w_unc = orc.raster_weight(ref, frag)
-        check_close(test, "weight.all_surfels", w_masked.cpu().numpy().astype(np.float64), w_ref, excluded=0, cond=np.zeros_like(w_ref), unc=w_unc, tail=tail)
+        check_close(test, "weight.all_surfels", w_masked.cpu().numpy().astype(np.float64), w_ref, excluded=0, cond=np.zeros_like(w_ref), unc=w_unc)
     # R6 values
     color, radii, allmap, weight = [o.cpu().numpy() for o in outs]
-    check_close(test, "color", color[:, ok], ref["out_color"][:, ok], excluded=nfr, tail=tail)
+    check_close(test, "color", color[:, ok], ref["out_color"][:, ok], excluded=nfr)
     for ch, nm in ((0, "depth"), (1, "alpha"), (2, "normal.x"), (3, "normal.y"), (4, "normal.z"), (5, "median")):
-        check_close(test, "allmap." + nm, allmap[ch][ok], ref["allmap"][ch][ok], excluded=nfr, tail=tail)
+        check_close(test, "allmap." + nm, allmap[ch][ok], ref["allmap"][ch][ok], excluded=nfr)
     # distortion: sum_i w_i (m_i^2 A + M2 - 2 m_i M1) cancels catastrophically in fp32 in BOTH implementations (tests/test_oracle_grad.py);
     # its floor is the magnitude of what is summed (~ the alpha channel), not of the remainder
     check_close(test, "allmap.dist", allmap[6][ok], ref["allmap"][6][ok], floor=float(np.abs(ref["allmap"][1][ok]).mean()), excluded=nfr)
@@ -412,7 +412,7 @@ def test_full_size_baseline_config_vs_oracle():
                              shs=g["shs"].numpy(), sh_degree=3, bg=bg.numpy())
     aud = orc.raster_audit(ref, want_contrib=True)             # contributor sets too: 640 k pixels x the longest tile list (~1.2 GB of flags per side)
     test = "full_size_300k_800x800"
-    _compare_forward(test, outs, saved, ref, aud, True, check_sets=True, tail=(2e-5, 1e-3))
+    _compare_forward(test, outs, saved, ref, aud, True, check_sets=True)          # no tail allowance: EVERY element within tolerance
     # gradients: upstream zeroed at the fragile pixels for both implementations
     dcol, dall = _masked_upstream(3, H, W, 1, aud["fragile"])
     grads = raster.rasterize_backward(saved, dcol.to(dev), dall.to(dev))
@@ -422,4 +422,57 @@ def test_full_size_baseline_config_vs_oracle():
     record(test, "sh_clamp_fragile_surfels", float(clampfrag.mean()), "(%d of %d surfels)" % (int(clampfrag.sum()), clampfrag.size))
     for k_hip, k_ref in GRAD_NAMES + (("shs", "dshs"),):
         check_close(test, k_ref, grads[k_hip].cpu().numpy().reshape(rb[k_ref].shape), rb[k_ref], excluded=int(aud["fragile"].sum()), cond=rb["cond"][k_ref], unc=rb["unc"][k_ref],
-                    tail=(2e-5, 1e-3), keep=(~clampfrag if k_ref == "dshs" else None))
+                    keep=(~clampfrag if k_ref == "dshs" else None))
+
+
+def test_exact_math_attribution():
+    """VERDICT r3 item 2, the attribution: what separates the HIP compositing kernels from the oracle's float code, measured WITHOUT any
+    uncertainty floor (K_UNC = 0 column) on a mid-size scene, in the two arithmetic forms the diagnostic library carries:
+      approx : the product kernels -- canonical operation order, 1/p.z = v_rcp_f32 + one Newton step, exp = v_exp_f32(x log2 e), other reciprocals v_rcp_f32
+      exact  : the same kernels with IEEE divisions and the library expf (envgs_debug_set(ENVGS_DBG_RASTER_EXACT, 1))
+    Rounds 1-3 (no canonical order: the compiler's FMA contraction against the oracle's uncontracted statements) are the r03 rows of
+    profiles/r03_parity_errors.txt.  Both forms must meet the contract; the recorded maxima are the attribution."""
+    from envgs_amd import raster, synth, _lib
+    from oracle import raster as orc
+    import diff_surfel_rasterization_wet as mod
+    dev = torch.device("cuda:0")
+    P, H, W = 40000, 400, 400
+    g = synth.base_gaussians(P, seed=5)
+    g["scales"] = g["scales"] * 1.5
+    cam = synth.orbit_camera(2, H=H, W=W, fx=1111.1 * W / 800.0)
+    bg = torch.ones(3)
+    st = _settings(mod, cam, bg, 3, dev)
+    ca = cam_args(cam)
+    ref = orc.raster_forward(g["means3D"].numpy(), g["opacities"].numpy(), ca["viewmatrix"].numpy(), ca["projmatrix"].numpy(),
+                             ca["campos"].numpy(), W, H, scales=g["scales"].numpy(), rotations=g["rotations"].numpy(),
+                             shs=g["shs"].numpy(), sh_degree=3, bg=bg.numpy())
+    aud = orc.raster_audit(ref)
+    ok = ~aud["fragile"]; nfr = int(aud["fragile"].sum())
+    dcol, dall = _masked_upstream(3, H, W, 1, aud["fragile"])
+    rb = orc.raster_backward(ref, dcol.numpy(), dall.numpy(), want_cond=True)
+    clampfrag = _sh_clamp_fragile(ref)
+    gd = {k: v.to(dev) for k, v in g.items()}
+    old = _lib.select("diag")
+    try:
+        lib = _lib.load()
+        for form, sw in (("approx", 0), ("exact", 1)):
+            lib.envgs_debug_set(3, sw)                      # ENVGS_DBG_RASTER_EXACT
+            outs, saved = raster.rasterize_forward(3, gd["means3D"], gd["shs"], None, gd["opacities"], gd["scales"], gd["rotations"], None, st, keep_binning=True)
+            grads = raster.rasterize_backward(saved, dcol.to(dev), dall.to(dev))
+            torch.cuda.synchronize()
+            test = "attribution." + form
+            record(test, "fragile_px", aud["fragile"].mean(), "(%d of %d pixels; by the round-1..3 definition: %d)" % (nfr, ok.size, int(aud["legacy_fragile"].sum())))
+            nc = saved["n_contrib"].cpu().numpy()
+            np.testing.assert_array_equal(nc[0][ok], ref["n_contrib"][0][ok])
+            np.testing.assert_array_equal(nc[1][ok], ref["n_contrib"][1][ok])
+            color, _, allmap, _ = [o.cpu().numpy() for o in outs]
+            check_close(test, "color", color[:, ok], ref["out_color"][:, ok], excluded=nfr)
+            for ch, nm in ((0, "depth"), (1, "alpha"), (2, "normal.x"), (3, "normal.y"), (4, "normal.z"), (5, "median")):
+                check_close(test, "allmap." + nm, allmap[ch][ok], ref["allmap"][ch][ok], excluded=nfr)
+            check_close(test, "final_T", saved["final_T"].cpu().numpy()[:, ok], ref["final_T"][:, ok], excluded=nfr)
+            for k_hip, k_ref in GRAD_NAMES + (("shs", "dshs"),):
+                check_close(test, k_ref, grads[k_hip].cpu().numpy().reshape(rb[k_ref].shape), rb[k_ref], excluded=nfr, cond=rb["cond"][k_ref], unc=rb["unc"][k_ref],
+                            keep=(~clampfrag if k_ref == "dshs" else None))
+    finally:
+        _lib.load().envgs_debug_set(3, 0)
+        _lib.select(old)

@@ -111,7 +111,9 @@ def test_training_fits_ground_truth_renders(storage):
         psnr1, env1 = evaluate(), evaluate_env()
     finally:
         envgs_step.FUSED["on"] = False
-        envgs_step.FEATURE_F16["on"] = False
+        envgs_step.FEATURE_F16["on"] = None
+        import envgs_amd
+        envgs_amd.set_feature_storage("f32")
     first, last = sum(losses[:VIEWS * 2]) / (VIEWS * 2), sum(losses[-VIEWS * 2:]) / (VIEWS * 2)
     print("PSNR %.2f -> %.2f dB, loss %.4f -> %.4f" % (psnr0, psnr1, first, last))
     assert all(math.isfinite(l) for l in losses)

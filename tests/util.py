@@ -87,11 +87,10 @@ def floor_rel_err(a, b, floor=None):
     return np.abs(a - b) / (np.abs(b) + floor), floor
 
 
-def check_close(test, name, a, b, tol=TOL, keep=None, floor=None, excluded=0, cond=None, unc=None, tail=None):
+def check_close(test, name, a, b, tol=TOL, keep=None, floor=None, excluded=0, cond=None, unc=None):
     """Assert the contract on (a, b) restricted to `keep` (boolean mask broadcastable to the leading dims, or None); record the result.
     cond / unc: per-element sum |term| and measured fp32 uncertainty from the oracle (gradients), see the comment above.
-    tail = (max_fraction, bound): only for the 3e8-evaluation full-size case -- at most that fraction of the elements may lie beyond
-    tol (the tail of the realised-vs-expected uncertainty ratio), none beyond `bound`; they are counted in the table."""
+    (Rounds 2-3 had a `tail=` allowance for the full-size raster comparisons; gone with the canonical operation order, round 4.)"""
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     assert a.shape == b.shape, (name, a.shape, b.shape)
     if cond is not None:
@@ -114,17 +113,13 @@ def check_close(test, name, a, b, tol=TOL, keep=None, floor=None, excluded=0, co
     if cond is not None and unc is not None and err.size:
         # sensitivity of the verdict to K_UNC: the same comparison with the measured-uncertainty term at 4x and at 1x instead of 16x
         sens = []
-        for k in (4.0, 1.0):
+        for k in (4.0, 1.0, 0.0):
             fl_k = 0.01 * float(np.abs(b).mean()) + KAPPA * cond + (k / tol) * unc
             e_k = np.abs(a - b) / (np.abs(b) + fl_k + 1e-300)
             sens.append("K_UNC=%g: max %.2e, %d beyond" % (k, float(e_k.max()), int((e_k > tol).sum())))
         note = (note + "  " if note else "") + "[" + "; ".join(sens) + "]"
     ERROR_TABLE.append(dict(test=test, tensor=name, max_err=mx, tol=tol, n=int(err.size), excluded=int(excluded), floor=fl, note=note))
     if os.environ.get("ENVGS_PARITY_COLLECT"):        # diagnosis runs: record everything, assert nothing -- and the session FAILS at the end (conftest.py)
-        return mx
-    if tail is not None and mx > tol:
-        frac = float((err > tol).mean())
-        assert frac <= tail[0] and mx <= tail[1], "%s / %s: %.3g of the elements beyond %.1e (allowed %.1e), max %.3g (allowed %.1e)" % (test, name, frac, tol, tail[0], mx, tail[1])
         return mx
     assert mx <= tol, "%s / %s: max elementwise error %.3g > %.1e (floor %.3g, %d elements, %d excluded as fragile)" % (test, name, mx, tol, fl, err.size, excluded)
     return mx
