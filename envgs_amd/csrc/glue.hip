@@ -15,8 +15,13 @@ __device__ __constant__ float gC3[7] = {-0.5900435899266435f, 2.890611442640554f
                                         0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                         -0.5900435899266435f};
 
+// The SH basis and its gradient are evaluated WITHOUT FMA contraction, statement by statement as oracle/surfel_raster_oracle.c does: a basis
+// function near one of its zeros (2 zz - xx - yy -> 0) is a cancellation whose relative rounding error is unbounded, so two evaluations agree on
+// dL/dSH = basis * dL/dcolour to 1e-4 RELATIVE only if they round the same way (round 4: the 16 of 14.4 M dshs elements beyond tolerance at
+// full size were exactly these; the rasterizer's forward colours, raster_project.hip, have been bit-exact this way since round 1).
 __device__ __forceinline__ void basis16(int D, float x, float y, float z, float *b)
 {
+#pragma clang fp contract(off)
 #pragma unroll
     for (int k = 0; k < 16; k++) b[k] = 0.f;
     b[0] = gC0;
@@ -36,6 +41,7 @@ __device__ __forceinline__ void basis16(int D, float x, float y, float z, float 
 
 __device__ __forceinline__ void basis16_grad(int D, float x, float y, float z, float *gx, float *gy, float *gz)
 {
+#pragma clang fp contract(off)
 #pragma unroll
     for (int k = 0; k < 16; k++) { gx[k] = 0.f; gy[k] = 0.f; gz[k] = 0.f; }
     if (D > 0) {
@@ -234,12 +240,17 @@ sh_record_bwd_q16(int P, int D, const float *__restrict__ means, const float *__
     const float *g = grad_rec + (size_t)ii * GREC + 15;
     const float gc[3] = {(vis && !clamped[3 * ii]) ? g[0] : 0.f, (vis && !clamped[3 * ii + 1]) ? g[1] : 0.f, (vis && !clamped[3 * ii + 2]) ? g[2] : 0.f};
     const float dx = means[3 * ii] - campos[0], dy = means[3 * ii + 1] - campos[1], dz = means[3 * ii + 2] - campos[2];
-    const float sum2 = dx * dx + dy * dy + dz * dz;
-    // a surfel that was not rendered -- or one sitting exactly on the camera centre (0 * inf) -- gets plain zeros, not basis * 0 (a NaN
+    float sum2, len;
+    {
+#pragma clang fp contract(off)
+        sum2 = dx * dx + dy * dy + dz * dz;           // the oracle's statements (orc_preprocess_bwd): uncontracted sum, sqrt, three divisions
+        len = sqrtf(sum2);
+    }
+    // a surfel that was not rendered -- or one sitting exactly on the camera centre (0 / 0) -- gets plain zeros, not basis * 0 (a NaN
     // written into dshs of a culled surfel would poison its Adam moments for good)
     const bool dead = !vis || !(sum2 > 0.0f);
-    const float il = dead ? 0.0f : 1.0f / sqrtf(sum2);
-    const float x = dx * il, y = dy * il, z = dz * il;
+    const float il = dead ? 0.0f : 1.0f / len;
+    const float x = dead ? 0.0f : dx / len, y = dead ? 0.0f : dy / len, z = dead ? 0.0f : dz / len;
     float b[16], gx[16], gy[16], gz[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) b[k] = 0.f;

@@ -94,7 +94,7 @@ int envgs_raster_backward(const envgs_raster_cfg *cfg, uint32_t N, const float *
     int rc = check_cfg(cfg);
     if (rc) return rc;
     if (cfg->P == 0) return 0;
-    if (!geom || !colors || !bg || !ranges || !final_T || !n_contrib || !dL_dcolor || !dL_dallmap || !grad_rec || !radii ||
+    if (!geom || !colors || !bg || !ranges || !final_T || !n_contrib || !grad_rec || !radii ||
         !dmeans2D || !dopacities || !viewmatrix || !projmatrix)
         return ENVGS_ERR_BAD_ARG;
     if (N > 0 && !point_list) return ENVGS_ERR_BAD_ARG;

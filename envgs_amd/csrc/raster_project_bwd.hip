@@ -126,8 +126,8 @@ project_surfels_bwd(int P, int D, int M, int f16, int C, int W, int H, float mod
             float *dsh = dshs + (size_t)i * M * 3;
             const float dirx = p0 - campos[0], diry = p1 - campos[1], dirz = p2 - campos[2];
             const float sum2 = dirx * dirx + diry * diry + dirz * dirz;
-            const float ilen = 1.0f / sqrtf(sum2);
-            const float x = dirx * ilen, y = diry * ilen, z = dirz * ilen;
+            const float len = sqrtf(sum2), ilen = 1.0f / len;
+            const float x = dirx / len, y = diry / len, z = dirz / len;           // (the oracle's normalisation: three divisions)
             float ddx = 0.f, ddy = 0.f, ddz = 0.f;
             const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
 #pragma unroll

@@ -134,6 +134,8 @@ ENVGS_API int envgs_raster_render_audit(const envgs_raster_cfg *cfg, const float
  *   dshs (P,sh_coeffs,3) when shs != NULL, else dcolors (P,C);
  *   dscales/drots/dmeans3D when transmat_precomp == NULL, else dtransmat_precomp (P,9).
  * dmeans2D (P,3) receives the densification proxy read by gaussian2d_utils.py:901-909.
+ * dL_dcolor (C,H,W) / dL_dallmap (7,H,W): the upstream gradients; either may be NULL = that output is not used by the loss (zero gradient;
+ * the autograd node passes undefined gradients through as NULL instead of materialising a buffer of zeros).
  */
 ENVGS_API int envgs_raster_backward(const envgs_raster_cfg *cfg, uint32_t N,
                           const float *geom, const float *colors, const float *bg,

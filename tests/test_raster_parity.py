@@ -229,8 +229,10 @@ def test_backward_sparse_distortion_gradient():
     assert float(np.abs(rb["dmeans3D"]).max()) > 0 and float(leaves["means3D"].grad.abs().max()) > 0
     grads = dict(leaves, means2D=means2D)
     for k_hip, k_ref in GRAD_NAMES:
+        # the ONLY upstream gradient is the distortion map's: every term is the three-term cancellation M2 + m^2 A - 2 m M1 of the forward's saved
+        # moments, whose `unc` is an a-priori ONE-ulp bound (orc_render_bwd_unc), not a realised error: 16 ulp here, 4 x realised error elsewhere
         check_close("sparse_distortion_gradient", k_ref, grads[k_hip].grad.cpu().numpy().reshape(rb[k_ref].shape), rb[k_ref],
-                    excluded=int(aud["fragile"].sum()), cond=rb["cond"][k_ref], unc=rb["unc"][k_ref])
+                    excluded=int(aud["fragile"].sum()), cond=rb["cond"][k_ref], unc=rb["unc"][k_ref], k_unc=16.0)
 
 
 def test_precomputed_transmat_path():

@@ -73,7 +73,8 @@ def assert_close_frac(a, b, tol, max_bad_frac=1e-4, flip_bound=None, what=""):
 # (tests/conftest.py), so the measured errors are part of the GPU test log.
 TOL = 1e-4
 KAPPA = 0.02
-K_UNC = 16.0
+K_UNC = 4.0     # rounds 1-3: 16 (plus, at full size, a tail allowance).  Round 4: with the canonical operation order (oracle/surfel_raster_oracle.c:eval_splat)
+                # every raster and tracer comparison of the suite but one also holds at K_UNC = 1, and at full size at K_UNC = 0 (profiles/r04_parity_errors.txt)
 ERROR_TABLE = []
 
 
@@ -87,10 +88,12 @@ def floor_rel_err(a, b, floor=None):
     return np.abs(a - b) / (np.abs(b) + floor), floor
 
 
-def check_close(test, name, a, b, tol=TOL, keep=None, floor=None, excluded=0, cond=None, unc=None):
+def check_close(test, name, a, b, tol=TOL, keep=None, floor=None, excluded=0, cond=None, unc=None, k_unc=None):
     """Assert the contract on (a, b) restricted to `keep` (boolean mask broadcastable to the leading dims, or None); record the result.
     cond / unc: per-element sum |term| and measured fp32 uncertainty from the oracle (gradients), see the comment above.
+    k_unc: multiple of `unc` in the floor (default K_UNC; the one test whose `unc` is an a-priori ulp bound instead of a realised error says 16).
     (Rounds 2-3 had a `tail=` allowance for the full-size raster comparisons; gone with the canonical operation order, round 4.)"""
+    k_assert = K_UNC if k_unc is None else float(k_unc)
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     assert a.shape == b.shape, (name, a.shape, b.shape)
     if cond is not None:
@@ -103,7 +106,7 @@ def check_close(test, name, a, b, tol=TOL, keep=None, floor=None, excluded=0, co
         if cond is not None: cond = cond[keep]
         if unc is not None: unc = unc[keep]
     if cond is not None:
-        fl_i = 0.01 * float(np.abs(b).mean() if b.size else 0.0) + KAPPA * cond + ((K_UNC / tol) * unc if unc is not None else 0.0)
+        fl_i = 0.01 * float(np.abs(b).mean() if b.size else 0.0) + KAPPA * cond + ((k_assert / tol) * unc if unc is not None else 0.0)
         err = np.abs(a - b) / (np.abs(b) + fl_i + 1e-300)
         fl = float(np.mean(fl_i)) if cond.size else 0.0
     else:
@@ -111,9 +114,10 @@ def check_close(test, name, a, b, tol=TOL, keep=None, floor=None, excluded=0, co
     mx = float(err.max()) if err.size else 0.0
     note = "" if mx <= tol else "%d elements beyond tol" % int((err > tol).sum())
     if cond is not None and unc is not None and err.size:
-        # sensitivity of the verdict to K_UNC: the same comparison with the measured-uncertainty term at 4x and at 1x instead of 16x
-        sens = []
-        for k in (4.0, 1.0, 0.0):
+        # sensitivity of the verdict to K_UNC: the same comparison with the measured-uncertainty term at other multiples,
+        # down to NONE (K_UNC=0: the plain 1e-4 |b| + 2e-6 sum|term| bound)
+        sens = ["asserted at K_UNC=%g" % k_assert]
+        for k in [kk for kk in (16.0, 4.0, 1.0, 0.0) if kk != k_assert]:
             fl_k = 0.01 * float(np.abs(b).mean()) + KAPPA * cond + (k / tol) * unc
             e_k = np.abs(a - b) / (np.abs(b) + fl_k + 1e-300)
             sens.append("K_UNC=%g: max %.2e, %d beyond" % (k, float(e_k.max()), int((e_k > tol).sum())))
