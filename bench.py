@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--prefer-rocblas", action="store_true", help="opt in to envgs_amd.prefer_rocblas() for the whole run (torch's tiny-K batched matmuls of the unchanged caller's get_disks, INTEGRATION.md section 5); the default run leaves torch's BLAS choice alone and times the reference-caller form under BOTH settings")
     ap.add_argument("--debug-trace", type=int, default=0, help="ENVGS_DBG_TRACE diagnostic switch mask (include/envgs_raster.h); reported in the JSON line")
     ap.add_argument("--diag", action="store_true", help="load the diagnostic build (A/B kernels of --debug-trace 8 / 16 / 512 / 2048; the product library rejects those switches)")
+    ap.add_argument("--debug-raykey", type=int, default=0, help="ENVGS_DBG_RAYKEY diagnostic switch: value - 1 = direction-only rounds of the ray coherence key (csrc/ray_key.h); 0 = default")
     ap.add_argument("--debug-collect-wgs", type=int, default=0, help="ENVGS_DBG_COLLECT_WGS diagnostic switch: workgroups per CU of the collection's persistent grid (default 8)")
     ap.add_argument("--debug-segments", type=int, default=0, help="ENVGS_DBG_SEGMENTS diagnostic switch; reported in the JSON line")
     ap.add_argument("--optim", default="fused", choices=["fused", "torch", "none"],
@@ -156,6 +157,7 @@ def main():
         _lib.select("diag")                        # libenvgs_hip_diag.so: the product kernels + the superseded A/B kernels behind --debug-trace
     lib = _lib.load()
     lib.envgs_debug_set(0, args.debug_trace); lib.envgs_debug_set(1, args.debug_segments); lib.envgs_debug_set(2, args.debug_collect_wgs)
+    lib.envgs_debug_set(4, args.debug_raykey)
     import torch.distributed as dist
 
     P, H, W = args.gaussians, (args.height or args.res), (args.width or args.res)

@@ -463,21 +463,64 @@ size_t ray_sort_temp_bytes(int R)
     return sizeof(uint32_t) * ((size_t)BIN_ROWS_MAX * nb + 5 * nb + 1 + 4 + (size_t)(R > 0 ? R : 1)) + 256;
 }
 
+// Bounding box of the ray origins, one partial (lo[3], hi[3]) per workgroup: the key pass reduces the <= BIN_ROWS_MAX partials itself (no atomics,
+// nothing to initialise).
+__global__ void __launch_bounds__(256)
+ray_origin_bounds(int R, int slice, const float *__restrict__ ray_o, float *__restrict__ partial)
+{
+    __shared__ float s_red[4][6];
+    const int g0 = blockIdx.x * slice, g1 = min(R, g0 + slice);
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = g0 + (int)threadIdx.x; i < g1; i += 256) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { const float x = ray_o[3 * i + c]; if (x == x && fabsf(x) < 1.0e30f) { lo[c] = fminf(lo[c], x); hi[c] = fmaxf(hi[c], x); } }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o)); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { for (int c = 0; c < 3; c++) { s_red[wave][c] = lo[c]; s_red[wave][3 + c] = hi[c]; } }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int c = threadIdx.x;
+        float v = s_red[0][c];
+        for (int w = 1; w < 4; w++) v = c < 3 ? fminf(v, s_red[w][c]) : fmaxf(v, s_red[w][c]);
+        partial[blockIdx.x * 6 + c] = v;
+    }
+}
+
 template <bool SCATTER>
 __global__ void __launch_bounds__(256)
 ray_bucket_pass(int R, int slice, int nb, int shift, const float *__restrict__ ray_o, const float *__restrict__ ray_d,
-                const float4 *__restrict__ nodes, int P, uint32_t *__restrict__ keys, uint32_t *hist, const uint32_t *__restrict__ bucket_start,
+                const float *__restrict__ bounds_partial, int nrows, int lead, uint32_t *__restrict__ keys, uint32_t *hist, const uint32_t *__restrict__ bucket_start,
                 uint64_t *__restrict__ pairs)
 {
     extern __shared__ uint32_t s_bin[];
+    __shared__ float s_box[6];
     const int g0 = blockIdx.x * slice, g1 = min(R, g0 + slice);
     uint32_t *row = hist + (size_t)blockIdx.x * nb;
     for (int t = threadIdx.x; t < nb; t += 256) s_bin[t] = SCATTER ? bucket_start[t] + row[t] : 0u;
+    if (!SCATTER && threadIdx.x < 64) {          // the origins' bounding box: min / max over the partials (6 lanes x strided rows, then across the wavefront)
+        const int c = threadIdx.x % 6, j0 = threadIdx.x / 6;
+        float v = c < 3 ? 3.0e38f : -3.0e38f;
+        if (j0 < 10)
+            for (int j = j0; j < nrows; j += 10) { const float x = bounds_partial[j * 6 + c]; v = c < 3 ? fminf(v, x) : fmaxf(v, x); }
+        // lanes c, c + 6, ..., c + 54 hold component c: gather them in lane c
+        float acc = v;
+        for (int k = 1; k < 10; k++) { const float x = __shfl(v, (int)(threadIdx.x % 6) + 6 * k); if (threadIdx.x < 6) acc = c < 3 ? fminf(acc, x) : fmaxf(acc, x); }
+        if (threadIdx.x < 6) s_box[c] = acc;
+    }
     __syncthreads();
+    float lo0 = 0.f, lo1 = 0.f, lo2 = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (!SCATTER) {
+        lo0 = s_box[0]; lo1 = s_box[1]; lo2 = s_box[2];
+        const float e0 = s_box[3] - lo0, e1 = s_box[4] - lo1, e2 = s_box[5] - lo2;
+        s0 = e0 > 0.f ? 32.0f / e0 : 0.f; s1 = e1 > 0.f ? 32.0f / e1 : 0.f; s2 = e2 > 0.f ? 32.0f / e2 : 0.f;
+    }
     for (int i = g0 + (int)threadIdx.x; i < g1; i += 256) {
         uint32_t key;
         if (SCATTER) key = keys[i];
-        else keys[i] = key = ray_coherence_key(i, ray_o, ray_d, nodes, P);
+        else keys[i] = key = ray_coherence_key(i, ray_o, ray_d, lo0, lo1, lo2, s0, s1, s2, lead);
         const uint32_t slot = atomicAdd(&s_bin[key >> shift], 1u);
         if (SCATTER) pairs[slot] = ((uint64_t)key << 32) | (uint32_t)i;
     }
@@ -489,6 +532,7 @@ ray_bucket_pass(int R, int slice, int nb, int shift, const float *__restrict__ r
 int launch_ray_sort(int R, const float *ray_o, const float *ray_d, const float4 *nodes, int P, uint64_t *pairs, uint32_t *order,
                     void *temp, size_t temp_bytes, hipStream_t stream)
 {
+    (void)nodes; (void)P;           // (rounds 1-3 quantised the origins inside the scene box; the key now uses the rays' own bounding box)
     if (R <= 0) return 0;
     if (temp_bytes < ray_sort_temp_bytes(R)) return ENVGS_ERR_TEMP_TOO_SMALL;
     const int bits = ray_bucket_bits(R), nb = 1 << bits, shift = 31 - bits;
@@ -503,12 +547,16 @@ int launch_ray_sort(int R, const float *ray_o, const float *ray_d, const float4 
     uint32_t *hdr = long_list + nb;
     uint32_t *ranges = hdr + 4;
     uint32_t *keys = ranges + 2 * (size_t)nb;
+    float *partial = (float *)(keys + (size_t)R);                          // (BIN_ROWS_MAX, 6) bounds partials
     const size_t lds = sizeof(uint32_t) * (size_t)nb;
-    hipLaunchKernelGGL(ray_bucket_pass<false>, dim3(rows), dim3(256), lds, stream, R, slice, nb, shift, ray_o, ray_d, nodes, P, keys, hist,
+    int lead = debug_switch(ENVGS_DBG_RAYKEY) > 0 ? debug_switch(ENVGS_DBG_RAYKEY) - 1 : RAY_KEY_LEAD;
+    lead = lead > 8 ? 8 : lead;
+    hipLaunchKernelGGL(ray_origin_bounds, dim3(rows), dim3(256), 0, stream, R, slice, ray_o, partial);
+    hipLaunchKernelGGL(ray_bucket_pass<false>, dim3(rows), dim3(256), lds, stream, R, slice, nb, shift, ray_o, ray_d, (const float *)partial, rows, lead, keys, hist,
                        (const uint32_t *)nullptr, (uint64_t *)nullptr);
     hipLaunchKernelGGL(bin_column_scan, dim3((nb + 15) / 16), dim3(256), 0, stream, rows, nb, hist, count);
     hipLaunchKernelGGL(bin_tile_scan, dim3(1), dim3(1024), 0, stream, nb, count, start, ranges, (uint32_t)R, hdr);
-    hipLaunchKernelGGL(ray_bucket_pass<true>, dim3(rows), dim3(256), lds, stream, R, slice, nb, shift, ray_o, ray_d, nodes, P, keys, hist, start, pairs);
+    hipLaunchKernelGGL(ray_bucket_pass<true>, dim3(rows), dim3(256), lds, stream, R, slice, nb, shift, ray_o, ray_d, (const float *)partial, rows, lead, keys, hist, start, pairs);
     launch_bucket_sorts(R, nb, ranges, pairs, (uint64_t *)nullptr, order, hdr, long_list, 0, stream);
     return (int)hipGetLastError();
 }

@@ -4,33 +4,38 @@
 
 namespace envgs {
 
-// Octahedral direction (2 x 8 bits, Morton-interleaved) in the high 16 bits, origin cell inside the scene box (3 x 5 bits) below: 31 bits.
+constexpr int RAY_KEY_LEAD = 4;      // direction-only rounds in front of the interleaved ones (see below); envgs_debug_set(ENVGS_DBG_RAYKEY, lead + 1) overrides
+
+// 31-bit key: octahedral direction (u, v: 8 bits each) and origin cell (x, y, z: 5 bits each) INSIDE THE BOUNDING BOX OF THE RAY ORIGINS,
+// Morton-interleaved from the top: `lead` rounds of (u, v) alone, then rounds of (u, v, x, y, z) until the origin bits are used up, then the
+// remaining direction bits.  Rounds 1-3 normalised the origin by the SCENE box and put all 16 direction bits first: the reflected rays of
+// EnvGS leave a +-1.3 object inside a +-50 environment, so every origin fell into one cell and a 64-ray batch -- one direction cell -- held
+// rays from all over the object: a bundle 2.6 units wide against surfels of radius ~3, each surfel met by ~25 of the batch's 64 rays.
+// A batch should be a THIN bundle at the distances where its rays hit things: its width there is (origin spread) + t x (direction spread),
+// and with ~10 k batches over a 4-dimensional ray space both factors matter -- hence the interleaving.  Measured on the bench scene (MI355X,
+// round 4, ms per training step; lead = 8 is the old direction-major layout with the origin bits made meaningful):
+//   lead 8: 9.53   5: 9.03   4: 8.96   3: 9.23   2: 9.72   1: 10.64   0: 12.10      entries per step 2.37 M (lead 8) -> 2.09 M (lead 4)
 __device__ __forceinline__ unsigned ray_coherence_key(int r, const float *__restrict__ ray_o, const float *__restrict__ ray_d,
-                                                      const float4 *__restrict__ nodes, int P)
+                                                      const float lo0, const float lo1, const float lo2, const float s0, const float s1, const float s2,
+                                                      const int lead)
 {
-    float lo[3] = {-1.f, -1.f, -1.f}, ext[3] = {2.f, 2.f, 2.f};
-    if (P > 0) {
-        const float4 n0 = nodes[0], n1 = nodes[1], n2 = nodes[2];
-        lo[0] = fminf(n0.x, n1.z); lo[1] = fminf(n0.y, n1.w); lo[2] = fminf(n0.z, n2.x);
-        ext[0] = fmaxf(n0.w, n2.y) - lo[0]; ext[1] = fmaxf(n1.x, n2.z) - lo[1]; ext[2] = fmaxf(n1.y, n2.w) - lo[2];
-    }
     const float dx = ray_d[3 * r], dy = ray_d[3 * r + 1], dz = ray_d[3 * r + 2];
     const float inv = 1.0f / (fabsf(dx) + fabsf(dy) + fabsf(dz) + 1e-30f);
     float u = dx * inv, v = dy * inv;
     if (dz < 0.f) { const float uu = (1.f - fabsf(v)) * (u >= 0.f ? 1.f : -1.f), vv = (1.f - fabsf(u)) * (v >= 0.f ? 1.f : -1.f); u = uu; v = vv; }
     const unsigned qu = (unsigned)fminf(fmaxf((u * 0.5f + 0.5f) * 256.f, 0.f), 255.f), qv = (unsigned)fminf(fmaxf((v * 0.5f + 0.5f) * 256.f, 0.f), 255.f);
-    unsigned dkey = 0;
+    // origin cell: (o - lo) * (32 / extent), s = 0 for a degenerate extent (camera rays: one origin)
+    const unsigned qx = (unsigned)fminf(fmaxf((ray_o[3 * r] - lo0) * s0, 0.f), 31.f);
+    const unsigned qy = (unsigned)fminf(fmaxf((ray_o[3 * r + 1] - lo1) * s1, 0.f), 31.f);
+    const unsigned qz = (unsigned)fminf(fmaxf((ray_o[3 * r + 2] - lo2) * s2, 0.f), 31.f);
+    unsigned key = 0;
+    int di = 7, oi = 4;
 #pragma unroll
-    for (int b = 0; b < 8; b++) dkey |= ((qu >> b) & 1u) << (2 * b) | ((qv >> b) & 1u) << (2 * b + 1);
-    unsigned okey = 0;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float t = ext[c] > 0.f ? (ray_o[3 * r + c] - lo[c]) / ext[c] : 0.f;
-        const unsigned q = (unsigned)fminf(fmaxf(t * 32.f, 0.f), 31.f);
-#pragma unroll
-        for (int b = 0; b < 5; b++) okey |= ((q >> b) & 1u) << (3 * b + c);
+    for (int k = 0; k < 13; k++) {
+        if (di >= 0) { key = (key << 2) | (((qv >> di) & 1u) << 1) | ((qu >> di) & 1u); di--; }
+        if (k >= lead && oi >= 0) { key = (key << 3) | (((qz >> oi) & 1u) << 2) | (((qy >> oi) & 1u) << 1) | ((qx >> oi) & 1u); oi--; }
     }
-    return (dkey << 15) | okey;
+    return key;
 }
 
 }  // namespace envgs

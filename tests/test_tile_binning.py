@@ -149,8 +149,10 @@ def test_scan_around_its_workgroup_granularity(P):
     np.testing.assert_array_equal(got, (want - 1)[keep.numpy()])
 
 
-def _numpy_ray_keys(ro, rd):
-    """envgs_amd/csrc/ray_key.h restated (float32; a ray exactly on a quantisation boundary may land one cell off: the test allows a handful)."""
+def _numpy_ray_keys(ro, rd, lead=4):
+    """envgs_amd/csrc/ray_key.h restated (float32; a ray exactly on a quantisation boundary may land one cell off: the test allows a handful):
+    octahedral direction 2 x 8 bits, origin cell 3 x 5 bits inside the bounding box of the ray origins, interleaved from the top -- `lead` rounds
+    of (u, v), then rounds of (u, v, x, y, z), then what is left of the direction."""
     f = np.float32
     inv = f(1) / (np.abs(rd).sum(1, dtype=f) + f(1e-30))
     u, v = rd[:, 0] * inv, rd[:, 1] * inv
@@ -159,13 +161,18 @@ def _numpy_ray_keys(ro, rd):
     u = np.where(neg, uu, u); v = np.where(neg, vv, v)
     q = lambda x: np.clip((x * f(0.5) + f(0.5)) * f(256), 0, 255).astype(np.uint32)
     qu, qv = q(u), q(v)
-    dkey = np.zeros(len(rd), np.uint32)
-    for b in range(8): dkey |= ((qu >> b) & 1) << (2 * b) | ((qv >> b) & 1) << (2 * b + 1)
-    okey = np.zeros(len(rd), np.uint32)
-    for c in range(3):
-        qc = np.clip(((ro[:, c] + f(1)) / f(2)) * f(32), 0, 31).astype(np.uint32)
-        for b in range(5): okey |= ((qc >> b) & 1) << (3 * b + c)
-    return (dkey << 15) | okey
+    lo, hi = ro.min(0), ro.max(0)
+    ext = (hi - lo).astype(f)
+    sc = np.where(ext > 0, f(32) / np.where(ext > 0, ext, f(1)), f(0)).astype(f)
+    qo = [np.clip((ro[:, c] - lo[c]) * sc[c], 0, 31).astype(np.uint32) for c in range(3)]
+    key = np.zeros(len(rd), np.uint32)
+    di, oi = 7, 4
+    for k in range(13):
+        if di >= 0:
+            key = (key << np.uint32(2)) | (((qv >> di) & 1) << 1) | ((qu >> di) & 1); di -= 1
+        if k >= lead and oi >= 0:
+            key = (key << np.uint32(3)) | (((qo[2] >> oi) & 1) << 2) | (((qo[1] >> oi) & 1) << 1) | ((qo[0] >> oi) & 1); oi -= 1
+    return key.astype(np.uint32)
 
 
 @pytest.mark.parametrize("R, kind", [(1, "random"), (63, "random"), (5000, "random"), (200000, "random"), (640000, "cone"), (300000, "parallel")])
