@@ -387,6 +387,28 @@ def main():
     tcounts = tracing.last_trace_counts() if envgs else None
     entries = sum(tracing.last_entry_counts()) if envgs else 0
 
+    # acceleration structure on its own (outside the timed region): a full build (Morton keys, sort, hierarchy, fit) against a REFIT of the same
+    # topology (envgs_bvh_refit: OptiX's "update", build_acceleration_structure(rebuild=False)) over the step's own environment set
+    bvh_times = None
+    if envgs and rank == 0:
+        from envgs_amd import fused as _fz
+        with torch.no_grad():
+            vq, _ = _fz.surfel_quads(env_params["means3D"], env_params["scales"], env_params["rotations"])
+            opq = env_params["opacities"].detach()
+            nodes0, _ = tracing.build_bvh(vq, opq)
+            def _ms(fn, reps=8):
+                fn(); torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps): fn()
+                e1.record(); torch.cuda.synchronize(dev)
+                return e0.elapsed_time(e1) / reps
+            b_ms = _ms(lambda: tracing.build_bvh(vq, opq))
+            r_ms = _ms(lambda: tracing.build_bvh(vq, opq, refit=nodes0))
+        bvh_times = {"surfels": int(env_params["means3D"].shape[0]), "build_ms": round(b_ms, 4), "refit_ms": round(r_ms, 4), "refit_over_build": round(r_ms / max(b_ms, 1e-9), 3),
+                     "note": "wall time of the launches on an otherwise idle GPU (incl. the temp allocation); per-kernel split in profiles/ (rocprofv3 kernel stats)"}
+        del nodes0, vq
+
     # the metric's second half, "render Mpix/s": forward only under no_grad (inference: no per-hit state, no entries), outside the timed region
     def render(it):
         vi = (it * world + rank) % 8
@@ -513,7 +535,7 @@ def main():
             "render_mpix_per_s": (round(world * HW / render_s / 1e6, 2) if n_render else None),
             "render_ms_per_view": (round(render_s * 1e3, 4) if n_render else None),
             "exchange": exch,
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "trace_counts": (dict(tcounts, entries=entries) if tcounts else None),
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "bvh": bvh_times, "trace_counts": (dict(tcounts, entries=entries) if tcounts else None),
         }
         print(json.dumps(line))
     if world > 1:

@@ -263,7 +263,7 @@ bin_tile_scan(int ntiles, const uint32_t *__restrict__ tile_count, uint32_t *__r
         ranges[2 * k + 1] = (c && ok) ? run + c : 0u;
         run += c;
     }
-    if (threadIdx.x == 0) { tile_start[ntiles] = total; hdr[0] = total; hdr[1] = 0u; }
+    if (threadIdx.x == 0) { tile_start[ntiles] = total; hdr[0] = total; hdr[1] = 0u; hdr[2] = 0u; hdr[3] = 0u; }      // [1] long lists; sort_long_lists: [2] items claimed, [3] items done
 }
 
 // Sort the power-of-two padded LDS array of 1 << lp entries (tile_sort.h: register-blocked bitonic network, one barrier per 4 steps;
@@ -342,49 +342,113 @@ sort_tile_lists(const uint32_t *__restrict__ ranges, const uint64_t *pairs, uint
     load_sort_write<NT>(s_k, pairs, n, t, b, keys_sorted, point_list, (int)threadIdx.x, full64);
 }
 
-// One workgroup per CU walks the long lists: up to 16 384 entries in LDS, beyond that chunk by chunk through LDS with the wide steps in HBM.
+// The long lists, one persistent workgroup per CU.  Up to 16 384 entries: one workgroup sorts the list in LDS (the lists are dealt round robin).
+// Beyond that (a few far outlier surfels collapse the Morton codes, a narrow cone of rays collapses the direction cells, a tile with
+// > 16 k instances -- and ONE workgroup merging a 600 k-entry list through HBM took ~20 ms): the whole grid works on the list.  Its sort is a
+// fixed sequence of PHASES (tile_sort.h: ts_sort_hybrid is the schedule) -- sort every 16 384-entry chunk in LDS; then per merge stage the
+// steps wider than a chunk on the segment in HBM, and an ascending merge of every chunk in LDS again -- and every phase is a number of
+// independent ITEMS (a chunk; 16 384 comparators of a wide step).  Items are numbered through all phases of all such lists and CLAIMED from one
+// counter (hdr[2]); an item of phase p starts when the completion counter (hdr[3]) says every item of the earlier phases is done.  No workgroup
+// ever waits for a workgroup that has not started: whatever is unfinished was claimed by a RUNNING workgroup, so the scheme cannot deadlock
+// however many of the grid's workgroups are resident (two such kernels on two streams, several processes on one GPU), and a late workgroup
+// finds its counters exhausted and falls through.  Lists that need no cooperation touch neither counter.
+constexpr int LONG_ITEM = 16384;      // comparators of a wide step per item
+
+__device__ __forceinline__ uint32_t long_claim(uint32_t *hdr, uint32_t *s_item)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) *s_item = atomicAdd(&hdr[2], 1u);
+    __syncthreads();
+    return *s_item;
+}
+__device__ __forceinline__ void long_wait(uint32_t *hdr, const uint32_t base)
+{
+    if (threadIdx.x == 0)
+        while (__hip_atomic_load(&hdr[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < base) __builtin_amdgcn_s_sleep(4);
+    __syncthreads();
+    __threadfence();                    // (every lane: the segment was written by other workgroups, possibly behind another XCD's L2)
+}
+__device__ __forceinline__ void long_done(uint32_t *hdr)
+{
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&hdr[3], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ void __launch_bounds__(1024)
 sort_long_lists(const uint32_t *__restrict__ ranges, uint64_t *pairs, uint64_t *keys_sorted, uint32_t *__restrict__ point_list,
-                const uint32_t *__restrict__ hdr, const uint32_t *__restrict__ long_list, int full64)
+                uint32_t *hdr, const uint32_t *__restrict__ long_list, int full64)
 {
     __shared__ uint64_t s_long[lds_slots(14)];
+    __shared__ uint32_t s_item;
     const uint32_t count = hdr[1];
-    const int tid = (int)threadIdx.x;
-    for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
+    const int tid = (int)threadIdx.x, G = (int)gridDim.x;
+    uint32_t small_seen = 0u, base = 0u, my = 0u;
+    bool claimed = false;
+    for (uint32_t w = 0; w < count; w++) {
         const uint32_t t = long_list[w], b = ranges[2 * t];
         const int n = (int)(ranges[2 * t + 1] - b);
         if (n <= SORT_LONG_N) {
+            if ((small_seen++ % (uint32_t)G) != blockIdx.x) continue;
             load_sort_write<1024>(s_long, pairs, n, t, b, keys_sorted, point_list, tid, full64);
-        } else {
-            // Too long for LDS: chunks of 16 384 entries are sorted in LDS, and of every later merge stage only the steps whose distance is
-            // at least a chunk touch the segment in HBM (all-ascending network: entries beyond n never move, so nothing is padded in
-            // memory); the rest of the stage is an ascending merge of each chunk in LDS again (tile_sort.h: ts_sort_hybrid).
-            uint64_t *seg = pairs + b;
-            constexpr int LC = 14, C = 1 << LC;
-            int lp = LC;
-            while ((1 << lp) < n) lp++;
-            const int nchunks = (n + C - 1) / C;
-            for (int lk = LC; lk <= lp; lk++) {
-                if (lk > LC)
-                    for (int q = 0; q <= lk - LC - 1; q++) {
-                        for (int idx = tid; idx < (1 << (lp - 1)); idx += 1024) ascending_step(seg, n, lk, q, idx);
-                        __syncthreads();
-                    }
-                for (int c = 0; c < nchunks; c++) {
-                    for (int i = tid; i < C; i += 1024) s_long[ts_slot(i)] = (c * C + i) < n ? seg[c * C + i] : ~0ull;
+            __syncthreads();
+            continue;
+        }
+        // all-ascending network: entries beyond n never move, so nothing is padded in memory
+        uint64_t *seg = pairs + b;
+        constexpr int LC = 14, C = 1 << LC;
+        int lp = LC;
+        while ((1 << lp) < n) lp++;
+        const uint32_t nchunks = (uint32_t)((n + C - 1) / C);
+        const uint32_t nwide = (uint32_t)(((1ll << (lp - 1)) + LONG_ITEM - 1) / LONG_ITEM);
+        const bool copy_out = !(full64 && keys_sorted == pairs);
+        if (!claimed) { my = long_claim(hdr, &s_item); claimed = true; }
+        // phase kinds: 0 = chunk sort / merge (lk), 1 = wide step (lk, q), 2 = copy the sorted segment out
+        auto run_phase = [&](const int kind, const int lk, const int q, const uint32_t items) {
+            while (my - base < items) {                  // (unsigned: my >= base always -- items are claimed in order)
+                long_wait(hdr, base);
+                const uint32_t it = my - base;
+                if (kind == 0) {
+                    const int c = (int)it;
+                    for (int i = tid; i < C; i += 1024) s_long[ts_slot(i)] = ((long long)c * C + i) < n ? seg[(size_t)c * C + i] : ~0ull;
                     __syncthreads();
                     if (lk == LC) sort_padded_lds<1024>(s_long, LC, tid);
                     else merge_padded_lds<1024>(s_long, LC, tid);
                     for (int i = tid; i < C; i += 1024)
-                        if (c * C + i < n) seg[c * C + i] = s_long[ts_slot(i)];
-                    __syncthreads();
+                        if ((long long)c * C + i < n) seg[(size_t)c * C + i] = s_long[ts_slot(i)];
+                } else if (kind == 1) {
+                    const long long i0 = (long long)it * LONG_ITEM, i1 = min(i0 + LONG_ITEM, 1ll << (lp - 1));
+                    for (long long idx = i0 + tid; idx < i1; idx += 1024) ascending_step(seg, n, lk, q, (int)idx);
+                } else {
+                    const long long i0 = (long long)it * C, i1 = min(i0 + C, (long long)n);
+                    for (long long i = i0 + tid; i < i1; i += 1024) store_sorted(seg[i], t, (size_t)b + (size_t)i, keys_sorted, point_list, full64);
                 }
+                long_done(hdr);
+                my = long_claim(hdr, &s_item);
             }
-            if (!(full64 && keys_sorted == pairs))
-                for (int i = tid; i < n; i += 1024) store_sorted(seg[i], t, (size_t)b + i, keys_sorted, point_list, full64);
+            base += items;
+        };
+        run_phase(0, LC, 0, nchunks);
+        for (int lk = LC + 1; lk <= lp; lk++) {
+            for (int q = 0; q <= lk - LC - 1; q++) run_phase(1, lk, q, nwide);
+            run_phase(0, lk, 0, nchunks);
         }
-        __syncthreads();
+        if (copy_out) run_phase(2, 0, 0, nchunks);
     }
+}
+
+// sort_long_lists' grid: one workgroup per CU of the device the stream runs on
+static int long_sort_grid()
+{
+    static int cached[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 64;
+    if (cached[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 64;
+        cached[dev] = cus < SORT_LONG_WGS ? cus : SORT_LONG_WGS;
+    }
+    return cached[dev];
 }
 
 int launch_bin(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const int32_t *radii, uint64_t *tile_pairs,
@@ -425,7 +489,7 @@ int launch_bin(const envgs_raster_cfg *cfg, uint32_t N, const float *geom, const
     else
         hipLaunchKernelGGL((sort_tile_lists<13, 512>), dim3(pl.ntiles), dim3(512), 0, stream, ranges, tile_pairs, keys_sorted, point_list, hdr, long_list, 0);
     ENVGS_CHECK_LAUNCH(cfg, stream);
-    hipLaunchKernelGGL(sort_long_lists, dim3(SORT_LONG_WGS), dim3(1024), 0, stream, ranges, tile_pairs,
+    hipLaunchKernelGGL(sort_long_lists, dim3(long_sort_grid()), dim3(1024), 0, stream, ranges, tile_pairs,
                        keys_sorted, point_list, hdr, long_list, 0);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return 0;
@@ -447,7 +511,7 @@ static void launch_bucket_sorts(uint64_t n, int nb, const uint32_t *ranges, uint
         hipLaunchKernelGGL((sort_tile_lists<12, 256>), dim3(nb), dim3(256), 0, stream, ranges, pairs, keys_sorted, point_list, hdr, long_list, full64);
     else
         hipLaunchKernelGGL((sort_tile_lists<13, 512>), dim3(nb), dim3(512), 0, stream, ranges, pairs, keys_sorted, point_list, hdr, long_list, full64);
-    hipLaunchKernelGGL(sort_long_lists, dim3(SORT_LONG_WGS), dim3(1024), 0, stream, ranges, pairs, keys_sorted, point_list, hdr, long_list, full64);
+    hipLaunchKernelGGL(sort_long_lists, dim3(long_sort_grid()), dim3(1024), 0, stream, ranges, pairs, keys_sorted, point_list, hdr, long_list, full64);
 }
 
 static int ray_bucket_bits(int R)

@@ -489,21 +489,29 @@ row_count(const TraceArgs A, unsigned *__restrict__ blk)
 __global__ void __launch_bounds__(1024)
 row_scan_blocks(unsigned *__restrict__ blk, int n)
 {
-    // exclusive scan in place, one workgroup: each thread owns a contiguous run (n <= a few thousand blocks)
-    __shared__ unsigned part[1024];
-    const int per = (n + 1023) / 1024, lo = (int)threadIdx.x * per, hi = min(n, lo + per);
-    unsigned s = 0u;
-    for (int i = lo; i < hi; i++) s += blk[i];
-    part[threadIdx.x] = s;
+    // exclusive scan in place, one workgroup, 1024 counts per pass: coalesced loads, integer wave scans (the totals exceed 2^24: no float scan),
+    // the 16 wavefront totals through LDS, a running base carried from pass to pass.  (Round 3: every thread summed a contiguous run of its own and
+    // a ten-round Hillis-Steele pass over LDS joined them: 23 us on the step's critical path, twice.)
+    __shared__ unsigned wtot[16];
+    __shared__ unsigned s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0u;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const unsigned v = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0u;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + (int)threadIdx.x;
+        const unsigned v = i < n ? blk[i] : 0u;
+        unsigned x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned y = (unsigned)__shfl_up((int)x, o); if (lane >= o) x += y; }
+        if (lane == 63) wtot[wave] = x;
         __syncthreads();
-        part[threadIdx.x] += v;
+        unsigned before = s_base;
+        for (int w = 0; w < wave; w++) before += wtot[w];
+        if (i < n) blk[i] = before + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_base = before + x;
         __syncthreads();
     }
-    unsigned run = part[threadIdx.x] - s;
-    for (int i = lo; i < hi; i++) { const unsigned v = blk[i]; blk[i] = run; run += v; }
 }
 
 __global__ void __launch_bounds__(256)

@@ -58,8 +58,10 @@ def _stream(dev):
     return _lib.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-def build_bvh(vertices, opacities=None, debug=False):
-    """LBVH over the (4P,3) quad vertices (leaf boxes tightened by `opacities` when given).  Returns (nodes: envgs_bvh_node_floats(P) floats, P)."""
+def build_bvh(vertices, opacities=None, debug=False, refit=None):
+    """LBVH over the (4P,3) quad vertices (leaf boxes tightened by `opacities` when given).  Returns (nodes: envgs_bvh_node_floats(P) floats, P).
+    refit: the `nodes` tensor of an earlier build over the same number of surfels -- its topology is kept and only the boxes are recomputed, in
+    place (envgs_bvh_refit; OptiX's "update")."""
     lib = _lib.load()
     v = _f32c(vertices.detach())
     if v.device.type != "cuda":
@@ -68,14 +70,22 @@ def build_bvh(vertices, opacities=None, debug=False):
         raise RuntimeError("vertices must be (4P,3) in the get_disks layout, got %s" % (tuple(v.shape),))
     P = v.shape[0] // 4
     dev = v.device
-    nodes = torch.empty(lib.envgs_bvh_node_floats(P), dtype=torch.float32, device=dev)    # binary nodes, then the 4-wide nodes
+    nf = lib.envgs_bvh_node_floats(P)
+    if refit is not None and (refit.numel() != nf or refit.device != dev):
+        refit = None                                                  # P changed (densify / prune) or another device: nothing to keep
+    nodes = torch.empty(nf, dtype=torch.float32, device=dev)         # binary nodes, 4-wide nodes, sorted leaf order (a refit writes a FRESH buffer:
+                                                                     # an earlier forward whose backward is outstanding may still hold the old one)
     tb = lib.envgs_bvh_temp_bytes(P)
     temp = torch.empty(max(tb, 1), dtype=torch.uint8, device=dev)
     op = None if opacities is None else _f32c(opacities.detach()).reshape(-1)
     if op is not None and op.numel() != P:
         raise RuntimeError("opacities (%d) do not match the %d surfels of the vertex buffer" % (op.numel(), P))
-    _lib.check(lib.envgs_bvh_build(P, _lib.ptr(v), _lib.ptr(op), _lib.ptr(nodes), _lib.ptr(temp), tb, 1 if debug else 0, _stream(dev)),
-               "envgs_bvh_build")
+    if refit is not None:
+        _lib.check(lib.envgs_bvh_refit(P, _lib.ptr(v), _lib.ptr(op), _lib.ptr(refit), _lib.ptr(nodes), _lib.ptr(temp), tb, 1 if debug else 0, _stream(dev)),
+                   "envgs_bvh_refit")
+    else:
+        _lib.check(lib.envgs_bvh_build(P, _lib.ptr(v), _lib.ptr(op), _lib.ptr(nodes), _lib.ptr(temp), tb, 1 if debug else 0, _stream(dev)), "envgs_bvh_build")
+    LAST_STATS["bvh"] = "refit" if refit is not None else "build"
     return nodes, P
 
 
@@ -401,6 +411,7 @@ class SurfelTracer(nn.Module):
         self.nodes = None
         self.num_surfels = 0
         self._pending = None
+        self._keep = None                 # the structure a refit request (rebuild=False) updates in place
         self.caps = CapState()            # this tracer's adaptive hit-list capacity (not shared with other tracers of the process)
 
     def build_acceleration_structure(self, vertices, faces=None, rebuild=True):
@@ -413,11 +424,15 @@ class SurfelTracer(nn.Module):
             raise RuntimeError("vertices must be (4P,3) in the get_disks layout, got %s" % (tuple(vertices.shape),))
         if vertices.device.type != "cuda":
             raise RuntimeError("envgs_amd tracer needs tensors on the GPU (got %s); there is no CPU path" % vertices.device)
-        # rebuild=False is OptiX's "update" (refit the boxes of the existing topology to the new vertices).  Hit sets do not depend on the
-        # topology, a full LBVH build is 0.2 ms at 164 k surfels, and a stale structure would be silently wrong -- so an update request
-        # rebuilds as well (the reference itself only ever passes rebuild=True: optix_utils.py:78).
+        # rebuild=False is OptiX's "update": the topology of the existing structure is kept and its boxes are refitted to the new vertices
+        # (envgs_bvh_refit) -- exact, the hit sets are those of a fresh build.  Nothing to update (first call, or P changed): a full build.
+        # The reference itself only ever passes rebuild=True (optix_utils.py:78), which rebuilds, like its OptiX GAS.
+        ev = self.__dict__.pop("_build_event", None)
+        if ev is not None and self.nodes is not None:
+            torch.cuda.current_stream(self.nodes.device).wait_event(ev)       # (a build started by prepare() that no trace has consumed)
+        have = self.nodes if self.nodes is not None else self._keep
+        self._keep = have if (not rebuild and have is not None and vertices.shape[0] // 4 == self.num_surfels) else None
         self._pending = vertices.detach()
-        self.__dict__.pop("_build_event", None)
         self.nodes = None
         self.num_surfels = vertices.shape[0] // 4
 
@@ -435,8 +450,11 @@ class SurfelTracer(nn.Module):
         if opacities is not None:
             opacities = opacities.detach()
             opacities.record_stream(side)
+        if self._keep is not None:
+            self._keep.record_stream(side)
         with torch.cuda.stream(side):
-            self.nodes, self.num_surfels = build_bvh(self._pending, opacities)
+            self.nodes, self.num_surfels = build_bvh(self._pending, opacities, refit=self._keep)
+        self._keep = None
         self._build_event = torch.cuda.Event()
         self._build_event.record(side)
         self._pending = None
@@ -461,8 +479,9 @@ class SurfelTracer(nn.Module):
         if self.nodes is None:
             if self._pending.shape[0] != 4 * means3D.shape[0]:
                 raise RuntimeError("SurfelTracer: acceleration structure was requested for %d surfels, call has %d" % (self._pending.shape[0] // 4, means3D.shape[0]))
-            self.nodes, self.num_surfels = build_bvh(self._pending, opacities)
+            self.nodes, self.num_surfels = build_bvh(self._pending, opacities, refit=self._keep)
             self._pending = None
+            self._keep = None
         ev = self.__dict__.pop("_build_event", None)
         if ev is not None:                                             # built ahead on the side stream (prepare()): order this stream behind it
             cur = torch.cuda.current_stream(self.nodes.device)

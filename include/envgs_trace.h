@@ -113,9 +113,10 @@ typedef struct envgs_trace_lists {
 
 /* Scratch bytes for the Morton sort + build of P surfels. */
 ENVGS_API size_t envgs_bvh_temp_bytes(int32_t P);
-/* Floats of the `nodes` buffer for P surfels: max(P-1,1) binary nodes of 16 floats, followed by as many 4-wide nodes of 32 floats (the
+/* Floats of the `nodes` buffer for P surfels: max(P-1,1) binary nodes of 16 floats (words 0-11 the two child boxes, 12-13 the child
+ * references, 14 the parent, 15 the other end of the node's run of sorted leaves), followed by as many 4-wide nodes of 32 floats (the
  * grandchildren of each binary node, 8 floats per slot: lo.x hi.x lo.y hi.y lo.z hi.z ref 0; what the packet traversal of coherence-sorted
- * rays walks). */
+ * rays walks), followed by the sorted leaf order (P int32).  Topology words + order are what envgs_bvh_refit reads. */
 ENVGS_API size_t envgs_bvh_node_floats(int32_t P);
 
 /*
@@ -127,6 +128,18 @@ ENVGS_API size_t envgs_bvh_node_floats(int32_t P);
  */
 ENVGS_API int envgs_bvh_build(int32_t P, const float *vertices, const float *opacities, float *nodes, void *temp, size_t temp_bytes,
                               int32_t debug, void *stream);
+
+/*
+ * build_acceleration_structure(vertices, faces, rebuild=False) -- OptiX's "update" (optix_utils.py:71-85 passes the flag through): REFIT the
+ * structure a previous envgs_bvh_build left in `nodes` (same P) to moved vertices / changed opacities.  The topology and the leaf order are
+ * kept (read from nodes_prev, carried over into `nodes`; the two may be the same buffer -- the drop-in module writes a fresh one because an
+ * earlier forward whose backward is outstanding may still hold the old one); the leaf boxes, the range-union tables and every node box are
+ * recomputed (no Morton keys, no sort, no hierarchy pass).  Exact: the
+ * boxes are the unions of the NEW leaf boxes, so the hit sets are those of a fresh build; only the tree's quality follows the old positions.
+ * Same temp size as the build.
+ */
+ENVGS_API int envgs_bvh_refit(int32_t P, const float *vertices, const float *opacities, const float *nodes_prev, float *nodes, void *temp,
+                              size_t temp_bytes, int32_t debug, void *stream);
 
 /*
  * SurfelTracer.forward (optix_utils.py:188-201): trace R rays through the surfel set, composite front to back.

@@ -16,7 +16,7 @@ def _leaf_boxes(v):
     return q.min(axis=1), q.max(axis=1)
 
 
-def _build(P, seed, clustered=False):
+def _build(P, seed, clustered=False, refit=False):
     g = torch.Generator().manual_seed(seed)
     xyz = torch.rand(P, 3, generator=g) * 2 - 1
     if clustered:
@@ -27,17 +27,35 @@ def _build(P, seed, clustered=False):
     nodes, n = tracing.build_bvh(v.cuda())
     torch.cuda.synchronize()
     assert n == P
+    if refit:
+        # OptiX's "update" (envgs_bvh_refit): same topology and leaf order, boxes refitted to MOVED quads -- every invariant below must hold for
+        # the new vertices, and the topology words / leaf order must be the first build's
+        xyz2 = xyz + 0.3 * torch.randn(P, 3, generator=g)
+        scales2 = scales * (0.5 + torch.rand(P, 2, generator=g))
+        v2, _ = synth.get_disks(xyz2, scales2, q)
+        nodes2, n2 = tracing.build_bvh(v2.cuda(), refit=nodes)
+        torch.cuda.synchronize()
+        assert n2 == P and tracing.LAST_STATS["bvh"] == "refit" and nodes2.data_ptr() != nodes.data_ptr()
+        a, b = nodes.cpu().numpy(), nodes2.cpu().numpy()
+        ni = max(P - 1, 1)
+        if P > 1:
+            assert np.array_equal(a[:16 * ni].reshape(ni, 16)[:, 12:].view(np.int32), b[:16 * ni].reshape(ni, 16)[:, 12:].view(np.int32))
+            assert np.array_equal(a[48 * ni:].view(np.int32), b[48 * ni:].view(np.int32))
+        return b, v2.numpy()
     return nodes.cpu().numpy(), v.numpy()
 
 
-@pytest.mark.parametrize("P,clustered", [(1, False), (2, False), (3, False), (5, False), (64, False), (1000, False), (777, True),
-                                         (12000, True), (40000, True)])      # half of the surfels on ONE Morton code: a 6 000- / 20 000-entry bucket of the key sort (LDS / chunked)
-def test_binary_and_wide_nodes(P, clustered):
-    flat, v = _build(P, 11 + P, clustered)
+@pytest.mark.parametrize("P,clustered,refit", [(1, False, False), (2, False, False), (3, False, False), (5, False, False), (64, False, False), (1000, False, False),
+                                               (777, True, False), (12000, True, False), (40000, True, False),      # half of the surfels on ONE Morton code: a 6 000- / 20 000-entry bucket of the key sort (LDS / chunked)
+                                               (1, False, True), (2, False, True), (65, False, True), (129, False, True), (1000, False, True), (9000, True, True)])
+def test_binary_and_wide_nodes(P, clustered, refit):
+    flat, v = _build(P, 11 + P, clustered, refit)
     ni = max(P - 1, 1)
-    assert flat.size == 48 * ni
+    assert flat.size == 48 * ni + P                                 # binary nodes, wide nodes, sorted leaf order
+    order = flat[48 * ni:].copy().view(np.int32)
+    assert np.array_equal(np.sort(order), np.arange(P))             # a permutation of the surfels
     nodes = flat[:16 * ni].reshape(ni, 16)
-    wide = flat[16 * ni:].reshape(ni, 32)
+    wide = flat[16 * ni:48 * ni].reshape(ni, 32)
     llo, lhi = _leaf_boxes(v)
     refs = nodes[:, 12:14].copy().view(np.int32)
     boxes = nodes[:, :12].reshape(ni, 2, 2, 3)                       # node, side, lo/hi, xyz
@@ -104,3 +122,53 @@ def test_binary_and_wide_nodes(P, clustered):
             else:
                 stack.append(c)
     assert (seen == 1).all()
+
+
+def _reach_counts(flat, P):
+    """Vectorised walk over the 4-wide nodes: how often each surfel is reached from the root (must be exactly once), and the tree's depth."""
+    ni = P - 1
+    w8 = flat[16 * ni:48 * ni].reshape(ni, 4, 8)
+    ref = np.ascontiguousarray(w8[:, :, 6]).view(np.int32)
+    used = ~((w8[:, :, 0] == np.float32(1e30)) & (w8[:, :, 1] == np.float32(1e30)))
+    seen = np.zeros(P, np.int64)
+    front = np.array([0], np.int64)
+    depth = 0
+    while front.size:
+        r = ref[front][used[front]]
+        np.add.at(seen, ~r[r < 0], 1)
+        front = r[r >= 0].astype(np.int64)
+        depth += 1
+        assert depth < 200
+    return seen, depth
+
+
+def test_far_outliers_do_not_collapse_the_tree_or_the_key_sort():
+    """a few far outlier surfels used to stretch the scene box until every other surfel shared a handful of Morton cells --
+    a tree ordered by surfel id and ONE giant bucket for the key sort, merged through HBM by one workgroup.  The Morton mapping is now linear over
+    mean +- 2.5 sigma with squeezed tails, and lists beyond LDS are sorted by the whole grid: the tree over the body of the scene must be as
+    shallow as without the outliers, and the build must stay fast.  Second scene: EVERY surfel on one Morton code (the sort's true worst case)."""
+    import time
+    P = 120000
+    g = torch.Generator().manual_seed(5)
+    xyz = (torch.rand(P, 3, generator=g) * 2 - 1) * 50.0
+    scales = torch.rand(P, 2, generator=g) * 0.5 + 0.2
+    q = torch.randn(P, 4, generator=g); q = q / q.norm(dim=-1, keepdim=True)
+    depths, times = {}, {}
+    for name in ("clean", "outliers", "one_cell"):
+        x = xyz.clone()
+        if name == "outliers":
+            x[:5] = torch.tensor([[4e4, 0, 0], [0, -7e4, 0], [0, 0, 9e4], [3e4, 3e4, 3e4], [-5e4, 2e4, 0]], dtype=torch.float32)
+        if name == "one_cell":
+            x[:] = x[0]                                         # every centre the same point: codes equal, the order is the id tie-break
+        v, _ = synth.get_disks(x, scales, q)
+        vd = v.cuda()
+        tracing.build_bvh(vd); torch.cuda.synchronize()          # warm-up (allocations)
+        t0 = time.perf_counter()
+        nodes, n = tracing.build_bvh(vd)
+        torch.cuda.synchronize()
+        times[name] = (time.perf_counter() - t0) * 1e3
+        seen, depths[name] = _reach_counts(nodes.cpu().numpy(), P)
+        assert (seen == 1).all(), name
+    print("bvh build ms:", times, "wide-tree depth:", depths)
+    assert depths["outliers"] <= depths["clean"] + 4            # (the outliers hang off the top; the body is split as finely as before)
+    assert times["outliers"] < 5.0 * max(times["clean"], 0.2) and times["one_cell"] < 20.0

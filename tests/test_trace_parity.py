@@ -594,8 +594,10 @@ def test_trace_forward_is_independent_of_the_traversal_interleaving():
 
 def test_trace_update_request_follows_the_new_vertices():
     """build_acceleration_structure(..., rebuild=False) is OptiX's update: the structure must follow the moved surfels (a stale one would be
-    silently wrong).  The result equals a fresh tracer's."""
+    silently wrong).  Round 4: it IS a refit (topology and leaf order of the previous build kept, boxes recomputed); the result equals a fresh
+    tracer's bit for bit -- hit sets do not depend on the topology."""
     import diff_surfel_tracing as mod
+    from envgs_amd import tracing
     dev = torch.device("cuda:0")
     P, R = 4000, 2048
     e = synth.env_gaussians(P, seed=7, device=dev)
@@ -605,18 +607,24 @@ def test_trace_update_request_follows_the_new_vertices():
     st = _settings(mod, torch.zeros(3), 3, dev)
 
     def trace(tracer, means, rebuild):
-        v, f = synth.get_disks(means, e["scales"] * 0.4, e["rotations"])
+        n = means.shape[0]
+        v, f = synth.get_disks(means, e["scales"][:n] * 0.4, e["rotations"][:n])
         tracer.build_acceleration_structure(v, f, rebuild=rebuild)
         with torch.no_grad():
-            return tracer(ro, rd, v, means3D=means, grads3D=None, shs=e["shs"], colors_precomp=None, others_precomp=None, opacities=e["opacities"],
-                          scales=e["scales"] * 0.4, rotations=e["rotations"], cov3D_precomp=None, tracer_settings=st, start_from_first=False)
+            return tracer(ro, rd, v, means3D=means, grads3D=None, shs=e["shs"][:n], colors_precomp=None, others_precomp=None, opacities=e["opacities"][:n],
+                          scales=e["scales"][:n] * 0.4, rotations=e["rotations"][:n], cov3D_precomp=None, tracer_settings=st, start_from_first=False)
     m0 = e["means3D"] * 0.1
     m1 = m0 + 0.5 * torch.randn_like(m0)
     with _Switch(force_cap=1024, rows_per_ray=1024.0):   # (one capacity for both tracers: the second call of `t` would otherwise run with a capacity adapted
         t = mod.SurfelTracer()                     #  to its first call, the fresh tracer with the default, and a ray near either takes a different kernel path)
         a0 = trace(t, m0, True)
-        a1 = trace(t, m1, False)                   # update request with moved surfels
+        assert tracing.LAST_STATS["bvh"] == "build"
+        a1 = trace(t, m1, False)                   # update request with moved surfels: the topology of the first build, refitted (envgs_bvh_refit)
+        assert tracing.LAST_STATS["bvh"] == "refit"
         b1 = trace(mod.SurfelTracer(), m1, True)
+        assert tracing.LAST_STATS["bvh"] == "build"
+        c1 = trace(t, m0[:P // 2], False)          # an update request after the surfel count changed: nothing to keep, a full build
+        assert tracing.LAST_STATS["bvh"] == "build" and c1[7].shape[0] == P // 2
     assert float(a1[2].mean()) > 0.05 and not torch.equal(a0[0], a1[0])
     for x, y in zip(a1, b1):
         assert torch.equal(x, y)
