@@ -137,6 +137,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         A.state = (float4 *)L->hit_state; A.entries = (unsigned long long *)L->entries; A.pairs = L->pairs; A.n_entries = L->n_entries;
         const bool compact = L->compact_rows > 0 && L->row_off && L->batch_rows && L->row_blk && L->hit_state;
         if (L->compact_rows > 0 && !compact) return ENVGS_ERR_BAD_ARG;
+        A.state_plane = compact ? (size_t)L->compact_rows : (size_t)cfg->num_rays * (size_t)L->cap;
         if (compact) { A.row_off = L->row_off; A.batch_rows = (const uint2 *)L->batch_rows; A.batch_cnt = L->row_blk; }
         if (L->sh_perm && shs && cfg->sh_coeffs == 16) {
             const size_t nw = (size_t)cfg->P * 48;
@@ -332,7 +333,15 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
                     if (!L->row_off || !L->batch_rows) return ENVGS_ERR_BAD_ARG;
                     A.row_off = L->row_off; A.batch_rows = (const uint2 *)L->batch_rows;
                 }
-                { ProfScope p5(K_TRACE_LIST_BWD, stream); hipLaunchKernelGGL(batch_surfel_bwd, dim3(stride_grid((cfg->num_rays + 63) / 64, 1)), dim3(64), 0, stream, A); }
+                A.state_plane = L->compact_rows > 0 ? (size_t)L->compact_rows : (size_t)cfg->num_rays * (size_t)L->cap;
+                {
+                    ProfScope p5(K_TRACE_LIST_BWD, stream);
+                    // the colour is the only output the loss uses (the EnvGS step): the specialisation that drops the other outputs' terms and state planes
+                    const bool rgb_only = dL_drgb && !dL_ddpt && !dL_dacc && !dL_dnorm && !dL_daux;
+                    const dim3 g(stride_grid((cfg->num_rays + 63) / 64, 1));
+                    if (rgb_only) hipLaunchKernelGGL(batch_surfel_bwd<true>, g, dim3(64), 0, stream, A);
+                    else hipLaunchKernelGGL(batch_surfel_bwd<false>, g, dim3(64), 0, stream, A);
+                }
                 { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, stream, A); }
             } else {
 #ifdef ENVGS_DIAG

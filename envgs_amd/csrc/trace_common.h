@@ -157,7 +157,10 @@ struct TraceArgs {
     unsigned *pairs;              // (batches, 64*cap) (lane << 16 | k) of every composited hit, grouped by entry
     int *n_entries;               // (batches, 2) table entries, single entries
     unsigned *long_list; // (R) scratch: slots of the rays whose lists exceed 256 hits, appended by the main sort pass (counter[24 + seg] = how many)
-    float4 *state;      // (R, cap, 2 | 3) x 16 B per composited hit: transmittance before it and the prefix sums after it (for the backward)
+    float4 *state;      // per composited hit, for the backward, as PLANES of 16 B rows (plane p of row i at state[p * state_plane + i]):
+                        // plane 0 = (transmittance before the hit, rgb prefix sums after it), plane 1 = (depth, normal prefix sums), plane 2 (only with
+                        // `others`) = the two aux sums.  A backward whose only upstream gradient is the colour's -- what EnvGS trains with -- reads plane 0 alone
+    size_t state_plane; // rows per plane (compact_rows, or R * cap)
     // compact per-hit buffers (envgs_trace.h: compact_rows): nullptr = the (R, cap) layouts
     unsigned *batch_cnt;          // (batches) written by the cooperative collection: rows the batch needs (sum of its listed rays' hit counts)
     const unsigned *row_off;      // (R) by sorted slot: the ray's first row of hit_state
@@ -626,7 +629,9 @@ __global__ void __launch_bounds__(256) row_offsets(const TraceArgs A, const unsi
                                                    unsigned long long base, unsigned long long limit);      // blk: exclusive scan of the per-BATCH row counts
 __global__ void __launch_bounds__(256) unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, unsigned *__restrict__ cnt,
                                                          float *__restrict__ wet);
-__global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd(const TraceArgs A);
+template <bool RGBO> __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd(const TraceArgs A);
+extern template __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd<false>(const TraceArgs A);
+extern template __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd<true>(const TraceArgs A);
 __global__ void __launch_bounds__(256) reduce_surfel_records(const TraceArgs A);
 __global__ void __launch_bounds__(256) finish_surfel_grads(int P, const float *__restrict__ rots, const float *__restrict__ geo_rec,
                                                            float *__restrict__ dmeans, float *__restrict__ dscales, float *__restrict__ dopac,

@@ -189,8 +189,7 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
     for (int j = 0; j < 10; j++) C[j] = 0.f;
     float dist = 0.f;                                   // per-lane partial sum
     int used = 0;
-    const int sstr = A.has_others ? 3 : 2;              // per-hit state row: 32 B, or 48 B when the two `others` sums are needed too
-    float4 *state = A.state ? A.state + state_row0(A, slot, r) * sstr : nullptr;
+    float4 *state = A.state ? A.state + state_row0(A, slot, r) : nullptr;      // per-hit state: 16 B rows in two planes (three with `others`)
 #pragma unroll
     for (int ce = 0; ce < E; ce++) {
         const int cb = ce * 64;
@@ -235,12 +234,12 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
             list[i] = make_uint2(__float_as_uint(w), (unsigned)sid);
             if (state) {
                 // (the acc sum S[4] is not stored: sum_{j<=k} w_j = 1 - T_before * (1 - alpha), which the backward rebuilds)
-                float4 *o = state + (size_t)i * sstr;
+                float4 *o = state + (size_t)i;
                 // streamed once, read once by the backward much later: non-temporal, so it does not evict the surfel records / SH blocks
                 typedef float nt4 __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store((nt4){Tb, S[0], S[1], S[2]}, reinterpret_cast<nt4 *>(o));
-                __builtin_nontemporal_store((nt4){S[3], S[5], S[6], S[7]}, reinterpret_cast<nt4 *>(o + 1));
-                if (A.has_others) __builtin_nontemporal_store((nt4){S[8], S[9], 0.f, 0.f}, reinterpret_cast<nt4 *>(o + 2));
+                __builtin_nontemporal_store((nt4){S[3], S[5], S[6], S[7]}, reinterpret_cast<nt4 *>(o + A.state_plane));
+                if (A.has_others) __builtin_nontemporal_store((nt4){S[8], S[9], 0.f, 0.f}, reinterpret_cast<nt4 *>(o + 2 * A.state_plane));
             }
         }
         const int nu = f < 64 ? f : min(64, n - cb);                    // hits of this chunk that were blended

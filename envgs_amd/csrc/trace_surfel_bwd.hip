@@ -55,6 +55,10 @@ composite_lists_bwd(const TraceArgs A)
 constexpr int BS_GROUP = 16;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int RECW = 64;      // floats per (batch, surfel) gradient record: 48 SH (or 3 colour) + 15 geometry + pad
+// RGBO: the colour is the only output with an upstream gradient (g_dpt / g_acc / g_norm / g_aux all NULL) -- the EnvGS training step: the env
+// pass's depth / accumulation / normal maps are not supervised.  Seven per-ray gradient constants and their terms drop out, and of the per-hit
+// state only plane 0 (16 B: transmittance before the hit + the three colour prefix sums) is fetched instead of 32 / 48 B.
+template <bool RGBO>
 __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64)
 batch_surfel_bwd(const TraceArgs A)
 {
@@ -84,7 +88,9 @@ batch_surfel_bwd(const TraceArgs A)
             sh_basis(A.D, B.ux, B.uy, B.uz, basis);
             if (A.M == 0) basis[0] = kC0;
             Box = B.ox; Boy = B.oy; Boz = B.oz; Bdx = B.dx; Bdy = B.dy; Bdz = B.dz;
-            gR0 = B.gR0; gR1 = B.gR1; gR2 = B.gR2; gD = B.gD; gA = B.gA; gN0 = B.gN0; gN1 = B.gN1; gN2 = B.gN2; gX0 = B.gX0; gX1 = B.gX1;
+            gR0 = B.gR0; gR1 = B.gR1; gR2 = B.gR2;
+            if constexpr (RGBO) { gD = gA = gN0 = gN1 = gN2 = gX0 = gX1 = 0.f; }
+            else { gD = B.gD; gA = B.gA; gN0 = B.gN0; gN1 = B.gN1; gN2 = B.gN2; gX0 = B.gX0; gX1 = B.gX1; }
             Fsum = B.gR0 * B.fr0 + B.gR1 * B.fr1 + B.gR2 * B.fr2 + B.gD * B.fD + B.gA * B.fA + B.gN0 * B.fN0 + B.gN1 * B.fN1 + B.gN2 * B.fN2 +
                    B.gX0 * B.fX0 + B.gX1 * B.fX1 + B.fT * B.bgdot;
         }
@@ -103,8 +109,8 @@ batch_surfel_bwd(const TraceArgs A)
 #pragma unroll
         for (int k = 0; k < 4; k++) SkM[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         float dO0 = 0.f, dO1 = 0.f, dO2 = 0.f, dD0 = 0.f, dD1 = 0.f, dD2 = 0.f;
-        const int sstr = A.has_others ? 3 : 2;
-        const float4 *state = A.state + state_row0(A, min(base + lane, A.R - 1), rr) * sstr;
+        const float4 *state = A.state + state_row0(A, min(base + lane, A.R - 1), rr);
+        const size_t plane = A.state_plane;
         size_t rstart, region;
         batch_region(A, batch, rstart, region);
         const unsigned long long *ent = A.entries + rstart;
@@ -206,8 +212,8 @@ batch_surfel_bwd(const TraceArgs A)
             const int ne = min(BS_GROUP, NE - g * BS_GROUP);
             // software pipeline over the entries: the per-hit state of entry el+1 is in flight while entry el is evaluated
             int k1 = valid ? (int)kmat[buf][0][lane] : 0;
-            float4 st0, st1, st2 = make_float4(0.f, 0.f, 0.f, 0.f);
-            { const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) * sstr : A.state; st0 = sp[0]; st1 = sp[1]; if (A.has_others) st2 = sp[2]; }      // unconditional (idle lanes share one address): no branch, no wait
+            float4 st0, st1 = make_float4(0.f, 0.f, 0.f, 0.f), st2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            { const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) : A.state; st0 = sp[0]; if constexpr (!RGBO) { st1 = sp[plane]; if (A.has_others) st2 = sp[2 * plane]; } }      // unconditional (idle lanes share one address): no branch, no wait
             for (int el = 0; el < ne; el++) {
                 const unsigned long long d = sdesc[buf][el];
                 const int sid = (int)(d & 0xFFFFFFull);
@@ -242,18 +248,20 @@ batch_surfel_bwd(const TraceArgs A)
 #pragma unroll
                         for (int c = 0; c < 3; c++) { const float v = rc[c] + 0.5f; cl[c] = v < 0.f; col[c] = cl[c] ? 0.f : v; }
                     } else { const float4 x = sdat[buf][el][4]; col[0] = x.x; col[1] = x.y; col[2] = x.z; }
-                    const float x0 = A.has_others ? A.others[2 * sid] : 0.f, x1 = A.has_others ? A.others[2 * sid + 1] : 0.f;
+                    const float x0 = (!RGBO && A.has_others) ? A.others[2 * sid] : 0.f, x1 = (!RGBO && A.has_others) ? A.others[2 * sid + 1] : 0.f;
                     const float alpha = h.alpha, Tb = st0.x;
                     const float w = alpha * Tb;
                     const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
                     const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
                     const float inv1m = __builtin_amdgcn_rcpf(1.0f - alpha);          // v_rcp_f32 (1 ulp): gradient-only terms need no IEEE division
-                    const float gv_ = gR0 * col[0] + gR1 * col[1] + gR2 * col[2] + gD * h.t + gA + gN0 * nf0 + gN1 * nf1 + gN2 * nf2 + gX0 * x0 + gX1 * x1;
-                    const float gS = gR0 * st0.y + gR1 * st0.z + gR2 * st0.w + gD * st1.x + gA * (1.0f - Tb * (1.0f - alpha)) + gN0 * st1.y + gN1 * st1.z +
-                                     gN2 * st1.w + gX0 * st2.x + gX1 * st2.y;
+                    float gv_ = gR0 * col[0] + gR1 * col[1] + gR2 * col[2], gS = gR0 * st0.y + gR1 * st0.z + gR2 * st0.w;
+                    if constexpr (!RGBO) {
+                        gv_ += gD * h.t + gA + gN0 * nf0 + gN1 * nf1 + gN2 * nf2 + gX0 * x0 + gX1 * x1;
+                        gS += gD * st1.x + gA * (1.0f - Tb * (1.0f - alpha)) + gN0 * st1.y + gN1 * st1.z + gN2 * st1.w + gX0 * st2.x + gX1 * st2.y;
+                    }
                     const float dLa = Tb * gv_ - (Fsum - gS) * inv1m;
                     const float dc[3] = {cl[0] ? 0.f : w * gR0, cl[1] ? 0.f : w * gR1, cl[2] ? 0.f : w * gR2};
-                    if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * gX1); }
+                    if constexpr (!RGBO) { if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * gX1); } }
                     const float dLG = s0.w * dLa;
                     const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
                     const float isu = __builtin_amdgcn_rcpf(s1.w), isv = __builtin_amdgcn_rcpf(s2.w);
@@ -280,8 +288,8 @@ batch_surfel_bwd(const TraceArgs A)
 #undef BT
                 if (el + 1 < ne) {                           // next entry's state: in flight during the reduction below
                     k1 = valid ? (int)kmat[buf][el + 1][lane] : 0;
-                    const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) * sstr : A.state;
-                    st0 = sp[0]; st1 = sp[1]; if (A.has_others) st2 = sp[2];
+                    const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) : A.state;
+                    st0 = sp[0]; if constexpr (!RGBO) { st1 = sp[plane]; if (A.has_others) st2 = sp[2 * plane]; }
                 }
                 // geometry: lane r*16 + k (k < 4) receives the sum over the 64 rays of word k + 4 r; record words 48 .. 62
                 {
@@ -353,6 +361,9 @@ batch_surfel_bwd(const TraceArgs A)
         }
     }
 }
+
+template __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd<false>(const TraceArgs A);
+template __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd<true>(const TraceArgs A);
 
 // Stage 2: sum each surfel's (batch, surfel) records into the (zeroed) gradient buffers -- plain stores, every word has one owner; the
 // K-buffer pass for overflowed rays runs afterwards and adds to the same buffers atomically.  16 lanes per surfel, 16 B per lane = one
