@@ -37,6 +37,14 @@ static bool lists_usable(const envgs_trace_cfg *cfg, const envgs_trace_lists *L)
     return L && L->cap > 0 && cfg->max_trace_depth == 0 && cfg->P > 0 && cfg->P < (1 << 24) && cfg->num_rays < (1 << 24) && L->hit_lists &&
            L->hit_cnt && L->n_used && L->stack_spill && L->surf_cnt && L->surf_off && L->surf_acc && L->scan_temp;
 }
+// The backward of the list path reads the hit COUNTS, the per-hit state, the entries / pairs and the per-surfel offsets -- not the lists
+// themselves (rays x capacity x 8 B, by far the largest buffer of a call) nor the forward's scratch: the caller may have released those
+// (hit_lists == NULL) between the two calls.  Same size limits as the forward's test.
+static bool lists_usable_bwd(const envgs_trace_cfg *cfg, const envgs_trace_lists *L)
+{
+    return L && L->cap > 0 && cfg->max_trace_depth == 0 && cfg->P > 0 && cfg->P < (1 << 24) && cfg->num_rays < (1 << 24) && L->hit_cnt && L->n_used &&
+           L->surf_cnt && L->surf_off;
+}
 
 
 }  // namespace envgs
@@ -258,14 +266,13 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         }
         for (int i = 1; i < nseg; i++)
             if (hipEventRecord(ev_join[i], aux[i]) != hipSuccess || hipStreamWaitEvent(stream, ev_join[i], 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
-        hipLaunchKernelGGL(unpack_surfel_acc, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, A.wfrac, A.surf_acc, L->surf_cnt, wet);
+        hipLaunchKernelGGL(unpack_surfel_acc, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, A.wfrac, A.surf_acc, L->surf_cnt, wet,
+                           counters);                                          // (also clears the ray-fetch counter of the overflow pass)
         ENVGS_CHECK_LAUNCH(dcfg, stream);
         {   // records of the backward are addressed through the inclusive scan of the per-surfel hit counts
             const int rc = launch_scan(L->surf_cnt, L->surf_off, cfg->P * NCOPY, L->scan_temp, L->scan_temp_bytes, stream);
             if (rc) return rc;
         }
-        e = hipMemsetAsync(counters, 0, sizeof(uint32_t), stream);          // ray-fetch counter for the overflow pass
-        if (e != hipSuccess) return (int)e;
         A.only_overflow = 1;
     }
     { ProfScope p4(K_TRACE_KBUF_FWD, stream); hipLaunchKernelGGL(trace_fwd, dim3(persistent_grid(cfg->num_rays)), dim3(64), 0, stream, A, rh, rw); }
@@ -294,6 +301,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
         ZERO(geo_rec, P * ENVGS_GEOREC_STRIDE); ZERO(dmeans3D, P * 3); ZERO(dgrads3D, P * 3); ZERO(dscales, P * 2); ZERO(drots, P * 4);
         ZERO(dopacities, P); ZERO(dothers, P * 2); ZERO(dray_o, R * 3); ZERO(dray_d, R * 3);
         if (cfg->sh_coeffs > 0) ZERO(dshs, P * cfg->sh_coeffs * 3); else ZERO(dcolors, P * 3);
+        if (counters && cfg->num_rays > 0 && cfg->P > 0) ZERO(reinterpret_cast<float *>(counters), 1);      // only the ray-fetch counter: [1] (largest list) and the stats stay readable
 #undef ZERO
         const int rcz = launch_zero_many(zb, stream);              // one launch instead of eleven fills
         if (rcz) return rcz;
@@ -302,8 +310,6 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     if (!nodes || !ray_o || !ray_d || !srec || !counters || !rgb || !dpt || !acc || !norm || !aux || !final_T || !geo_rec || !dmeans3D || !dscales || !drots || !dopacities || !dray_o || !dray_d || !rotations || !bg)
         return ENVGS_ERR_BAD_ARG;
     if (cfg->sh_coeffs > 0 ? (!shs || !dshs) : (!colors_precomp || !dcolors)) return ENVGS_ERR_BAD_ARG;
-    e = hipMemsetAsync(counters, 0, sizeof(uint32_t), stream);      // only the ray-fetch counter: [1] (largest list) and the stats stay readable
-    if (e != hipSuccess) return (int)e;
     TraceArgs A;
     A = TraceArgs{};
     A.P = cfg->P; A.R = cfg->num_rays; A.D = cfg->sh_degree; A.M = cfg->sh_coeffs; A.ND = 1;
@@ -322,7 +328,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     int rh, rw; ray_layout(cfg, &rh, &rw);
     {
         ProfScope prof_(K_TRACE_BWD, stream);
-        if (lists_usable(cfg, L)) {                    // the same test as the forward: the lists exist exactly when it filled them
+        if (lists_usable_bwd(cfg, L)) {                // the forward's test minus the forward-only buffers: the list path ran exactly when it holds
             A.hits = (uint2 *)L->hit_lists; A.hit_cnt = L->hit_cnt; A.n_used = L->n_used; A.cap = L->cap;
             if (L->ray_keys && L->ray_order && L->ray_sort_temp && !(A.exp & 64)) A.order = L->ray_order + cfg->num_rays;
             if (L->records && L->num_records > 0 && L->surf_cnt && L->surf_off && L->hit_state && L->entries && L->pairs && L->n_entries && !(A.exp & 8)) {
@@ -345,6 +351,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
                 { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, stream, A); }
             } else {
 #ifdef ENVGS_DIAG
+                if (!L->hit_lists) return ENVGS_ERR_BAD_ARG;       // the per-ray atomic-flush backward walks the lists themselves
                 ProfScope p5(K_TRACE_LIST_BWD, stream);
                 hipLaunchKernelGGL(composite_lists_bwd, dim3(stride_grid(cfg->num_rays, 64)), dim3(64), 0, stream, A);
 #else

@@ -628,7 +628,7 @@ __global__ void __launch_bounds__(1024) row_scan_blocks(unsigned *__restrict__ b
 __global__ void __launch_bounds__(256) row_offsets(const TraceArgs A, const unsigned *__restrict__ blk, unsigned *__restrict__ row_off, uint2 *__restrict__ batch_rows,
                                                    unsigned long long base, unsigned long long limit);      // blk: exclusive scan of the per-BATCH row counts
 __global__ void __launch_bounds__(256) unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, unsigned *__restrict__ cnt,
-                                                         float *__restrict__ wet);
+                                                         float *__restrict__ wet, unsigned *ray_counter);
 template <bool RGBO> __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd(const TraceArgs A);
 extern template __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd<false>(const TraceArgs A);
 extern template __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd<true>(const TraceArgs A);

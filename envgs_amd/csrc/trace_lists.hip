@@ -496,9 +496,19 @@ row_scan_blocks(unsigned *__restrict__ blk, int n)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_base = 0u;
     __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += 1024) {
+    constexpr int PRE = 8;                     // passes whose loads are issued up front (8192 batches = 524 k rays per segment; beyond that the loop loads as it goes)
+    unsigned pre[PRE];
+#pragma unroll
+    for (int c = 0; c < PRE; c++) { const int i = c * 1024 + (int)threadIdx.x; pre[c] = i < n ? blk[i] : 0u; }
+    int c = 0;
+    for (int c0 = 0; c0 < n; c0 += 1024, c++) {
         const int i = c0 + (int)threadIdx.x;
-        const unsigned v = i < n ? blk[i] : 0u;
+        unsigned v;
+        if (c < PRE) {
+            v = pre[0];
+#pragma unroll
+            for (int q = 1; q < PRE; q++) v = c == q ? pre[q] : v;
+        } else v = i < n ? blk[i] : 0u;
         unsigned x = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const unsigned y = (unsigned)__shfl_up((int)x, o); if (lane >= o) x += y; }
@@ -544,9 +554,10 @@ row_offsets(const TraceArgs A, const unsigned *__restrict__ blk, unsigned *__res
 // Split the packed per-surfel accumulators of composite_lists_fwd into hit counts (for the scan) and weights (added to `wet`,
 // which the K-buffer path may already have contributed to in float).
 __global__ void __launch_bounds__(256)
-unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, unsigned *__restrict__ cnt, float *__restrict__ wet)
+unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, unsigned *__restrict__ cnt, float *__restrict__ wet, unsigned *ray_counter)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && ray_counter) *ray_counter = 0u;          // the ray-fetch counter of the K-buffer overflow pass that follows (was a memset launch of its own)
     if (i >= P) return;
     unsigned long long wsum = 0;
 #pragma unroll

@@ -151,12 +151,12 @@ class CapState:
 
     def next_rows(self, R, cap):
         """Rows of the compact per-hit buffers (hit_state / entries / pairs; include/envgs_trace.h: compact_rows) for a call with R rays:
-        30 % above the previous call's hits found per ray (a first call assumes 192 per ray), never more than the (R, cap) layout would take.
+        15 % above the previous call's hits found per ray (a first call assumes 192 per ray), never more than the (R, cap) layout would take.
         Rays that do not fit fall back to the K-buffer kernels -- slower, never wrong -- and the next call has the right size."""
         if ROW_CAP.get("force_per_ray") is not None:                   # tests: pin the rows per ray (tight: exercises the fall-back)
             per = float(ROW_CAP["force_per_ray"])
         else:
-            per = 192.0 if self.found_per_ray is None else 1.3 * self.found_per_ray + 4.0
+            per = 192.0 if self.found_per_ray is None else 1.15 * self.found_per_ray + 4.0
         return int(min(R * cap, max(int(per * R) + 4096, 4096)))
 
     def publish(self, counters, dev, rays=1):
@@ -270,6 +270,12 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     LAST_STATS.update(P=P, R=R, caps=caps, rows=rows, counters=counters, n_entries=(keep.get("n_entries") if "hit_state" in keep else None), cap=cap,
                       lists=((keep["hit_lists"], keep["n_used"], keep["hit_cnt"]) if (cap and KEEP_LISTS["on"]) else None))
     if cap:
+        if "hit_state" in keep and not KEEP_LISTS["on"]:
+            # the record backward reads the hit counts, the per-hit state and the entries / pairs -- not the lists themselves (rays x capacity
+            # x 8 B: the largest buffer of the call, 4.9 GB per stage of the 1200x1600 two-bounce configuration): released here, so that the
+            # next stage / the next call re-uses the block instead of three stages holding one each until their backward
+            keep.pop("hit_lists")
+            lists.hit_lists = None
         # asynchronous read-backs for later: the longest list (sizes the next call's cap) and the number of gradient records
         caps.publish(counters, dev, rays=R)
         if "hit_state" in keep:                                   # (a pinned word from the tracer's ring: pinning host memory per call is ~0.1 ms)

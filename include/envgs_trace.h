@@ -71,7 +71,9 @@ typedef struct envgs_trace_cfg {
  * takes the K-buffer kernels in both directions, which have no such limits.
  */
 typedef struct envgs_trace_lists {
-    uint32_t *hit_lists;     /* (R, cap, 2): after the forward the first n_used entries are sorted by (t, id); word 1 = surfel id */
+    uint32_t *hit_lists;     /* (R, cap, 2): after the forward the first n_used entries are sorted by (t, id); word 1 = surfel id.  Forward only:
+                                envgs_trace_backward reads hit_cnt / n_used / hit_state / entries / pairs / surf_cnt / surf_off, so a caller may
+                                release this buffer -- the largest of a call -- and pass NULL to the backward */
     int32_t *hit_cnt;        /* (R) hits found; > cap => that ray took the K-buffer path */
     int32_t *n_used;         /* (R) hits composited before termination */
     int32_t cap;             /* list capacity per ray, <= 1024; 0 disables the list path */
@@ -89,8 +91,10 @@ typedef struct envgs_trace_lists {
     size_t ray_sort_temp_bytes;
     float *records;          /* backward only: (num_records, 64) one 256 B gradient record per (batch, surfel) entry, grouped by surfel */
     uint64_t num_records;    /* backward only: capacity of `records` in records (>= surf_off[P-1]) */
-    float *hit_state;        /* (R, cap, 8) -- (R, cap, 12) with has_others -- written by the forward for the backward: transmittance
-                                before each composited hit and the prefix sums after it; NULL = forward only (then no record backward) */
+    float *hit_state;        /* 16 B rows in PLANES, written by the forward for the backward -- plane p of row i at float4 index p * rows + i, rows =
+                                compact_rows (or R * cap): plane 0 = (transmittance before the composited hit, the three colour prefix sums after it),
+                                plane 1 = (depth, normal prefix sums), plane 2 (only with has_others) = the two aux sums.  8 floats per row and hit, 12
+                                with has_others.  A backward whose only upstream gradient is the colour's reads plane 0 alone */
     uint64_t *entries;       /* (ceil(R/64), 64*cap) distinct surfels of every batch, packed id | hits-1 << 24 | slot << 32 */
     uint32_t *pairs;         /* (ceil(R/64), 64*cap) (lane << 16 | list position) of every composited hit, grouped by entry */
     int32_t *n_entries;      /* (ceil(R/64), 2) entries merged in the batch's table, single entries filed from the top */
