@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # development aid: ENVGS_TEST_DEBUG_TRACE=<bits> runs the whole suite with that ENVGS_DBG_TRACE default (e.g. a collection kernel under test);
+    # tests that pin the switch themselves still do
+    v = os.environ.get("ENVGS_TEST_DEBUG_TRACE")
+    if v:
+        from envgs_amd import _lib
+        for kind in ("product", "diag"):
+            old = _lib.select(kind)
+            _lib.load().envgs_debug_set(0, int(v))
+            _lib.select(old)
 
 
 @pytest.fixture(scope="session")
