@@ -239,14 +239,14 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
                 // the rows that corresponds to its share of the batches
                 const int nb_seg = S.batch1 - S.batch0, nblk = (rays_seg + 255) / 256;
                 unsigned *cntb = L->row_blk;                                       // (batches) row counts, scanned in place per segment
-                const unsigned long long base = (unsigned long long)((long double)L->compact_rows * S.batch0 / nbatch_all);
-                const unsigned long long limit = (unsigned long long)((long double)L->compact_rows * S.batch1 / nbatch_all);
+                // the segment claims its rows from a counter shared by the call's segments (counters[22]); its first row lands in counters[28 + seg]
+                const unsigned long long limit = (unsigned long long)L->compact_rows;
 #ifdef ENVGS_DIAG
                 if (!(S.order && !(S.exp & 512) && !(S.exp & 16) && !(S.exp & 2048)))     // the A/B collection kernels do not write batch counts
                     hipLaunchKernelGGL(row_count, dim3(nblk), dim3(256), 0, st, S, cntb);
 #endif
-                hipLaunchKernelGGL(row_scan_blocks, dim3(1), dim3(1024), 0, st, cntb + S.batch0, nb_seg);
-                hipLaunchKernelGGL(row_offsets, dim3(nblk), dim3(256), 0, st, S, cntb, L->row_off, (uint2 *)L->batch_rows, base, limit);
+                hipLaunchKernelGGL(row_scan_blocks, dim3(1), dim3(1024), 0, st, cntb + S.batch0, nb_seg, counters + 22, counters + 28 + sg);
+                hipLaunchKernelGGL(row_offsets, dim3(nblk), dim3(256), 0, st, S, cntb, L->row_off, (uint2 *)L->batch_rows, (const unsigned *)(counters + 28 + sg), limit);
                 ENVGS_CHECK_LAUNCH(dcfg, st);
             }
             {

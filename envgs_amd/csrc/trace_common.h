@@ -624,9 +624,9 @@ extern template __global__ void __launch_bounds__(256) sort_composite_fwd<8, tru
 extern template __global__ void __launch_bounds__(256) sort_composite_fwd<16, true, true>(const TraceArgs A);
 __global__ void __launch_bounds__(64 * RH_W) register_hits(const TraceArgs A);
 __global__ void __launch_bounds__(256) row_count(const TraceArgs A, unsigned *__restrict__ blk);
-__global__ void __launch_bounds__(1024) row_scan_blocks(unsigned *__restrict__ blk, int n);
+__global__ void __launch_bounds__(1024) row_scan_blocks(unsigned *__restrict__ blk, int n, unsigned *rows_used, unsigned *seg_base);
 __global__ void __launch_bounds__(256) row_offsets(const TraceArgs A, const unsigned *__restrict__ blk, unsigned *__restrict__ row_off, uint2 *__restrict__ batch_rows,
-                                                   unsigned long long base, unsigned long long limit);      // blk: exclusive scan of the per-BATCH row counts
+                                                   const unsigned *__restrict__ seg_base, unsigned long long limit);      // blk: exclusive scan of the per-BATCH row counts
 __global__ void __launch_bounds__(256) unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, unsigned *__restrict__ cnt,
                                                          float *__restrict__ wet, unsigned *ray_counter);
 template <bool RGBO> __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd(const TraceArgs A);

@@ -486,8 +486,11 @@ row_count(const TraceArgs A, unsigned *__restrict__ blk)
 }
 
 __global__ void __launch_bounds__(1024)
-row_scan_blocks(unsigned *__restrict__ blk, int n)
+row_scan_blocks(unsigned *__restrict__ blk, int n, unsigned *rows_used, unsigned *seg_base)
 {
+    // (rows_used / seg_base: this segment CLAIMS its rows of the compact per-hit buffers from one counter shared by the call's segments -- round 3
+    //  gave every segment the share of the rows that matched its share of the RAYS, which starves a segment whose rays happen to find most of
+    //  the hits (the parked rays of a bounce stage sort into batches of their own: one segment may hold nearly all the live ones))
     // exclusive scan in place, one workgroup, 1024 counts per pass: coalesced loads, integer wave scans (the totals exceed 2^24: no float scan),
     // the 16 wavefront totals through LDS, a running base carried from pass to pass.  (Round 3: every thread summed a contiguous run of its own and
     // a ten-round Hillis-Steele pass over LDS joined them: 23 us on the step's critical path, twice.)
@@ -521,12 +524,14 @@ row_scan_blocks(unsigned *__restrict__ blk, int n)
         if (threadIdx.x == 1023) s_base = before + x;
         __syncthreads();
     }
+    if (threadIdx.x == 0 && rows_used && seg_base) *seg_base = atomicAdd(rows_used, s_base);
 }
 
 __global__ void __launch_bounds__(256)
 row_offsets(const TraceArgs A, const unsigned *__restrict__ blk, unsigned *__restrict__ row_off, uint2 *__restrict__ batch_rows,
-            unsigned long long base, unsigned long long limit)
+            const unsigned *__restrict__ seg_base, unsigned long long limit)
 {
+    const unsigned long long base = (unsigned long long)*seg_base;        // claimed by row_scan_blocks
     // one wavefront per batch; blk[batch] = rows of the segment's batches before this one (exclusive scan of the counts the collection wrote)
     const int slot_end = min(A.R, A.batch1 * 64);
     const int slot = A.batch0 * 64 + (int)blockIdx.x * 256 + (int)threadIdx.x;

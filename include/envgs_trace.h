@@ -102,8 +102,9 @@ typedef struct envgs_trace_lists {
      * capacity on average, so hit_state / entries / pairs are addressed through per-ray ROW offsets instead: after the collection the rays'
      * hit counts are scanned in coherence-sorted order (a batch's rows are contiguous), ray at sorted slot s owns rows
      * [row_off[s], row_off[s] + min(hit_cnt, cap)) of hit_state (compact_rows x 8|12 floats), and batch b owns the same row range
-     * batch_rows[b] = {first row, rows} of entries / pairs (compact_rows elements each).  Each forward segment is given the share of the
-     * rows that corresponds to its share of the rays; rays that do not fit are handed to the K-buffer kernels like rays whose list overflowed
+     * batch_rows[b] = {first row, rows} of entries / pairs (compact_rows elements each).  Each forward segment CLAIMS its rows from a counter
+     * shared by the call's segments once its hit counts are known (round 4; a fixed share per segment starved whichever held the busier rays);
+     * rays that do not fit are handed to the K-buffer kernels like rays whose list overflowed
      * (hit_cnt := cap + 1, counters[21] counts them) -- slower, never wrong.  The caller sizes compact_rows from the previous call's
      * total of hits found (counters[8..9]). */
     uint64_t compact_rows;   /* rows of hit_state / elements of entries and pairs; 0 = (R, cap) layouts */
