@@ -52,13 +52,15 @@ def algorithmic_bytes(kernel, P, N, HW, C, sh_in_kernel):
     return 0
 
 
-def trace_algorithmic_bytes(kernel, tc, P_env, R, entries, others=False):
+def trace_algorithmic_bytes(kernel, tc, P_env, R, entries, others=False, rgb_only=True):
     """Deduplicated algorithmic HBM bytes of the tracer kernels PER STEP: what the kernel must move at minimum -- each input structure
     read ONCE (BVH nodes 64 B + wide nodes 128 B + surfel record 64 B + SH block 192 B per env surfel, 24 B + 4 B order per ray), each
     list / state / record element read or written once -- however often the implementation re-fetches them from L2 / MALL.
     (SURVEY.md 8(d)'s per-RAY units -- 64 B per node visit of every ray -- counted a node once per ray although a 64-ray packet fetches it
     once, which put 'achieved' above the HBM peak; those units are kept only as the `per_ray_model_MB` diagnostic.)
-    hits = composited hits, found = collected hits, entries = distinct (batch, surfel) pairs of the backward."""
+    hits = composited hits, found = collected hits, entries = distinct (batch, surfel) pairs of the backward.
+    rgb_only: the colour is the only traced output the loss uses (this bench, the EnvGS step): the backward then reads plane 0 of the per-hit
+    state alone, 16 B per hit (batch_surfel_bwd<true>)."""
     hits, found = tc["hits"], tc["found"]
     st = 48 if others else 32
     if kernel == "trace.collect_hits":
@@ -68,7 +70,7 @@ def trace_algorithmic_bytes(kernel, tc, P_env, R, entries, others=False):
     if kernel == "trace.register_hits":
         return hits * (8 + 4) + entries * 8 + R * 4 + P_env * 8 * 16
     if kernel == "trace.batch_surfel_bwd":
-        return hits * (st + 4) + entries * (8 + 256) + P_env * (64 + 192) + R * (24 + 48 + 48 + 24)
+        return hits * ((16 if (rgb_only and not others) else st) + 4) + entries * (8 + 256) + P_env * (64 + 192) + R * (24 + 48 + 48 + 24)
     if kernel == "trace.reduce_surfel_records":
         return entries * 256 + P_env * (32 + 192 + 64)
     if kernel == "bvh_build":
@@ -93,7 +95,7 @@ def trace_per_ray_model_bytes(kernel, tc, R):
 VALU_PEAK_GINST = 256 * 2 * 2.4
 VALU_MEASURED_GINST = 898.0     # what the chip sustains: independent v_fma_f32 / mixed VALU, 8 waves per SIMD (scratch/valu_peak.hip -> profiles/r02_valu_peak.txt)
 SALU_PEAK_GINST = 256 * 1 * 2.4
-PMC_SUMMARY = os.path.join("profiles", "r03_pmc_envgs.json")
+PMC_SUMMARY = os.path.join("profiles", "r04_pmc_envgs.json")
 
 
 def main():

@@ -2,7 +2,7 @@
 import collections, csv, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def short(n):
@@ -86,6 +86,19 @@ def pmc():
 stats('envgs', 24, 'full EnvGS step: 300k base surfels ch05 raster + 163840 env surfels LBVH trace, 800x800; python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-render (the tracer forward runs as two batch segments on two streams: 2 launches per step, overlapping, so the kernel times sum to more than the step)')
 stats('raster', 34, 'raster only: 300k surfels, SH deg 3 in-kernel, 800x800; python bench.py --workload raster --steps 30 --warmup 4 --no-cpu-baseline --no-render')
 pmc()
+for src_, dst_ in (("step_inventory.txt", "step_inventory.txt"),):
+    sp = os.path.join(ROOT, 'gpurun_out', src_)
+    if os.path.exists(sp) and os.path.getsize(sp) > 10:
+        open(os.path.join(ROOT, 'profiles', '%s_%s' % (TAG, dst_)), 'w').write(open(sp).read())
+for P_ in (163840, 700000):
+    sp = os.path.join(ROOT, 'gpurun_out', 'p_bvh', 'bvh%d_kernel_stats.csv' % P_)
+    if os.path.exists(sp):
+        rows = list(csv.DictReader(open(sp)))
+        with open(os.path.join(ROOT, 'profiles', '%s_bvh_%d_kernel_stats.csv' % (TAG, P_)), 'w') as f:
+            f.write("# rocprofv3 --kernel-trace --stats: python scratch/bvh_prof.py %d  (1 + 6 full builds, then 6 refits of the same topology; MI355X)\n" % P_)
+            f.write("name,calls,avg_us\n")
+            for r in rows[:20]:
+                f.write("%s,%s,%.1f\n" % (short(r['Name']), r['Calls'], float(r['AverageNs']) / 1e3))
 for n in ('envgs', 'envgs_reference_caller', 'envgs_twin_caller', 'envgs_f16', 'raster', 'env700k', 'caps', 'config5'):
     src = os.path.join(ROOT, 'gpurun_out', 'bench_%s_final.json' % n)
     if os.path.exists(src) and os.path.getsize(src) > 10:
