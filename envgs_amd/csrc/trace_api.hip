@@ -91,20 +91,24 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     envgs_raster_cfg dbg; dbg.debug = cfg->debug;
     const envgs_raster_cfg *dcfg = &dbg;
     hipError_t e;
-    {   // counters, wet, mid and (list path) the per-surfel accumulators: one launch instead of four fills
-        ZeroBatch zb; zb.count = 0;
+    ForwardPrepare FP;                      // queued as ONE launch further down, once the list path has said whether it wants permuted SH blocks
+    std::memset(&FP, 0, sizeof(FP));
+    {   // counters, wet, mid and (list path) the per-surfel accumulators
+        ZeroBatch &zb = FP.zero; zb.count = 0;
         zb.ptr[zb.count] = reinterpret_cast<float *>(counters); zb.n[zb.count++] = 96;
         if (cfg->P > 0) { zb.ptr[zb.count] = wet; zb.n[zb.count++] = (unsigned long long)cfg->P; }
         zb.ptr[zb.count] = mid; zb.n[zb.count++] = (unsigned long long)cfg->num_rays * MID * (cfg->max_trace_depth + 1);
         if (lists_usable(cfg, L)) { zb.ptr[zb.count] = reinterpret_cast<float *>(L->surf_acc); zb.n[zb.count++] = (unsigned long long)cfg->P * NCOPY * 2; }
-        const int rcz = launch_zero_many(zb, stream);
-        if (rcz) return rcz;
+        FP.zero_blocks = 512 * zb.count;
     }
     if (cfg->P > 0) {
-        hipLaunchKernelGGL(make_surfel_records, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, cfg->scale_modifier,
-                           means3D, scales, rotations, opacities, srec);
-        ENVGS_CHECK_LAUNCH(dcfg, stream);
+        FP.P = cfg->P; FP.rec_blocks = (cfg->P + 255) / 256; FP.mod = cfg->scale_modifier;
+        FP.means = means3D; FP.scales = scales; FP.rots = rotations; FP.opac = opacities; FP.srec = srec;
     }
+    auto launch_prepare = [&]() -> int {
+        hipLaunchKernelGGL(forward_prepare, dim3((unsigned)(FP.zero_blocks + FP.rec_blocks + FP.perm_blocks)), dim3(256), 0, stream, FP);
+        return (int)hipGetLastError();
+    };
     TraceArgs A;
     A = TraceArgs{};
     A.P = cfg->P; A.R = cfg->num_rays; A.D = cfg->sh_degree; A.M = cfg->sh_coeffs; A.ND = cfg->max_trace_depth + 1;
@@ -149,11 +153,12 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         if (compact) { A.row_off = L->row_off; A.batch_rows = (const uint2 *)L->batch_rows; A.batch_cnt = L->row_blk; }
         if (L->sh_perm && shs && cfg->sh_coeffs == 16) {
             const size_t nw = (size_t)cfg->P * 48;
-            hipLaunchKernelGGL(permute_sh, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, cfg->P, (cfg->sh_degree + 1) * (cfg->sh_degree + 1),
-                               cfg->feature_f16, (const void *)shs, L->sh_perm);
-            ENVGS_CHECK_LAUNCH(dcfg, stream);
+            FP.perm_blocks = (int)((nw + 255) / 256); FP.nb = (cfg->sh_degree + 1) * (cfg->sh_degree + 1); FP.f16 = cfg->feature_f16;
+            FP.shs = (const void *)shs; FP.shp = L->sh_perm;
             A.shp = L->sh_perm;
         }
+        { const int rcp = launch_prepare(); if (rcp) return rcp; }
+        ENVGS_CHECK_LAUNCH(dcfg, stream);
         // The ray batches are split into two segments that run collect -> sort+composite -> register on two streams: the collection
         // kernel is a persistent grid whose wavefronts drain over the time of one whole batch, and the second segment's wavefronts
         // (and the first segment's next kernel) move into the CUs it leaves idle.
@@ -274,6 +279,10 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             if (rc) return rc;
         }
         A.only_overflow = 1;
+    } else {
+        const int rcp = launch_prepare();
+        if (rcp) return rcp;
+        ENVGS_CHECK_LAUNCH(dcfg, stream);
     }
     { ProfScope p4(K_TRACE_KBUF_FWD, stream); hipLaunchKernelGGL(trace_fwd, dim3(persistent_grid(cfg->num_rays)), dim3(64), 0, stream, A, rh, rw); }
     ENVGS_CHECK_LAUNCH(dcfg, stream);

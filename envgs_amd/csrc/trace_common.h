@@ -17,6 +17,7 @@
 #define ENVGS_TRACE_COMMON_H
 
 #include "common.h"
+#include "prof.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -600,8 +601,12 @@ constexpr int RH_W = 8;         // register_hits: wavefronts per batch -- wave q
 
 // ---- kernels (the launch bounds / occupancy attributes are repeated here: a declaration without them makes the compiler assume 1024-thread
 //      workgroups, i.e. a 128-VGPR budget, for every other translation unit AND for the definition that follows it) ------------------------------
-__global__ void __launch_bounds__(256) make_surfel_records(int P, float mod, const float *__restrict__ means, const float *__restrict__ scales,
-                                                           const float *__restrict__ rots, const float *__restrict__ opac, float *__restrict__ srec);
+struct ForwardPrepare {
+    ZeroBatch zero; int zero_blocks;                                                                      // 512 blocks per buffer to clear
+    int P, rec_blocks; float mod; const float *means, *scales, *rots, *opac; float *srec;                 // surfel records (rec_blocks = 0: none)
+    int perm_blocks, nb, f16; const void *shs; void *shp;                                                 // quad-permuted SH blocks (perm_blocks = 0: none)
+};
+__global__ void __launch_bounds__(256) forward_prepare(const ForwardPrepare F);
 __global__ void __launch_bounds__(64) trace_fwd(const TraceArgs A, const int ray_h, const int ray_w);
 __global__ void __launch_bounds__(64) trace_bwd(const TraceArgs A, const int ray_h, const int ray_w);
 #ifdef ENVGS_DIAG
@@ -614,7 +619,7 @@ __global__ void __launch_bounds__(64) composite_lists_bwd(const TraceArgs A);
 #endif
 __global__ void __launch_bounds__(256, 8)
 collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec);
-__global__ void __launch_bounds__(256) permute_sh(int P, int nb, int f16, const void *__restrict__ shs, void *__restrict__ shp);
+
 template <int EMAX, bool LONG, bool QSH> __global__ void __launch_bounds__(256) sort_composite_fwd(const TraceArgs A);
 extern template __global__ void __launch_bounds__(256) sort_composite_fwd<4, false, false>(const TraceArgs A);
 extern template __global__ void __launch_bounds__(256) sort_composite_fwd<8, true, false>(const TraceArgs A);

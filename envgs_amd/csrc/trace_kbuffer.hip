@@ -1,27 +1,8 @@
-// trace_kbuffer.hip -- the per-surfel record kernel and the K-nearest-buffer tracer (T2 trace_fwd, T3 trace_bwd): bounces, rays whose hit list
+// trace_kbuffer.hip -- the K-nearest-buffer tracer (T2 trace_fwd, T3 trace_bwd): bounces, rays whose hit list
 // overflowed, and callers that pass no list scratch.  One lane = one ray; see trace_common.h.
 #include "trace_common.h"
 
 namespace envgs {
-
-// ---- per-surfel record ----------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-make_surfel_records(int P, float mod, const float *__restrict__ means, const float *__restrict__ scales,
-                    const float *__restrict__ rots, const float *__restrict__ opac, float *__restrict__ srec)
-{
-#pragma clang fp contract(off)      // the frame feeds the hit distance t, a sort key that is bit-exact against the oracle (see hit_surfel)
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
-    const float q0 = rots[4 * i], q1 = rots[4 * i + 1], q2 = rots[4 * i + 2], q3 = rots[4 * i + 3];
-    const float inv = 1.0f / sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
-    const float r = q0 * inv, x = q1 * inv, y = q2 * inv, z = q3 * inv;
-    const float su = scales[2 * i] * mod, sv = scales[2 * i + 1] * mod;
-    float4 *o = reinterpret_cast<float4 *>(srec + (size_t)i * SREC);
-    o[0] = make_float4(means[3 * i], means[3 * i + 1], means[3 * i + 2], opac[i]);
-    o[1] = make_float4((1.f - 2.f * (y * y + z * z)) / su, (2.f * (x * y + r * z)) / su, (2.f * (x * z - r * y)) / su, su);
-    o[2] = make_float4((2.f * (x * y - r * z)) / sv, (1.f - 2.f * (x * x + z * z)) / sv, (2.f * (y * z + r * x)) / sv, sv);
-    o[3] = make_float4(2.f * (x * z + r * y), 2.f * (y * z - r * x), 1.f - 2.f * (x * x + y * y), 0.f);
-}
 
 // ------------------------------------------------------------------------------------------ T2 ---
 __global__ void __launch_bounds__(64)

@@ -76,10 +76,8 @@ __device__ __forceinline__ void bitonic_sort_192(unsigned long long (&k)[3], con
 // lanes of a quad -- lane q owns coefficients 4q .. 4q+3, i.e. source words [12q, 12q+12) -- and stored so that load i (of three) of the four
 // lanes is ONE contiguous, aligned 64 B run (32 B with fp16 storage): word 4i + j of lane q sits at (4i + q) * 4 + j.  Coefficients beyond the
 // active degree are stored as zeros.  31 MB per step at the bench size: noise next to what it saves (see sort_composite_ray).
-__global__ void __launch_bounds__(256)
-permute_sh(int P, int nb, int f16, const void *__restrict__ shs, void *__restrict__ shp)
+static __device__ void permute_sh_word(const size_t i, int P, int nb, int f16, const void *__restrict__ shs, void *__restrict__ shp)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)P * 48) return;
     const int sid = (int)(i / 48), pos = (int)(i % 48);
     const int piece = pos >> 2, j = pos & 3, ii = piece >> 2, q = piece & 3;
@@ -87,6 +85,46 @@ permute_sh(int P, int nb, int f16, const void *__restrict__ shs, void *__restric
     const bool live = src < nb * 3;
     if (f16) reinterpret_cast<__half *>(shp)[i] = live ? reinterpret_cast<const __half *>(shs)[(size_t)sid * 48 + src] : __float2half(0.f);
     else reinterpret_cast<float *>(shp)[i] = live ? reinterpret_cast<const float *>(shs)[(size_t)sid * 48 + src] : 0.f;
+}
+
+// ---- per-surfel record ----------------------------------------------------------------------------
+static __device__ void surfel_record(const int i, const float mod, const float *__restrict__ means, const float *__restrict__ scales,
+                                     const float *__restrict__ rots, const float *__restrict__ opac, float *__restrict__ srec)
+{
+#pragma clang fp contract(off)      // the frame feeds the hit distance t, a sort key that is bit-exact against the oracle (see hit_surfel)
+    const float q0 = rots[4 * i], q1 = rots[4 * i + 1], q2 = rots[4 * i + 2], q3 = rots[4 * i + 3];
+    const float inv = 1.0f / sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    const float r = q0 * inv, x = q1 * inv, y = q2 * inv, z = q3 * inv;
+    const float su = scales[2 * i] * mod, sv = scales[2 * i + 1] * mod;
+    float4 *o = reinterpret_cast<float4 *>(srec + (size_t)i * SREC);
+    o[0] = make_float4(means[3 * i], means[3 * i + 1], means[3 * i + 2], opac[i]);
+    o[1] = make_float4((1.f - 2.f * (y * y + z * z)) / su, (2.f * (x * y + r * z)) / su, (2.f * (x * z - r * y)) / su, su);
+    o[2] = make_float4((2.f * (x * y - r * z)) / sv, (1.f - 2.f * (x * x + z * z)) / sv, (2.f * (y * z + r * x)) / sv, sv);
+    o[3] = make_float4(2.f * (x * z + r * y), 2.f * (y * z - r * x), 1.f - 2.f * (x * x + y * y), 0.f);
+}
+
+// What a forward needs before its first traversal, in ONE launch (round 4; three until then): the zero fill of the call's counters and
+// accumulators, the per-surfel records, and (list path, SH colours) the quad-permuted copy of the SH blocks.  Block ranges: [0, zero_blocks)
+// fill -- 512 blocks per buffer, grid-stride --, then one thread per surfel, then one thread per permuted SH word.
+__global__ void __launch_bounds__(256)
+forward_prepare(const ForwardPrepare F)
+{
+    int b = (int)blockIdx.x;
+    if (b < F.zero_blocks) {
+        const int which = b / 512, bx = b % 512;
+        float *p = F.zero.ptr[which];
+        const unsigned long long n = F.zero.n[which];
+        for (unsigned long long i = (unsigned long long)bx * 256 + threadIdx.x; i < n; i += 512ull * 256ull) p[i] = 0.f;
+        return;
+    }
+    b -= F.zero_blocks;
+    if (b < F.rec_blocks) {
+        const int i = b * 256 + (int)threadIdx.x;
+        if (i < F.P) surfel_record(i, F.mod, F.means, F.scales, F.rots, F.opac, F.srec);
+        return;
+    }
+    b -= F.rec_blocks;
+    permute_sh_word((size_t)b * 256 + threadIdx.x, F.P, F.nb, F.f16, F.shs, F.shp);
 }
 
 template <int CTRL> __device__ __forceinline__ float quad_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }

@@ -121,7 +121,7 @@ class CapState:
     def mirror(self, dev):
         m = self._mirrors.get(dev)
         if m is None:
-            m = self._mirrors[dev] = dict(host=torch.zeros(4, dtype=torch.int32).pin_memory(), event=torch.cuda.Event(), valid=False, rays=1)
+            m = self._mirrors[dev] = dict(host=torch.zeros(16, dtype=torch.int32).pin_memory(), event=torch.cuda.Event(), valid=False, rays=1)
         return m
 
     def next_cap(self, dev):
@@ -129,10 +129,10 @@ class CapState:
             return int(HIT_CAP["force"])
         m = self.mirror(dev)
         if m["valid"] and m["event"].query():
-            mx = int(m["host"][0])
+            mx = int(m["host"][1])
             want = ((int(mx * 1.2) + 8 + 63) // 64) * 64          # 20 % headroom, multiple of 64 entries (512 B)
             self.cap = max(64, min(want, 1024))
-            found = (int(m["host"][2]) & 0xFFFFFFFF) | ((int(m["host"][3]) & 0xFFFFFFFF) << 32)
+            found = (int(m["host"][8]) & 0xFFFFFFFF) | ((int(m["host"][9]) & 0xFFFFFFFF) << 32)
             self.found_per_ray = found / max(1, m["rays"])
         return self.cap
 
@@ -162,7 +162,7 @@ class CapState:
     def publish(self, counters, dev, rays=1):
         """Queue the asynchronous read-back of this call's longest list (counters[1]) and of its total of hits found (counters[8:10])."""
         m = self.mirror(dev)
-        m["host"][0:1].copy_(counters[1:2], non_blocking=True); m["host"][2:4].copy_(counters[8:10], non_blocking=True)
+        m["host"].copy_(counters[0:16], non_blocking=True)                 # (one copy of the head of the counter block: words 1 and 8..9 are read)
         m["event"].record(torch.cuda.current_stream(dev)); m["valid"] = True; m["rays"] = int(rays)
 
 
