@@ -5,9 +5,10 @@
 //      no library sort is left in the library) -> Karras-2012 hierarchy (one lane per internal node, clz on key pairs)
 //   -> box unions over the SORTED leaves: an LBVH node covers a contiguous run of sorted leaves, so each internal node reads both child boxes
 //      as range unions -- fully parallel, no bottom-up walk, no atomics (the bottom-up fit was 1 ms of dependent device-scope round trips).
-//      Round 4: TWO-LEVEL table instead of floor(log2 P) + 1 full levels (18 levels x P x 24 B = 70 MB and nine launches at 163 840 surfels):
-//      a sparse table over windows of 1 .. 64 leaves (7 levels), and a sparse table over 64-leaf BLOCKS (P / 64 entries per level, built by one
-//      workgroup); a range longer than 64 leaves = its first 64-window + the aligned blocks inside it + its last 64-window.
+//      Round 4: THREE tiers instead of floor(log2 P) + 1 full levels (18 levels x P x 24 B = 70 MB and nine launches at 163 840 surfels):
+//      windows of 1 .. 64 sorted leaves (7 levels), windows of 1 .. 64 BLOCKS of 64 leaves (7 levels of P / 64 entries, built the same way),
+//      and a full sparse table over SUPER-blocks of 4096 leaves (a handful of entries); a range = its first and last leaf window + the aligned
+//      blocks inside it (first and last block window + the aligned super-blocks inside those).  28 MB, three launches.
 //   -> the fit (fit_nodes) reads only the stored TOPOLOGY (child references + the other end of each node's leaf range) and the tables, so the
 //      same kernel REFITS an existing tree to moved vertices / changed opacities (envgs_bvh_refit: no Morton keys, no sort, no Karras pass).
 // Node = 64 B with both child boxes inline, so one 64 B fetch during traversal decides both children.
