@@ -96,6 +96,23 @@ VALU_PEAK_GINST = 256 * 2 * 2.4
 VALU_MEASURED_GINST = 898.0     # what the chip sustains: independent v_fma_f32 / mixed VALU, 8 waves per SIMD (scratch/valu_peak.hip -> profiles/r02_valu_peak.txt)
 SALU_PEAK_GINST = 256 * 1 * 2.4
 PMC_SUMMARY = os.path.join("profiles", "r04_pmc_envgs.json")
+STEP_INVENTORY = os.path.join("profiles", "r04_step_inventory.txt")     # rocprofv3 kernel trace of this workload's step (scratch/step_inventory.py)
+
+
+def step_inventory():
+    """Kernels per step and idle GPU time per step, from the committed kernel trace of the default EnvGS workload (a kernel trace cannot be
+    taken from inside the timed run; the file names the command it came from)."""
+    import re
+    try:
+        txt = open(os.path.join(ROOT, STEP_INVENTORY)).read()
+    except OSError:
+        return None
+    m = re.search(r"step: (\d+) kernels", txt)
+    per = [(int(k), float(i)) for i, k in re.findall(r"^step [0-9.]+ ms, idle ([0-9.]+) ms, (\d+) kernels", txt, flags=re.M)]
+    if not m or not per:
+        return None
+    return {"kernels_per_step": int(m.group(1)), "kernels_per_step_sampled": [k for k, _ in per],
+            "idle_gpu_ms_per_step": round(sum(i for _, i in per) / len(per), 3), "source": STEP_INVENTORY}
 
 
 def main():
@@ -542,6 +559,7 @@ def main():
             "render_mpix_per_s": (round(world * HW / render_s / 1e6, 2) if n_render else None),
             "render_ms_per_view": (round(render_s * 1e3, 4) if n_render else None),
             "exchange": exch,
+            "launches": (step_inventory() if (envgs and args.caller == "fused" and H == 800 and W == 800 and not args.trace_depth) else None),
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "bvh": bvh_times, "trace_counts": (dict(tcounts, entries=entries) if tcounts else None),
         }
         print(json.dumps(line))
