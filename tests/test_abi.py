@@ -47,6 +47,9 @@ def test_struct_layouts_match_headers():
     fields = re.findall(r"^\s+(?:int32_t|float)\s+([\w, ]+);", hdr[hdr.index("typedef struct envgs_trace_cfg"):hdr.index("} envgs_trace_cfg")], re.M)
     flat = [f.strip() for grp in fields for f in grp.split(",")]
     assert flat == [n for n, _ in _lib.TraceCfg._fields_]
+    body = hdr[hdr.index("typedef struct envgs_trace_lists"):hdr.index("} envgs_trace_lists")]
+    names = re.findall(r"^\s+(?:u?int\d+_t|size_t|void|float)\s+\*?\s*(\w+);", body, re.M)
+    assert names == [n for n, _ in _lib.TraceLists._fields_]
 
 
 def test_bad_arguments_are_rejected_before_any_gpu_work(lib):
