@@ -559,7 +559,7 @@ def main():
             "render_mpix_per_s": (round(world * HW / render_s / 1e6, 2) if n_render else None),
             "render_ms_per_view": (round(render_s * 1e3, 4) if n_render else None),
             "exchange": exch,
-            "launches": (step_inventory() if (envgs and args.caller == "fused" and H == 800 and W == 800 and not args.trace_depth) else None),
+            "launches": (step_inventory() if (envgs and args.caller == "fused" and H == 800 and W == 800 and not args.trace_depth and P == 300000 and args.env_gaussians == 163840 and args.bvh_rebuild_every == 16) else None),
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "bvh": bvh_times, "trace_counts": (dict(tcounts, entries=entries) if tcounts else None),
         }
         print(json.dumps(line))
