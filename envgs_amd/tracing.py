@@ -542,20 +542,22 @@ class SurfelTracer(nn.Module):
                 sel = go.nonzero(as_tuple=False)[:, 0]
             if sel.numel() == 0:
                 break
-            po, pd = p["o"][sel], p["d"][sel]
-            nsel = norm[sel]
+            # (index_select, not x[sel]: the backward of advanced indexing is a SORTED index_put -- 4 ms per step of radix sorts at 1.9 M rays --
+            #  while index_select's is a plain index_add; the indices are unique, so both are exact)
+            po, pd = p["o"].index_select(0, sel), p["d"].index_select(0, sel)
+            nsel = norm.index_select(0, sel)
             nh = nsel / nsel.norm(dim=-1, keepdim=True)
-            tdep = dpt[sel] / acc[sel]
+            tdep = dpt.index_select(0, sel) / acc.index_select(0, sel)
             o2 = po + pd * tdep
             d2 = pd - 2.0 * (pd * nh).sum(-1, keepdim=True) * nh
             out = _TraceSurfels.apply(o2, d2, *args, s0, 2, self.nodes, self.bounce_caps(k))
-            stages.append(dict(o=o2, d=d2, out=out, idx=p["idx"][sel], sel=sel))
+            stages.append(dict(o=o2, d=d2, out=out, idx=p["idx"].index_select(0, sel), sel=sel))
         col = stages[-1]["out"][0]
         for k in range(len(stages) - 2, -1, -1):
             p, c = stages[k], stages[k + 1]
             prgb = p["out"][0]
-            s = p["out"][5][c["sel"], 0:1]
-            col = prgb.index_put((c["sel"],), (1.0 - s) * prgb[c["sel"]] + s * col)
+            s = p["out"][5].index_select(0, c["sel"])[:, 0:1]
+            col = prgb.index_put((c["sel"],), (1.0 - s) * prgb.index_select(0, c["sel"]) + s * col)
         with torch.no_grad():
             mid = torch.zeros(R, 16 * (depth + 1), dtype=torch.float32, device=dev)
             for k, st in enumerate(stages):
