@@ -110,6 +110,7 @@ constexpr int BIN_SLICE_MIN = 1024;              // surfels per workgroup at lea
 constexpr int BIN_BAND = 16384;                  // tiles per LDS histogram (64 KB); larger images are walked band by band
 constexpr int BIG_RECT = 32;                     // rectangles above this many tiles are walked by the whole wavefront
 constexpr int SORT_LONG_N = 16384;               // sort_long_lists: 132 KB of LDS
+constexpr int SORT_SOLO_N = 8 * SORT_LONG_N;     // up to here a list is sorted by one workgroup (chunks in LDS, wide steps in HBM); beyond, by the whole grid
 constexpr int SORT_LONG_WGS = 256;               // one per CU
 
 struct BinPlan { int rows, slice, ntiles; };
@@ -402,27 +403,47 @@ sort_long_lists(const uint32_t *__restrict__ ranges, uint64_t *pairs, uint64_t *
         const uint32_t nchunks = (uint32_t)((n + C - 1) / C);
         const uint32_t nwide = (uint32_t)(((1ll << (lp - 1)) + LONG_ITEM - 1) / LONG_ITEM);
         const bool copy_out = !(full64 && keys_sorted == pairs);
-        if (!claimed) { my = long_claim(hdr, &s_item); claimed = true; }
         // phase kinds: 0 = chunk sort / merge (lk), 1 = wide step (lk, q), 2 = copy the sorted segment out
+        auto do_item = [&](const int kind, const int lk, const int q, const uint32_t it) {
+            if (kind == 0) {
+                const int c = (int)it;
+                for (int i = tid; i < C; i += 1024) s_long[ts_slot(i)] = ((long long)c * C + i) < n ? seg[(size_t)c * C + i] : ~0ull;
+                __syncthreads();
+                if (lk == LC) sort_padded_lds<1024>(s_long, LC, tid);
+                else merge_padded_lds<1024>(s_long, LC, tid);
+                for (int i = tid; i < C; i += 1024)
+                    if ((long long)c * C + i < n) seg[(size_t)c * C + i] = s_long[ts_slot(i)];
+            } else if (kind == 1) {
+                const long long i0 = (long long)it * LONG_ITEM, i1 = min(i0 + LONG_ITEM, 1ll << (lp - 1));
+                for (long long idx = i0 + tid; idx < i1; idx += 1024) ascending_step(seg, n, lk, q, (int)idx);
+            } else {
+                const long long i0 = (long long)it * C, i1 = min(i0 + C, (long long)n);
+                for (long long i = i0 + tid; i < i1; i += 1024) store_sorted(seg[i], t, (size_t)b + (size_t)i, keys_sorted, point_list, full64);
+            }
+        };
+        if (n <= SORT_SOLO_N) {
+            // A list of a few chunks is sorted by ONE workgroup, start to finish, the lists spread over the grid like the short ones: the
+            // grid-cooperative phases below take ~0.2 ms per list whatever its length, ONE LIST AT A TIME (the items are claimed in a global
+            // order) -- thirty ray buckets of 17-40 k entries, a bounce stage of the 1200x1600 configuration, were 6.8 ms of the step.
+            if ((small_seen++ % (uint32_t)G) != blockIdx.x) continue;
+            auto solo_phase = [&](const int kind, const int lk, const int q, const uint32_t items) {
+                for (uint32_t it = 0; it < items; it++) { do_item(kind, lk, q, it); __syncthreads(); }
+                __threadfence();                         // (the next phase reads what other wavefronts of this workgroup wrote to the segment)
+                __syncthreads();
+            };
+            solo_phase(0, LC, 0, nchunks);
+            for (int lk = LC + 1; lk <= lp; lk++) {
+                for (int q = 0; q <= lk - LC - 1; q++) solo_phase(1, lk, q, nwide);
+                solo_phase(0, lk, 0, nchunks);
+            }
+            if (copy_out) solo_phase(2, 0, 0, nchunks);
+            continue;
+        }
+        if (!claimed) { my = long_claim(hdr, &s_item); claimed = true; }
         auto run_phase = [&](const int kind, const int lk, const int q, const uint32_t items) {
             while (my - base < items) {                  // (unsigned: my >= base always -- items are claimed in order)
                 long_wait(hdr, base);
-                const uint32_t it = my - base;
-                if (kind == 0) {
-                    const int c = (int)it;
-                    for (int i = tid; i < C; i += 1024) s_long[ts_slot(i)] = ((long long)c * C + i) < n ? seg[(size_t)c * C + i] : ~0ull;
-                    __syncthreads();
-                    if (lk == LC) sort_padded_lds<1024>(s_long, LC, tid);
-                    else merge_padded_lds<1024>(s_long, LC, tid);
-                    for (int i = tid; i < C; i += 1024)
-                        if ((long long)c * C + i < n) seg[(size_t)c * C + i] = s_long[ts_slot(i)];
-                } else if (kind == 1) {
-                    const long long i0 = (long long)it * LONG_ITEM, i1 = min(i0 + LONG_ITEM, 1ll << (lp - 1));
-                    for (long long idx = i0 + tid; idx < i1; idx += 1024) ascending_step(seg, n, lk, q, (int)idx);
-                } else {
-                    const long long i0 = (long long)it * C, i1 = min(i0 + C, (long long)n);
-                    for (long long i = i0 + tid; i < i1; i += 1024) store_sorted(seg[i], t, (size_t)b + (size_t)i, keys_sorted, point_list, full64);
-                }
+                do_item(kind, lk, q, my - base);
                 long_done(hdr);
                 my = long_claim(hdr, &s_item);
             }

@@ -175,11 +175,13 @@ def _numpy_ray_keys(ro, rd, lead=4):
     return key.astype(np.uint32)
 
 
-@pytest.mark.parametrize("R, kind", [(1, "random"), (63, "random"), (5000, "random"), (200000, "random"), (640000, "cone"), (300000, "parallel")])
+@pytest.mark.parametrize("R, kind", [(1, "random"), (63, "random"), (5000, "random"), (200000, "random"), (640000, "cone"), (300000, "parallel"), (500000, "clumps")])
 def test_ray_coherence_order_is_the_stable_key_sort(R, kind):
     """The tracer's ray order (raster_bin.hip: launch_ray_sort -- buckets by the key's top bits, one LDS sort per bucket) is the order a
     stable sort of the 31-bit keys gives: ray ids by (key, id).  'cone': camera-like directions (few direction cells, long buckets);
-    'parallel': every ray the same direction, i.e. ONE bucket: the long-list kernel sorts its 300 000 entries chunk by chunk."""
+    'parallel': every ray the same direction, i.e. ONE bucket: the long-list kernel sorts its 300 000 entries chunk by chunk, the whole grid
+    on each phase; 'clumps': ten buckets of 17 000 - 100 000 rays (the bounce stages of the 1200x1600 configuration have dozens of them): each is
+    sorted by one workgroup -- chunks in LDS, wide steps in HBM."""
     from envgs_amd import _lib
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -187,6 +189,15 @@ def test_ray_coherence_order_is_the_stable_key_sort(R, kind):
     ro = (torch.rand(R, 3, generator=gen) * 2 - 1) * 0.98
     if kind == "random": rd = torch.randn(R, 3, generator=gen)
     elif kind == "cone": rd = torch.cat([0.35 * (torch.rand(R, 2, generator=gen) * 2 - 1), torch.ones(R, 1)], 1)
+    elif kind == "clumps":
+        rd = torch.randn(R, 3, generator=gen)
+        sizes = [17000, 20000, 24000, 30000, 33000, 40000, 50000, 65536, 80000, 100000]
+        at = 0
+        for i, n_ in enumerate(sizes):                                     # one direction cell + one origin octant each; the low key bits still differ
+            dc = torch.tensor([0.9 * np.cos(0.6 * i), 0.9 * np.sin(0.6 * i), 0.4 + 0.05 * i], dtype=torch.float32)
+            rd[at:at + n_] = dc + 0.004 * torch.randn(n_, 3, generator=gen)
+            ro[at:at + n_] = 0.3 + 0.1 * torch.rand(n_, 3, generator=gen)
+            at += n_
     else: rd = torch.tensor([[0.3, -0.2, 0.9]]).repeat(R, 1)
     rod, rdd = ro.to(dev).contiguous(), rd.to(dev).contiguous()
     pairs = torch.zeros(R, dtype=torch.int64, device=dev)
