@@ -79,6 +79,11 @@ SYMBOLS = {
     "envgs_surfel_quads": (c_int, [ctypes.c_int32] + [_P] * 5 + [_P]),
     "envgs_blend_forward": (c_int, [ctypes.c_int32] * 3 + [_P] * 3 + [_P]),
     "envgs_blend_backward": (c_int, [ctypes.c_int32] * 3 + [_P] * 5 + [_P]),
+    "envgs_bounce_rays_forward": (c_int, [ctypes.c_int32] + [_P] * 8 + [_P]),
+    "envgs_bounce_rays_backward": (c_int, [ctypes.c_int32] + [_P] * 13 + [_P]),
+    "envgs_bounce_blend_forward": (c_int, [ctypes.c_int32] + [_P] * 5 + [_P]),
+    "envgs_bounce_blend_backward": (c_int, [ctypes.c_int32] + [_P] * 8 + [_P]),
+    "envgs_bounce_pack_mid": (c_int, [ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32] + [_P] * 8 + [_P]),
     "envgs_reflect_forward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float] + [_P] * 8 + [_P]),
     "envgs_reflect_backward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float] + [_P] * 11 + [_P]),
     "envgs_surface_normal_forward": (c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_float, ctypes.c_float] + [_P] * 4 + [_P]),

@@ -557,6 +557,111 @@ blend_bwd(int HW, int C, const float *__restrict__ img, const float *__restrict_
     dimg[(size_t)(C - 1) * HW + p] = 0.f;
 }
 
+
+// ---- bounce stages of a multi-depth trace (tracing.py:_forward_bounces; gaussian2d_sampler.py:413-426, optix_utils.py:117-118) ----------------
+// Stage k's rays that bounce (rows `sel` of its per-ray tensors) become stage k+1's rays:
+//     n = norm / |norm|      t = dpt / acc      o2 = o + d t      d2 = d - 2 (d . n) n
+// and on the way back the colour of stage k+1 is blended into stage k's:   col[sel] = (1 - s) rgb[sel] + s col_next,  s = aux[sel, 0].
+// One launch each way instead of ~20 torch kernels forward and ~30 backward per stage (gathers, a norm, divisions, the index_put chain
+// and their scatter-adds); `sel` holds unique row indices (a nonzero() result), so the backward writes each row once -- no atomics.
+__global__ void __launch_bounds__(256)
+bounce_rays_fwd(int n, const long long *__restrict__ sel, const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ dpt,
+                const float *__restrict__ acc, const float *__restrict__ norm, float *__restrict__ o2, float *__restrict__ d2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t r = (size_t)sel[i];
+    const float ox = o[3 * r], oy = o[3 * r + 1], oz = o[3 * r + 2], dx = d[3 * r], dy = d[3 * r + 1], dz = d[3 * r + 2];
+    const float nx = norm[3 * r], ny = norm[3 * r + 1], nz = norm[3 * r + 2];
+    const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    const float hx = nx / len, hy = ny / len, hz = nz / len;
+    const float t = dpt[r] / acc[r];
+    o2[3 * i] = ox + dx * t; o2[3 * i + 1] = oy + dy * t; o2[3 * i + 2] = oz + dz * t;
+    const float dn = dx * hx + dy * hy + dz * hz;
+    d2[3 * i] = dx - 2.0f * dn * hx; d2[3 * i + 1] = dy - 2.0f * dn * hy; d2[3 * i + 2] = dz - 2.0f * dn * hz;
+}
+
+// g_o / g_d / g_dpt / g_acc / g_norm: (R_k, .) buffers ZEROED by the caller (rows that do not bounce receive nothing)
+__global__ void __launch_bounds__(256)
+bounce_rays_bwd(int n, const long long *__restrict__ sel, const float *__restrict__ o, const float *__restrict__ d, const float *__restrict__ dpt,
+                const float *__restrict__ acc, const float *__restrict__ norm, const float *__restrict__ g_o2, const float *__restrict__ g_d2,
+                float *__restrict__ g_o, float *__restrict__ g_d, float *__restrict__ g_dpt, float *__restrict__ g_acc, float *__restrict__ g_norm)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t r = (size_t)sel[i];
+    const float dx = d[3 * r], dy = d[3 * r + 1], dz = d[3 * r + 2];
+    const float nx = norm[3 * r], ny = norm[3 * r + 1], nz = norm[3 * r + 2];
+    const float len = sqrtf(nx * nx + ny * ny + nz * nz), il = 1.0f / len;
+    const float hx = nx * il, hy = ny * il, hz = nz * il;
+    const float a = acc[r], t = dpt[r] / a;
+    const float ax = g_o2 ? g_o2[3 * i] : 0.f, ay = g_o2 ? g_o2[3 * i + 1] : 0.f, az = g_o2 ? g_o2[3 * i + 2] : 0.f;
+    const float bx = g_d2 ? g_d2[3 * i] : 0.f, by = g_d2 ? g_d2[3 * i + 1] : 0.f, bz = g_d2 ? g_d2[3 * i + 2] : 0.f;
+    const float dn = dx * hx + dy * hy + dz * hz, bn = bx * hx + by * hy + bz * hz;
+    if (g_o) { g_o[3 * r] = ax; g_o[3 * r + 1] = ay; g_o[3 * r + 2] = az; }
+    if (g_d) {                                            // d o2 / d d = t I ;  d d2 / d d = I - 2 n n^T (symmetric)
+        g_d[3 * r] = ax * t + bx - 2.0f * bn * hx; g_d[3 * r + 1] = ay * t + by - 2.0f * bn * hy; g_d[3 * r + 2] = az * t + bz - 2.0f * bn * hz;
+    }
+    const float gt = ax * dx + ay * dy + az * dz;         // dL/dt
+    if (g_dpt) g_dpt[r] = gt / a;
+    if (g_acc) g_acc[r] = -gt * t / a;
+    if (g_norm) {
+        // dL/dn_hat = -2 [(d . n) g_d2 + (g_d2 . n) d], projected off n_hat and scaled by 1 / |norm|
+        const float qx = -2.0f * (dn * bx + bn * dx), qy = -2.0f * (dn * by + bn * dy), qz = -2.0f * (dn * bz + bn * dz);
+        const float qn = qx * hx + qy * hy + qz * hz;
+        g_norm[3 * r] = (qx - qn * hx) * il; g_norm[3 * r + 1] = (qy - qn * hy) * il; g_norm[3 * r + 2] = (qz - qn * hz) * il;
+    }
+}
+
+// col: a COPY of rgb (R_k, 3) made by the caller; rows sel are overwritten with the blend
+__global__ void __launch_bounds__(256)
+bounce_blend_fwd(int n, const long long *__restrict__ sel, const float *__restrict__ rgb, const float *__restrict__ aux,
+                 const float *__restrict__ col_next, float *__restrict__ col)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t r = (size_t)sel[i];
+    const float s = aux[2 * r];
+#pragma unroll
+    for (int c = 0; c < 3; c++) col[3 * r + c] = (1.0f - s) * rgb[3 * r + c] + s * col_next[3 * i + c];
+}
+
+// g_rgb: a COPY of g_col (R_k, 3) made by the caller (rows that do not bounce pass their gradient through); g_aux (R_k, 2) zeroed by the caller
+__global__ void __launch_bounds__(256)
+bounce_blend_bwd(int n, const long long *__restrict__ sel, const float *__restrict__ rgb, const float *__restrict__ aux,
+                 const float *__restrict__ col_next, const float *__restrict__ g_col, float *__restrict__ g_rgb, float *__restrict__ g_aux,
+                 float *__restrict__ g_col_next)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t r = (size_t)sel[i];
+    const float s = aux[2 * r];
+    float gs = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float g = g_col[3 * r + c];
+        gs += (col_next[3 * i + c] - rgb[3 * r + c]) * g;
+        if (g_rgb) g_rgb[3 * r + c] = (1.0f - s) * g;
+        if (g_col_next) g_col_next[3 * i + c] = s * g;
+    }
+    if (g_aux) g_aux[2 * r] = gs;
+}
+
+// mid (R, 16 * stages): the 16 channels [o 3 | d 3 | dpt | acc | norm 3 | aux 2 | rgb 3] of stage k's rays at the rows `idx` (their pixels)
+__global__ void __launch_bounds__(256)
+bounce_pack_mid(int n, const long long *__restrict__ idx, int stride, int k, const float *__restrict__ o, const float *__restrict__ d,
+                const float *__restrict__ dpt, const float *__restrict__ acc, const float *__restrict__ norm, const float *__restrict__ aux,
+                const float *__restrict__ rgb, float *__restrict__ mid)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 *m = reinterpret_cast<float4 *>(mid + (size_t)(idx ? idx[i] : i) * stride + 16 * k);
+    m[0] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i]);
+    m[1] = make_float4(d[3 * i + 1], d[3 * i + 2], dpt[i], acc[i]);
+    m[2] = make_float4(norm[3 * i], norm[3 * i + 1], norm[3 * i + 2], aux[2 * i]);
+    m[3] = make_float4(aux[2 * i + 1], rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+}
+
 }  // namespace envgs
 
 using namespace envgs;
@@ -658,6 +763,59 @@ int envgs_blend_backward(int32_t H, int32_t W, int32_t channels, const float *im
     if (H <= 0 || W <= 0 || (channels != 5 && channels != 7) || !img || !rgb_env || !drgb || !dimg) return ENVGS_ERR_BAD_ARG;
     const int HW = H * W;
     hipLaunchKernelGGL(blend_bwd, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, HW, channels, img, rgb_env, drgb, dimg, drgb_env);
+    return (int)hipGetLastError();
+}
+
+int envgs_bounce_rays_forward(int32_t n, const int64_t *sel, const float *ray_o, const float *ray_d, const float *dpt, const float *acc,
+                              const float *norm, float *o2, float *d2, void *stream)
+{
+    if (n < 0) return ENVGS_ERR_BAD_ARG;
+    if (n == 0) return 0;
+    if (!sel || !ray_o || !ray_d || !dpt || !acc || !norm || !o2 || !d2) return ENVGS_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bounce_rays_fwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, (const long long *)sel, ray_o, ray_d, dpt, acc, norm, o2, d2);
+    return (int)hipGetLastError();
+}
+
+int envgs_bounce_rays_backward(int32_t n, const int64_t *sel, const float *ray_o, const float *ray_d, const float *dpt, const float *acc,
+                               const float *norm, const float *g_o2, const float *g_d2, float *g_ray_o, float *g_ray_d, float *g_dpt,
+                               float *g_acc, float *g_norm, void *stream)
+{
+    if (n < 0) return ENVGS_ERR_BAD_ARG;
+    if (n == 0) return 0;
+    if (!sel || !ray_o || !ray_d || !dpt || !acc || !norm) return ENVGS_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bounce_rays_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, (const long long *)sel, ray_o, ray_d, dpt, acc, norm,
+                       g_o2, g_d2, g_ray_o, g_ray_d, g_dpt, g_acc, g_norm);
+    return (int)hipGetLastError();
+}
+
+int envgs_bounce_blend_forward(int32_t n, const int64_t *sel, const float *rgb, const float *aux, const float *col_next, float *col, void *stream)
+{
+    if (n < 0) return ENVGS_ERR_BAD_ARG;
+    if (n == 0) return 0;
+    if (!sel || !rgb || !aux || !col_next || !col) return ENVGS_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bounce_blend_fwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, (const long long *)sel, rgb, aux, col_next, col);
+    return (int)hipGetLastError();
+}
+
+int envgs_bounce_blend_backward(int32_t n, const int64_t *sel, const float *rgb, const float *aux, const float *col_next, const float *g_col,
+                                float *g_rgb, float *g_aux, float *g_col_next, void *stream)
+{
+    if (n < 0) return ENVGS_ERR_BAD_ARG;
+    if (n == 0) return 0;
+    if (!sel || !rgb || !aux || !col_next || !g_col) return ENVGS_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bounce_blend_bwd, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, (const long long *)sel, rgb, aux, col_next, g_col,
+                       g_rgb, g_aux, g_col_next);
+    return (int)hipGetLastError();
+}
+
+int envgs_bounce_pack_mid(int32_t n, const int64_t *idx, int32_t stages, int32_t k, const float *ray_o, const float *ray_d, const float *dpt,
+                          const float *acc, const float *norm, const float *aux, const float *rgb, float *mid, void *stream)
+{
+    if (n < 0 || stages <= 0 || k < 0 || k >= stages) return ENVGS_ERR_BAD_ARG;
+    if (n == 0) return 0;
+    if (!ray_o || !ray_d || !dpt || !acc || !norm || !aux || !rgb || !mid) return ENVGS_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bounce_pack_mid, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, (const long long *)idx, 16 * stages, k, ray_o, ray_d,
+                       dpt, acc, norm, aux, rgb, mid);
     return (int)hipGetLastError();
 }
 

@@ -194,3 +194,82 @@ def blend(img, rgb_env):
     traced colour rgb_env (H,W,3): envgs_sampler.py:474, one launch each way instead of ~20 (include/envgs_glue.h)."""
     return _Blend.apply(img, rgb_env)
 
+
+
+class _BounceRays(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ray_o, ray_d, dpt, acc, norm, sel):
+        lib = _lib.load()
+        if ray_o.device.type != "cuda":
+            raise RuntimeError("envgs_amd.fused needs tensors on the GPU; there is no CPU path")
+        ray_o, ray_d, dpt, acc, norm = (_f32c(t) for t in (ray_o, ray_d, dpt, acc, norm))
+        sel = sel.contiguous()
+        n = int(sel.numel())
+        o2 = torch.empty(n, 3, dtype=torch.float32, device=ray_o.device); d2 = torch.empty_like(o2)
+        p = _lib.ptr
+        _lib.check(lib.envgs_bounce_rays_forward(n, p(sel), p(ray_o), p(ray_d), p(dpt), p(acc), p(norm), p(o2), p(d2), _stream(ray_o.device)),
+                   "envgs_bounce_rays_forward")
+        ctx.save_for_backward(ray_o, ray_d, dpt, acc, norm, sel)
+        return o2, d2
+
+    @staticmethod
+    def backward(ctx, g_o2, g_d2):
+        lib = _lib.load()
+        ray_o, ray_d, dpt, acc, norm, sel = ctx.saved_tensors
+        n = int(sel.numel())
+        need = ctx.needs_input_grad
+        outs = [torch.zeros_like(t) if need[i] else None for i, t in enumerate((ray_o, ray_d, dpt, acc, norm))]
+        p = _lib.ptr
+        _lib.check(lib.envgs_bounce_rays_backward(n, p(sel), p(ray_o), p(ray_d), p(dpt), p(acc), p(norm), p(_f32c(g_o2)), p(_f32c(g_d2)),
+                                                  *[p(t) for t in outs], _stream(ray_o.device)), "envgs_bounce_rays_backward")
+        return (*outs, None)
+
+
+def bounce_rays(ray_o, ray_d, dpt, acc, norm, sel):
+    """Rays of the next bounce stage from the rows `sel` (unique int64 indices) of a stage's rays (R,3) and outputs dpt / acc (R,1), norm (R,3):
+    o2 = o + d dpt/acc, d2 = d - 2 (d.n) n with n = norm/|norm| -- (n,3) each; differentiable in everything but `sel`; one launch each way
+    (include/envgs_glue.h: envgs_bounce_rays_forward)."""
+    return _BounceRays.apply(ray_o, ray_d, dpt, acc, norm, sel)
+
+
+class _BounceBlend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, aux, col_next, sel):
+        lib = _lib.load()
+        rgb, aux, col_next = _f32c(rgb), _f32c(aux), _f32c(col_next)
+        sel = sel.contiguous()
+        col = rgb.clone()
+        p = _lib.ptr
+        _lib.check(lib.envgs_bounce_blend_forward(int(sel.numel()), p(sel), p(rgb), p(aux), p(col_next), p(col), _stream(rgb.device)),
+                   "envgs_bounce_blend_forward")
+        ctx.save_for_backward(rgb, aux, col_next, sel)
+        return col
+
+    @staticmethod
+    def backward(ctx, g_col):
+        lib = _lib.load()
+        rgb, aux, col_next, sel = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        g_col = _f32c(g_col)
+        g_rgb = g_col.clone() if need[0] else None
+        g_aux = torch.zeros_like(aux) if need[1] else None
+        g_next = torch.empty_like(col_next) if need[2] else None
+        p = _lib.ptr
+        _lib.check(lib.envgs_bounce_blend_backward(int(sel.numel()), p(sel), p(rgb), p(aux), p(col_next), p(g_col), p(g_rgb), p(g_aux), p(g_next),
+                                                   _stream(rgb.device)), "envgs_bounce_blend_backward")
+        return g_rgb, g_aux, g_next, None
+
+
+def bounce_blend(rgb, aux, col_next, sel):
+    """A stage's colour with the next stage blended in at the rows that bounced: rgb (R,3) with rows sel replaced by
+    (1 - s) rgb[sel] + s col_next, s = aux[sel, 0]; differentiable in rgb, aux, col_next (include/envgs_glue.h: envgs_bounce_blend_forward)."""
+    return _BounceBlend.apply(rgb, aux, col_next, sel)
+
+
+def bounce_pack_mid(mid, k, stages, idx, ray_o, ray_d, dpt, acc, norm, aux, rgb):
+    """Write stage k's 16 `mid` channels [o | d | dpt | acc | norm | aux | rgb] into mid (R, 16 * stages) at rows idx (None: row i).  No gradient."""
+    lib = _lib.load()
+    p = _lib.ptr
+    ts = [_f32c(t.detach()) for t in (ray_o, ray_d, dpt, acc, norm, aux, rgb)]
+    _lib.check(lib.envgs_bounce_pack_mid(int(ts[0].shape[0]), p(idx.contiguous()) if idx is not None else None, int(stages), int(k), *[p(t) for t in ts],
+                                         p(mid), _stream(mid.device)), "envgs_bounce_pack_mid")

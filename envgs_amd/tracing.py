@@ -512,7 +512,8 @@ class SurfelTracer(nn.Module):
 
     def _forward_bounces(self, ray_o, ray_d, args, settings, start_from_first):
         """max_trace_depth > 0 (gaussian2d_sampler.py:413-426, optix_utils.py:117-118): every stage is one bounce-free traced call
-        (the differentiable `_TraceSurfels` node, list path), glued by ordinary torch expressions that autograd differentiates:
+        (the differentiable `_TraceSurfels` node, list path), glued by two differentiable kernels of envgs_amd.fused (bounce_rays: the next
+        stage's rays; bounce_blend: the next stage's colour blended back -- one launch each way; round 4, torch expressions until then):
 
             stage k bounces where aux_k[0] > specular_threshold, acc_k > 0.5 and |norm_k| > 0
             o_{k+1} = o_k + d_k * dpt_k / acc_k          d_{k+1} = d_k - 2 (d_k . n) n,  n = norm_k / |norm_k|       (t_min = 1e-3)
@@ -527,6 +528,7 @@ class SurfelTracer(nn.Module):
         thr = float(settings.specular_threshold)
         s0 = settings._replace(max_trace_depth=0)
         lead = tuple(ray_o.shape[:-1])
+        from . import fused
         o = ray_o.reshape(-1, 3); d = ray_d.reshape(-1, 3)
         R = o.shape[0]
         dev = o.device
@@ -542,27 +544,21 @@ class SurfelTracer(nn.Module):
                 sel = go.nonzero(as_tuple=False)[:, 0]
             if sel.numel() == 0:
                 break
-            # (index_select, not x[sel]: the backward of advanced indexing is a SORTED index_put -- 4 ms per step of radix sorts at 1.9 M rays --
-            #  while index_select's is a plain index_add; the indices are unique, so both are exact)
-            po, pd = p["o"].index_select(0, sel), p["d"].index_select(0, sel)
-            nsel = norm.index_select(0, sel)
-            nh = nsel / nsel.norm(dim=-1, keepdim=True)
-            tdep = dpt.index_select(0, sel) / acc.index_select(0, sel)
-            o2 = po + pd * tdep
-            d2 = pd - 2.0 * (pd * nh).sum(-1, keepdim=True) * nh
+            # one launch each way (envgs_amd.fused.bounce_rays) instead of five gathers, a norm, two divisions and the reflection -- whose
+            # backward, through advanced indexing, was a SORTED index_put: 4 ms of radix sorts per 1200x1600 step
+            o2, d2 = fused.bounce_rays(p["o"], p["d"], dpt, acc, norm, sel)
             out = _TraceSurfels.apply(o2, d2, *args, s0, 2, self.nodes, self.bounce_caps(k))
             stages.append(dict(o=o2, d=d2, out=out, idx=p["idx"].index_select(0, sel), sel=sel))
         col = stages[-1]["out"][0]
         for k in range(len(stages) - 2, -1, -1):
             p, c = stages[k], stages[k + 1]
             prgb = p["out"][0]
-            s = p["out"][5].index_select(0, c["sel"])[:, 0:1]
-            col = prgb.index_put((c["sel"],), (1.0 - s) * prgb.index_select(0, c["sel"]) + s * col)
+            col = fused.bounce_blend(prgb, p["out"][5], col, c["sel"])
         with torch.no_grad():
             mid = torch.zeros(R, 16 * (depth + 1), dtype=torch.float32, device=dev)
             for k, st in enumerate(stages):
                 r_, dp_, ac_, no_, _, au_ = st["out"][:6]
-                mid[st["idx"], 16 * k:16 * k + 16] = torch.cat([st["o"], st["d"], dp_, ac_, no_, au_, r_], dim=1).float()
+                fused.bounce_pack_mid(mid, k, depth + 1, (st["idx"] if k else None), st["o"], st["d"], dp_, ac_, no_, au_, r_)
         rgb0, dpt0, acc0, norm0, dist0, aux0, mid0, wet = out0
         with torch.no_grad():
             # wet = the blend weights every surfel received over ALL stages: a surfel that only bounce rays blend contributes to the returned

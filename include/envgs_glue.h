@@ -81,6 +81,28 @@ ENVGS_API int envgs_blend_forward(int32_t H, int32_t W, int32_t channels, const 
 ENVGS_API int envgs_blend_backward(int32_t H, int32_t W, int32_t channels, const float *img, const float *rgb_env, const float *drgb,
                                    float *dimg, float *drgb_env, void *stream);
 
+/*
+ * Bounce stages of a multi-depth trace (gaussian2d_sampler.py:413-426 / optix_utils.py:117-118; envgs_amd/tracing.py:_forward_bounces):
+ * rows `sel` (n UNIQUE int64 row indices, e.g. a nonzero() result) of stage k's per-ray tensors -- rays (R_k,3), dpt / acc (R_k,1), norm (R_k,3),
+ * aux (R_k,2), rgb (R_k,3) -- become stage k+1's rays:  n^ = norm/|norm|, t = dpt/acc, o2 = o + d t, d2 = d - 2 (d.n^) n^   (o2, d2: (n,3));
+ * and stage k+1's colour col_next (n,3) is blended back:  col[sel] = (1 - s) rgb[sel] + s col_next, s = aux[sel,0]  (col: the caller's COPY of rgb).
+ * Backwards: g_ray_o / g_ray_d / g_dpt / g_acc / g_norm / g_aux are (R_k, .) buffers the caller has ZEROED (rows outside sel receive nothing);
+ * g_rgb is the caller's COPY of g_col (rows outside sel pass through).  Any gradient pointer may be NULL.  One launch each.
+ * envgs_bounce_pack_mid: the 16 `mid` channels [o 3 | d 3 | dpt | acc | norm 3 | aux 2 | rgb 3] of stage k (of `stages`) at rows idx (NULL: row i).
+ */
+ENVGS_API int envgs_bounce_rays_forward(int32_t n, const int64_t *sel, const float *ray_o, const float *ray_d, const float *dpt, const float *acc,
+                                        const float *norm, float *o2, float *d2, void *stream);
+ENVGS_API int envgs_bounce_rays_backward(int32_t n, const int64_t *sel, const float *ray_o, const float *ray_d, const float *dpt, const float *acc,
+                                         const float *norm, const float *g_o2, const float *g_d2, float *g_ray_o, float *g_ray_d, float *g_dpt,
+                                         float *g_acc, float *g_norm, void *stream);
+ENVGS_API int envgs_bounce_blend_forward(int32_t n, const int64_t *sel, const float *rgb, const float *aux, const float *col_next, float *col,
+                                         void *stream);
+ENVGS_API int envgs_bounce_blend_backward(int32_t n, const int64_t *sel, const float *rgb, const float *aux, const float *col_next,
+                                          const float *g_col, float *g_rgb, float *g_aux, float *g_col_next, void *stream);
+ENVGS_API int envgs_bounce_pack_mid(int32_t n, const int64_t *idx, int32_t stages, int32_t k, const float *ray_o, const float *ray_d,
+                                    const float *dpt, const float *acc, const float *norm, const float *aux, const float *rgb, float *mid,
+                                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,3 +149,61 @@ def test_blend_matches_torch(C):
     assert float((gi - img.grad).abs().max()) <= 1e-5 * float(img.grad.abs().max()) and float((ge - env.grad).abs().max()) <= 1e-6
     assert float(gi[C - 1].abs().max()) == 0.0
 
+
+
+def test_bounce_stage_glue_matches_torch_f64():
+    """fused.bounce_rays / bounce_blend / bounce_pack_mid == the torch expressions of a bounce stage (gaussian2d_sampler.py:413-426 as restated in
+    tracing.py:_forward_bounces), values and every gradient against float64 autograd; rows that do not bounce receive exactly zero (rays) or pass
+    their gradient through (colour)."""
+    from envgs_amd import fused
+    dev = torch.device("cuda:0")
+    R = 5000
+    gen = torch.Generator().manual_seed(11)
+    mk = lambda *s: torch.randn(*s, generator=gen)
+    o, d = mk(R, 3), mk(R, 3)
+    d = d / d.norm(dim=-1, keepdim=True)
+    dpt = torch.rand(R, 1, generator=gen) * 3 + 0.5; acc = torch.rand(R, 1, generator=gen) * 0.5 + 0.5
+    norm = mk(R, 3) * 0.3; aux = torch.rand(R, 2, generator=gen); rgb = torch.rand(R, 3, generator=gen)
+    sel = torch.nonzero(torch.rand(R, generator=gen) < 0.6)[:, 0]
+    n = sel.numel()
+    col_next = torch.rand(n, 3, generator=gen)
+    up_o, up_d, up_c = mk(n, 3), mk(n, 3), mk(R, 3)
+
+    def run(dtype, device, fusedp):
+        L = [t.to(device=device, dtype=dtype).requires_grad_(True) for t in (o, d, dpt, acc, norm, aux, rgb, col_next)]
+        o_, d_, dpt_, acc_, norm_, aux_, rgb_, cn_ = L
+        s_ = sel.to(device)
+        if fusedp:
+            o2, d2 = fused.bounce_rays(o_, d_, dpt_, acc_, norm_, s_)
+            col = fused.bounce_blend(rgb_, aux_, cn_, s_)
+        else:
+            nh = norm_[s_] / norm_[s_].norm(dim=-1, keepdim=True)
+            o2 = o_[s_] + d_[s_] * (dpt_[s_] / acc_[s_])
+            d2 = d_[s_] - 2.0 * (d_[s_] * nh).sum(-1, keepdim=True) * nh
+            sp = aux_[s_, 0:1]
+            col = rgb_.index_put((s_,), (1.0 - sp) * rgb_[s_] + sp * cn_)
+        loss = (o2 * up_o.to(device=device, dtype=dtype)).sum() + (d2 * up_d.to(device=device, dtype=dtype)).sum() + (col * up_c.to(device=device, dtype=dtype)).sum()
+        loss.backward()
+        return [x.detach().double().cpu() for x in (o2, d2, col)], [t.grad.detach().double().cpu() for t in L]
+
+    (ro2, rd2, rcol), rg = run(torch.float64, "cpu", False)
+    (go2, gd2, gcol), gg = run(torch.float32, dev, True)
+    for a, b in ((ro2, go2), (rd2, gd2), (rcol, gcol)):
+        assert float((a - b).abs().max()) <= 2e-6 * (1.0 + float(a.abs().max()))
+    names = ("ray_o", "ray_d", "dpt", "acc", "norm", "aux", "rgb", "col_next")
+    for nm, a, b in zip(names, rg, gg):
+        assert float((a - b).abs().max()) <= 2e-5 * (float(a.abs().max()) + 1e-12), nm
+    keep = torch.ones(R, dtype=torch.bool); keep[sel] = False
+    for i in (0, 1, 2, 3, 4):                                                # ray-side inputs: rows that do not bounce get exactly nothing
+        assert float(gg[i][keep].abs().max()) == 0.0
+    assert torch.equal(gg[6][keep].float(), up_c[keep])                      # colour: passed through
+    # mid: 16 channels of stage 1 at the rows `sel`, stage 0 at every row
+    mid = torch.zeros(R, 32, device=dev)
+    st0 = [t.to(dev) for t in (o, d, dpt, acc, norm, aux, rgb)]
+    fused.bounce_pack_mid(mid, 0, 2, None, *st0)
+    st1 = [t.to(dev) for t in (go2.float(), gd2.float(), dpt[sel], acc[sel], norm[sel], aux[sel], col_next)]
+    fused.bounce_pack_mid(mid, 1, 2, sel.to(dev), *st1)
+    want = torch.zeros(R, 32)
+    want[:, :16] = torch.cat([o, d, dpt, acc, norm, aux, rgb], 1)
+    want[sel, 16:] = torch.cat([t.cpu() for t in st1], 1)
+    assert torch.equal(mid.cpu(), want)
