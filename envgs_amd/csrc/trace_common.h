@@ -160,7 +160,7 @@ struct TraceArgs {
     unsigned *long_list; // (R) scratch: slots of the rays whose lists exceed 256 hits, appended by the main sort pass (counter[24 + seg] = how many)
     float4 *state;      // per composited hit, for the backward, as PLANES of 16 B rows (plane p of row i at state[p * state_plane + i]):
                         // plane 0 = (transmittance before the hit, rgb prefix sums after it), plane 1 = (depth, normal prefix sums), plane 2 (only with
-                        // `others`) = the two aux sums.  A backward whose only upstream gradient is the colour's -- what EnvGS trains with -- reads plane 0 alone
+                        // `others`; 8 B rows, i.e. float2 index i behind the two 16 B planes) = the two aux sums.  A backward whose only upstream gradient is the colour's -- what EnvGS trains with -- reads plane 0 alone
     size_t state_plane; // rows per plane (compact_rows, or R * cap)
     // compact per-hit buffers (envgs_trace.h: compact_rows): nullptr = the (R, cap) layouts
     unsigned *batch_cnt;          // (batches) written by the cooperative collection: rows the batch needs (sum of its listed rays' hit counts)

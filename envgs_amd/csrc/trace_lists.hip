@@ -227,7 +227,7 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
     for (int j = 0; j < 10; j++) C[j] = 0.f;
     float dist = 0.f;                                   // per-lane partial sum
     int used = 0;
-    float4 *state = A.state ? A.state + state_row0(A, slot, r) : nullptr;      // per-hit state: 16 B rows in two planes (three with `others`)
+    float4 *state = A.state ? A.state + state_row0(A, slot, r) : nullptr;      // per-hit state: two planes of 16 B rows (+ one of 8 B rows with `others`)
 #pragma unroll
     for (int ce = 0; ce < E; ce++) {
         const int cb = ce * 64;
@@ -277,7 +277,10 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
                 typedef float nt4 __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store((nt4){Tb, S[0], S[1], S[2]}, reinterpret_cast<nt4 *>(o));
                 __builtin_nontemporal_store((nt4){S[3], S[5], S[6], S[7]}, reinterpret_cast<nt4 *>(o + A.state_plane));
-                if (A.has_others) __builtin_nontemporal_store((nt4){S[8], S[9], 0.f, 0.f}, reinterpret_cast<nt4 *>(o + 2 * A.state_plane));
+                if (A.has_others) {                                          // (third plane: 8 B rows -- the two aux sums)
+                    typedef float nt2 __attribute__((ext_vector_type(2)));
+                    __builtin_nontemporal_store((nt2){S[8], S[9]}, reinterpret_cast<nt2 *>(A.state + 2 * A.state_plane) + (size_t)(o - A.state));
+                }
             }
         }
         const int nu = f < 64 ? f : min(64, n - cb);                    // hits of this chunk that were blended

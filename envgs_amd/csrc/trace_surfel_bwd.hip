@@ -213,7 +213,7 @@ batch_surfel_bwd(const TraceArgs A)
             // software pipeline over the entries: the per-hit state of entry el+1 is in flight while entry el is evaluated
             int k1 = valid ? (int)kmat[buf][0][lane] : 0;
             float4 st0, st1 = make_float4(0.f, 0.f, 0.f, 0.f), st2 = make_float4(0.f, 0.f, 0.f, 0.f);
-            { const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) : A.state; st0 = sp[0]; if constexpr (!RGBO) { st1 = sp[plane]; if (A.has_others) st2 = sp[2 * plane]; } }      // unconditional (idle lanes share one address): no branch, no wait
+            { const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) : A.state; st0 = sp[0]; if constexpr (!RGBO) { st1 = sp[plane]; if (A.has_others) { const float2 t2 = reinterpret_cast<const float2 *>(A.state + 2 * plane)[(size_t)(sp - A.state)]; st2.x = t2.x; st2.y = t2.y; } } }      // unconditional (idle lanes share one address): no branch, no wait
             for (int el = 0; el < ne; el++) {
                 const unsigned long long d = sdesc[buf][el];
                 const int sid = (int)(d & 0xFFFFFFull);
@@ -289,7 +289,7 @@ batch_surfel_bwd(const TraceArgs A)
                 if (el + 1 < ne) {                           // next entry's state: in flight during the reduction below
                     k1 = valid ? (int)kmat[buf][el + 1][lane] : 0;
                     const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) : A.state;
-                    st0 = sp[0]; if constexpr (!RGBO) { st1 = sp[plane]; if (A.has_others) st2 = sp[2 * plane]; }
+                    st0 = sp[0]; if constexpr (!RGBO) { st1 = sp[plane]; if (A.has_others) { const float2 t2 = reinterpret_cast<const float2 *>(A.state + 2 * plane)[(size_t)(sp - A.state)]; st2.x = t2.x; st2.y = t2.y; } }
                 }
                 // geometry: lane r*16 + k (k < 4) receives the sum over the 64 rays of word k + 4 r; record words 48 .. 62
                 {

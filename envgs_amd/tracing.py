@@ -248,7 +248,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
             # what the record backward needs from the forward: per-hit state, and the (batch, surfel) entries with their (lane, k) pairs.
             # COMPACT: rows follow the hits the rays actually have (a prefix sum of the hit counts, taken on the device between the collection
             # and the sort) instead of rays x capacity -- a ray uses a third of its capacity (42 -> 19 GB for a 1.92 M-ray stage)
-            sw = 12 if others_precomp is not None else 8
+            sw = 10 if others_precomp is not None else 8            # floats per row: two 16 B planes (+ one 8 B plane with `others`)
             if COMPACT["on"] and srt:
                 rows = caps.next_rows(R, cap)
                 keep.update(hit_state=_scratch((rows, sw), torch.float32, dev), entries=_scratch((rows,), torch.int64, dev), pairs=_scratch((rows,), torch.int32, dev))

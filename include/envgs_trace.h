@@ -91,17 +91,18 @@ typedef struct envgs_trace_lists {
     size_t ray_sort_temp_bytes;
     float *records;          /* backward only: (num_records, 64) one 256 B gradient record per (batch, surfel) entry, grouped by surfel */
     uint64_t num_records;    /* backward only: capacity of `records` in records (>= surf_off[P-1]) */
-    float *hit_state;        /* 16 B rows in PLANES, written by the forward for the backward -- plane p of row i at float4 index p * rows + i, rows =
-                                compact_rows (or R * cap): plane 0 = (transmittance before the composited hit, the three colour prefix sums after it),
-                                plane 1 = (depth, normal prefix sums), plane 2 (only with has_others) = the two aux sums.  8 floats per row and hit, 12
-                                with has_others.  A backward whose only upstream gradient is the colour's reads plane 0 alone */
+    float *hit_state;        /* PLANES of per-hit rows, written by the forward for the backward; rows = compact_rows (or R * cap).  Plane 0 (16 B rows, at
+                                float index 0): (transmittance before the composited hit, the three colour prefix sums after it); plane 1 (16 B rows,
+                                at float index 4 * rows): (depth, normal prefix sums); plane 2 (only with has_others; 8 B rows, at float index
+                                8 * rows): the two aux sums.  8 floats per row and hit, 10 with has_others (12 until round 4).  A backward whose only
+                                upstream gradient is the colour's reads plane 0 alone */
     uint64_t *entries;       /* (ceil(R/64), 64*cap) distinct surfels of every batch, packed id | hits-1 << 24 | slot << 32 */
     uint32_t *pairs;         /* (ceil(R/64), 64*cap) (lane << 16 | list position) of every composited hit, grouped by entry */
     int32_t *n_entries;      /* (ceil(R/64), 2) entries merged in the batch's table, single entries filed from the top */
     /* COMPACT per-hit buffers (optional; compact_rows == 0 selects the (R, cap) layouts documented above).  A ray uses a third of its list
      * capacity on average, so hit_state / entries / pairs are addressed through per-ray ROW offsets instead: after the collection the rays'
      * hit counts are scanned in coherence-sorted order (a batch's rows are contiguous), ray at sorted slot s owns rows
-     * [row_off[s], row_off[s] + min(hit_cnt, cap)) of hit_state (compact_rows x 8|12 floats), and batch b owns the same row range
+     * [row_off[s], row_off[s] + min(hit_cnt, cap)) of hit_state (compact_rows x 8|10 floats), and batch b owns the same row range
      * batch_rows[b] = {first row, rows} of entries / pairs (compact_rows elements each).  Each forward segment CLAIMS its rows from a counter
      * shared by the call's segments once its hit counts are known (round 4; a fixed share per segment starved whichever held the busier rays);
      * rays that do not fit are handed to the K-buffer kernels like rays whose list overflowed
