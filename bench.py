@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--no-render", action="store_true", help="skip the forward-only render timing (profiling runs: keeps the kernel statistics to the training steps)")
     ap.add_argument("--bvh-rebuild-every", type=int, default=16, help="fused caller: full LBVH build on every K-th step, a refit (same topology, new boxes) on the others; "
                     "1 = rebuild every step, as the unchanged EasyVolcap caller does (the reference caller always rebuilds)")
+    ap.add_argument("--no-colour-only-state", action="store_true", help="fused caller: let the env trace keep the full per-hit state (as for a caller that may differentiate "
+                    "its depth / accumulation / normal outputs) instead of the colour's plane only (SurfelTracer.set_colour_only_backward)")
     ap.add_argument("--no-prebuild", action="store_true", help="fused caller: build the environment structure inside the traced call (as the reference caller does) instead of ahead, under the base pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-caller", action="store_true", help="skip the extra few steps that time the unchanged-EasyVolcap-caller form of the step (config.reference_caller_ms_per_step)")
@@ -224,6 +226,7 @@ def main():
         set_caller(args.caller)
         envgs_step.PREBUILD["on"] = not args.no_prebuild
         envgs_step.REFIT["every"] = max(1, args.bvh_rebuild_every)
+        envgs_step.COLOUR_ONLY["on"] = not args.no_colour_only_state
         dnorm_hw = (torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)) / HW).to(dev)
         tracer = tpkg.SurfelTracer()
         rays = [synth.get_rays(c) for c in cams]
@@ -551,6 +554,8 @@ def main():
                        "reference_caller_note": "the same step with the UNCHANGED EasyVolcap caller's expression forms around the same extensions (--caller reference), a few steps outside the timed region; reference_caller_ms_per_step is under torch's OWN BLAS choice (importing the packages changes nothing process-wide), reference_caller_ms_by_torch_blas has it under both (cublas = rocBLAS, cublaslt = hipBLASLt; the one-line pin of INTEGRATION.md section 5)",
                        "env_structure": (None if not envgs else ("LBVH rebuilt every step" if (args.caller != "fused" or args.bvh_rebuild_every <= 1) else
                                          "LBVH full build every %d steps, refit (same topology, new boxes) on the others" % args.bvh_rebuild_every)),
+                       "env_per_hit_state": (None if not envgs else ("colour plane only: the caller promises a colour-only backward (16 B per hit; another gradient raises)"
+                                             if (args.caller == "fused" and not args.no_colour_only_state and not args.trace_depth) else "all planes (32 B per hit, 40 with `others`)")),
                        "torch_blas": str(torch.backends.cuda.preferred_blas_library()).split(".")[-1],
                        "dist_backend": (dist.get_backend() if world > 1 else None),
                        "debug_switches": {"trace": args.debug_trace, "segments": args.debug_segments, "collect_wgs": args.debug_collect_wgs},

@@ -150,6 +150,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         const bool compact = L->compact_rows > 0 && L->row_off && L->batch_rows && L->row_blk && L->hit_state;
         if (L->compact_rows > 0 && !compact) return ENVGS_ERR_BAD_ARG;
         A.state_plane = compact ? (size_t)L->compact_rows : (size_t)cfg->num_rays * (size_t)L->cap;
+        A.colour_state = L->state_planes == 1 ? 1 : 0;
         if (compact) { A.row_off = L->row_off; A.batch_rows = (const uint2 *)L->batch_rows; A.batch_cnt = L->row_blk; }
         if (L->sh_perm && shs && cfg->sh_coeffs == 16) {
             const size_t nw = (size_t)cfg->P * 48;
@@ -353,6 +354,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
                     ProfScope p5(K_TRACE_LIST_BWD, stream);
                     // the colour is the only output the loss uses (the EnvGS step): the specialisation that drops the other outputs' terms and state planes
                     const bool rgb_only = dL_drgb && !dL_ddpt && !dL_dacc && !dL_dnorm && !dL_daux;
+                    if (L->state_planes == 1 && !rgb_only) return ENVGS_ERR_BAD_ARG;      // the forward was told to keep the colour's plane only
                     const dim3 g(stride_grid((cfg->num_rays + 63) / 64, 1));
                     if (rgb_only) hipLaunchKernelGGL(batch_surfel_bwd<true>, g, dim3(64), 0, stream, A);
                     else hipLaunchKernelGGL(batch_surfel_bwd<false>, g, dim3(64), 0, stream, A);

@@ -162,6 +162,7 @@ struct TraceArgs {
                         // plane 0 = (transmittance before the hit, rgb prefix sums after it), plane 1 = (depth, normal prefix sums), plane 2 (only with
                         // `others`; 8 B rows, i.e. float2 index i behind the two 16 B planes) = the two aux sums.  A backward whose only upstream gradient is the colour's -- what EnvGS trains with -- reads plane 0 alone
     size_t state_plane; // rows per plane (compact_rows, or R * cap)
+    int colour_state;   // 1: only plane 0 exists (envgs_trace_lists::state_planes == 1: the backward will be the colour-only one)
     // compact per-hit buffers (envgs_trace.h: compact_rows): nullptr = the (R, cap) layouts
     unsigned *batch_cnt;          // (batches) written by the cooperative collection: rows the batch needs (sum of its listed rays' hit counts)
     const unsigned *row_off;      // (R) by sorted slot: the ray's first row of hit_state

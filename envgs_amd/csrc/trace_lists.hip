@@ -276,8 +276,8 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
                 // streamed once, read once by the backward much later: non-temporal, so it does not evict the surfel records / SH blocks
                 typedef float nt4 __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store((nt4){Tb, S[0], S[1], S[2]}, reinterpret_cast<nt4 *>(o));
-                __builtin_nontemporal_store((nt4){S[3], S[5], S[6], S[7]}, reinterpret_cast<nt4 *>(o + A.state_plane));
-                if (A.has_others) {                                          // (third plane: 8 B rows -- the two aux sums)
+                if (!A.colour_state) __builtin_nontemporal_store((nt4){S[3], S[5], S[6], S[7]}, reinterpret_cast<nt4 *>(o + A.state_plane));
+                if (A.has_others && !A.colour_state) {                                          // (third plane: 8 B rows -- the two aux sums)
                     typedef float nt2 __attribute__((ext_vector_type(2)));
                     __builtin_nontemporal_store((nt2){S[8], S[9]}, reinterpret_cast<nt2 *>(A.state + 2 * A.state_plane) + (size_t)(o - A.state));
                 }

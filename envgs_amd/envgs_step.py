@@ -109,6 +109,9 @@ PREBUILD = {"on": True}            # fused caller: start the environment structu
 # builds -- a training step moves the surfels by a learning rate, not across the scene.  every = 1: rebuild on every call, as the unchanged
 # EasyVolcap caller does (optix_utils.py:73-78 always passes rebuild=True while training)
 REFIT = {"every": 16}
+# fused caller, bounce-free env pass: only its colour is supervised (envgs_sampler.py: the loss sees the blended rgb; dpt / acc / norm are
+# visualisation outputs) -> SurfelTracer.set_colour_only_backward: the forward stores the colour's per-hit state only
+COLOUR_ONLY = {"on": True}
 TRACE = {"depth": 0, "specular_threshold": 0.0}    # EnvGS hard-codes 0 bounces (envgs_sampler.py:510,548); bench.py --trace-depth overrides
 
 
@@ -145,6 +148,8 @@ def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree, prepared_v
     else:
         v, f = (REFERENCE_FORMS["get_disks"] if REFERENCE_FORMS["on"] else synth.get_disks)(env["means3D"], env["scales"], env["rotations"])
         tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
+    if hasattr(tracer, "set_colour_only_backward"):
+        tracer.set_colour_only_backward(bool(FUSED["on"] and not REFERENCE_FORMS["on"] and COLOUR_ONLY["on"] and int(TRACE["depth"]) == 0))
     if FUSED["on"] and not REFERENCE_FORMS["on"]:
         grads3D = torch.empty_like(env["means3D"]).requires_grad_(True)          # (gradient sink, never read: no fill, no `+ 0`)
     else:

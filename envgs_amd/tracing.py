@@ -116,6 +116,7 @@ class CapState:
     def __init__(self, cap=512):
         self.cap = int(cap)
         self.found_per_ray = None   # hits found per ray in the previous call: sizes the COMPACT per-hit buffers (rows) of the next one
+        self.colour_only = False    # SurfelTracer.set_colour_only_backward: the backward will see the colour's gradient only -> store plane 0 alone
         self._mirrors = {}          # device -> dict(host, event, valid)
 
     def mirror(self, dev):
@@ -248,7 +249,8 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
             # what the record backward needs from the forward: per-hit state, and the (batch, surfel) entries with their (lane, k) pairs.
             # COMPACT: rows follow the hits the rays actually have (a prefix sum of the hit counts, taken on the device between the collection
             # and the sort) instead of rays x capacity -- a ray uses a third of its capacity (42 -> 19 GB for a 1.92 M-ray stage)
-            sw = 10 if others_precomp is not None else 8            # floats per row: two 16 B planes (+ one 8 B plane with `others`)
+            colour_only = bool(getattr(caps, "colour_only", False))
+            sw = 4 if colour_only else (10 if others_precomp is not None else 8)     # floats per row: two 16 B planes (+ one 8 B plane with `others`); colour only: plane 0
             if COMPACT["on"] and srt:
                 rows = caps.next_rows(R, cap)
                 keep.update(hit_state=_scratch((rows, sw), torch.float32, dev), entries=_scratch((rows,), torch.int64, dev), pairs=_scratch((rows,), torch.int32, dev))
@@ -262,7 +264,10 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
                                 *[(keep[k].data_ptr() if k in keep else None) for k in ("hit_state", "entries", "pairs")],
                                 keep["n_entries"].data_ptr() if "hit_state" in keep else None, rows,
                                 *[(keep[k].data_ptr() if (k in keep and rows) else None) for k in ("row_off", "batch_rows", "row_blk")],
-                                keep["sh_perm"].data_ptr() if "sh_perm" in keep else None)
+                                keep["sh_perm"].data_ptr() if "sh_perm" in keep else None, 0)
+        if "hit_state" in keep and getattr(caps, "colour_only", False):
+            lists.state_planes = 1
+            keep["colour_only"] = True
     p = _lib.ptr
     _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
                                        p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),
@@ -311,6 +316,9 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
     s = saved
     lists = s["lists"]
     records = None
+    if lists is not None and s["keep"].get("colour_only") and any(g_ is not None for g_ in (g_dpt, g_acc, g_norm, g_aux)):
+        raise RuntimeError("SurfelTracer: set_colour_only_backward(True) promised that only the colour output would be differentiated, but a gradient "
+                           "arrived for dpt / acc / norm / aux -- the forward kept the colour's per-hit state only; switch the promise off")
     if lists is not None and USE_RECORDS["on"] and "hit_state" in s["keep"]:
         # atomic-free backward: one 256 B record per (batch, surfel) entry, grouped by surfel.  The count is known on the device
         # (inclusive scan of the per-surfel entry counts, done at the end of the forward); reading it is the one host sync here.
@@ -442,6 +450,13 @@ class SurfelTracer(nn.Module):
         self.nodes = None
         self.num_surfels = vertices.shape[0] // 4
 
+    def set_colour_only_backward(self, on=True):
+        """OPTIONAL, not part of the reference interface (include/envgs_trace.h: state_planes): a promise that the backward of this tracer's
+        bounce-free calls will receive a gradient for the COLOUR output only -- the EnvGS training step (the env pass's depth / accumulation /
+        normal maps are not supervised).  The forward then stores a quarter to a half of the per-hit state.  A gradient for another output
+        raises instead of being dropped."""
+        self.caps.colour_only = bool(on)
+
     def prepare(self, opacities=None):
         """OPTIONAL, not part of the reference interface: start the structure build requested by build_acceleration_structure() NOW, on a side
         stream, instead of inside the next traced call.  A caller that knows the environment set before it renders the base pass (the fused
@@ -532,7 +547,12 @@ class SurfelTracer(nn.Module):
         o = ray_o.reshape(-1, 3); d = ray_d.reshape(-1, 3)
         R = o.shape[0]
         dev = o.device
-        out0 = _TraceSurfels.apply(o, d, *args, s0, start_from_first, self.nodes, self.caps)
+        was = self.caps.colour_only
+        self.caps.colour_only = False                  # (its depth / accumulation / normal / specular outputs build the next stage's rays)
+        try:
+            out0 = _TraceSurfels.apply(o, d, *args, s0, start_from_first, self.nodes, self.caps)
+        finally:
+            self.caps.colour_only = was
         stages = [dict(o=o, d=d, out=out0, idx=torch.arange(R, device=dev), sel=None)]
         for k in range(1, depth + 1):
             p = stages[-1]
@@ -547,7 +567,9 @@ class SurfelTracer(nn.Module):
             # one launch each way (envgs_amd.fused.bounce_rays) instead of five gathers, a norm, two divisions and the reflection -- whose
             # backward, through advanced indexing, was a SORTED index_put: 4 ms of radix sorts per 1200x1600 step
             o2, d2 = fused.bounce_rays(p["o"], p["d"], dpt, acc, norm, sel)
-            out = _TraceSurfels.apply(o2, d2, *args, s0, 2, self.nodes, self.bounce_caps(k))
+            bc = self.bounce_caps(k)
+            bc.colour_only = k == depth                 # the last stage's other outputs go into `mid` (no gradient) and nowhere else
+            out = _TraceSurfels.apply(o2, d2, *args, s0, 2, self.nodes, bc)
             stages.append(dict(o=o2, d=d2, out=out, idx=p["idx"].index_select(0, sel), sel=sel))
         col = stages[-1]["out"][0]
         for k in range(len(stages) - 2, -1, -1):

@@ -115,6 +115,10 @@ typedef struct envgs_trace_lists {
     void *sh_perm;           /* optional scratch, (P, 48) elements of the shs storage type (used when sh_coeffs == 16): a quad-permuted copy of the SH
                                 blocks, rebuilt by every forward, that lets four lanes fetch one surfel's block as contiguous 64 B runs; NULL = each
                                 lane gathers its own block from shs */
+    int32_t state_planes;    /* 0 (or >= 2): hit_state holds every plane.  1: the caller DECLARES that the backward of this forward will receive the
+                                colour's upstream gradient only (dL_ddpt = dL_dacc = dL_dnorm = dL_daux = NULL) -- what EnvGS trains with, and the last
+                                stage of a bounce chain: the forward writes plane 0 alone (hit_state: 4 floats per row) -- half of the per-hit bytes it
+                                stores.  envgs_trace_backward returns ENVGS_ERR_BAD_ARG if another gradient arrives after all */
 } envgs_trace_lists;
 
 /* Scratch bytes for the Morton sort + build of P surfels. */

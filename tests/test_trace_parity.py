@@ -694,3 +694,46 @@ def test_trace_compact_per_hit_buffers(mode, request):
         assert cnt["compact_rows"] > 0 and cnt["rays_without_rows"] > 50 and 0 < res["n_listed"] < res["R"]
     else:
         assert cnt["compact_rows"] == 0 and res["n_listed"] == res["R"]
+
+
+def test_trace_colour_only_state_promise():
+    """SurfelTracer.set_colour_only_backward (include/envgs_trace.h: state_planes = 1): the forward keeps plane 0 of the per-hit state only; the
+    colour's backward is the one of the full state (same kernel, same inputs), and a gradient for another output raises instead of being dropped."""
+    import diff_surfel_tracing as mod
+    dev = torch.device("cuda:0")
+    g, _, _ = trace_scene(P=1500, R=4, seed=17, camera=False)
+    g["scales"] = g["scales"] * 0.5
+    cam = synth.orbit_camera(3, H=96, W=96, fx=80.0, radius=1.0)
+    ro, rd = synth.get_rays(cam)
+    ro, rd = ro.reshape(-1, 3).contiguous().to(dev), rd.reshape(-1, 3).contiguous().to(dev)
+    R = ro.shape[0]
+    up = torch.randn(R, 3, generator=torch.Generator().manual_seed(2)).to(dev) / R
+
+    def run(promise, extra):
+        L = {k: g[k].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs", "others")}
+        o = ro.clone().requires_grad_(True); d = rd.clone().requires_grad_(True)
+        v, f = synth.get_disks(L["means3D"].detach(), L["scales"].detach(), L["rotations"].detach())
+        tracer = mod.SurfelTracer()
+        tracer.set_colour_only_backward(promise)
+        tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
+        outs = tracer(o, d, v, means3D=L["means3D"], grads3D=None, shs=L["shs"], colors_precomp=None, others_precomp=L["others"],
+                      opacities=L["opacities"], scales=L["scales"], rotations=L["rotations"], cov3D_precomp=None,
+                      tracer_settings=_settings(mod, torch.tensor([0.2, 0.3, 0.1]), 3, dev), start_from_first=False)
+        loss = (outs[0] * up).sum()
+        if extra:
+            loss = loss + outs[1].sum() * 1e-3
+        loss.backward()
+        torch.cuda.synchronize()
+        return [x.detach().clone() for x in outs[:6]], {k: t.grad.clone() for k, t in L.items() if t.grad is not None}, o.grad.clone(), d.grad.clone()
+
+    ref_o, ref_g, ref_do, ref_dd = run(False, False)
+    got_o, got_g, got_do, got_dd = run(True, False)
+    for a, b in zip(ref_o, got_o):
+        assert torch.equal(a, b)
+    assert set(ref_g) == set(got_g)
+    for k in ref_g:
+        err = float((ref_g[k] - got_g[k]).abs().max())
+        assert err <= 2e-5 * float(ref_g[k].abs().max()) + 1e-12, (k, err)
+    assert float((ref_do - got_do).abs().max()) <= 2e-5 * float(ref_do.abs().max()) and float((ref_dd - got_dd).abs().max()) <= 2e-5 * float(ref_dd.abs().max())
+    with pytest.raises(RuntimeError, match="colour"):
+        run(True, True)
