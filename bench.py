@@ -52,7 +52,7 @@ def algorithmic_bytes(kernel, P, N, HW, C, sh_in_kernel):
     return 0
 
 
-def trace_algorithmic_bytes(kernel, tc, P_env, R, entries, others=False, rgb_only=True):
+def trace_algorithmic_bytes(kernel, tc, P_env, R, entries, others=False, rgb_only=True, colour_state=False):
     """Deduplicated algorithmic HBM bytes of the tracer kernels PER STEP: what the kernel must move at minimum -- each input structure
     read ONCE (BVH nodes 64 B + wide nodes 128 B + surfel record 64 B + SH block 192 B per env surfel, 24 B + 4 B order per ray), each
     list / state / record element read or written once -- however often the implementation re-fetches them from L2 / MALL.
@@ -60,9 +60,9 @@ def trace_algorithmic_bytes(kernel, tc, P_env, R, entries, others=False, rgb_onl
     once, which put 'achieved' above the HBM peak; those units are kept only as the `per_ray_model_MB` diagnostic.)
     hits = composited hits, found = collected hits, entries = distinct (batch, surfel) pairs of the backward.
     rgb_only: the colour is the only traced output the loss uses (this bench, the EnvGS step): the backward then reads plane 0 of the per-hit
-    state alone, 16 B per hit (batch_surfel_bwd<true>)."""
+    state alone, 16 B per hit (batch_surfel_bwd<true>).  colour_state: the forward was told so (set_colour_only_backward) and WRITES plane 0 alone."""
     hits, found = tc["hits"], tc["found"]
-    st = 48 if others else 32
+    st = 16 if colour_state else (40 if others else 32)
     if kernel == "trace.collect_hits":
         return P_env * (64 + 128 + 64) + R * (24 + 4 + 4) + found * 8
     if kernel == "trace.sort_composite_fwd":
@@ -468,7 +468,8 @@ def main():
             ab = algorithmic_bytes(name, P, N_avg, HW, C, not envgs)
             pr = 0
             if not ab and envgs and tcounts:
-                ab = trace_algorithmic_bytes(name, tcounts, args.env_gaussians, HW, entries, others=args.trace_depth > 0)
+                ab = trace_algorithmic_bytes(name, tcounts, args.env_gaussians, HW, entries, others=args.trace_depth > 0,
+                                             colour_state=(args.caller == "fused" and not args.no_colour_only_state and not args.trace_depth))
                 pr = trace_per_ray_model_bytes(name, tcounts, HW)
             if name == "fused_adam_multi":        # 28 B per updated element (p,g,m,v in; p,m,v out), 4 B per skipped one (g only)
                 nz = sum(int((g_ != 0).sum()) for g_ in last_grads if g_ is not None)
