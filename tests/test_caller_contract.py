@@ -186,3 +186,23 @@ def test_hip_packages_reproduce_the_recorded_boundary(fx):
     for i, nm in ((0, "rgb"), (1, "dpt"), (2, "acc"), (3, "norm")):
         got = outs[i].detach().cpu().numpy().reshape(H * W, -1)[okr]; want = tt["outputs"][i].numpy().reshape(H * W, -1)[okr]
         check_close("recorded_boundary", "trace." + nm, got, want, excluded=int((~okr).sum()))
+
+
+def test_fused_caller_rebuild_cadence():
+    """envgs_step._rebuild_now: a full LBVH build on every K-th prepared call of a tracer, refits in between (north_star: Morton build + per-step
+    refit); K = 1 rebuilds always, like the unchanged EasyVolcap caller.  Counted per tracer."""
+    from envgs_amd import envgs_step
+
+    class T:
+        pass
+
+    old = envgs_step.REFIT["every"]
+    try:
+        envgs_step.REFIT["every"] = 4
+        a, b = T(), T()
+        assert [envgs_step._rebuild_now(a) for _ in range(9)] == [True, False, False, False, True, False, False, False, True]
+        assert envgs_step._rebuild_now(b) is True                      # another tracer starts its own count
+        envgs_step.REFIT["every"] = 1
+        assert all(envgs_step._rebuild_now(a) for _ in range(3))
+    finally:
+        envgs_step.REFIT["every"] = old
