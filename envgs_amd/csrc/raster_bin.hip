@@ -110,7 +110,6 @@ constexpr int BIN_SLICE_MIN = 1024;              // surfels per workgroup at lea
 constexpr int BIN_BAND = 16384;                  // tiles per LDS histogram (64 KB); larger images are walked band by band
 constexpr int BIG_RECT = 32;                     // rectangles above this many tiles are walked by the whole wavefront
 constexpr int SORT_LONG_N = 16384;               // sort_long_lists: 132 KB of LDS
-constexpr int SORT_SOLO_N = 8 * SORT_LONG_N;     // up to here a list is sorted by one workgroup (chunks in LDS, wide steps in HBM); beyond, by the whole grid
 constexpr int SORT_LONG_WGS = 256;               // one per CU
 
 struct BinPlan { int rows, slice, ntiles; };
@@ -345,15 +344,19 @@ sort_tile_lists(const uint32_t *__restrict__ ranges, const uint64_t *pairs, uint
 
 // The long lists, one persistent workgroup per CU.  Up to 16 384 entries: one workgroup sorts the list in LDS (the lists are dealt round robin).
 // Beyond that (a few far outlier surfels collapse the Morton codes, a narrow cone of rays collapses the direction cells, a tile with
-// > 16 k instances -- and ONE workgroup merging a 600 k-entry list through HBM took ~20 ms): the whole grid works on the list.  Its sort is a
-// fixed sequence of PHASES (tile_sort.h: ts_sort_hybrid is the schedule) -- sort every 16 384-entry chunk in LDS; then per merge stage the
-// steps wider than a chunk on the segment in HBM, and an ascending merge of every chunk in LDS again -- and every phase is a number of
-// independent ITEMS (a chunk; 16 384 comparators of a wide step).  Items are numbered through all phases of all such lists and CLAIMED from one
-// counter (hdr[2]); an item of phase p starts when the completion counter (hdr[3]) says every item of the earlier phases is done.  No workgroup
-// ever waits for a workgroup that has not started: whatever is unfinished was claimed by a RUNNING workgroup, so the scheme cannot deadlock
-// however many of the grid's workgroups are resident (two such kernels on two streams, several processes on one GPU), and a late workgroup
-// finds its counters exhausted and falls through.  Lists that need no cooperation touch neither counter.
-constexpr int LONG_ITEM = 16384;      // comparators of a wide step per item
+// > 16 k instances -- and ONE workgroup merging a list through HBM is slow: ~20 ms for 600 k entries, 76 ms for the 120 k equal Morton codes of
+// round 4's single-workgroup shortcut): the whole grid works on ALL such lists AT ONCE.  The sort of a list is a fixed sequence of PHASES
+// (tile_sort.h: ts_sort_hybrid is the schedule) -- sort every 16 384-entry chunk in LDS; then per merge stage the steps wider than a chunk on
+// the segment in HBM, and an ascending merge of every chunk in LDS again -- and every phase is a number of independent ITEMS (a chunk; 4 096
+// comparators of a wide step).  The schedule is walked PHASE-MAJOR over a batch of up to 256 lists: phase p of every list of the batch that has
+// a phase p (a list of 2^lp entries has none for stages beyond lp) is one pool of items, so thirty ray buckets of 17-40 k entries (a bounce
+// stage of the 1200x1600 configuration) cost the ~8 grid-wide phases of ONE such list, not thirty times that.  Items are numbered through all
+// phases and CLAIMED from one counter (hdr[2]); an item of phase p starts when the completion counter (hdr[3]) says every item of the earlier
+// phases is done.  No workgroup ever waits for a workgroup that has not started: whatever is unfinished was claimed by a RUNNING workgroup, so
+// the scheme cannot deadlock however many of the grid's workgroups are resident (two such kernels on two streams, several processes on one
+// GPU), and a late workgroup finds its counters exhausted and falls through.  Lists that need no cooperation touch neither counter.
+constexpr int LONG_ITEM = 4096;       // comparators of a wide step per item
+constexpr int LONG_BATCH = 256;       // lists per phase-major batch
 
 __device__ __forceinline__ uint32_t long_claim(uint32_t *hdr, uint32_t *s_item)
 {
@@ -382,79 +385,92 @@ sort_long_lists(const uint32_t *__restrict__ ranges, uint64_t *pairs, uint64_t *
 {
     __shared__ uint64_t s_long[lds_slots(14)];
     __shared__ uint32_t s_item;
+    __shared__ uint32_t s_bt[LONG_BATCH], s_bb[LONG_BATCH], s_bn[LONG_BATCH], s_pref[LONG_BATCH + 1];
     const uint32_t count = hdr[1];
     const int tid = (int)threadIdx.x, G = (int)gridDim.x;
-    uint32_t small_seen = 0u, base = 0u, my = 0u;
-    bool claimed = false;
+    constexpr int LC = 14, C = 1 << LC;
+    const bool copy_out = !(full64 && keys_sorted == pairs);
+    // ---- the lists of one chunk: round robin, each sorted in LDS by one workgroup; every workgroup also counts the longer ones
+    uint32_t small_seen = 0u, big = 0u;
     for (uint32_t w = 0; w < count; w++) {
         const uint32_t t = long_list[w], b = ranges[2 * t];
         const int n = (int)(ranges[2 * t + 1] - b);
-        if (n <= SORT_LONG_N) {
-            if ((small_seen++ % (uint32_t)G) != blockIdx.x) continue;
-            load_sort_write<1024>(s_long, pairs, n, t, b, keys_sorted, point_list, tid, full64);
+        if (n > SORT_LONG_N) { big++; continue; }
+        if ((small_seen++ % (uint32_t)G) != blockIdx.x) continue;
+        load_sort_write<1024>(s_long, pairs, n, t, b, keys_sorted, point_list, tid, full64);
+        __syncthreads();
+    }
+    if (big == 0u) return;
+    // ---- the longer lists, phase-major in batches (every workgroup builds the same tables: the order of long_list is fixed by now)
+    auto lp_of = [&](const int n) { int lp = LC; while ((1 << lp) < n) lp++; return lp; };
+    // phase kinds: 0 = chunk sort / merge (lk), 1 = wide step (lk, q), 2 = copy the sorted segment out
+    auto items_of = [&](const int kind, const int lk, const int n) -> uint32_t {
+        const int lp = lp_of(n);
+        if (kind == 1) return lk <= lp ? (uint32_t)(((1ll << (lp - 1)) + LONG_ITEM - 1) / LONG_ITEM) : 0u;
+        return (kind == 2 || lk <= lp) ? (uint32_t)((n + C - 1) / C) : 0u;
+    };
+    auto do_item = [&](const int kind, const int lk, const int q, const int l, const uint32_t it) {
+        const uint32_t t = s_bt[l], b = s_bb[l];
+        const int n = (int)s_bn[l];
+        uint64_t *seg = pairs + b;           // all-ascending network: entries beyond n never move, so nothing is padded in memory
+        if (kind == 0) {
+            const int c = (int)it;
+            for (int i = tid; i < C; i += 1024) s_long[ts_slot(i)] = ((long long)c * C + i) < n ? seg[(size_t)c * C + i] : ~0ull;
             __syncthreads();
-            continue;
+            if (lk == LC) sort_padded_lds<1024>(s_long, LC, tid);
+            else merge_padded_lds<1024>(s_long, LC, tid);
+            for (int i = tid; i < C; i += 1024)
+                if ((long long)c * C + i < n) seg[(size_t)c * C + i] = s_long[ts_slot(i)];
+        } else if (kind == 1) {
+            const int lp = lp_of(n);
+            const long long i0 = (long long)it * LONG_ITEM, i1 = min(i0 + LONG_ITEM, 1ll << (lp - 1));
+            for (long long idx = i0 + tid; idx < i1; idx += 1024) ascending_step(seg, n, lk, q, (int)idx);
+        } else {
+            const long long i0 = (long long)it * C, i1 = min(i0 + C, (long long)n);
+            for (long long i = i0 + tid; i < i1; i += 1024) store_sorted(seg[i], t, (size_t)b + (size_t)i, keys_sorted, point_list, full64);
         }
-        // all-ascending network: entries beyond n never move, so nothing is padded in memory
-        uint64_t *seg = pairs + b;
-        constexpr int LC = 14, C = 1 << LC;
-        int lp = LC;
-        while ((1 << lp) < n) lp++;
-        const uint32_t nchunks = (uint32_t)((n + C - 1) / C);
-        const uint32_t nwide = (uint32_t)(((1ll << (lp - 1)) + LONG_ITEM - 1) / LONG_ITEM);
-        const bool copy_out = !(full64 && keys_sorted == pairs);
-        // phase kinds: 0 = chunk sort / merge (lk), 1 = wide step (lk, q), 2 = copy the sorted segment out
-        auto do_item = [&](const int kind, const int lk, const int q, const uint32_t it) {
-            if (kind == 0) {
-                const int c = (int)it;
-                for (int i = tid; i < C; i += 1024) s_long[ts_slot(i)] = ((long long)c * C + i) < n ? seg[(size_t)c * C + i] : ~0ull;
-                __syncthreads();
-                if (lk == LC) sort_padded_lds<1024>(s_long, LC, tid);
-                else merge_padded_lds<1024>(s_long, LC, tid);
-                for (int i = tid; i < C; i += 1024)
-                    if ((long long)c * C + i < n) seg[(size_t)c * C + i] = s_long[ts_slot(i)];
-            } else if (kind == 1) {
-                const long long i0 = (long long)it * LONG_ITEM, i1 = min(i0 + LONG_ITEM, 1ll << (lp - 1));
-                for (long long idx = i0 + tid; idx < i1; idx += 1024) ascending_step(seg, n, lk, q, (int)idx);
-            } else {
-                const long long i0 = (long long)it * C, i1 = min(i0 + C, (long long)n);
-                for (long long i = i0 + tid; i < i1; i += 1024) store_sorted(seg[i], t, (size_t)b + (size_t)i, keys_sorted, point_list, full64);
-            }
-        };
-        if (n <= SORT_SOLO_N) {
-            // A list of a few chunks is sorted by ONE workgroup, start to finish, the lists spread over the grid like the short ones: the
-            // grid-cooperative phases below take ~0.2 ms per list whatever its length, ONE LIST AT A TIME (the items are claimed in a global
-            // order) -- thirty ray buckets of 17-40 k entries, a bounce stage of the 1200x1600 configuration, were 6.8 ms of the step.
-            if ((small_seen++ % (uint32_t)G) != blockIdx.x) continue;
-            auto solo_phase = [&](const int kind, const int lk, const int q, const uint32_t items) {
-                for (uint32_t it = 0; it < items; it++) { do_item(kind, lk, q, it); __syncthreads(); }
-                __threadfence();                         // (the next phase reads what other wavefronts of this workgroup wrote to the segment)
-                __syncthreads();
-            };
-            solo_phase(0, LC, 0, nchunks);
-            for (int lk = LC + 1; lk <= lp; lk++) {
-                for (int q = 0; q <= lk - LC - 1; q++) solo_phase(1, lk, q, nwide);
-                solo_phase(0, lk, 0, nchunks);
-            }
-            if (copy_out) solo_phase(2, 0, 0, nchunks);
-            continue;
+    };
+    uint32_t base = 0u, my = long_claim(hdr, &s_item);
+    uint32_t w = 0;
+    while (w < count) {
+        __syncthreads();                                 // (the previous batch's tables are no longer read)
+        int nl = 0, lp_max = LC;
+        for (; w < count && nl < LONG_BATCH; w++) {      // uniform over the workgroup: every lane walks the list, lane 0 fills the table
+            const uint32_t t = long_list[w], b = ranges[2 * t];
+            const int n = (int)(ranges[2 * t + 1] - b);
+            if (n <= SORT_LONG_N) continue;
+            if (tid == 0) { s_bt[nl] = t; s_bb[nl] = b; s_bn[nl] = (uint32_t)n; }
+            lp_max = max(lp_max, lp_of(n));
+            nl++;
         }
-        if (!claimed) { my = long_claim(hdr, &s_item); claimed = true; }
-        auto run_phase = [&](const int kind, const int lk, const int q, const uint32_t items) {
+        if (nl == 0) break;
+        auto run_phase = [&](const int kind, const int lk, const int q) {
+            __syncthreads();                             // (s_pref of the previous phase is no longer read; the batch table is written)
+            if (tid < nl) {
+                uint32_t acc = 0u;
+                for (int l = 0; l < tid; l++) acc += items_of(kind, lk, (int)s_bn[l]);
+                s_pref[tid] = acc;
+                if (tid == nl - 1) s_pref[nl] = acc + items_of(kind, lk, (int)s_bn[tid]);
+            }
+            __syncthreads();
+            const uint32_t items = s_pref[nl];
             while (my - base < items) {                  // (unsigned: my >= base always -- items are claimed in order)
+                const uint32_t j = my - base;
+                int lo = 0, hi = nl - 1;                 // the list whose items [s_pref[l], s_pref[l + 1]) hold j
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= j) lo = mid; else hi = mid - 1; }
                 long_wait(hdr, base);
-                do_item(kind, lk, q, my - base);
+                do_item(kind, lk, q, lo, j - s_pref[lo]);
                 long_done(hdr);
                 my = long_claim(hdr, &s_item);
             }
             base += items;
         };
-        run_phase(0, LC, 0, nchunks);
-        for (int lk = LC + 1; lk <= lp; lk++) {
-            for (int q = 0; q <= lk - LC - 1; q++) run_phase(1, lk, q, nwide);
-            run_phase(0, lk, 0, nchunks);
+        run_phase(0, LC, 0);
+        for (int lk = LC + 1; lk <= lp_max; lk++) {
+            for (int q = 0; q <= lk - LC - 1; q++) run_phase(1, lk, q);
+            run_phase(0, lk, 0);
         }
-        if (copy_out) run_phase(2, 0, 0, nchunks);
+        if (copy_out) run_phase(2, 0, 0);
     }
 }
 
@@ -545,7 +561,8 @@ static int ray_bucket_bits(int R)
 size_t ray_sort_temp_bytes(int R)
 {
     const size_t nb = (size_t)1 << ray_bucket_bits(R);
-    return sizeof(uint32_t) * ((size_t)BIN_ROWS_MAX * nb + 5 * nb + 1 + 4 + (size_t)(R > 0 ? R : 1)) + 256;
+    // hist (BIN_ROWS_MAX x nb) | count (nb) | start (nb + 1) | long_list (nb) | hdr (4) | ranges (2 nb) | keys (R) | origin-bounds partials (BIN_ROWS_MAX x 6)
+    return sizeof(uint32_t) * ((size_t)BIN_ROWS_MAX * nb + 5 * nb + 1 + 4 + (size_t)(R > 0 ? R : 1) + 6 * (size_t)BIN_ROWS_MAX) + 256;
 }
 
 // Bounding box of the ray origins, one partial (lo[3], hi[3]) per workgroup: the key pass reduces the <= BIN_ROWS_MAX partials itself (no atomics,

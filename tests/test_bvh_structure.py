@@ -142,18 +142,12 @@ def _reach_counts(flat, P):
     return seen, depth
 
 
-def test_far_outliers_do_not_collapse_the_tree_or_the_key_sort():
-    """ADVICE r3 (medium): a few far outlier surfels used to stretch the scene box until every other surfel shared a handful of Morton cells --
-    a tree ordered by surfel id and ONE giant bucket for the key sort, merged through HBM by one workgroup.  The Morton mapping is now linear over
-    mean +- 2.5 sigma with squeezed tails, and lists beyond LDS are sorted by the whole grid: the tree over the body of the scene must be as
-    shallow as without the outliers, and the build must stay fast.  Second scene: EVERY surfel on one Morton code (the sort's true worst case)."""
-    import time
+def _degenerate_scenes():
     P = 120000
     g = torch.Generator().manual_seed(5)
     xyz = (torch.rand(P, 3, generator=g) * 2 - 1) * 50.0
     scales = torch.rand(P, 2, generator=g) * 0.5 + 0.2
     q = torch.randn(P, 4, generator=g); q = q / q.norm(dim=-1, keepdim=True)
-    depths, times = {}, {}
     for name in ("clean", "outliers", "one_cell"):
         x = xyz.clone()
         if name == "outliers":
@@ -161,14 +155,47 @@ def test_far_outliers_do_not_collapse_the_tree_or_the_key_sort():
         if name == "one_cell":
             x[:] = x[0]                                         # every centre the same point: codes equal, the order is the id tie-break
         v, _ = synth.get_disks(x, scales, q)
-        vd = v.cuda()
-        tracing.build_bvh(vd); torch.cuda.synchronize()          # warm-up (allocations)
-        t0 = time.perf_counter()
-        nodes, n = tracing.build_bvh(vd)
+        yield name, P, v.cuda()
+
+
+def _build_ms(vd, reps=5):
+    """Median DEVICE time of a build (HIP events on the stream the build runs on; no host clock)."""
+    tracing.build_bvh(vd); torch.cuda.synchronize()              # warm-up (allocations)
+    ms = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); out = tracing.build_bvh(vd); e1.record()
         torch.cuda.synchronize()
-        times[name] = (time.perf_counter() - t0) * 1e3
+        ms.append(e0.elapsed_time(e1))
+    return float(np.median(ms)), out
+
+
+def test_far_outliers_do_not_collapse_the_tree_or_the_key_sort():
+    """ADVICE r3 (medium): a few far outlier surfels used to stretch the scene box until every other surfel shared a handful of Morton cells --
+    a tree ordered by surfel id and ONE giant bucket for the key sort.  The Morton mapping is now linear over mean +- 2.5 sigma with squeezed
+    tails, and lists beyond LDS are sorted by the whole grid: the tree over the body of the scene must be as shallow as without the outliers.
+    Second scene: EVERY surfel on one Morton code (the sort's true worst case) -- the tree must still reach every surfel exactly once.
+    The build TIMES of the three scenes are recorded in the log (tests/util.py:TIMINGS), not asserted here: a stopwatch must never gate the
+    parity suite; the bound is asserted by test_degenerate_builds_stay_fast under `-m perf`."""
+    from tests.util import TIMINGS
+    depths = {}
+    for name, P, vd in _degenerate_scenes():
+        ms, (nodes, n) = _build_ms(vd, reps=3)
+        TIMINGS.append(dict(test="bvh_build_P120000", case=name, ms=ms))
         seen, depths[name] = _reach_counts(nodes.cpu().numpy(), P)
         assert (seen == 1).all(), name
-    print("bvh build ms:", times, "wide-tree depth:", depths)
+    print("wide-tree depth:", depths)
     assert depths["outliers"] <= depths["clean"] + 4            # (the outliers hang off the top; the body is split as finely as before)
-    assert times["outliers"] < 5.0 * max(times["clean"], 0.2) and times["one_cell"] < 20.0
+
+
+@pytest.mark.perf
+def test_degenerate_builds_stay_fast():
+    """Device-time bounds of the degenerate builds (selected only by `-m perf`; tests/conftest.py deselects perf tests from every other run).
+    One-cell scene = ONE 120 000-entry key list: the grid-cooperative sort does it in well under 2 ms (round 4's single-workgroup shortcut took
+    76 ms on the driver's box)."""
+    times = {}
+    for name, P, vd in _degenerate_scenes():
+        times[name], _ = _build_ms(vd)
+    print("bvh build ms (device):", times)
+    assert times["outliers"] < 5.0 * max(times["clean"], 0.2)
+    assert times["one_cell"] < 2.0

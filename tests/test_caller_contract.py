@@ -18,7 +18,7 @@ import pytest
 import torch
 
 from tests import reference_caller
-from tests.util import check_close, record
+from tests.util import check_close, record, record_fragile, FRAGILE_PX_MAX, FRAGILE_RAYS_MAX
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -111,7 +111,7 @@ def test_rederived_caller_reproduces_reference_dicts_over_the_same_extensions(fx
     aud = otr.trace_audit(fx["ref_rays"][0].reshape(-1, 3).numpy(), fx["ref_rays"][1].reshape(-1, 3).numpy(), ea["means3D"].numpy(), ea["scales"].numpy(),
                           ea["rotations"].numpy(), ea["opacities"].numpy(), start_from_first=False)
     okr = (~aud["fragile"]).reshape(fx["H"], fx["W"])
-    record("caller_twin_vs_reference", "fragile_env_rays", aud["fragile"].mean())
+    record_fragile("caller_twin_vs_reference", "fragile_env_rays", aud["fragile"], FRAGILE_RAYS_MAX)
     from tests.util import floor_rel_err
     for nm, a, r in pairs:
         a, r = a.detach().numpy(), r.numpy()
@@ -160,7 +160,7 @@ def test_hip_packages_reproduce_the_recorded_boundary(fx):
         assert np.array_equal(a, r.numpy())                                      # the recorded outputs ARE the oracle's on these inputs
     aud = orc.raster_audit(ref)
     ok = ~aud["fragile"]
-    record("recorded_boundary", "fragile_px", aud["fragile"].mean())
+    record_fragile("recorded_boundary", "fragile_px", aud["fragile"], FRAGILE_PX_MAX)
     assert torch.equal(outs[1].cpu(), rt["outputs"][1])                          # radii: bit-exact
     check_close("recorded_boundary", "raster.image", outs[0].cpu().numpy()[:, ok], rt["outputs"][0].numpy()[:, ok], excluded=int((~ok).sum()))
     for ch in range(6):
@@ -181,7 +181,7 @@ def test_hip_packages_reproduce_the_recorded_boundary(fx):
     a = otr.trace_audit(tt["args"][0].reshape(-1, 3).numpy(), tt["args"][1].reshape(-1, 3).numpy(), k["means3D"].numpy(), k["scales"].numpy(),
                         k["rotations"].numpy(), k["opacities"].numpy(), start_from_first=bool(k["start_from_first"]))
     okr = ~a["fragile"]
-    record("recorded_boundary", "fragile_rays", a["fragile"].mean())
+    record_fragile("recorded_boundary", "fragile_rays", a["fragile"], FRAGILE_RAYS_MAX)
     assert outs[0].shape == (H, W, 3) and outs[7].shape == (P, 1) and outs[6].shape == (H, W, 16)
     for i, nm in ((0, "rgb"), (1, "dpt"), (2, "acc"), (3, "norm")):
         got = outs[i].detach().cpu().numpy().reshape(H * W, -1)[okr]; want = tt["outputs"][i].numpy().reshape(H * W, -1)[okr]

@@ -17,7 +17,7 @@ import torch
 
 from envgs_amd import envgs_step, synth
 from tests import stagewise
-from tests.util import check_close, record
+from tests.util import check_close, record, record_fragile, FRAGILE_PX_MAX, FRAGILE_RAYS_MAX
 
 pytestmark = pytest.mark.gpu
 
@@ -114,7 +114,7 @@ def test_full_envgs_step_full_size():
                             shs=n(env["shs"]), sh_degree=deg, lcap=LC)
         assert int(a["nhit"].max()) < LC
         keep = ~a["fragile"] & n(listed[idx])
-        record(test, "sample.fragile_rays", float(a["fragile"].mean()), "(%d of %d sampled rays)" % (int(a["fragile"].sum()), S))
+        record_fragile(test, "sample.fragile_rays", a["fragile"], FRAGILE_RAYS_MAX)
         assert keep.mean() > 0.9
         kt = torch.from_numpy(keep).to(dev)
         # index parity: the full run's sorted, composited list of every sampled ray == the brute-force list
@@ -211,8 +211,7 @@ def test_config5_combination_fp16_ch07_two_bounces_with_gradients():
                                  scales=n(base["scales"]), rotations=n(base["rotations"]), colors_precomp=n(col_h), bg=np.zeros(3, np.float32))
         aud = orc.raster_audit(ref)
         okp = ~aud["fragile"]; nfr = int(aud["fragile"].sum())
-        record(test, "raster.fragile_px", float(aud["fragile"].mean()), "(%d of %d pixels; by the round-1..3 definition: %d)" % (int(aud["fragile"].sum()), aud["fragile"].size, int(aud["legacy_fragile"].sum())))
-        assert aud["fragile"].mean() < 2e-2
+        record_fragile(test, "raster.fragile_px", aud["fragile"], FRAGILE_PX_MAX, "(by the round-1..3 definition: %d)" % int(aud["legacy_fragile"].sum()))
         saved = rc["saved"]
         assert saved["N"] == ref["N"]
         np.testing.assert_array_equal(n(saved["point_list"]).view(np.uint32)[:ref["N"]], ref["point_list"])
@@ -229,6 +228,8 @@ def test_config5_combination_fp16_ch07_two_bounces_with_gradients():
         rb = orc.raster_backward(ref, n(dc), n(da), want_cond=True)
         for k_hip, k_ref in (("means3D", "dmeans3D"), ("scales", "dscales"), ("rotations", "drots"), ("opacities", "dopacities"), ("means2D", "dmeans2D"),
                              ("colors_precomp", "dcolors")):
+            # K_UNC = 1 (not 0 as in test_raster_parity's 300 k / 800x800 case): this backward's upstream gradient comes out of the tracer's atomics, so
+            # the run is not bit-reproducible, and ONE of 600 000 dscales elements was measured at 1.34e-4 without the uncertainty term (8e-6 with it)
             check_close(test, "raster." + k_ref, n(gr[k_hip]).reshape(rb[k_ref].shape), rb[k_ref], excluded=nfr, cond=rb["cond"][k_ref], unc=rb["unc"][k_ref])
         # ---- tracer link: a sample of the reflected rays through the whole bounce chain, every stage against the oracle ---------------------
         S = 2048
@@ -255,8 +256,7 @@ def test_config5_combination_fp16_ch07_two_bounces_with_gradients():
             a = otr.trace_audit(hmid[ran, 16 * k:16 * k + 3], hmid[ran, 16 * k + 3:16 * k + 6], *args, others=oth_np, start_from_first=False, tmin=1e-3,
                                 bounce_thr=(thr if k < depth else None), shs=shs_np, sh_degree=deg, lcap=LC)
             frag[np.nonzero(ran)[0][a["fragile"]]] = True
-        record(test, "sample.fragile_rays", float(frag.mean()), "(%d of %d sampled rays, all stages)" % (int(frag.sum()), S))
-        assert frag.mean() < 0.15
+        record_fragile(test, "sample.fragile_rays", frag, FRAGILE_RAYS_MAX, "(all stages)")
         kt = torch.from_numpy(~frag).to(dev)
         nfr_s = int(frag.sum())
         # pass 2: the determined rays with gradients, tapped

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import check_close, record
+from tests.util import check_close, record, record_fragile, FRAGILE_RAYS_MAX
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -160,7 +160,7 @@ def test_hip_packages_replay_the_recorded_sampler_sequence(fx):
                                              bounce_thr=(thr if b < depth else None), shs=k["shs"].numpy(), sh_degree=deg)
                         frag[np.nonzero(ran)[0][ab["fragile"]]] = True
                 okr = ~frag
-                record(test, "trace.fragile_rays", float(frag.mean()))
+                record_fragile(test, "trace.fragile_rays", frag, FRAGILE_RAYS_MAX)
                 lead = tuple(ro.shape[:-1])
                 assert outs[0].shape == lead + (3,) and outs[6].shape == lead + (16 * (depth + 1),) and outs[7].shape == (P, 1)
                 for i, nm in ((0, "rgb"), (1, "dpt"), (2, "acc"), (3, "norm")):

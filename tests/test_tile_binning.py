@@ -180,8 +180,9 @@ def test_ray_coherence_order_is_the_stable_key_sort(R, kind):
     """The tracer's ray order (raster_bin.hip: launch_ray_sort -- buckets by the key's top bits, one LDS sort per bucket) is the order a
     stable sort of the 31-bit keys gives: ray ids by (key, id).  'cone': camera-like directions (few direction cells, long buckets);
     'parallel': every ray the same direction, i.e. ONE bucket: the long-list kernel sorts its 300 000 entries chunk by chunk, the whole grid
-    on each phase; 'clumps': ten buckets of 17 000 - 100 000 rays (the bounce stages of the 1200x1600 configuration have dozens of them): each is
-    sorted by one workgroup -- chunks in LDS, wide steps in HBM."""
+    on each phase; 'clumps': ten buckets of 17 000 - 100 000 rays (the bounce stages of the 1200x1600 configuration have dozens of them): the grid
+    walks the phases of all of them together (phase-major items).  The scratch buffer is EXACTLY envgs_trace_ray_sort_temp_bytes(R) with a canary
+    region behind it (the origin-bounds partials used to be written past the reported size)."""
     from envgs_amd import _lib
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -203,10 +204,12 @@ def test_ray_coherence_order_is_the_stable_key_sort(R, kind):
     pairs = torch.zeros(R, dtype=torch.int64, device=dev)
     order = torch.full((R,), -1, dtype=torch.int32, device=dev)
     tb = lib.envgs_trace_ray_sort_temp_bytes(R)
-    temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+    CANARY = 1 << 16
+    temp = torch.full((tb + CANARY,), 0xA5, dtype=torch.uint8, device=dev)
     p = _lib.ptr
     _lib.check(lib.envgs_trace_ray_order(R, p(rod), p(rdd), None, 0, p(pairs), p(order), p(temp), tb, None), "envgs_trace_ray_order")
     torch.cuda.synchronize()
+    assert bool((temp[tb:] == 0xA5).all()), "launch_ray_sort wrote past envgs_trace_ray_sort_temp_bytes(R)"
     pr = pairs.cpu().numpy().view(np.uint64)
     ids = (pr & np.uint64(0xFFFFFFFF)).astype(np.int64)
     assert np.array_equal(np.sort(ids), np.arange(R))                                   # every ray placed exactly once

@@ -73,8 +73,13 @@ def assert_close_frac(a, b, tol, max_bad_frac=1e-4, flip_bound=None, what=""):
 # (tests/conftest.py), so the measured errors are part of the GPU test log.
 TOL = 1e-4
 KAPPA = 0.02
-K_UNC = 4.0     # rounds 1-3: 16 (plus, at full size, a tail allowance).  Round 4: with the canonical operation order (oracle/surfel_raster_oracle.c:eval_splat)
-                # every raster and tracer comparison of the suite but one also holds at K_UNC = 1, and at full size at K_UNC = 0 (profiles/r04_parity_errors.txt)
+K_UNC = 1.0     # rounds 1-3: 16 (plus, at full size, a tail allowance); round 4: 4.  Round 5: 1 everywhere, and 0 (NO measured-uncertainty term: the plain
+                # 1e-4 |b| + 2e-6 sum|term| bound) on the full-size raster tensors (k_unc=0.0 at those call sites) -- what profiles/r04_parity_errors.txt
+                # measured for every comparison of the suite.  The one exception is the test whose `unc` is an a-priori ulp bound, not a realised error
+                # (test_raster_parity.py: sparse_distortion_gradient, k_unc=16).
+FRAGILE_PX_MAX = 2e-3       # stated bounds on what the oracle's audit may exclude from a comparison (fail, do not only count): pixels whose
+FRAGILE_RAYS_MAX = 5e-2     # outcome hangs on a threshold inside fp32 noise (measured: <= 7.2e-4 of the pixels, <= 3.3e-2 of the rays of the deep-list cases)
+TIMINGS = []                # device times recorded by tests (printed in the summary; never asserted under -m gpu)
 ERROR_TABLE = []
 
 
@@ -112,17 +117,18 @@ def check_close(test, name, a, b, tol=TOL, keep=None, floor=None, excluded=0, co
     else:
         err, fl = floor_rel_err(a, b, floor)
     mx = float(err.max()) if err.size else 0.0
+    plain = float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300)) if err.size else 0.0      # the plain reading: max|a-b| / max|b| over the tensor
     note = "" if mx <= tol else "%d elements beyond tol" % int((err > tol).sum())
     if cond is not None and unc is not None and err.size:
         # sensitivity of the verdict to K_UNC: the same comparison with the measured-uncertainty term at other multiples,
         # down to NONE (K_UNC=0: the plain 1e-4 |b| + 2e-6 sum|term| bound)
         sens = ["asserted at K_UNC=%g" % k_assert]
-        for k in [kk for kk in (16.0, 4.0, 1.0, 0.0) if kk != k_assert]:
+        for k in [kk for kk in (4.0, 1.0, 0.0) if kk != k_assert]:
             fl_k = 0.01 * float(np.abs(b).mean()) + KAPPA * cond + (k / tol) * unc
             e_k = np.abs(a - b) / (np.abs(b) + fl_k + 1e-300)
             sens.append("K_UNC=%g: max %.2e, %d beyond" % (k, float(e_k.max()), int((e_k > tol).sum())))
         note = (note + "  " if note else "") + "[" + "; ".join(sens) + "]"
-    ERROR_TABLE.append(dict(test=test, tensor=name, max_err=mx, tol=tol, n=int(err.size), excluded=int(excluded), floor=fl, note=note))
+    ERROR_TABLE.append(dict(test=test, tensor=name, max_err=mx, plain=plain, tol=tol, n=int(err.size), excluded=int(excluded), floor=fl, note=note))
     if os.environ.get("ENVGS_PARITY_COLLECT"):        # diagnosis runs: record everything, assert nothing -- and the session FAILS at the end (conftest.py)
         return mx
     assert mx <= tol, "%s / %s: max elementwise error %.3g > %.1e (floor %.3g, %d elements, %d excluded as fragile)" % (test, name, mx, tol, fl, err.size, excluded)
@@ -131,3 +137,13 @@ def check_close(test, name, a, b, tol=TOL, keep=None, floor=None, excluded=0, co
 
 def record(test, name, value, note=""):
     ERROR_TABLE.append(dict(test=test, tensor=name, max_err=float(value), tol=None, n=0, excluded=0, floor=0.0, note=note))
+
+
+def record_fragile(test, name, mask, bound, note=""):
+    """Record the fraction of pixels / rays the oracle's audit excludes from a comparison and FAIL when it exceeds the stated bound."""
+    mask = np.asarray(mask)
+    frac = float(mask.mean()) if mask.size else 0.0
+    ERROR_TABLE.append(dict(test=test, tensor=name, max_err=frac, tol=None, n=0, excluded=int(mask.sum()), floor=0.0,
+                            note=(note + " " if note else "") + "(%d of %d; bound %.0e)" % (int(mask.sum()), mask.size, bound)))
+    assert frac <= bound, "%s / %s: %.3g of the elements are fragile (bound %.1e): the comparison would not mean anything" % (test, name, frac, bound)
+    return frac
