@@ -120,7 +120,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     A.f16 = cfg->feature_f16;
     A.exp = debug_switch(ENVGS_DBG_TRACE);
 #ifndef ENVGS_DIAG
-    if (A.exp & (8 | 16 | 512 | 2048)) return ENVGS_ERR_BAD_ARG;      // A/B kernels of the diagnostic build (libenvgs_hip_diag.so) were requested
+    if (A.exp & (8 | 16 | 512 | 2048 | 4096 | 8192)) return ENVGS_ERR_BAD_ARG;      // A/B kernels of the diagnostic build (libenvgs_hip_diag.so) were requested
 #endif
     int rh, rw; ray_layout(cfg, &rh, &rw);
     const bool lists = lists_usable(cfg, L);
@@ -224,12 +224,16 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
 #ifndef ENVGS_DIAG
                 // product library: the cooperative collection is the only collection kernel (without a coherence sort its batches are the
                 // rays in the order given: correct, slower)
-                hipLaunchKernelGGL(collect_hits_coop, dim3(persistent_grid(rays_seg, seg_wgs)), dim3(256), 0, st, S, S.nodes,
-                                   S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4, S.srec);
+                const dim3 cg(persistent_grid(rays_seg, seg_wgs));
+                const float4 *n4 = S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4;
+                hipLaunchKernelGGL((collect_hits_coop<false, 8>), cg, dim3(256), 0, st, S, S.nodes, n4, S.srec);
 #else
-                if (S.order && !(S.exp & 512) && !(S.exp & 16) && !(S.exp & 2048))
-                    hipLaunchKernelGGL(collect_hits_coop, dim3(persistent_grid(rays_seg, seg_wgs)), dim3(256), 0, st, S, S.nodes,
-                                       S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4, S.srec);
+                const dim3 cg(persistent_grid(rays_seg, seg_wgs));
+                const float4 *n4 = S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4;
+                const bool coop = S.order && !(S.exp & 512) && !(S.exp & 16) && !(S.exp & 2048);
+                if (coop && (S.exp & 4096)) hipLaunchKernelGGL((collect_hits_coop<true, 8>), cg, dim3(256), 0, st, S, S.nodes, n4, S.srec);       // A/B: deferred exact tests
+                else if (coop && (S.exp & 8192)) hipLaunchKernelGGL((collect_hits_coop<true, 6>), cg, dim3(256), 0, st, S, S.nodes, n4, S.srec);
+                else if (coop) hipLaunchKernelGGL((collect_hits_coop<false, 8>), cg, dim3(256), 0, st, S, S.nodes, n4, S.srec);
                 else if (S.order && !(S.exp & 512) && !(S.exp & 16))
                     hipLaunchKernelGGL(collect_hits_packet4, dim3(persistent_grid(rays_seg, 24)), dim3(64), 0, st, S, S.nodes,
                                        S.nodes + (size_t)(cfg->P > 1 ? cfg->P - 1 : 1) * 4, S.srec);
@@ -331,7 +335,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     A.geo_rec = geo_rec; A.dshs = dshs; A.dcolors = dcolors;
     A.exp = debug_switch(ENVGS_DBG_TRACE);
 #ifndef ENVGS_DIAG
-    if (A.exp & (8 | 16 | 512 | 2048)) return ENVGS_ERR_BAD_ARG;
+    if (A.exp & (8 | 16 | 512 | 2048 | 4096 | 8192)) return ENVGS_ERR_BAD_ARG;
 #endif
     A.f16 = cfg->feature_f16;
     A.dothers = dothers; A.dray_o = dray_o; A.dray_d = dray_d; A.mod = cfg->scale_modifier;

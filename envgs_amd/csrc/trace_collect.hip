@@ -440,6 +440,8 @@ constexpr int COOP_FRONT = 64;            // stop expanding once a level has thi
                                           // (bench scene): 16 -> 93.8 M hits found, collect 2.70 ms; 32 -> 83.3 M, 1.97 ms; 64 -> 79.1 M, 1.87 ms (one wavefront
                                           // per batch, depth first: 85.2 M, 3.35 ms): the ranked frontier is a better visiting order than the local one
 constexpr int COOP_ITEMS = 256;           // >= 4 * (largest front - 1)
+constexpr int COOP_QFLUSH = 8;           // deferred exact tests: a wavefront's queue of entered leaf slots is worked off when it holds this many ...
+constexpr int COOP_QCAP = COOP_QFLUSH + 3 + 1;   // ... (a step adds at most four)
 struct CoopLds {
     float od[COOP_NBIN][64];
     float odtot[64];
@@ -449,11 +451,29 @@ struct CoopLds {
     int nitems[2];
     int next, ovf, batch, pad;
 };
+// the queue of the deferred form: surfel id, the ballot of the rays that passed the slot's slab test, and the staged 64 B surfel records
+struct CoopQueue {
+    int sid[COOP_W][COOP_QCAP];
+    unsigned mlo[COOP_W][COOP_QCAP], mhi[COOP_W][COOP_QCAP];
+    float4 rec[COOP_W][COOP_QCAP][4];
+};
 
-__global__ void __launch_bounds__(64 * COOP_W, 8)
+// DEFER (round 5 experiment, diagnostic library only -- measured SLOWER, profiles/r05_ab_collect.txt): the exact ray / surfel tests leave the
+// traversal's dependent chain.  The product form (DEFER = false) tests a leaf slot the moment some ray's slab test enters it: an s_load of the
+// 64 B record, ~60 VALU, a returning LDS atomic for the list slot, a global store and two more LDS atomics, all in front of the next node's
+// s_load.  The deferred form only QUEUES the slot (surfel id + the ballot of the entering rays, lane 0, LDS); when eight are queued the wavefront
+// fetches all their records with ONE vector load (lane l: float4 l & 3 of entry l >> 2), stages them in LDS and runs the exact tests from
+// broadcast ds_reads.  Same node steps / leaf tests / hits within 1.5 %, bit-identical composited lists -- and 1.92 ms per launch against 1.77:
+// the in-kernel timers of the same round (ENVGS_COOP_TIMING) show why: a node's s_load costs 310 cycles of a 3 500-cycle step and the leaf
+// records 600 of the 1 270 cycles of a leaf test; the rest is INSTRUCTION ISSUE (~200 instructions per step at ~1 instruction per 4 cycles per
+// SIMD, 4.5 wavefronts taking turns), and the deferred form adds instructions (LDS staging, ballot bits, VGPR operands) while removing latency
+// that was not the bound.
+template <bool DEFER, int WAVES>
+__global__ void __launch_bounds__(64 * COOP_W, WAVES)
 collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec)
 {
     __shared__ CoopLds L;
+    __shared__ CoopQueue Q;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slimit = (A.exp & 1024) ? 2 : COOP_STK;     // (test switch: forces the overflow hand-off)
     unsigned found_tot = 0, psteps = 0, pleaves = 0;
@@ -508,12 +528,70 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
 
         // one wide node for all 64 rays: slab tests of its four slots, exact tests of the leaf slots some ray may hit; returns the internal
         // children some ray enters (ref) with the entry distance of each one's first hitting lane (key)
+        int qn = 0;                                            // queued leaf slots of this wavefront (DEFER)
+        // an accepted hit: list slot from the ray's LDS cursor, optical depth into the ray's distance bin
+        auto record_hit = [&](const SurfHit &h, const int sid) {
+            const int slot = atomicAdd(&L.cnt[lane], 1);
+            if (slot < A.cap) list[slot] = make_uint2(__float_as_uint(h.t), (unsigned)sid);
+            const float x = (h.t - tA) * inv_bin_w;
+            int b = x <= 0.0f ? 0 : (int)ceilf(x + 1e-3f);
+            b = b > COOP_NBIN - 1 ? COOP_NBIN - 1 : b;
+            const float dep = -__logf(1.0f - h.alpha);
+            atomicAdd(&L.od[b][lane], dep);
+            atomicAdd(&L.odtot[lane], dep);
+        };
+        // look at the bound -- and recompute it (31 LDS reads and ~125 VALU, as much as two leaf tests) only when some ray that can be cut at all
+        // has gathered noticeably more optical depth than at its last recomputation
+        auto refresh_bound = [&]() {
+            const float tot = ENVGS_LDS_READ(L.odtot[lane]);
+            if (__builtin_amdgcn_ballot_w64(tot >= KILL_OD && tot > seen + COOP_REFRESH_OD) != 0ull) {
+                seen = tot;
+                float cum = 0.f; int kb = COOP_NBIN - 1;
+#pragma unroll
+                for (int q = 0; q < COOP_NBIN - 1; q++) { cum += ENVGS_LDS_READ(L.od[q][lane]); kb = (cum >= KILL_OD && kb == COOP_NBIN - 1) ? q : kb; }
+                tkill = kb < COOP_NBIN - 1 ? tA + (float)kb * bin_w : tk_open;
+            }
+        };
+        // DEFER: the queued slots' records in one vector load, staged in LDS, tested from broadcast reads
+        auto flush = [&]() {
+            if (qn == 0) return;
+            const int e = lane >> 2;
+            if (e < qn) Q.rec[wave][e][lane & 3] = srec[(size_t)Q.sid[wave][e] * 4 + (lane & 3)];
+            __builtin_amdgcn_wave_barrier();                   // (one wavefront: its LDS operations execute in order; this only pins the compiler's order)
+            for (int k = 0; k < qn; k++) {
+                const float4 s0 = Q.rec[wave][k][0], s1 = Q.rec[wave][k][1], s2 = Q.rec[wave][k][2], s3 = Q.rec[wave][k][3];
+                const int sid = Q.sid[wave][k];
+                const unsigned mw = lane < 32 ? Q.mlo[wave][k] : Q.mhi[wave][k];
+                const bool hit = ((mw >> (lane & 31)) & 1u) != 0u;
+                const SurfHit h = hit_surfel(s0, s1, s2, s3, ox, oy, oz, dx, dy, dz);
+                if (hit && h.ok && h.t > tmin && h.t <= tkill) record_hit(h, sid);
+            }
+            __builtin_amdgcn_wave_barrier();
+            qn = 0;
+            refresh_bound();
+        };
         auto step = [&](const int cur, int (&key)[4], int (&ref)[4]) -> int {
             const float4 *nd = nodes4 + (size_t)cur * 8;
             psteps++;
             float4 qa[4], qb[4];
+#if defined(ENVGS_COOP_TIMING) && ENVGS_COOP_TIMING == 2      // scratch/ measurement build: stats[6] = node loads, stats[8] = the four slots (slab tests, ballots, leaf tests)
+            const unsigned long long ta = __builtin_readcyclecounter();
+            {
+                typedef float f8_ __attribute__((ext_vector_type(8)));
+                f8_ r0, r1, r2, r3;
+                asm volatile("s_load_dwordx8 %0, %4, 0\n s_load_dwordx8 %1, %4, 32\n s_load_dwordx8 %2, %4, 64\n s_load_dwordx8 %3, %4, 96\n s_waitcnt lgkmcnt(0)"
+                             : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3) : "s"(nd));
+                qa[0] = make_float4(r0[0], r0[1], r0[2], r0[3]); qb[0] = make_float4(r0[4], r0[5], r0[6], r0[7]);
+                qa[1] = make_float4(r1[0], r1[1], r1[2], r1[3]); qb[1] = make_float4(r1[4], r1[5], r1[6], r1[7]);
+                qa[2] = make_float4(r2[0], r2[1], r2[2], r2[3]); qb[2] = make_float4(r2[4], r2[5], r2[6], r2[7]);
+                qa[3] = make_float4(r3[0], r3[1], r3[2], r3[3]); qb[3] = make_float4(r3[4], r3[5], r3[6], r3[7]);
+            }
+            const unsigned long long tb = __builtin_readcyclecounter();
+            cyc_expand += tb - ta;
+#else
 #pragma unroll
             for (int c = 0; c < 4; c++) { qa[c] = nd[2 * c]; qb[c] = nd[2 * c + 1]; }
+#endif
             int ninner = 0;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -530,19 +608,31 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
                     if (ch < 0) {
                         const int sid = ~ch;
                         pleaves++;
-                        const float4 *sr = srec + (size_t)sid * 4;
-                        const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], sr[3], ox, oy, oz, dx, dy, dz);
-                        if (hit && h.ok && h.t > tmin && h.t <= tkill) {
-                            const int slot = atomicAdd(&L.cnt[lane], 1);
-                            if (slot < A.cap) list[slot] = make_uint2(__float_as_uint(h.t), (unsigned)sid);
-                            const float x = (h.t - tA) * inv_bin_w;
-                            int b = x <= 0.0f ? 0 : (int)ceilf(x + 1e-3f);
-                            b = b > COOP_NBIN - 1 ? COOP_NBIN - 1 : b;
-                            const float dep = -__logf(1.0f - h.alpha);
-                            atomicAdd(&L.od[b][lane], dep);
-                            atomicAdd(&L.odtot[lane], dep);
+                        if (DEFER) {
+                            if (lane == 0) { Q.sid[wave][qn] = sid; Q.mlo[wave][qn] = (unsigned)m; Q.mhi[wave][qn] = (unsigned)(m >> 32); }
+                            qn++;
+                        } else {
+#if defined(ENVGS_COOP_TIMING) && ENVGS_COOP_TIMING == 1      // scratch/ measurement build: where the immediate form's leaf test spends its cycles (stats[6] = whole leaf tests, stats[8] = their record loads)
+                            const unsigned long long ta = __builtin_readcyclecounter();
+                            typedef float f8_ __attribute__((ext_vector_type(8)));
+                            f8_ r0, r1;
+                            const float4 *sr = srec + (size_t)sid * 4;
+                            asm volatile("s_load_dwordx8 %0, %2, 0\n s_load_dwordx8 %1, %2, 32\n s_waitcnt lgkmcnt(0)" : "=&s"(r0), "=&s"(r1) : "s"(sr));
+                            const unsigned long long tb = __builtin_readcyclecounter();
+                            const SurfHit h = hit_surfel(make_float4(r0[0], r0[1], r0[2], r0[3]), make_float4(r0[4], r0[5], r0[6], r0[7]),
+                                                         make_float4(r1[0], r1[1], r1[2], r1[3]), make_float4(r1[4], r1[5], r1[6], r1[7]), ox, oy, oz, dx, dy, dz);
+                            if (hit && h.ok && h.t > tmin && h.t <= tkill) record_hit(h, sid);
+                            pend++;
+                            asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory");
+                            const unsigned long long tc = __builtin_readcyclecounter();
+                            cyc_expand += tc - ta; cyc_wait += tb - ta;
+#else
+                            const float4 *sr = srec + (size_t)sid * 4;
+                            const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], sr[3], ox, oy, oz, dx, dy, dz);
+                            if (hit && h.ok && h.t > tmin && h.t <= tkill) record_hit(h, sid);
+                            pend++;
+#endif
                         }
-                        pend++;
                     } else {
                         const int fl = (int)__builtin_ctzll(m);
                         key[c] = __builtin_amdgcn_readlane(__float_as_int(tn), fl);      // tn >= tmin >= 0: the float bits order like integers
@@ -551,18 +641,15 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
                     }
                 }
             }
-            if (pend >= 3) {               // look at the bound every third leaf test (a stale bound only collects a little more) ...
+#if defined(ENVGS_COOP_TIMING) && ENVGS_COOP_TIMING == 2
+            asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory");
+            cyc_wait += __builtin_readcyclecounter() - tb;
+#endif
+            if (DEFER) {
+                if (qn >= COOP_QFLUSH) flush();
+            } else if (pend >= 3) {        // look at the bound every third leaf test (a stale bound only collects a little more)
                 pend = 0;
-                // ... and recompute it -- 31 LDS reads and ~125 VALU, as much as two leaf tests -- only when some ray that can be cut at all has
-                // gathered noticeably more optical depth than at its last recomputation
-                const float tot = ENVGS_LDS_READ(L.odtot[lane]);
-                if (__builtin_amdgcn_ballot_w64(tot >= KILL_OD && tot > seen + COOP_REFRESH_OD) != 0ull) {
-                    seen = tot;
-                    float cum = 0.f; int kb = COOP_NBIN - 1;
-#pragma unroll
-                    for (int q = 0; q < COOP_NBIN - 1; q++) { cum += ENVGS_LDS_READ(L.od[q][lane]); kb = (cum >= KILL_OD && kb == COOP_NBIN - 1) ? q : kb; }
-                    tkill = kb < COOP_NBIN - 1 ? tA + (float)kb * bin_w : tk_open;
-                }
+                refresh_bound();
             }
             return ninner;
         };
@@ -581,6 +668,7 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
                         if (ref[c] >= 0) L.items[buf ^ 1][atomicAdd(&L.nitems[buf ^ 1], 1)] = ((unsigned long long)(unsigned)key[c] << 32) | (unsigned)ref[c];
                 }
             }
+            if (DEFER) flush();                                 // (the next level's slab tests see this level's hits)
             __syncthreads();
             if (tid == 0) L.nitems[buf] = 0;
             buf ^= 1;
@@ -636,11 +724,16 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
 #undef ENVGS_CSWAP
             }
         }
+        if (DEFER) flush();
         if (ovf && lane == 0) L.ovf = 1;
         const unsigned long long c2 = __builtin_readcyclecounter();
         __syncthreads();
         const unsigned long long c3 = __builtin_readcyclecounter();
+#ifdef ENVGS_COOP_TIMING
+        cyc_walk += c2 - c0; (void)c1; (void)c3;              // expansion + walks; the other two slots hold the leaf-test split
+#else
         cyc_expand += c1 - c0; cyc_walk += c2 - c1; cyc_wait += c3 - c2;
+#endif
         if (wave == 0) {
             int n = L.cnt[lane];
             if (L.ovf) {
@@ -670,5 +763,12 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
     }
 #undef ENVGS_LDS_READ
 }
+#define ENVGS_COOP_INST(D, W) template __global__ void __launch_bounds__(64 * COOP_W, W) \
+    collect_hits_coop<D, W>(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec);
+ENVGS_COOP_INST(false, 8)
+#ifdef ENVGS_DIAG
+ENVGS_COOP_INST(true, 8) ENVGS_COOP_INST(true, 6)
+#endif
+#undef ENVGS_COOP_INST
 
 }  // namespace envgs

@@ -618,8 +618,15 @@ __global__ void __attribute__((amdgpu_waves_per_eu(6, 8))) __launch_bounds__(64)
 collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec);
 __global__ void __launch_bounds__(64) composite_lists_bwd(const TraceArgs A);
 #endif
-__global__ void __launch_bounds__(256, 8)
+template <bool DEFER, int WAVES> __global__ void __launch_bounds__(256, WAVES)
 collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec);
+#define ENVGS_COOP_DECL(D, W) extern template __global__ void __launch_bounds__(256, W) \
+    collect_hits_coop<D, W>(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec);
+ENVGS_COOP_DECL(false, 8)
+#ifdef ENVGS_DIAG
+ENVGS_COOP_DECL(true, 8) ENVGS_COOP_DECL(true, 6)
+#endif
+#undef ENVGS_COOP_DECL
 
 template <int EMAX, bool LONG, bool QSH> __global__ void __launch_bounds__(256) sort_composite_fwd(const TraceArgs A);
 extern template __global__ void __launch_bounds__(256) sort_composite_fwd<4, false, false>(const TraceArgs A);
