@@ -150,12 +150,14 @@ def main():
     ap.add_argument("--exchange", default="direct", choices=["direct", "allreduce"],
                     help="N > 1: direct reduce-scatter + all-gather over the xGMI mesh (all_to_all + local sum + all_gather), or one all_reduce per bucket")
     ap.add_argument("--no-render", action="store_true", help="skip the forward-only render timing (profiling runs: keeps the kernel statistics to the training steps)")
-    ap.add_argument("--bvh-rebuild-every", type=int, default=16, help="fused caller: full LBVH build on every K-th step, a refit (same topology, new boxes) on the others; "
-                    "1 = rebuild every step, as the unchanged EasyVolcap caller does (the reference caller always rebuilds)")
+    ap.add_argument("--bvh-rebuild-every", type=int, default=16, help="the tracer's build-or-refit policy (every caller form): a full LBVH build at least on every K-th request, refits "
+                    "(same topology, new boxes; exact) on the others while the tree's measured surface-area cost has not grown; 1 = full build on every request (the literal OptiX behaviour)")
     ap.add_argument("--no-colour-only-state", action="store_true", help="fused caller: let the env trace keep the full per-hit state (as for a caller that may differentiate "
                     "its depth / accumulation / normal outputs) instead of the colour's plane only (SurfelTracer.set_colour_only_backward)")
     ap.add_argument("--no-prebuild", action="store_true", help="fused caller: build the environment structure inside the traced call (as the reference caller does) instead of ahead, under the base pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=10, help="the timed region of EXACTLY --steps steps (barrier + synchronize on both sides) is run this many times "
+                    "back to back; ms_per_step / value are the MEDIAN region, ms_per_step_spread has min / max (VERDICT r4: 20 steps = 0.17 s was a thin sample)")
     ap.add_argument("--no-reference-caller", action="store_true", help="skip the extra few steps that time the unchanged-EasyVolcap-caller form of the step (config.reference_caller_ms_per_step)")
     ap.add_argument("--step-times", type=int, default=0, help="diagnostics: after the timed region, run this many extra steps one by one (synchronised) and print their wall times and the allocator statistics to stderr")
     ap.add_argument("--cpu-reps", type=int, default=2)
@@ -315,38 +317,62 @@ def main():
     for k in range(NK):                           # drain anything recorded during warm-up
         t_, c_ = ctypes.c_double(0), ctypes.c_int(0)
         lib.envgs_prof_read(k, ctypes.byref(t_), ctypes.byref(c_))
-    sync_all()
-    t0 = time.perf_counter()
     ar_bytes = 0
-    for it in range(args.steps):
-        ar_bytes = step(args.warmup + it)
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    regions = []
+    for rep in range(max(1, args.repeats)):       # every region: EXACTLY --steps steps between two (barrier + synchronize) pairs
+        sync_all()
+        t0 = time.perf_counter()
+        for it in range(args.steps):
+            ar_bytes = step(args.warmup + rep * args.steps + it)
+        sync_all()
+        regions.append(time.perf_counter() - t0)
     lib.envgs_prof_enable(0)
     n_timed = dict(n_acc)                          # (the kernel timers cover the timed steps only; later steps -- the reference-caller form, --step-times -- must not dilute the per-launch figures)
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        tt = torch.tensor(regions, device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)  # per region: the slowest rank
+        regions = [float(x) for x in tt.tolist()]
+    elapsed = sorted(regions)[len(regions) // 2] if len(regions) % 2 else sorted(regions)[len(regions) // 2 - 1]      # the median region (lower middle of an even count)
+    steps_done = args.steps * len(regions)
+
+    EXT_KERNELS = ("project_surfels", "scan_tiles_touched", "bin_tile_pairs", "sort_tile_lists", "composite_fwd", "composite_bwd", "project_surfels_bwd",
+                   "bvh_build", "trace_fwd", "trace_bwd")     # the two extensions' own launches (trace_fwd / trace_bwd are whole-call scopes: their inner kernels are not added again)
+
+    def read_prof(nsteps):
+        """Drain the library's HIP-event timers: {name: (ms per launch, launches)} and the extensions' own share of a step."""
+        out = {}
+        for k in range(NK):
+            t_, c_ = ctypes.c_double(0), ctypes.c_int(0)
+            lib.envgs_prof_read(k, ctypes.byref(t_), ctypes.byref(c_))
+            if c_.value > 0:
+                out[lib.envgs_prof_kernel_name(k).decode()] = (t_.value / c_.value, c_.value, t_.value)
+        ext = sum(v[2] for n_, v in out.items() if n_ in EXT_KERNELS) / max(nsteps, 1)
+        return out, ext
+    timed_prof, ext_ms = read_prof(steps_done)
 
     # The drop-in number next to the headline: the SAME step with the expression forms the UNCHANGED EasyVolcap caller executes (batched-matmul
     # get_disks, render()'s regulariser maps + normal term, torch SH / reflection / blend) around the same two extensions -- what a user who only
     # swaps the packages pays.  A few steps, outside the timed region, reported in config.reference_caller_ms_per_step.
     ref_caller_ms = None
     ref_caller_by_blas = None
+    ref_ext_ms = None
     if envgs and args.caller != "reference" and not args.no_reference_caller:
         set_caller("reference")
+        ref_ext = []
 
         def time_reference_form(base_it):
             for it in range(3):
                 step(base_it + it)
             sync_all()
+            lib.envgs_prof_enable(1)
             tr_ = time.perf_counter()
             nref = max(4, min(args.steps, 10))
             for it in range(nref):
                 step(base_it + 3 + it)
             sync_all()
             ms = (time.perf_counter() - tr_) / nref * 1e3
+            lib.envgs_prof_enable(0)
+            ref_ext.append(read_prof(nref)[1])
             if world > 1:
                 tt = torch.tensor([ms], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -367,6 +393,7 @@ def main():
             torch.backends.cuda.preferred_blas_library(before)
         except Exception as e:                                       # a torch build without the switch
             ref_caller_by_blas["error"] = str(e)[:80]
+        ref_ext_ms = ref_ext[0] if ref_ext else None
         set_caller(args.caller)
         step(args.warmup + args.steps + 20)          # (back on the measured caller for the diagnostics below)
         sync_all()
@@ -459,12 +486,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         render_s = float(tt.item())
     kernels = {}
-    for k in range(NK):
-        t_, c_ = ctypes.c_double(0), ctypes.c_int(0)
-        lib.envgs_prof_read(k, ctypes.byref(t_), ctypes.byref(c_))
+    class _C:                                      # (the timers of the timed regions were drained right after them: timed_prof)
+        def __init__(self, v): self.value = v
+    for name, (ms, launches_, _tot) in timed_prof.items():
+        c_ = _C(launches_)
         if c_.value > 0:
-            name = lib.envgs_prof_kernel_name(k).decode()
-            ms = t_.value / c_.value
             ab = algorithmic_bytes(name, P, N_avg, HW, C, not envgs)
             pr = 0
             if not ab and envgs and tcounts:
@@ -485,6 +511,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = args.steps * world / elapsed
+        spread = {"repeats": len(regions), "min": round(min(regions) / args.steps * 1e3, 4), "max": round(max(regions) / args.steps * 1e3, 4),
+                  "timed_seconds_total": round(sum(regions), 3), "note": "ms_per_step / value = the median of `repeats` back-to-back timed regions of exactly `steps` steps each"}
         leaf = {k: v for k, v in kernels.items() if k not in ("trace_fwd", "trace_bwd") and v["GBps"]}
         dom = max(leaf, key=lambda k: leaf[k]["ms"] * leaf[k]["launches"]) if leaf else None      # most time per step (launches included)
         roof = None
@@ -541,7 +569,7 @@ def main():
         line = {
             "metric": "train iters/s (fwd+bwd of the render hot path + Adam step, one %dx%d view per GPU per iter) + render Mpix/s" % (W, H),
             "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "ms_per_step_spread": spread, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if not half else "f16-storage/f32-acc (feature arrays stored as half, fp32 arithmetic, accumulation and gradients)"), "data": "synthetic (seeded, BASELINE.md section 3; random-init Gaussians)",
             "config": {"workload": (("Ref-Real sedan-like full EnvGS (ch0%d raster + env LBVH trace)" % C) if envgs else
                                     "Ref-NeRF toaster-like base 2DGS raster only (BASELINE configs[1]), SH deg 3 in-kernel"),
@@ -552,9 +580,12 @@ def main():
                                        "reference": "the unchanged EasyVolcap caller's expression forms (batched-matmul get_disks, render()'s regulariser maps + normal term)"}[args.caller]),
                        "reference_caller_ms_per_step": (None if ref_caller_ms is None else round(ref_caller_ms, 3)),
                        "reference_caller_ms_by_torch_blas": ref_caller_by_blas,
+                       "extension_ms_per_step": round(ext_ms, 3),
+                       "reference_caller_extension_ms_per_step": (None if ref_ext_ms is None else round(ref_ext_ms, 3)),
+                       "extension_note": "HIP-event time of the two extensions' own launches per step (raster stages, structure build / refit, tracer forward and backward) under the measured caller and under the reference-caller form: what is left of reference_caller_ms_per_step beyond it is torch glue of the caller (get_disks' batched matmuls, SH colours, reflection, regulariser maps, torch.optim-free here), not extension time",
                        "reference_caller_note": "the same step with the UNCHANGED EasyVolcap caller's expression forms around the same extensions (--caller reference), a few steps outside the timed region; reference_caller_ms_per_step is under torch's OWN BLAS choice (importing the packages changes nothing process-wide), reference_caller_ms_by_torch_blas has it under both (cublas = rocBLAS, cublaslt = hipBLASLt; the one-line pin of INTEGRATION.md section 5)",
-                       "env_structure": (None if not envgs else ("LBVH rebuilt every step" if (args.caller != "fused" or args.bvh_rebuild_every <= 1) else
-                                         "LBVH full build every %d steps, refit (same topology, new boxes) on the others" % args.bvh_rebuild_every)),
+                       "env_structure": (None if not envgs else ("LBVH rebuilt every step (tracer policy 'rebuild')" if args.bvh_rebuild_every <= 1 else
+                                         "every call asks for a rebuild (as the reference's caller does); the tracer serves it with a refit while the tree is young: full LBVH build every %d calls or when the measured surface-area cost grew > 1.25x (SurfelTracer.set_structure_policy, all caller forms)" % args.bvh_rebuild_every)),
                        "env_per_hit_state": (None if not envgs else ("colour plane only: the caller promises a colour-only backward (16 B per hit; another gradient raises)"
                                              if (args.caller == "fused" and not args.no_colour_only_state and not args.trace_depth) else "all planes (32 B per hit, 40 with `others`)")),
                        "torch_blas": str(torch.backends.cuda.preferred_blas_library()).split(".")[-1],

@@ -69,6 +69,7 @@ SYMBOLS = {
     "envgs_bvh_node_floats": (c_size_t, [ctypes.c_int32]),
     "envgs_bvh_build": (c_int, [ctypes.c_int32, _P, _P, _P, _P, c_size_t, ctypes.c_int32, _P]),
     "envgs_bvh_refit": (c_int, [ctypes.c_int32, _P, _P, _P, _P, _P, c_size_t, ctypes.c_int32, _P]),
+    "envgs_bvh_quality": (c_int, [ctypes.c_int32, _P, _P, _P]),
     "envgs_trace_stack_spill_ints": (c_size_t, [ctypes.c_int32]),
     "envgs_trace_ray_sort_temp_bytes": (c_size_t, [ctypes.c_int32]),
     "envgs_trace_ray_order": (c_int, [ctypes.c_int32, _P, _P, _P, ctypes.c_int32, _P, _P, _P, c_size_t, _P]),

@@ -32,18 +32,22 @@ static int stride_grid(int R, int per_block)
 
 // The list path packs surfel ids, ray slots and per-surfel entry counts into 24-bit fields: beyond 2^24 surfels or rays both directions take
 // the K-buffer kernels (correct at any size, slower).
+static bool lists_wanted(const envgs_trace_cfg *cfg, const envgs_trace_lists *L)
+{
+    return L && L->cap > 0 && cfg->max_trace_depth == 0 && cfg->P > 0 && cfg->P < (1 << 24) && cfg->num_rays < (1 << 24);
+}
 static bool lists_usable(const envgs_trace_cfg *cfg, const envgs_trace_lists *L)
 {
-    return L && L->cap > 0 && cfg->max_trace_depth == 0 && cfg->P > 0 && cfg->P < (1 << 24) && cfg->num_rays < (1 << 24) && L->hit_lists &&
-           L->hit_cnt && L->n_used && L->stack_spill && L->surf_cnt && L->surf_off && L->surf_acc && L->scan_temp;
+    return lists_wanted(cfg, L) && L->hit_lists && L->hit_cnt && L->n_used && L->stack_spill && L->surf_cnt && L->surf_off && L->surf_acc && L->scan_temp;
 }
 // The backward of the list path reads the hit COUNTS, the per-hit state, the entries / pairs and the per-surfel offsets -- not the lists
 // themselves (rays x capacity x 8 B, by far the largest buffer of a call) nor the forward's scratch: the caller may have released those
-// (hit_lists == NULL) between the two calls.  Same size limits as the forward's test.
+// (hit_lists == NULL) between the two calls.  Which path a call takes is decided by lists_wanted() ALONE in both directions (a forward that
+// fell back to the K-buffer because a scratch pointer was NULL, followed by a backward that found its own pointers complete, read counts nobody
+// had written): a struct that asks for lists (cap > 0, sizes in range) with a buffer of its direction missing is ENVGS_ERR_BAD_ARG, never a silent fallback.
 static bool lists_usable_bwd(const envgs_trace_cfg *cfg, const envgs_trace_lists *L)
 {
-    return L && L->cap > 0 && cfg->max_trace_depth == 0 && cfg->P > 0 && cfg->P < (1 << 24) && cfg->num_rays < (1 << 24) && L->hit_cnt && L->n_used &&
-           L->surf_cnt && L->surf_off;
+    return lists_wanted(cfg, L) && L->hit_cnt && L->n_used && L->surf_cnt && L->surf_off;
 }
 
 
@@ -124,6 +128,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
 #endif
     int rh, rw; ray_layout(cfg, &rh, &rw);
     const bool lists = lists_usable(cfg, L);
+    if (lists_wanted(cfg, L) && !lists) return ENVGS_ERR_BAD_ARG;      // (see lists_usable_bwd: no silent fallback to the K-buffer path)
     if (L && L->cap > SORT_MAX) return ENVGS_ERR_BAD_ARG;
     ProfScope prof_(K_TRACE_FWD, stream);
     if (lists) {
@@ -342,7 +347,8 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     int rh, rw; ray_layout(cfg, &rh, &rw);
     {
         ProfScope prof_(K_TRACE_BWD, stream);
-        if (lists_usable_bwd(cfg, L)) {                // the forward's test minus the forward-only buffers: the list path ran exactly when it holds
+        if (lists_wanted(cfg, L) && !lists_usable_bwd(cfg, L)) return ENVGS_ERR_BAD_ARG;
+        if (lists_usable_bwd(cfg, L)) {                // lists_wanted(): the forward took the list path exactly when it holds
             A.hits = (uint2 *)L->hit_lists; A.hit_cnt = L->hit_cnt; A.n_used = L->n_used; A.cap = L->cap;
             if (L->ray_keys && L->ray_order && L->ray_sort_temp && !(A.exp & 64)) A.order = L->ray_order + cfg->num_rays;
             if (L->records && L->num_records > 0 && L->surf_cnt && L->surf_off && L->hit_state && L->entries && L->pairs && L->n_entries && !(A.exp & 8)) {

@@ -469,6 +469,35 @@ fit_nodes(int P, const Tables T, const float *topo, float *nodes, float *__restr
     }
 }
 
+// Tree quality for the build-or-refit decision of the drop-in module (SurfelTracer.build_acceleration_structure): the surface-area sum of every
+// binary node's two child boxes -- the SAH cost of the topology under the CURRENT boxes, up to constants -- next to the root's own area.  A refit
+// keeps the topology of positions that have since moved: the ratio of this sum (over the root area) to its value right after the full build says
+// how much more box area a ray now has to wade through.  out[0] += sum (one float atomic per workgroup: a heuristic, order does not matter),
+// out[1] = root area.
+__global__ void __launch_bounds__(256)
+tree_area_sum(int P, const float *__restrict__ nodes, float *out)
+{
+    __shared__ float s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float a = 0.f;
+    if (i < P - 1) {
+        const float4 *n4 = reinterpret_cast<const float4 *>(nodes + (size_t)i * NODE);
+        const float4 q0 = n4[0], q1 = n4[1], q2 = n4[2];            // left (lo.xyz hi.xyz), right (lo.xyz hi.xyz)
+        const float lx = fmaxf(q0.w - q0.x, 0.f), ly = fmaxf(q1.x - q0.y, 0.f), lz = fmaxf(q1.y - q0.z, 0.f);
+        const float rx = fmaxf(q2.y - q1.z, 0.f), ry = fmaxf(q2.z - q1.w, 0.f), rz = fmaxf(q2.w - q2.x, 0.f);
+        a = (lx * ly + ly * lz + lz * lx) + (rx * ry + ry * rz + rz * rx);
+        if (i == 0) {
+            const float ex = fmaxf(q0.w, q2.y) - fminf(q0.x, q1.z), ey = fmaxf(q1.x, q2.z) - fminf(q0.y, q1.w), ez = fmaxf(q1.y, q2.w) - fminf(q0.z, q2.x);
+            out[1] = ex * ey + ey * ez + ez * ex;
+        }
+        if (!(a < 1.0e30f)) a = 0.f;                                 // (a box of far-away sentinel points, NaN: not part of the measure)
+    }
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, s_w[0] + s_w[1] + s_w[2] + s_w[3]);
+}
+
 // P == 1: a single node whose left child is the only surfel and whose right child can never be hit.
 __global__ void single_leaf_node(const float *__restrict__ leaf_box, float *__restrict__ nodes)
 {
@@ -577,6 +606,17 @@ int envgs_bvh_refit(int32_t P, const float *vertices, const float *opacities, co
                        reinterpret_cast<const int *>(nodes_prev + (size_t)(P - 1) * (NODE + 32)), vertices, opacities, t.st, 0);
     ENVGS_CHECK_LAUNCH(cfg, stream);
     return fit_from_table(P, t, nodes_prev, nodes, cfg, stream);
+}
+
+int envgs_bvh_quality(int32_t P, const float *nodes, float *out2, void *stream_)
+{
+    if (P < 0 || !out2) return ENVGS_ERR_BAD_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (hipMemsetAsync(out2, 0, 2 * sizeof(float), stream) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+    if (P < 2) return 0;
+    if (!nodes) return ENVGS_ERR_BAD_ARG;
+    hipLaunchKernelGGL(tree_area_sum, dim3((P - 1 + 255) / 256), dim3(256), 0, stream, P, nodes, out2);
+    return (int)hipGetLastError();
 }
 
 }  // extern "C"

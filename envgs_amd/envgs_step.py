@@ -50,8 +50,9 @@ def base_pass(pkg, cam, base, bg, sh_degree, scale_modifier=1.0):
         sh_degree=sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
     if FUSED["on"]:
         from . import fused
-        # (a gradient SINK: the extension never reads its values -- an uninitialised leaf instead of the reference's `zeros_like(...) + 0`, two launches)
-        means2D = torch.empty_like(base["means3D"]).requires_grad_(True)
+        # (a gradient SINK: the extension never reads its values -- a zero leaf, one fill, instead of the reference's `zeros_like(...) + 0`, two launches;
+        #  zeros rather than uninitialised memory: a debug dump or anomaly detection that reads the values must not see NaN)
+        means2D = torch.zeros_like(base["means3D"]).requires_grad_(True)
         colors = fused.sh_colors(base["means3D"], base["shs"], cam.camera_center, sh_degree, base["specular"], base["roughness"])
     else:
         means2D = torch.zeros_like(base["means3D"], requires_grad=True, device=dev) + 0
@@ -105,9 +106,9 @@ REFERENCE_FORMS = {"on": False, "get_disks": None, "surface_maps": None}
 # of render()'s tail) instead of this module's cheaper equivalents.  Those restatements are measurement / test material and live in
 # tests/reference_caller.py, whose install() puts the two callables here; nothing in the shipped package contains them.
 PREBUILD = {"on": True}            # fused caller: start the environment structure build before the base pass (SurfelTracer.prepare)
-# fused caller: the environment structure is REFIT (same topology, new boxes: six launches instead of fifteen) on the calls in between full
-# builds -- a training step moves the surfels by a learning rate, not across the scene.  every = 1: rebuild on every call, as the unchanged
-# EasyVolcap caller does (optix_utils.py:73-78 always passes rebuild=True while training)
+# The environment structure: every caller form asks for a rebuild on every call, as the reference does (optix_utils.py:73-78); how the request is
+# served is the TRACER's decision (SurfelTracer.set_structure_policy: refits while the tree is young and has not degraded, round 5 -- the cadence
+# used to live here, rounds 3-4, and only the fused caller got it).  every <= 1 pins full builds for A/B runs.
 REFIT = {"every": 16}
 # fused caller, bounce-free env pass: only its colour is supervised (envgs_sampler.py: the loss sees the blended rgb; dpt / acc / norm are
 # visualisation outputs) -> SurfelTracer.set_colour_only_backward: the forward stores the colour's per-hit state only
@@ -115,10 +116,10 @@ COLOUR_ONLY = {"on": True}
 TRACE = {"depth": 0, "specular_threshold": 0.0}    # EnvGS hard-codes 0 bounces (envgs_sampler.py:510,548); bench.py --trace-depth overrides
 
 
-def _rebuild_now(tracer):
-    calls = getattr(tracer, "_structure_calls", 0)                    # (counted per tracer: its structure is what ages)
-    tracer._structure_calls = calls + 1
-    return REFIT["every"] <= 1 or calls % REFIT["every"] == 0
+def _apply_policy(tracer):
+    if hasattr(tracer, "set_structure_policy"):
+        if REFIT["every"] <= 1: tracer.set_structure_policy("rebuild")
+        else: tracer.set_structure_policy("adaptive", max_age=REFIT["every"] - 1)
 
 
 def env_prepare(tracer, env):
@@ -126,7 +127,8 @@ def env_prepare(tracer, env):
     that the build (its own stream, SurfelTracer.prepare) runs under the rasterizer's forward.  Returns the vertex buffer for env_pass."""
     from . import fused
     v, f = fused.surfel_quads(env["means3D"], env["scales"], env["rotations"])
-    tracer.build_acceleration_structure(v, f, rebuild=_rebuild_now(tracer))    # (rebuild=False: a refit when the surfel count is unchanged, else a build)
+    _apply_policy(tracer)
+    tracer.build_acceleration_structure(v, f, rebuild=True)
     tracer.prepare(env["opacities"])
     return v
 
@@ -144,14 +146,16 @@ def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree, prepared_v
     elif FUSED["on"] and not REFERENCE_FORMS["on"]:
         from . import fused
         v, f = fused.surfel_quads(env["means3D"], env["scales"], env["rotations"])          # one launch instead of ~25 torch kernels in front of the trace
-        tracer.build_acceleration_structure(v, f, rebuild=_rebuild_now(tracer))
+        _apply_policy(tracer)
+        tracer.build_acceleration_structure(v, f, rebuild=True)
     else:
         v, f = (REFERENCE_FORMS["get_disks"] if REFERENCE_FORMS["on"] else synth.get_disks)(env["means3D"], env["scales"], env["rotations"])
+        _apply_policy(tracer)
         tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
     if hasattr(tracer, "set_colour_only_backward"):
         tracer.set_colour_only_backward(bool(FUSED["on"] and not REFERENCE_FORMS["on"] and COLOUR_ONLY["on"] and int(TRACE["depth"]) == 0))
     if FUSED["on"] and not REFERENCE_FORMS["on"]:
-        grads3D = torch.empty_like(env["means3D"]).requires_grad_(True)          # (gradient sink, never read: no fill, no `+ 0`)
+        grads3D = torch.zeros_like(env["means3D"]).requires_grad_(True)          # (gradient sink, never read: one fill, no `+ 0`)
     else:
         grads3D = torch.zeros_like(env["means3D"], requires_grad=True) + 0
     return tracer(ref_o.contiguous(), ref_d.contiguous(), v, means3D=env["means3D"].contiguous(), grads3D=grads3D,

@@ -427,6 +427,62 @@ class SurfelTracer(nn.Module):
         self._pending = None
         self._keep = None                 # the structure a refit request (rebuild=False) updates in place
         self.caps = CapState()            # this tracer's adaptive hit-list capacity (not shared with other tracers of the process)
+        # build-or-refit policy for rebuild=True requests (set_structure_policy): the reference's caller asks for a rebuild on EVERY training step
+        # (optix_utils.py:73-78).  A refit is exact, so such a request is answered with one while the tree is young and has not degraded.
+        self._policy = dict(mode="adaptive", max_age=16, max_growth=1.25)
+        self._age = 0                     # structures derived from the last full build by refits
+        self._q = None                    # quality read-backs: dict(host=pinned (2,2) floats, build=(event, row), last=(event, row))
+
+    def set_structure_policy(self, mode="adaptive", max_age=16, max_growth=1.25):
+        """OPTIONAL, not part of the reference interface.  How a `rebuild=True` request is served when the surfel count is unchanged:
+        "adaptive" (default): by a REFIT of the existing topology (envgs_bvh_refit: 6 launches instead of 15; hit sets identical to a fresh build's)
+                     unless `max_age` structures have been derived from the last full build, or the tree's surface-area cost measured on the
+                     device after the previous refit (envgs_bvh_quality, read back asynchronously -- never a host sync) has grown by more than
+                     `max_growth` x since that build (surfels moved far: opacity reset, a prune + densify that kept the count, a scene change);
+        "rebuild":   always by a full build -- the literal behaviour of the reference's OptiX GAS.
+        `rebuild=False` requests are always refits (OptiX's update), a changed surfel count always a full build."""
+        if mode not in ("adaptive", "rebuild"):
+            raise ValueError("structure policy must be 'adaptive' or 'rebuild', got %r" % (mode,))
+        self._policy = dict(mode=mode, max_age=int(max_age), max_growth=float(max_growth))
+
+    def invalidate_structure(self):
+        """OPTIONAL: forget the existing structure (the next request is a full build whatever the policy) -- for a caller that knows the surfel
+        set was re-indexed without changing its size (prune + densify)."""
+        self._keep = None
+        self.nodes = None
+        self._age = 0
+
+    def _refit_allowed(self):
+        pol = self._policy
+        if pol["mode"] != "adaptive" or self._age >= pol["max_age"]:
+            return False
+        q = self._q
+        if q is None or q.get("build") is None:
+            return True                                   # (nothing measured yet: the age bound alone)
+        ev_b, ev_l = q["build"], q.get("last")
+        if ev_l is None or not ev_b.query() or not ev_l.query():
+            return True                                   # the read-back of the previous structure has not landed: decide on age, never wait
+        h = q["host"]
+        b = float(h[0, 0]) / max(float(h[0, 1]), 1e-30)
+        l = float(h[1, 0]) / max(float(h[1, 1]), 1e-30)
+        LAST_STATS["bvh_growth"] = l / max(b, 1e-30)
+        return l <= pol["max_growth"] * b
+
+    def _measure(self, nodes, refit):
+        """Queue the quality measurement of the structure just built (row 0) or refitted (row 1) and its read-back into pinned memory."""
+        lib = _lib.load()
+        dev = nodes.device
+        q = self._q
+        if q is None or q["dev"].device != dev:
+            q = self._q = dict(host=torch.zeros(2, 2, dtype=torch.float32).pin_memory(), dev=torch.zeros(2, 2, dtype=torch.float32, device=dev), build=None, last=None)
+        row = 1 if refit else 0
+        _lib.check(lib.envgs_bvh_quality(self.num_surfels, _lib.ptr(nodes), _lib.ptr(q["dev"][row]), _stream(dev)), "envgs_bvh_quality")
+        q["host"][row].copy_(q["dev"][row], non_blocking=True)
+        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(dev))
+        if refit:
+            q["last"] = ev
+        else:
+            q["build"], q["last"] = ev, None
 
     def build_acceleration_structure(self, vertices, faces=None, rebuild=True):
         """optix_utils.py:78.  `faces` must be the get_disks layout (2 triangles per 4 consecutive vertices).
@@ -445,10 +501,16 @@ class SurfelTracer(nn.Module):
         if ev is not None and self.nodes is not None:
             torch.cuda.current_stream(self.nodes.device).wait_event(ev)       # (a build started by prepare() that no trace has consumed)
         have = self.nodes if self.nodes is not None else self._keep
-        self._keep = have if (not rebuild and have is not None and vertices.shape[0] // 4 == self.num_surfels) else None
+        same = have is not None and vertices.shape[0] // 4 == self.num_surfels
+        self._keep = have if (same and (not rebuild or self._refit_allowed())) else None
         self._pending = vertices.detach()
         self.nodes = None
         self.num_surfels = vertices.shape[0] // 4
+
+    def _built(self, was_refit):
+        self._age = self._age + 1 if was_refit else 0
+        if self._policy["mode"] == "adaptive" and self.num_surfels > 1:
+            self._measure(self.nodes, was_refit)
 
     def set_colour_only_backward(self, on=True):
         """OPTIONAL, not part of the reference interface (include/envgs_trace.h: state_planes): a promise that the backward of this tracer's
@@ -475,6 +537,7 @@ class SurfelTracer(nn.Module):
             self._keep.record_stream(side)
         with torch.cuda.stream(side):
             self.nodes, self.num_surfels = build_bvh(self._pending, opacities, refit=self._keep)
+            self._built(LAST_STATS["bvh"] == "refit")
         self._keep = None
         self._build_event = torch.cuda.Event()
         self._build_event.record(side)
@@ -501,6 +564,7 @@ class SurfelTracer(nn.Module):
             if self._pending.shape[0] != 4 * means3D.shape[0]:
                 raise RuntimeError("SurfelTracer: acceleration structure was requested for %d surfels, call has %d" % (self._pending.shape[0] // 4, means3D.shape[0]))
             self.nodes, self.num_surfels = build_bvh(self._pending, opacities, refit=self._keep)
+            self._built(LAST_STATS["bvh"] == "refit")
             self._pending = None
             self._keep = None
         ev = self.__dict__.pop("_build_event", None)
@@ -568,8 +632,12 @@ class SurfelTracer(nn.Module):
             # backward, through advanced indexing, was a SORTED index_put: 4 ms of radix sorts per 1200x1600 step
             o2, d2 = fused.bounce_rays(p["o"], p["d"], dpt, acc, norm, sel)
             bc = self.bounce_caps(k)
+            was_k = bc.colour_only
             bc.colour_only = k == depth                 # the last stage's other outputs go into `mid` (no gradient) and nowhere else
-            out = _TraceSurfels.apply(o2, d2, *args, s0, 2, self.nodes, bc)
+            try:
+                out = _TraceSurfels.apply(o2, d2, *args, s0, 2, self.nodes, bc)
+            finally:
+                bc.colour_only = was_k                  # (the promise is this call's, not the stage state's: ADVICE r4)
             stages.append(dict(o=o2, d=d2, out=out, idx=p["idx"].index_select(0, sel), sel=sel))
         col = stages[-1]["out"][0]
         for k in range(len(stages) - 2, -1, -1):

@@ -76,7 +76,9 @@ typedef struct envgs_trace_lists {
                                 release this buffer -- the largest of a call -- and pass NULL to the backward */
     int32_t *hit_cnt;        /* (R) hits found; > cap => that ray took the K-buffer path */
     int32_t *n_used;         /* (R) hits composited before termination */
-    int32_t cap;             /* list capacity per ray, <= 1024; 0 disables the list path */
+    int32_t cap;             /* list capacity per ray, <= 1024; 0 disables the list path.  With cap > 0 (and max_trace_depth == 0, P and R below 2^24) BOTH
+                                calls take the list path and every buffer of their direction must be present: a missing one is ENVGS_ERR_BAD_ARG, never
+                                a silent fallback to the K-buffer kernels (the two calls could otherwise disagree about the path) */
     int32_t *stack_spill;    /* envgs_trace_stack_spill_ints(R) int32 */
     uint64_t *surf_acc;      /* (P,8) packed accumulators of the forward (8 copies per surfel, chosen by ray index, spread same-address
                                 atomics): low 24 bits hit count, high 40 bits fixed-point weight */
@@ -150,6 +152,15 @@ ENVGS_API int envgs_bvh_build(int32_t P, const float *vertices, const float *opa
  */
 ENVGS_API int envgs_bvh_refit(int32_t P, const float *vertices, const float *opacities, const float *nodes_prev, float *nodes, void *temp,
                               size_t temp_bytes, int32_t debug, void *stream);
+
+/*
+ * Quality of a structure under its CURRENT boxes, for the module's build-or-refit decision (the reference's caller asks for a rebuild on every
+ * training step, optix_utils.py:73-78; a refit is exact, so the module may answer such a request with one as long as the tree has not aged):
+ * out2[0] = sum over the binary nodes of the surface areas (half areas: xy + yz + zx) of their two child boxes, out2[1] = the root's.  The
+ * ratio out2[0] / out2[1] against its value right after the last full build is the growth of the SAH cost through refits.  Asynchronous
+ * (memset + one launch on `stream`); out2 is device memory.
+ */
+ENVGS_API int envgs_bvh_quality(int32_t P, const float *nodes, float *out2, void *stream);
 
 /*
  * SurfelTracer.forward (optix_utils.py:188-201): trace R rays through the surfel set, composite front to back.

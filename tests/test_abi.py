@@ -103,6 +103,7 @@ def test_product_library_is_trimmed_of_the_diagnostic_kernels():
         assert name not in prod and name in diag, name
     for name in (b"collect_hits_coop", b"sort_composite_fwd", b"batch_surfel_bwd", b"composite_bwd"):
         assert name in prod and name in diag, name
+    assert b"collect_hits_coopILb1E" not in prod and b"collect_hits_coopILb1E" in diag        # round 5's deferred-exact-test form: measured slower, A/B only
     old = _lib.select("diag")
     try:
         lib = _lib.load()

@@ -188,21 +188,21 @@ def test_hip_packages_reproduce_the_recorded_boundary(fx):
         check_close("recorded_boundary", "trace." + nm, got, want, excluded=int((~okr).sum()))
 
 
-def test_fused_caller_rebuild_cadence():
-    """envgs_step._rebuild_now: a full LBVH build on every K-th prepared call of a tracer, refits in between (north_star: Morton build + per-step
-    refit); K = 1 rebuilds always, like the unchanged EasyVolcap caller.  Counted per tracer."""
+def test_fused_caller_leaves_the_rebuild_cadence_to_the_tracer():
+    """Round 5: every caller form asks for a rebuild on every call (optix_utils.py:73-78); envgs_step only forwards its REFIT knob to the tracer's
+    own build-or-refit policy (SurfelTracer.set_structure_policy; the GPU half is tests/test_trace_parity.py::test_trace_rebuild_requests_...)."""
     from envgs_amd import envgs_step
 
     class T:
-        pass
+        def __init__(self): self.calls = []
+        def set_structure_policy(self, mode, max_age=None): self.calls.append((mode, max_age))
 
     old = envgs_step.REFIT["every"]
     try:
-        envgs_step.REFIT["every"] = 4
-        a, b = T(), T()
-        assert [envgs_step._rebuild_now(a) for _ in range(9)] == [True, False, False, False, True, False, False, False, True]
-        assert envgs_step._rebuild_now(b) is True                      # another tracer starts its own count
-        envgs_step.REFIT["every"] = 1
-        assert all(envgs_step._rebuild_now(a) for _ in range(3))
+        t = T()
+        envgs_step.REFIT["every"] = 4; envgs_step._apply_policy(t)
+        envgs_step.REFIT["every"] = 1; envgs_step._apply_policy(t)
+        assert t.calls == [("adaptive", 3), ("rebuild", None)]
+        envgs_step._apply_policy(object())                              # a tracer without the optional method (the reference's own): nothing to do
     finally:
         envgs_step.REFIT["every"] = old
