@@ -136,8 +136,8 @@ def test_held_out_view_psnr_against_oracle_rendered_ground_truth():
     from tests import oracle_packages
     from tests.util import record
     dev = torch.device("cuda:0")
-    Hh, Ww, NV = 64, 64, 6
-    TRAIN, HELD = (0, 1, 3, 4), (2, 5)
+    Hh, Ww, NV = 64, 64, 12
+    TRAIN, HELD = (0, 1, 2, 4, 5, 6, 8, 9, 10), (3, 7, 11)
     gt_b = synth.base_gaussians(1500, seed=3)
     gt_b["scales"] = gt_b["scales"] * 5.0
     gt_b["opacities"] = torch.sigmoid(torch.randn(1500, 1, generator=torch.Generator().manual_seed(1)) + 1.5)
@@ -189,7 +189,7 @@ def test_held_out_view_psnr_against_oracle_rendered_ground_truth():
                 with torch.no_grad():
                     return sum(_psnr(render(base, env, v), target[v]) for v in HELD) / len(HELD)
             h0 = held()
-            for it in range(320):
+            for it in range(540):
                 v = TRAIN[it % len(TRAIN)]
                 loss = l1_ssim_loss(render(base, env, v).permute(2, 0, 1), target[v].permute(2, 0, 1))
                 loss.backward()
@@ -203,11 +203,11 @@ def test_held_out_view_psnr_against_oracle_rendered_ground_truth():
         import envgs_amd
         envgs_amd.set_feature_storage("f32")
     for s_, r in results.items():
-        print("storage %s: HIP render of the ground-truth parameters vs oracle images %.1f dB (worst view); held-out views %.2f -> %.2f dB after 320 steps on the "
+        print("storage %s: HIP render of the ground-truth parameters vs oracle images %.1f dB (worst view); held-out views %.2f -> %.2f dB after 540 steps on the "
               "training views (training views: %.2f dB)" % (s_, r["forward"], r["held0"], r["held1"], r["train1"]))
         record("held_out_psnr", "psnr_dB.%s.heldout_after" % s_, r["held1"], "(before %.2f dB; training views %.2f dB; forward-only vs oracle %.1f dB)" % (r["held0"], r["train1"], r["forward"]))
     assert results["f32"]["forward"] > 60.0                       # fp32 storage: the HIP images ARE the oracle's images (mse < 1e-6)
     assert results["f16"]["forward"] > 45.0                       # half-rounded SH / colour features: a visible but small forward difference
     for r in results.values():
-        assert r["held1"] > r["held0"] + 3.0, r                   # what was learned on the training views transfers to views never trained on
+        assert r["held1"] > r["held0"] + 2.0 and r["train1"] > 30.0, r     # what was learned on the training views transfers to views never trained on
     assert abs(results["f32"]["held1"] - results["f16"]["held1"]) < 1.0, results       # matched PSNR between the storage variants
