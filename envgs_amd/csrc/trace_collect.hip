@@ -433,7 +433,9 @@ collect_hits_packet4(const TraceArgs A, const float4 *__restrict__ nodes, const 
 // near the origin.  The bound only ever tightens and a stale (larger) one only collects more, so the collected set is a superset of
 // what the compositing needs whatever the interleaving; the lists are sorted afterwards.
 constexpr int COOP_W = 4;
-constexpr float COOP_REFRESH_OD = 0.5f;   // recompute a ray's bound when its optical depth has grown by this much (the bound cuts at ~9.5)
+constexpr float COOP_REFRESH_OD = 1.0f;   // recompute a ray's bound when its optical depth has grown by this much (the bound cuts at ~9.5).  Round 5, with the
+                                          // ray-major bin table: 0.5 -> collect 1.733 ms, 68.9 M hits found; 1.0 -> 1.718 ms, 69.3 M; 2.0 -> 1.745 ms, 70.5 M (profiles/r05_ab_collect.txt)
+constexpr int COOP_ODROW = 36;            // floats per ray of the bin table: 32 bins + pad -- rows stay 16 B aligned (ds_read_b128) and 64 rows spread over the banks
 constexpr int COOP_NBIN = 32;             // distance bins of the termination bound (LDS: the update is one ds_add_f32 whatever their number)
 constexpr int COOP_STK = 96;
 constexpr int COOP_FRONT = 64;            // stop expanding once a level has this many entered subtrees (the next level holds at most 4x that).  Measured
@@ -443,7 +445,7 @@ constexpr int COOP_ITEMS = 256;           // >= 4 * (largest front - 1)
 constexpr int COOP_QFLUSH = 8;           // deferred exact tests: a wavefront's queue of entered leaf slots is worked off when it holds this many ...
 constexpr int COOP_QCAP = COOP_QFLUSH + 3 + 1;   // ... (a step adds at most four)
 struct CoopLds {
-    float od[COOP_NBIN][64];
+    float od[64][COOP_ODROW];                 // ray-major (round 5): a ray's 32 bins are eight ds_read_b128, four in flight at a time, instead of 31 serialised ds_read_b32
     float odtot[64];
     int cnt[64];
     unsigned long long items[2][COOP_ITEMS];      // entry-distance bits << 32 | wide-node index
@@ -496,7 +498,7 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             if (lane == 0) { L.batch = b; L.nitems[0] = 1; L.nitems[1] = 0; L.items[0][0] = 0ull; L.next = 0; L.ovf = 0; }
         }
 #pragma unroll
-        for (int q = 0; q < COOP_NBIN * 64 / (64 * COOP_W); q++) (&L.od[0][0])[q * 64 * COOP_W + tid] = 0.f;
+        for (int q = 0; q < (int)(sizeof(L.od) / sizeof(float)) / (64 * COOP_W); q++) (&L.od[0][0])[q * 64 * COOP_W + tid] = 0.f;
         if (tid < 64) { L.odtot[tid] = 0.f; L.cnt[tid] = 0; }
         __syncthreads();
         const int fb = L.batch;
@@ -537,7 +539,7 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             int b = x <= 0.0f ? 0 : (int)ceilf(x + 1e-3f);
             b = b > COOP_NBIN - 1 ? COOP_NBIN - 1 : b;
             const float dep = -__logf(1.0f - h.alpha);
-            atomicAdd(&L.od[b][lane], dep);
+            atomicAdd(&L.od[lane][b], dep);
             atomicAdd(&L.odtot[lane], dep);
         };
         // look at the bound -- and recompute it (31 LDS reads and ~125 VALU, as much as two leaf tests) only when some ray that can be cut at all
@@ -547,8 +549,24 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             if (__builtin_amdgcn_ballot_w64(tot >= KILL_OD && tot > seen + COOP_REFRESH_OD) != 0ull) {
                 seen = tot;
                 float cum = 0.f; int kb = COOP_NBIN - 1;
+                // (what other wavefronts add meanwhile may or may not be seen: either way the sums are lower bounds of the true optical depth, the bound stays conservative)
+                const float4 *row = reinterpret_cast<const float4 *>(&L.od[lane][0]);
+                asm volatile("" ::: "memory");                 // (re-read: nothing cached from an earlier refresh)
 #pragma unroll
-                for (int q = 0; q < COOP_NBIN - 1; q++) { cum += ENVGS_LDS_READ(L.od[q][lane]); kb = (cum >= KILL_OD && kb == COOP_NBIN - 1) ? q : kb; }
+                for (int h = 0; h < COOP_NBIN / 16; h++) {    // sixteen bins per round: four ds_read_b128 in flight, 16 VGPRs
+                    float4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = row[4 * h + q];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int bin = 16 * h + 4 * q + j;
+                            if (bin < COOP_NBIN - 1) { cum += e[j]; kb = (cum >= KILL_OD && kb == COOP_NBIN - 1) ? bin : kb; }
+                        }
+                    }
+                }
                 tkill = kb < COOP_NBIN - 1 ? tA + (float)kb * bin_w : tk_open;
             }
         };
