@@ -95,8 +95,8 @@ def trace_per_ray_model_bytes(kernel, tc, R):
 VALU_PEAK_GINST = 256 * 2 * 2.4
 VALU_MEASURED_GINST = 898.0     # what the chip sustains: independent v_fma_f32 / mixed VALU, 8 waves per SIMD (scratch/valu_peak.hip -> profiles/r02_valu_peak.txt)
 SALU_PEAK_GINST = 256 * 1 * 2.4
-PMC_SUMMARY = os.path.join("profiles", "r04_pmc_envgs.json")
-STEP_INVENTORY = os.path.join("profiles", "r04_step_inventory.txt")     # rocprofv3 kernel trace of this workload's step (scratch/step_inventory.py)
+PMC_SUMMARY = os.path.join("profiles", "r05_pmc_envgs.json")
+STEP_INVENTORY = os.path.join("profiles", "r05_step_inventory.txt")     # rocprofv3 kernel trace of this workload's step (scratch/step_inventory.py)
 
 
 def step_inventory():
@@ -538,11 +538,19 @@ def main():
             out["source"] = PMC_SUMMARY
             return out
 
+        def calibrated(name):
+            """Counter traffic by the calibrated reading of profiles/r03_fetch_calibration.txt: FETCH_SIZE counts read REQUESTS x 64 B, so for gather-dominated
+            kernels (one request per lane access) the prescribed 2 x FETCH_SIZE over-states the reads; fetch_requests x 64 B + WRITE_SIZE is the lower reading."""
+            r = pm.get(name) or {}
+            if "fetch_requests" not in r:
+                return None
+            return int(r["fetch_requests"] * 64 + r.get("WRITE_SIZE_KB", 0.0) * 1024)
+
         if dom:
             A = kernels[dom]["GBps"]
             traffic = pm.get(dom, {}).get("hbm_bytes")
             roof = {"kernel": dom, "bound": "hbm", "achieved": A, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(A / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "frac": round(A / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_calibrated": calibrated(dom),
                     "alg_bytes_per_launch": int(kernels[dom]["alg_MB"] * 1e6), "ms_per_launch": kernels[dom]["ms"],
                     "tile_instances_N": int(N_avg), "issue": issue_of(dom),
                     "step_total": {"alg_MB": round(sum(v["alg_MB"] * max(1, round(v["launches"] / max(n_timed["steps"], 1))) for v in leaf.values()), 1),
@@ -556,7 +564,8 @@ def main():
             # overtook the sort / composite pass, which got 20 % faster while the collection gave up half of its wavefront slots to it)
             order = sorted(leaf, key=lambda k: -leaf[k]["ms"] * leaf[k]["launches"])
             roof["next_kernels"] = [{"kernel": k, "ms_per_launch": kernels[k]["ms"], "launches_per_step": max(1, round(kernels[k]["launches"] / max(n_timed["steps"], 1))),
-                                     "achieved": kernels[k]["GBps"], "frac": round(kernels[k]["GBps"] / HBM_PEAK_GBS, 5), "traffic": pm.get(k, {}).get("hbm_bytes"),
+                                     "achieved": kernels[k]["GBps"], "frac": round(kernels[k]["GBps"] / HBM_PEAK_GBS, 5), "traffic": pm.get(k, {}).get("hbm_bytes"), "traffic_calibrated": calibrated(k),
+                                     "alg_bytes_per_launch": int(kernels[k]["alg_MB"] * 1e6),
                                      "valu_util_measured_peak": (issue_of(k) or {}).get("valu_util_measured_peak")} for k in order[1:4]]
             rb = kernels.get("composite_bwd")
             if rb and rb["GBps"]:

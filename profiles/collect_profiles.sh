@@ -1,4 +1,4 @@
-# Run on the GPU box (gpurun):  bash profiles/collect_profiles.sh   -> raw outputs under gpurun_out/, then `python profiles/summarize.py r04` here.
+# Run on the GPU box (gpurun):  bash profiles/collect_profiles.sh   -> raw outputs under gpurun_out/, then `python profiles/summarize.py r05` here.
 # Every command is bounded by `timeout` (round 3 lost 15 GPU-minutes to a counter pass that aborted and then hung).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
@@ -13,7 +13,7 @@ timeout 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_V
 timeout 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_active -o c -- $B --steps 3 --warmup 1 > /dev/null 2>&1
 timeout 120 rocprofv3 --pmc TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum --kernel-trace --output-format csv -d $O/pmc_tcp -o c -- $B --steps 3 --warmup 1 > /dev/null 2>&1
 cd $R
-python profiles/summarize.py r04 > /dev/null 2>&1     # the bench lines below quote the counters of THIS collection (profiles/r04_pmc_envgs.json)
+python profiles/summarize.py r05 > /dev/null 2>&1     # the bench lines below quote the counters of THIS collection (profiles/r05_pmc_envgs.json)
 timeout 400 python bench.py > $O/bench_envgs_final.json 2> $O/bench_envgs_final.err
 timeout 120 python bench.py --caller reference --no-cpu-baseline > $O/bench_envgs_reference_caller_final.json 2> $O/bench_envgs_reference_caller_final.err
 timeout 120 python bench.py --caller twin --no-cpu-baseline --no-reference-caller > $O/bench_envgs_twin_caller_final.json 2> $O/bench_envgs_twin_caller_final.err
