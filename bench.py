@@ -533,6 +533,11 @@ def main():
             out = {"valu_insts_per_launch": int(valu), "salu_insts_per_launch": int(salu),
                    "valu_ginst_per_s": round(valu / t / 1e9, 1), "valu_peak_ginst_per_s": VALU_PEAK_GINST, "valu_util": round(valu / t / 1e9 / VALU_PEAK_GINST, 4),
                    "salu_ginst_per_s": round(salu / t / 1e9, 1), "salu_peak_ginst_per_s": SALU_PEAK_GINST, "salu_util": round(salu / t / 1e9 / SALU_PEAK_GINST, 4)}
+            tot = sum(r.get(k_, 0.0) for k_ in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM", "SQ_INSTS_LDS"))
+            out["all_insts_per_launch"] = int(tot)                       # every instruction type: what an issue-bound kernel pays for (profiles/r05_ab_collect.txt)
+            out["all_ginst_per_s"] = round(tot / t / 1e9, 1)
+            if r.get("SQ_WAVE_CYCLES"):
+                out["wait_share_of_wave_cycles"] = round(r.get("SQ_WAIT_ANY", 0.0) / r["SQ_WAVE_CYCLES"], 3)
             out["valu_measured_peak_ginst_per_s"] = VALU_MEASURED_GINST
             out["valu_util_measured_peak"] = round(valu / t / 1e9 / VALU_MEASURED_GINST, 4)
             out["source"] = PMC_SUMMARY

@@ -602,6 +602,9 @@ constexpr int RH_W = 8;         // register_hits: wavefronts per batch -- wave q
 
 // ---- kernels (the launch bounds / occupancy attributes are repeated here: a declaration without them makes the compiler assume 1024-thread
 //      workgroups, i.e. a 128-VGPR budget, for every other translation unit AND for the definition that follows it) ------------------------------
+#ifndef ENVGS_BSB_WAVES
+#define ENVGS_BSB_WAVES 2       // wavefronts per SIMD of batch_surfel_bwd (223 / 231 VGPRs): 3 needs 168 VGPRs = 41 / 52 spilled dwords -- measured, see DESIGN.md section 9
+#endif
 struct ForwardPrepare {
     ZeroBatch zero; int zero_blocks;                                                                      // 512 blocks per buffer to clear
     int P, rec_blocks; float mod; const float *means, *scales, *rots, *opac; float *srec;                 // surfel records (rec_blocks = 0: none)
@@ -642,9 +645,9 @@ __global__ void __launch_bounds__(256) row_offsets(const TraceArgs A, const unsi
                                                    const unsigned *__restrict__ seg_base, unsigned long long limit);      // blk: exclusive scan of the per-BATCH row counts
 __global__ void __launch_bounds__(256) unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, unsigned *__restrict__ cnt,
                                                          float *__restrict__ wet, unsigned *ray_counter);
-template <bool RGBO> __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd(const TraceArgs A);
-extern template __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd<false>(const TraceArgs A);
-extern template __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd<true>(const TraceArgs A);
+template <bool RGBO> __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd(const TraceArgs A);
+extern template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<false>(const TraceArgs A);
+extern template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<true>(const TraceArgs A);
 __global__ void __launch_bounds__(256) reduce_surfel_records(const TraceArgs A);
 __global__ void __launch_bounds__(256) finish_surfel_grads(int P, const float *__restrict__ rots, const float *__restrict__ geo_rec,
                                                            float *__restrict__ dmeans, float *__restrict__ dscales, float *__restrict__ dopac,

@@ -59,7 +59,7 @@ constexpr int RECW = 64;      // floats per (batch, surfel) gradient record: 48 
 // pass's depth / accumulation / normal maps are not supervised.  Seven per-ray gradient constants and their terms drop out, and of the per-hit
 // state only plane 0 (16 B: transmittance before the hit + the three colour prefix sums) is fetched instead of 32 / 48 B.
 template <bool RGBO>
-__global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64)
+__global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64)
 batch_surfel_bwd(const TraceArgs A)
 {
     __shared__ float4 sdat[2][BS_GROUP][16];               // per entry: surfel record (4 x 16 B) + SH block (12 x 16 B)
@@ -362,8 +362,8 @@ batch_surfel_bwd(const TraceArgs A)
     }
 }
 
-template __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd<false>(const TraceArgs A);
-template __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) batch_surfel_bwd<true>(const TraceArgs A);
+template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<false>(const TraceArgs A);
+template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<true>(const TraceArgs A);
 
 // Stage 2: sum each surfel's (batch, surfel) records into the (zeroed) gradient buffers -- plain stores, every word has one owner; the
 // K-buffer pass for overflowed rays runs afterwards and adds to the same buffers atomically.  16 lanes per surfel, 16 B per lane = one
