@@ -87,6 +87,12 @@ batch_surfel_bwd(const TraceArgs A)
             for (int k = 0; k < 16; k++) basis[k] = 0.f;
             sh_basis(A.D, B.ux, B.uy, B.uz, basis);
             if (A.M == 0) basis[0] = kC0;
+            if (!(B.il > 0.0f && B.il < 3.0e38f)) {
+                // a ray without a direction (zero, NaN or infinite d) composited nothing, but its basis is a row of the MFMA operand that sums the
+                // batch's colour gradients: 0 * NaN there would poison dL/dshs of every surfel the OTHER 63 rays blended
+#pragma unroll
+                for (int k = 0; k < 16; k++) basis[k] = 0.f;
+            }
             Box = B.ox; Boy = B.oy; Boz = B.oz; Bdx = B.dx; Bdy = B.dy; Bdz = B.dz;
             gR0 = B.gR0; gR1 = B.gR1; gR2 = B.gR2;
             if constexpr (RGBO) { gD = gA = gN0 = gN1 = gN2 = gX0 = gX1 = 0.f; }
@@ -451,7 +457,8 @@ finish_surfel_grads(int P, const float *__restrict__ rots, const float *__restri
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
     const float q0 = rots[4 * i], q1 = rots[4 * i + 1], q2 = rots[4 * i + 2], q3 = rots[4 * i + 3];
-    const float inv = 1.0f / sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    const float qq = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
+    const float inv = qq > 0.0f ? 1.0f / sqrtf(qq) : 0.0f;      // (a zero quaternion has no frame: no ray can have hit it, its gradient is zero -- not 0 * inf)
     const float r = q0 * inv, x = q1 * inv, y = q2 * inv, z = q3 * inv;
     const float *g = geo_rec + (size_t)i * GEO;
     const float *rr = g + 3;
