@@ -145,3 +145,59 @@ def test_tracer_on_a_side_stream_with_views_and_double_rays():
     # debug=True
     outs, _, _, _ = run(e, ro, rd, ts._replace(debug=True))
     assert torch.equal(outs[0], ref[0])
+
+
+def test_two_outstanding_forwards_and_a_repeated_backward():
+    """Multi-view accumulation (north_star's 8-view batch on fewer GPUs): several forwards of BOTH extensions are outstanding when backward() runs --
+    each call's saved state must be its own (no scratch shared between calls that a later forward overwrites) -- and backward(retain_graph=True)
+    may run twice over the same saved state."""
+    import diff_surfel_rasterization_wet_ch05 as pkg
+    import diff_surfel_tracing as tpkg
+    from envgs_amd import envgs_step
+    dev = torch.device("cuda:0")
+    Hh, Ww = 64, 80
+    base = {k: v.to(dev) for k, v in synth.base_gaussians(1500, seed=3).items()}
+    base["scales"] = base["scales"] * 5.0
+    env = {k: v.to(dev) for k, v in synth.env_gaussians(800, seed=4, bound=12.0).items()}
+    cams = [synth.orbit_camera(v, n_views=4, H=Hh, W=Ww, fx=1111.1 * Ww / 800.0, device=dev) for v in range(3)]
+    rays = [synth.get_rays(c) for c in cams]
+    bg = torch.zeros(3, device=dev); env_bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    deg = torch.tensor([2], device=dev)
+    gen = torch.Generator().manual_seed(5)
+    ups = [torch.randn(Hh, Ww, 3, generator=gen).to(dev) / (Hh * Ww) for _ in cams]
+    for fused in (False, True):
+        envgs_step.FUSED["on"] = fused
+        try:
+            def leaves():
+                return ({k: v.clone().requires_grad_(True) for k, v in base.items()}, {k: v.clone().requires_grad_(True) for k, v in env.items()})
+
+            def grads_of(b, e):
+                return {**{"base." + k: v.grad.clone() for k, v in b.items() if v.grad is not None}, **{"env." + k: v.grad.clone() for k, v in e.items() if v.grad is not None}}
+            # reference: one view at a time, gradients accumulated by autograd
+            b, e = leaves()
+            tracer = tpkg.SurfelTracer()
+            for v in range(3):
+                out = envgs_step.envgs_forward(pkg, tpkg, tracer, cams[v], rays[v], b, e, bg, env_bg, deg)
+                (out["rgb"] * ups[v]).sum().backward()
+            want = grads_of(b, e)
+            # three forwards outstanding, ONE backward
+            b, e = leaves()
+            tracer = tpkg.SurfelTracer()
+            loss = 0.0
+            for v in range(3):
+                out = envgs_step.envgs_forward(pkg, tpkg, tracer, cams[v], rays[v], b, e, bg, env_bg, deg)
+                loss = loss + (out["rgb"] * ups[v]).sum()
+            loss.backward(retain_graph=True)
+            torch.cuda.synchronize()
+            got = grads_of(b, e)
+            assert set(got) == set(want)
+            for k in want:
+                assert _close(got[k], want[k], 2e-5), (fused, k, float((got[k] - want[k]).abs().max()), float(want[k].abs().max()))
+            # ... and once more over the same saved state: the accumulated gradients double
+            loss.backward()
+            torch.cuda.synchronize()
+            twice = grads_of(b, e)
+            for k in want:
+                assert _close(twice[k], 2.0 * want[k], 2e-5), (fused, "second backward", k)
+        finally:
+            envgs_step.FUSED["on"] = False
