@@ -24,7 +24,7 @@ def pytest_configure(config):
 
 # Collection order under -m gpu: the oracle-parity files first, so that a late failure under `-x` costs the least evidence (a failing
 # stopwatch in an alphabetically early file hid 140 parity tests); the structural / stress / multi-process files last.
-_ORDER = ["test_raster_parity", "test_trace_parity", "test_envgs_step_parity", "test_full_size_gpu", "test_tile_binning", "test_fp16_storage",
+_ORDER = ["test_raster_parity", "test_trace_parity", "test_envgs_step_parity", "test_full_size_gpu", "test_independent_f64_gpu", "test_tile_binning", "test_fp16_storage",
           "test_fused_glue", "test_fused_adam", "test_loss", "test_densify", "test_densify_schedule", "test_caller_contract", "test_sampler_replay",
           "test_reference_kernel_golden", "test_robustness_gpu", "test_boundary_variations_gpu", "test_scratch_buckets", "test_bvh_structure", "test_train_convergence", "test_stress_gpu",
           "test_bench_two_ranks", "test_two_gpus_nccl"]
