@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--optim", default="fused", choices=["fused", "torch", "none"],
                     help="optimizer step inside the timed iteration: sparse fused Adam (envgs_amd.optim, SURVEY 8(f).2), torch.optim.Adam, or none")
     ap.add_argument("--no-overlap-allreduce", action="store_true", help="N > 1: exchange the gradient buckets after backward() instead of launching them from backward hooks")
-    ap.add_argument("--exchange", default="direct", choices=["direct", "allreduce"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "direct", "allreduce"],
                     help="N > 1: direct reduce-scatter + all-gather over the xGMI mesh (all_to_all + local sum + all_gather), or one all_reduce per bucket")
     ap.add_argument("--no-render", action="store_true", help="skip the forward-only render timing (profiling runs: keeps the kernel statistics to the training steps)")
     ap.add_argument("--bvh-rebuild-every", type=int, default=16, help="the tracer's build-or-refit policy (every caller form): a full LBVH build at least on every K-th request, refits "
@@ -310,6 +310,9 @@ def main():
 
     for it in range(args.warmup):
         step(it)
+    exch_tune = None
+    if reducer is not None and args.exchange == "auto":
+        exch_tune = reducer.autotune()             # N > 1: both exchange forms measured on this machine between warm-up and the timed regions; the faster one is used
     n_acc.update(N=0, steps=0)
     lib.envgs_prof_enable(1)
     NK = 0
@@ -588,7 +591,7 @@ def main():
             "config": {"workload": (("Ref-Real sedan-like full EnvGS (ch0%d raster + env LBVH trace)" % C) if envgs else
                                     "Ref-NeRF toaster-like base 2DGS raster only (BASELINE configs[1]), SH deg 3 in-kernel"),
                        "gaussians": P, "env_gaussians": (args.env_gaussians if envgs else 0), "resolution": [H, W], "trace_depth": (args.trace_depth if envgs else None), "channels": C, "views": 8,
-                       "parallelism": "dp%d (camera batch sharded, %s)" % (world, ("env / base flat grad buffers, %s, %s" % (args.exchange, "launched from backward hooks" if not args.no_overlap_allreduce else "after backward")) if reducer is not None else "single GPU"),
+                       "parallelism": "dp%d (camera batch sharded, %s)" % (world, ("env / base flat grad buffers, %s, %s" % ((args.exchange if exch_tune is None else "auto -> %s (direct %.3f ms, allreduce %.3f ms per exchange of both buckets)" % (exch_tune["chosen"], exch_tune["direct"], exch_tune["allreduce"])), "launched from backward hooks" if not args.no_overlap_allreduce else "after backward")) if reducer is not None else "single GPU"),
                        "optimizer": {"fused": "sparse fused Adam, one launch (envgs_amd.optim)", "torch": "torch.optim.Adam", "none": "none"}[args.optim],
                        "caller_glue": ("n/a (raster only)" if not envgs else {"fused": "fused HIP (envgs_amd.fused)", "twin": "torch expressions (envgs_amd/envgs_step.py)",
                                        "reference": "the unchanged EasyVolcap caller's expression forms (batched-matmul get_disks, render()'s regulariser maps + normal term)"}[args.caller]),

@@ -166,6 +166,10 @@ class GradExchange:
 
     def __init__(self, get_buckets, average=True, group=None, algo="direct", overlap=True):
         self.get_buckets = get_buckets if callable(get_buckets) else (lambda b=get_buckets: b)
+        if algo not in ("direct", "allreduce", "auto"):
+            raise ValueError("algo must be 'direct', 'allreduce' or 'auto', got %r" % (algo,))
+        self.auto = algo == "auto"                       # "auto": the direct form until autotune() has measured both on this machine
+        algo = "direct" if self.auto else algo
         self.average, self.group, self.algo, self.overlap = average, group, algo, overlap
         self.enabled = _active(group)
         self.world = dist.get_world_size(group) if self.enabled else 1
@@ -280,6 +284,46 @@ class GradExchange:
                 B.done = None
             nbytes += B.flat.numel() * 4
         return nbytes
+
+    def autotune(self, reps=3):
+        """Measure BOTH exchange forms on buffers of this exchange's own sizes and keep the faster one (collective: every rank calls it at the same
+        point, between steps; the decision is taken on the MAX over ranks, so all ranks switch together).  The direct form assumes that RCCL's
+        all-to-all drives the seven xGMI links of a GPU concurrently -- an assumption no run had checked when this was
+        written; `algo="auto"` callers (bench.py's default for N > 1) let the first steps on real hardware decide instead.  Returns
+        {"direct": ms, "allreduce": ms, "chosen": name} (None with one process)."""
+        import time
+        if not self.enabled:
+            return None
+        if not self.buckets:
+            self._rebuild(self.get_buckets())
+        dev = self.buckets[0].flat.device if self.buckets else torch.device("cpu")
+
+        def sync():
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            dist.barrier(group=self.group)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+        tmp = [torch.zeros_like(B.flat) for B in self.buckets]                       # (the gradients themselves are not touched)
+        scratch = [(torch.empty_like(B.flat), torch.empty(B.flat.numel() // self.world, dtype=torch.float32, device=B.flat.device)) for B in self.buckets]
+        ms = {}
+        for algo in ("direct", "allreduce"):
+            for it in range(reps + 1):
+                if it == 1:
+                    sync(); t0 = time.perf_counter()
+                for t, (rv, mn) in zip(tmp, scratch):
+                    if t.numel():
+                        exchange_flat(t, average=self.average, group=self.group, algo=algo, recv=rv, mine=mn)
+            sync()
+            ms[algo] = (time.perf_counter() - t0) / reps * 1e3
+        tt = torch.tensor([ms["direct"], ms["allreduce"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.group)
+        ms = {"direct": float(tt[0]), "allreduce": float(tt[1])}
+        self.algo = "direct" if ms["direct"] <= ms["allreduce"] else "allreduce"
+        for B, (rv, mn) in zip(self.buckets, scratch):                                # the direct form's persistent scratch, if it won
+            B.recv, B.mine = (rv, mn) if self.algo == "direct" else (None, None)
+        ms["chosen"] = self.algo
+        return ms
 
     def remove(self):
         for h in self._hooks:

@@ -19,7 +19,7 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("exchange", ["direct", "allreduce"])
+@pytest.mark.parametrize("exchange", ["direct", "allreduce", "auto"])
 def test_bench_two_ranks_gloo_on_one_gpu(exchange):
     env = dict(os.environ, ENVGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),

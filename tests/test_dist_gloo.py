@@ -64,7 +64,10 @@ def _worker_exchange(rank, world, port, q):
                 base=[torch.nn.Parameter(torch.randn(4, 2)), torch.nn.Parameter(torch.randn(4)), torch.nn.Parameter(torch.randn(3))])   # base[2] stays unused
     ex = edist.GradExchange(lambda: [sets["env"], sets["base"]], average=True, algo="direct", overlap=True)
     out = []
-    for step in range(4):
+    tune = None
+    for step in range(5):
+        if step == 4:
+            tune = ex.autotune(reps=1)         # both exchange forms measured between two steps; every rank keeps the same (faster) one
         if step == 2:
             # "densification": every tensor of the base set is replaced by a fresh, LONGER nn.Parameter (gaussian2d_utils.py:526-621)
             sets["base"] = [torch.nn.Parameter(torch.cat([p.detach(), p.detach()[:1]])) for p in sets["base"]]
@@ -91,7 +94,7 @@ def _worker_exchange(rank, world, port, q):
     a = torch.zeros(5, 3, requires_grad=True); a.grad = torch.full((5, 3), float(rank + 1))
     edist.allreduce_grads([a], average=False, algo="direct")
     ex.remove()
-    q.put((rank, out, a.grad.tolist()))
+    q.put((rank, out, a.grad.tolist(), tune))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -109,7 +112,9 @@ def test_grad_exchange_flat_views_overlap_densify_and_multi_backward_world2():
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
-    for step in range(4):
+    assert res[0][3] is not None and res[0][3]["chosen"] == res[1][3]["chosen"] and res[0][3]["chosen"] in ("direct", "allreduce")
+    assert res[0][3]["direct"] == res[1][3]["direct"] > 0 and res[0][3]["allreduce"] == res[1][3]["allreduce"] > 0       # decided on the MAX over ranks
+    for step in range(5):
         vals = [torch.tensor(v) for v in res[0][1][step][2]]             # same seed: identical parameters on both ranks
         assert all(torch.equal(torch.tensor(a), torch.tensor(b)) for a, b in zip(res[0][1][step][2], res[1][1][step][2]))
         xs = [1.0 + step, 2.0 + step]
@@ -118,12 +123,12 @@ def test_grad_exchange_flat_views_overlap_densify_and_multi_backward_world2():
         cross_env = vals[2].sum() * (0.5 if step == 3 else 1.0)           # step 3: only rank 0 has the coupling term
         cross_base = vals[0].sum() * (0.5 if step == 3 else 1.0)
         exp = [torch.full((6, 3), xm) + cross_env, 2 * vals[1] * xm, torch.full((nb, 2), 2 * xm) + cross_base, torch.full((nb,), xm), torch.zeros(nb - 1)]
-        for rank, out, _ in res:
+        for rank, out, _, _ in res:
             nbytes, grads, _ = out[step]
             assert nbytes == (18 + 6 + (4 * nb - 1) + ((4 * nb - 1) % 2)) * 4        # two flat buckets (padded to the world size)
             for g, e in zip(grads, exp):
                 assert torch.allclose(torch.tensor(g), e, atol=1e-5), (step, rank, g, e)
-    for rank, _, ga in res:
+    for rank, _, ga, _ in res:
         assert torch.allclose(torch.tensor(ga), torch.full((5, 3), 3.0))
 
 
