@@ -489,11 +489,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         render_s = float(tt.item())
     kernels = {}
-    class _C:                                      # (the timers of the timed regions were drained right after them: timed_prof)
-        def __init__(self, v): self.value = v
-    for name, (ms, launches_, _tot) in timed_prof.items():
-        c_ = _C(launches_)
-        if c_.value > 0:
+    for name, (ms, launches, _tot) in timed_prof.items():      # (the timers of the timed regions were drained right after them: timed_prof)
+        if launches > 0:
             ab = algorithmic_bytes(name, P, N_avg, HW, C, not envgs)
             pr = 0
             if not ab and envgs and tcounts:
@@ -504,9 +501,9 @@ def main():
                 nz = sum(int((g_ != 0).sum()) for g_ in last_grads if g_ is not None)
                 tot = sum(g_.numel() for g_ in last_grads if g_ is not None)
                 ab = 28 * nz + 4 * (tot - nz)
-            per_step = max(1, round(c_.value / max(n_timed["steps"], 1)))      # the tracer forward runs its kernels once per batch segment
+            per_step = max(1, round(launches / max(n_timed["steps"], 1)))      # the tracer forward runs its kernels once per batch segment
             ab = ab / per_step                                               # (2 segments on 2 streams, overlapping): bytes per LAUNCH
-            kernels[name] = {"ms": round(ms, 4), "launches": c_.value, "alg_MB": round(ab / 1e6, 2),
+            kernels[name] = {"ms": round(ms, 4), "launches": launches, "alg_MB": round(ab / 1e6, 2),
                              "GBps": round(ab / 1e9 / (ms / 1e3), 1) if ab and ms > 0 else None}
             if pr:
                 kernels[name]["per_ray_model_MB"] = round(pr / per_step / 1e6, 1)
