@@ -622,6 +622,9 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
                 const float tf = fminf(fminf(fminf(fmaxf(sx.x, sx.y), fmaxf(sy.x, sy.y)), fmaxf(sz.x, sz.y)), tkill);
                 const bool hit = tn <= tf;                        // (tmin <= tkill always, so this is the three-way test of the other kernels)
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+#if defined(ENVGS_COOP_TIMING) && ENVGS_COOP_TIMING == 3      // scratch/ measurement build: stats[6] = leaf slots slab-tested, stats[8] = lanes that passed a leaf slot's slab test
+                if (ch < 0) { cyc_expand += 1ull; cyc_wait += (unsigned long long)__builtin_popcountll(m); }
+#endif
                 if (m != 0ull) {
                     if (ch < 0) {
                         const int sid = ~ch;
@@ -747,7 +750,9 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
         const unsigned long long c2 = __builtin_readcyclecounter();
         __syncthreads();
         const unsigned long long c3 = __builtin_readcyclecounter();
-#ifdef ENVGS_COOP_TIMING
+#if defined(ENVGS_COOP_TIMING) && ENVGS_COOP_TIMING == 3
+        (void)c0; (void)c1; (void)c2; (void)c3;               // (counters, not cycles, in the slots)
+#elif defined(ENVGS_COOP_TIMING)
         cyc_walk += c2 - c0; (void)c1; (void)c3;              // expansion + walks; the other two slots hold the leaf-test split
 #else
         cyc_expand += c1 - c0; cyc_walk += c2 - c1; cyc_wait += c3 - c2;
