@@ -542,8 +542,8 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             atomicAdd(&L.od[lane][b], dep);
             atomicAdd(&L.odtot[lane], dep);
         };
-        // look at the bound -- and recompute it (31 LDS reads and ~125 VALU, as much as two leaf tests) only when some ray that can be cut at all
-        // has gathered noticeably more optical depth than at its last recomputation
+        // look at the bound -- and recompute it (eight ds_read_b128 and ~125 VALU, as much as two leaf tests) only when some ray that can be cut at
+        // all has gathered noticeably more optical depth than at its last recomputation
         auto refresh_bound = [&]() {
             const float tot = ENVGS_LDS_READ(L.odtot[lane]);
             if (__builtin_amdgcn_ballot_w64(tot >= KILL_OD && tot > seen + COOP_REFRESH_OD) != 0ull) {
