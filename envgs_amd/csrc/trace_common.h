@@ -69,6 +69,27 @@ __device__ __forceinline__ SurfHit hit_surfel(const float4 s0, const float4 s1, 
     return h;
 }
 
+// The same hit at a KNOWN distance: the sort / composite pass holds t as the high word of the (t, id) key the collection wrote -- computed there by
+// hit_surfel's own expression -- so the IEEE division and the numerator's dot product are not repeated (round 5: ~15 VALU per 64-hit chunk less).
+__device__ __forceinline__ SurfHit hit_surfel_at(const float4 s0, const float4 s1, const float4 s2, const float4 s3, const float t,
+                                                 const float ox, const float oy, const float oz, const float dx, const float dy, const float dz)
+{
+    SurfHit h;
+    {
+#pragma clang fp contract(off)
+        h.denom = s3.x * dx + s3.y * dy + s3.z * dz;
+    }
+    h.t = t;
+    const float qx = ox + h.t * dx - s0.x, qy = oy + h.t * dy - s0.y, qz = oz + h.t * dz - s0.z;
+    h.u = s1.x * qx + s1.y * qy + s1.z * qz;
+    h.v = s2.x * qx + s2.y * qy + s2.z * qz;
+    h.G = __expf(-0.5f * (h.u * h.u + h.v * h.v));
+    const float a = s0.w * h.G;
+    h.alpha = a < ALPHA_CAP ? a : ALPHA_CAP;
+    h.ok = true;
+    return h;
+}
+
 __device__ __forceinline__ void sh_basis(int D, float x, float y, float z, float *b)
 {
     b[0] = kC0;

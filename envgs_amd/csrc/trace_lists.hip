@@ -241,7 +241,11 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
             sid = (int)(unsigned)kreg[ce];
             const float4 *sr = A.srec + (size_t)sid * 4;
             s3 = sr[3];
+#ifdef ENVGS_SORT_RECOMPUTE_T
             const SurfHit h = hit_surfel(sr[0], sr[1], sr[2], s3, ox, oy, oz, dx, dy, dz);
+#else
+            const SurfHit h = hit_surfel_at(sr[0], sr[1], sr[2], s3, __uint_as_float((unsigned)(kreg[ce] >> 32)), ox, oy, oz, dx, dy, dz);      // t = the key's own high word
+#endif
             alpha = h.alpha; t = h.t; sg = h.denom < 0.0f ? 1.f : -1.f;
         }
         const float P = wave_scan_mul(1.0f - alpha);                    // prod_{j<=i} (1 - alpha_j) within the chunk
