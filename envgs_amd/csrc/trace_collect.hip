@@ -606,7 +606,9 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             qn = 0;
             refresh_bound();
         };
-        auto step = [&](const int cur, int (&key)[4], int (&ref)[4]) -> int {
+        // (kr[c]: entry-distance bits << 32 | child reference of an entered internal child -- the frontier's item format; 0x7fffffff'ffffffff = not entered.
+        //  One aligned scalar pair per child: a compare-exchange of the ordering network is one s_cmp on the high words and two 64-bit selects)
+        auto step = [&](const int cur, unsigned long long (&kr)[4]) -> int {
             const float4 *nd = nodes4 + (size_t)cur * 8;
             psteps++;
             float4 qa[4], qb[4];
@@ -632,7 +634,7 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int ch = __builtin_amdgcn_readfirstlane(__float_as_int(qb[c].z));
-                key[c] = 0x7fffffff; ref[c] = -1;
+                kr[c] = 0x7fffffffffffffffull;
                 if (ch == WIDE_EMPTY) continue;                  // (a fifth of the slots of the bench tree: bottom nodes with leaf children)
                 const f32x2 sx = (f32x2{qa[c].x, qa[c].y} - o2x) * i2x, sy = (f32x2{qa[c].z, qa[c].w} - o2y) * i2y,
                             sz = (f32x2{qb[c].x, qb[c].y} - o2z) * i2z;
@@ -686,8 +688,7 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
                         }
                     } else {
                         const int fl = (int)__builtin_ctzll(m);
-                        key[c] = __builtin_amdgcn_readlane(__float_as_int(tn), fl);      // tn >= tmin >= 0: the float bits order like integers
-                        ref[c] = ch;
+                        kr[c] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(__float_as_int(tn), fl) << 32) | (unsigned)ch;      // tn >= tmin >= 0: the float bits order like integers
                         ninner++;
                     }
                 }
@@ -712,11 +713,11 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             if (ncur >= COOP_FRONT || ncur == 0) break;
             for (int i = wave; i < ncur; i += COOP_W) {
                 const int cur = __builtin_amdgcn_readfirstlane((int)(unsigned)L.items[buf][i]);
-                int key[4], ref[4];
-                if (step(cur, key, ref) > 0 && lane == 0) {
+                unsigned long long kr[4];
+                if (step(cur, kr) > 0 && lane == 0) {
 #pragma unroll
                     for (int c = 0; c < 4; c++)
-                        if (ref[c] >= 0) L.items[buf ^ 1][atomicAdd(&L.nitems[buf ^ 1], 1)] = ((unsigned long long)(unsigned)key[c] << 32) | (unsigned)ref[c];
+                        if ((int)(unsigned)kr[c] >= 0) L.items[buf ^ 1][atomicAdd(&L.nitems[buf ^ 1], 1)] = kr[c];
                 }
             }
             if (DEFER) flush();                                 // (the next level's slab tests see this level's hits)
@@ -758,18 +759,17 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
                     --sp;
                     cur = __builtin_amdgcn_readfirstlane(stk[sp]);
                 }
-                int key[4], ref[4];
-                const int ninner = step(cur, key, ref);
-#define ENVGS_CSWAP(a, b) { const bool sw = key[a] > key[b]; const int ka = sw ? key[b] : key[a], kb2 = sw ? key[a] : key[b], \
-                                       ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b]; key[a] = ka; key[b] = kb2; ref[a] = ra; ref[b] = rb; }
+                unsigned long long kr[4];
+                const int ninner = step(cur, kr);
+#define ENVGS_CSWAP(a, b) { const bool sw = (unsigned)(kr[a] >> 32) > (unsigned)(kr[b] >> 32); const unsigned long long lo_ = sw ? kr[b] : kr[a], hi_ = sw ? kr[a] : kr[b]; kr[a] = lo_; kr[b] = hi_; }
                 if (ninner >= 2) {
                     ENVGS_CSWAP(0, 1) ENVGS_CSWAP(2, 3) ENVGS_CSWAP(0, 2) ENVGS_CSWAP(1, 3) ENVGS_CSWAP(1, 2)
 #pragma unroll
                     for (int c = 3; c >= 1; c--)
-                        if (ref[c] >= 0) { if (sp < slimit) stk[sp++] = ref[c]; else ovf = true; }
-                    cur = ref[0];
+                        if ((int)(unsigned)kr[c] >= 0) { if (sp < slimit) stk[sp++] = (int)(unsigned)kr[c]; else ovf = true; }
+                    cur = (int)(unsigned)kr[0];
                 } else {
-                    cur = max(max(ref[0], ref[1]), max(ref[2], ref[3]));
+                    cur = max(max((int)(unsigned)kr[0], (int)(unsigned)kr[1]), max((int)(unsigned)kr[2], (int)(unsigned)kr[3]));
                 }
 #undef ENVGS_CSWAP
             }
