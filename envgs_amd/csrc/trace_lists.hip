@@ -411,7 +411,10 @@ register_hits(const TraceArgs A)
         int n = 0;
         uint2 *list = A.hits;
         if (r < A.R && A.hit_cnt[r] <= A.cap) { n = A.n_used[r]; list = A.hits + (size_t)r * A.cap; }
-        constexpr int U = 4;
+#ifndef ENVGS_RH_U
+#define ENVGS_RH_U 4
+#endif
+        constexpr int U = ENVGS_RH_U;
         // (each lane walks its own list row: the loads of one step are 64 different cache lines, so the next step's entries are requested
         //  before this step's chain of LDS atomics starts)
         uint2 nxt[U];
@@ -477,7 +480,7 @@ register_hits(const TraceArgs A)
             // the first phase) and takes the next free position of that surfel's run of pairs: acc[h] holds the run's offset in its low word
             // and hands out ranks from its high word.  (Writing slot and rank back into the list in the first phase instead cost a scattered
             // 4 B store -- a whole 32 B sector of write traffic -- and a second gather per hit: 2 GB per step.)
-            constexpr int U2 = 4;                               // independent loads first: one memory round trip per 4 hits, not per hit
+            constexpr int U2 = ENVGS_RH_U;                      // independent loads first: one memory round trip per 4 hits, not per hit
             for (int kb = part; kb < n; kb += U2 * RH_W) {
                 unsigned sidv[U2];
 #pragma unroll
