@@ -27,6 +27,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # N > 1: the host driver only supports dmabuf IPC (RCCL's buffer exchange fails with the legacy mode)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
