@@ -54,6 +54,7 @@ composite_lists_bwd(const TraceArgs A)
 // per-hit gathers of surfel data, no dependent chain along the ray, no atomics.
 constexpr int BS_GROUP = 16;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int BT_PITCH = 96;  // words per row of the reduction tile: 64 rays + the skew of 2 words per row (<= 30), never wrapped
 constexpr int RECW = 64;      // floats per (batch, surfel) gradient record: 48 SH (or 3 colour) + 15 geometry + pad
 // RGBO: the colour is the only output with an upstream gradient (g_dpt / g_acc / g_norm / g_aux all NULL) -- the EnvGS training step: the env
 // pass's depth / accumulation / normal maps are not supervised.  Seven per-ray gradient constants and their terms drop out, and of the per-hit
@@ -67,7 +68,7 @@ batch_surfel_bwd(const TraceArgs A)
     __shared__ unsigned short kmat[2][BS_GROUP][64];       // per entry and ray: list position of the hit + 1, 0 = the ray did not blend it
     __shared__ unsigned spb[2][BS_GROUP];                  // per entry: index of its first pair
     __shared__ unsigned scn[2][BS_GROUP];                  // per entry: hits
-    __shared__ float btile[16][64];                        // B operand of the reduction MFMAs: 16 words per ray, swizzled (see below)
+    __shared__ float btile[16][BT_PITCH];                  // B operand of the reduction MFMAs: 16 words per ray, skewed (see below)
     const int lane = threadIdx.x;
     const int nb = (A.D + 1) * (A.D + 1);
     const int nbatch = (A.R + 63) >> 6;
@@ -104,10 +105,18 @@ batch_surfel_bwd(const TraceArgs A)
         float Areg[16];
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; k++) btile[k][(lane + 2 * k) & 63] = (valid && k < nb) ? basis[k] : (k == 0 ? kC0 : 0.f);
+        for (int k = 0; k < 16; k++) btile[k][lane + 2 * k] = (valid && k < nb) ? basis[k] : (k == 0 ? kC0 : 0.f);
         __syncthreads();
 #pragma unroll
-        for (int sI = 0; sI < 16; sI++) Areg[sI] = btile[lane & 15][(4 * sI + (lane >> 4) + 2 * (lane & 15)) & 63];
+        for (int sI = 0; sI < 16; sI++) Areg[sI] = btile[lane & 15][4 * sI + (lane >> 4) + 2 * (lane & 15)];
+        // ... and of the COLOUR MFMAs (the other orientation: rows = rays): Acol[4 b + s] of lane l = basis_{4 s + (l >> 4)} of ray 16 b + (l & 15).
+        // The rays' own basis[] registers are dead from here on (16 VGPRs either way).
+        float Acol[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int k = 4 * (q & 3) + (lane >> 4);
+            Acol[q] = btile[k][16 * (q >> 2) + (lane & 15) + 2 * k];
+        }
         __syncthreads();
         // dL/d(SH basis) of the rays, accumulated on the matrix cores in the MFMA output layout: SkM[b][i] of lane l = (ray 16 b + 4 (l >> 4) + i,
         // basis l & 15); handed to the rays through LDS at the end of the batch
@@ -229,7 +238,7 @@ batch_surfel_bwd(const TraceArgs A)
                 // entry's place in a run of FIVE: all entries of a batch share the A operand (the rays' basis values), so one set of sixteen
                 // MFMAs reduces the colour columns of five entries (the matrix pipe's 16 x 32 cycles per set are not hidden by the other
                 // wavefront: 0.66 of 3.64 ms when every entry had its own set).  The 15 geometry words only ever needed the plain sum over the
-                // rays and take the rasterizer's wavefront transpose-reduce instead.  Tile layout: word n of ray j at n*64 + ((j + 2n) & 63):
+                // rays and take the rasterizer's wavefront transpose-reduce instead.  Tile layout: word n of ray j at n*BT_PITCH + j + 2n (round 5: rows of 96 words, the skew no longer wraps -- every operand address is one base + an immediate):
                 // conflict-free both for the writes (fixed n, 64 rays) and for the MFMA operand reads (16 words x 4 rays).  One wavefront
                 // per workgroup: its LDS operations execute in program order, so no barrier is needed -- and a barrier's vmcnt(0) would
                 // drain the state prefetch that is in flight.
@@ -237,20 +246,39 @@ batch_surfel_bwd(const TraceArgs A)
                 float gw[16];
 #pragma unroll
                 for (int n = 0; n < 16; n++) gw[n] = 0.f;
-#define BT(n) btile[3 * e5 + (n)][(lane + 2 * (3 * e5 + (n))) & 63]
+#define BT(n) btile[3 * e5 + (n)][lane + 2 * (3 * e5 + (n))]
+                // The SH colours of the run's five entries for all 64 rays, on the matrix cores (round 5; every lane used to evaluate its own:
+                // 48 FMAs and twelve 16 B LDS reads per entry and lane):  [64 rays x 16 basis values] . [16 x 15]  (column 3 e + c = colour c of
+                // the run's e-th surfel, straight from the staged SH blocks) = 16 MFMAs per run, written into the tile's columns 3 e + c --
+                // exactly the slots that receive the entry's colour GRADIENT a few lines below, once the lane has read its colour from them.
+                if (A.M > 0 && e5 == 0) {
+                    const int nrun = min(5, ne - el);
+                    const int kk = lane >> 4, nn = lane & 15, ee = nn / 3, c2 = nn - 3 * ee;
+                    f32x4 cc0 = {0.f, 0.f, 0.f, 0.f}, cc1 = cc0, cc2 = cc0, cc3 = cc0;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) {
+                        float bval = 0.f;
+                        if (nn < 15 && ee < nrun) bval = reinterpret_cast<const float *>(&sdat[buf][el + ee][4])[(4 * ks + kk) * 3 + c2];
+                        cc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Acol[ks], bval, cc0, 0, 0, 0);
+                        cc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Acol[4 + ks], bval, cc1, 0, 0, 0);
+                        cc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Acol[8 + ks], bval, cc2, 0, 0, 0);
+                        cc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(Acol[12 + ks], bval, cc3, 0, 0, 0);
+                    }
+                    if (nn < 15) {
+                        float *trow = &btile[nn][0];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int j = 4 * kk + i + 2 * nn;                 // (output layout: element i of lane l = row 4 (l >> 4) + i, column l & 15)
+                            trow[j] = cc0[i]; trow[j + 16] = cc1[i]; trow[j + 32] = cc2[i]; trow[j + 48] = cc3[i];
+                        }
+                    }
+                }
                 if (act) {
                     const float4 s0 = sdat[buf][el][0], s1 = sdat[buf][el][1], s2 = sdat[buf][el][2], s3 = sdat[buf][el][3];
                     const SurfHit h = hit_surfel(s0, s1, s2, s3, Box, Boy, Boz, Bdx, Bdy, Bdz);
                     float col[3]; bool cl[3] = {false, false, false};
                     if (A.M > 0) {
-                        float rc[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int q4 = 0; q4 < 12; q4++) {
-                            const float4 x = sdat[buf][el][4 + q4];
-                            const float xe[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                            for (int e = 0; e < 4; e++) { const int idx = 4 * q4 + e; rc[idx % 3] += basis[idx / 3] * xe[e]; }
-                        }
+                        const float rc[3] = {BT(0), BT(1), BT(2)};
 #pragma unroll
                         for (int c = 0; c < 3; c++) { const float v = rc[c] + 0.5f; cl[c] = v < 0.f; col[c] = cl[c] ? 0.f : v; }
                     } else { const float4 x = sdat[buf][el][4]; col[0] = x.x; col[1] = x.y; col[2] = x.z; }
@@ -314,10 +342,10 @@ batch_surfel_bwd(const TraceArgs A)
                         const int rot = 2 * n + j;
 #pragma unroll
                         for (int sI = 0; sI < 16; sI += 4) {
-                            acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI], brow[(4 * sI + rot) & 63], acc4, 0, 0, 0);
-                            accB = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 1], brow[(4 * sI + 4 + rot) & 63], accB, 0, 0, 0);
-                            accC = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 2], brow[(4 * sI + 8 + rot) & 63], accC, 0, 0, 0);
-                            accD = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 3], brow[(4 * sI + 12 + rot) & 63], accD, 0, 0, 0);
+                            acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI], brow[4 * sI + rot], acc4, 0, 0, 0);
+                            accB = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 1], brow[4 * sI + 4 + rot], accB, 0, 0, 0);
+                            accC = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 2], brow[4 * sI + 8 + rot], accC, 0, 0, 0);
+                            accD = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 3], brow[4 * sI + 12 + rot], accD, 0, 0, 0);
                         }
                     }
                     acc4 = (acc4 + accB) + (accC + accD);
@@ -343,7 +371,7 @@ batch_surfel_bwd(const TraceArgs A)
                             const float *arow = &btile[col][0];
 #pragma unroll
                             for (int rb = 0; rb < 4; rb++)
-                                SkM[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[(16 * rb + nn + 2 * col) & 63], bval, SkM[rb], 0, 0, 0);
+                                SkM[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[16 * rb + nn + 2 * col], bval, SkM[rb], 0, 0, 0);
                         }
                     }
                 }
