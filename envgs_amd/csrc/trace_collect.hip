@@ -608,7 +608,8 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
         };
         // (kr[c]: entry-distance bits << 32 | child reference of an entered internal child -- the frontier's item format; 0x7fffffff'ffffffff = not entered.
         //  One aligned scalar pair per child: a compare-exchange of the ordering network is one s_cmp on the high words and two 64-bit selects)
-        auto step = [&](const int cur, unsigned long long (&kr)[4]) -> int {
+        auto step = [&](const int cur_, unsigned long long (&kr)[4]) -> int {
+            const int cur = __builtin_amdgcn_readfirstlane(cur_);      // (the walk's `cur` reaches here through a vector phi: without this the node address is computed in VALU and read back lane by lane)
             const float4 *nd = nodes4 + (size_t)cur * 8;
             psteps++;
             float4 qa[4], qb[4];
@@ -635,7 +636,8 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             for (int c = 0; c < 4; c++) {
                 const int ch = __builtin_amdgcn_readfirstlane(__float_as_int(qb[c].z));
                 kr[c] = 0x7fffffffffffffffull;
-                if (ch == WIDE_EMPTY) continue;                  // (a fifth of the slots of the bench tree: bottom nodes with leaf children)
+                if (c >= 2 && ch == WIDE_EMPTY) continue;        // (a fifth of the slots of the bench tree: bottom nodes with leaf children; slots 0 and 1 are
+                                                                 //  always filled -- fit_nodes -- so their boxes are loaded with the node, not behind a branch)
                 const f32x2 sx = (f32x2{qa[c].x, qa[c].y} - o2x) * i2x, sy = (f32x2{qa[c].z, qa[c].w} - o2y) * i2y,
                             sz = (f32x2{qb[c].x, qb[c].y} - o2z) * i2z;
                 float tn, tf;
