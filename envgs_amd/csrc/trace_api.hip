@@ -366,8 +366,9 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
                     const bool rgb_only = dL_drgb && !dL_ddpt && !dL_dacc && !dL_dnorm && !dL_daux;
                     if (L->state_planes == 1 && !rgb_only) return ENVGS_ERR_BAD_ARG;      // the forward was told to keep the colour's plane only
                     const dim3 g(stride_grid((cfg->num_rays + 63) / 64, 1));
-                    if (rgb_only) hipLaunchKernelGGL(batch_surfel_bwd<true>, g, dim3(64), 0, stream, A);
-                    else hipLaunchKernelGGL(batch_surfel_bwd<false>, g, dim3(64), 0, stream, A);
+                    if (rgb_only) hipLaunchKernelGGL((batch_surfel_bwd<true, false>), g, dim3(64), 0, stream, A);
+                    else if (cfg->has_others) hipLaunchKernelGGL((batch_surfel_bwd<false, true>), g, dim3(64), 0, stream, A);
+                    else hipLaunchKernelGGL((batch_surfel_bwd<false, false>), g, dim3(64), 0, stream, A);
                 }
                 { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, stream, A); }
             } else {

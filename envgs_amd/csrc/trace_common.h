@@ -179,9 +179,10 @@ struct TraceArgs {
     unsigned *pairs;              // (batches, 64*cap) (lane << 16 | k) of every composited hit, grouped by entry
     int *n_entries;               // (batches, 2) table entries, single entries
     unsigned *long_list; // (R) scratch: slots of the rays whose lists exceed 256 hits, appended by the main sort pass (counter[24 + seg] = how many)
-    float4 *state;      // per composited hit, for the backward, as PLANES of 16 B rows (plane p of row i at state[p * state_plane + i]):
-                        // plane 0 = (transmittance before the hit, rgb prefix sums after it), plane 1 = (depth, normal prefix sums), plane 2 (only with
-                        // `others`; 8 B rows, i.e. float2 index i behind the two 16 B planes) = the two aux sums.  A backward whose only upstream gradient is the colour's -- what EnvGS trains with -- reads plane 0 alone
+    float4 *state;      // per composited hit, for the backward, as two PLANES: plane 0 (16 B rows, row i at state[i]) = (transmittance before the hit, rgb
+                        // prefix sums after it); plane 1 (behind the state_plane rows of plane 0; state_row1) = (depth, normal prefix sums) in 16 B rows, or
+                        // -- with `others` -- (depth, normal, the two aux sums) in 24 B rows (round 6: the aux sums used to be a third plane of 8 B rows, a
+                        // third gather per hit in the generic backward).  A backward whose only upstream gradient is the colour's -- what EnvGS trains with -- reads plane 0 alone
     size_t state_plane; // rows per plane (compact_rows, or R * cap)
     int colour_state;   // 1: only plane 0 exists (envgs_trace_lists::state_planes == 1: the backward will be the colour-only one)
     // compact per-hit buffers (envgs_trace.h: compact_rows): nullptr = the (R, cap) layouts
@@ -600,6 +601,11 @@ __device__ __forceinline__ size_t state_row0(const TraceArgs &A, const int slot,
 {
     return A.row_off ? (size_t)A.row_off[slot] : (size_t)r * A.cap;
 }
+// Plane 1 of the per-hit state, row i: 16 B rows behind plane 0's state_plane rows -- 24 B rows with `others` (TraceArgs::state)
+__device__ __forceinline__ char *state_row1(const TraceArgs &A, const size_t i)
+{
+    return reinterpret_cast<char *>(A.state + A.state_plane) + i * (A.has_others ? (size_t)24 : (size_t)16);
+}
 __device__ __forceinline__ void batch_region(const TraceArgs &A, const int batch, size_t &start, size_t &size)
 {
     if (A.batch_rows) { const uint2 br = A.batch_rows[batch]; start = br.x; size = br.y; }
@@ -666,9 +672,10 @@ __global__ void __launch_bounds__(256) row_offsets(const TraceArgs A, const unsi
                                                    const unsigned *__restrict__ seg_base, unsigned long long limit);      // blk: exclusive scan of the per-BATCH row counts
 __global__ void __launch_bounds__(256) unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, unsigned *__restrict__ cnt,
                                                          float *__restrict__ wet, unsigned *ray_counter);
-template <bool RGBO> __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd(const TraceArgs A);
-extern template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<false>(const TraceArgs A);
-extern template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<true>(const TraceArgs A);
+template <bool RGBO, bool OTH> __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd(const TraceArgs A);
+extern template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<false, false>(const TraceArgs A);
+extern template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<false, true>(const TraceArgs A);
+extern template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<true, false>(const TraceArgs A);
 __global__ void __launch_bounds__(256) reduce_surfel_records(const TraceArgs A);
 __global__ void __launch_bounds__(256) finish_surfel_grads(int P, const float *__restrict__ rots, const float *__restrict__ geo_rec,
                                                            float *__restrict__ dmeans, float *__restrict__ dscales, float *__restrict__ dopac,

@@ -227,7 +227,7 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
     for (int j = 0; j < 10; j++) C[j] = 0.f;
     float dist = 0.f;                                   // per-lane partial sum
     int used = 0;
-    float4 *state = A.state ? A.state + state_row0(A, slot, r) : nullptr;      // per-hit state: two planes of 16 B rows (+ one of 8 B rows with `others`)
+    float4 *state = A.state ? A.state + state_row0(A, slot, r) : nullptr;      // per-hit state: plane 0 = 16 B rows, plane 1 = 16 B rows (24 B with `others`)
 #pragma unroll
     for (int ce = 0; ce < E; ce++) {
         const int cb = ce * 64;
@@ -280,10 +280,13 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
                 // streamed once, read once by the backward much later: non-temporal, so it does not evict the surfel records / SH blocks
                 typedef float nt4 __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store((nt4){Tb, S[0], S[1], S[2]}, reinterpret_cast<nt4 *>(o));
-                if (!A.colour_state) __builtin_nontemporal_store((nt4){S[3], S[5], S[6], S[7]}, reinterpret_cast<nt4 *>(o + A.state_plane));
-                if (A.has_others && !A.colour_state) {                                          // (third plane: 8 B rows -- the two aux sums)
-                    typedef float nt2 __attribute__((ext_vector_type(2)));
-                    __builtin_nontemporal_store((nt2){S[8], S[9]}, reinterpret_cast<nt2 *>(A.state + 2 * A.state_plane) + (size_t)(o - A.state));
+                if (!A.colour_state) {
+                    if (A.has_others) {     // plane 1 with `others`: 24 B rows (depth, normal, the two aux sums) as two 12 B halves (4 B alignment is all a dwordx3 needs)
+                        typedef float nt3 __attribute__((ext_vector_type(3), aligned(4)));      // (sizeof is 16: the halves are addressed in floats)
+                        float *q = reinterpret_cast<float *>(state_row1(A, (size_t)(o - A.state)));
+                        __builtin_nontemporal_store((nt3){S[3], S[5], S[6]}, reinterpret_cast<nt3 *>(q));
+                        __builtin_nontemporal_store((nt3){S[7], S[8], S[9]}, reinterpret_cast<nt3 *>(q + 3));
+                    } else __builtin_nontemporal_store((nt4){S[3], S[5], S[6], S[7]}, reinterpret_cast<nt4 *>(o + A.state_plane));
                 }
             }
         }

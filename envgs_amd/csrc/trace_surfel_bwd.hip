@@ -53,22 +53,30 @@ composite_lists_bwd(const TraceArgs A)
 // 256 B record per (batch, surfel) written by the 64 lanes as one coalesced line pair.  ~27x fewer records than one per hit, no
 // per-hit gathers of surfel data, no dependent chain along the ray, no atomics.
 constexpr int BS_GROUP = 16;
+#ifndef ENVGS_BSB_KO
+#define ENVGS_BSB_KO 0          // measurement builds only (scratch/ab_bsb.sh): 1 = no dothers, 2 = no aux-plane fetch, 4 = no plane-1 fetch -- results wrong by construction
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BT_PITCH = 96;  // words per row of the reduction tile: 64 rays + the skew of 2 words per row (<= 30), never wrapped
 constexpr int RECW = 64;      // floats per (batch, surfel) gradient record: 48 SH (or 3 colour) + 15 geometry + pad
 // RGBO: the colour is the only output with an upstream gradient (g_dpt / g_acc / g_norm / g_aux all NULL) -- the EnvGS training step: the env
 // pass's depth / accumulation / normal maps are not supervised.  Seven per-ray gradient constants and their terms drop out, and of the per-hit
 // state only plane 0 (16 B: transmittance before the hit + the three colour prefix sums) is fetched instead of 32 / 48 B.
-template <bool RGBO>
+// OTH (generic form only): the call has `others_precomp` -- a kernel parameter rather than a run-time test of A.has_others because the two
+// plane-1 row forms would otherwise meet in PHI copies right behind the branch, and the wait for them would undo the state prefetch (measured)
+template <bool RGBO, bool OTH>
 __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64)
 batch_surfel_bwd(const TraceArgs A)
 {
+    static_assert(!(RGBO && OTH), "the colour-only form never touches `others`");
     __shared__ float4 sdat[2][BS_GROUP][16];               // per entry: surfel record (4 x 16 B) + SH block (12 x 16 B)
     __shared__ unsigned long long sdesc[2][BS_GROUP];      // sid | (hits-1) << 24 ; record index << 32
     __shared__ unsigned short kmat[2][BS_GROUP][64];       // per entry and ray: list position of the hit + 1, 0 = the ray did not blend it
     __shared__ unsigned spb[2][BS_GROUP];                  // per entry: index of its first pair
     __shared__ unsigned scn[2][BS_GROUP];                  // per entry: hits
     __shared__ float btile[16][BT_PITCH];                  // B operand of the reduction MFMAs: 16 words per ray, skewed (see below)
+    __shared__ float2 sox[2][BS_GROUP];                    // per entry: the surfel's two `others` values (generic form only)
     const int lane = threadIdx.x;
     const int nb = (A.D + 1) * (A.D + 1);
     const int nbatch = (A.R + 63) >> 6;
@@ -125,7 +133,7 @@ batch_surfel_bwd(const TraceArgs A)
         for (int k = 0; k < 4; k++) SkM[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         float dO0 = 0.f, dO1 = 0.f, dO2 = 0.f, dD0 = 0.f, dD1 = 0.f, dD2 = 0.f;
         const float4 *state = A.state + state_row0(A, min(base + lane, A.R - 1), rr);
-        const size_t plane = A.state_plane;
+        const char *plane1 = reinterpret_cast<const char *>(A.state + A.state_plane);
         size_t rstart, region;
         batch_region(A, batch, rstart, region);
         const unsigned long long *ent = A.entries + rstart;
@@ -187,6 +195,7 @@ batch_surfel_bwd(const TraceArgs A)
                     const size_t ci = (size_t)sid * NCOPY + copy;
                     const unsigned rec = A.surf_off[ci] - A.surf_cnt[ci] + (unsigned)(d >> 32);
                     sdesc[buf][el] = (d & 0x3FFFFFFFull) | ((unsigned long long)rec << 32);
+                    if constexpr (OTH) sox[buf][el] = reinterpret_cast<const float2 *>(A.others)[sid];
                 }
             }
             if (part == 0) scn[buf][el] = e < NE ? (unsigned)((d >> 24) & 63ull) + 1u : 0u;
@@ -228,7 +237,21 @@ batch_surfel_bwd(const TraceArgs A)
             // software pipeline over the entries: the per-hit state of entry el+1 is in flight while entry el is evaluated
             int k1 = valid ? (int)kmat[buf][0][lane] : 0;
             float4 st0, st1 = make_float4(0.f, 0.f, 0.f, 0.f), st2 = make_float4(0.f, 0.f, 0.f, 0.f);
-            { const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) : A.state; st0 = sp[0]; if constexpr (!RGBO) { st1 = sp[plane]; if (A.has_others) { const float2 t2 = reinterpret_cast<const float2 *>(A.state + 2 * plane)[(size_t)(sp - A.state)]; st2.x = t2.x; st2.y = t2.y; } } }      // unconditional (idle lanes share one address): no branch, no wait
+            // per-hit state of one list position: plane 0 (16 B) -- and, generic form, plane 1: 16 B rows, or 24 B rows = two 12 B halves with `others`
+            auto fetch_state = [&](const int k) {
+                const float4 *sp = k > 0 ? state + (size_t)(k - 1) : A.state;      // unconditional (idle lanes share one address): no branch, no wait
+                st0 = sp[0];
+                if constexpr (!RGBO) {
+                    if (ENVGS_BSB_KO & 4) return;
+                    if constexpr (OTH) {
+                        typedef float f3 __attribute__((ext_vector_type(3), aligned(4)));       // (sizeof is 16: the halves are addressed in floats)
+                        const float *q = reinterpret_cast<const float *>(plane1 + (size_t)(sp - A.state) * 24);
+                        const f3 a = *reinterpret_cast<const f3 *>(q); st1.x = a.x; st1.y = a.y; st1.z = a.z;
+                        if (!(ENVGS_BSB_KO & 2)) { const f3 b = *reinterpret_cast<const f3 *>(q + 3); st1.w = b.x; st2.x = b.y; st2.y = b.z; }
+                    } else st1 = *reinterpret_cast<const float4 *>(plane1 + (size_t)(sp - A.state) * 16);
+                }
+            };
+            fetch_state(k1);
             for (int el = 0; el < ne; el++) {
                 const unsigned long long d = sdesc[buf][el];
                 const int sid = (int)(d & 0xFFFFFFull);
@@ -246,6 +269,7 @@ batch_surfel_bwd(const TraceArgs A)
                 float gw[16];
 #pragma unroll
                 for (int n = 0; n < 16; n++) gw[n] = 0.f;
+                [[maybe_unused]] float gx1 = 0.f;
 #define BT(n) btile[3 * e5 + (n)][lane + 2 * (3 * e5 + (n))]
                 // The SH colours of the run's five entries for all 64 rays, on the matrix cores (round 5; every lane used to evaluate its own:
                 // 48 FMAs and twelve 16 B LDS reads per entry and lane):  [64 rays x 16 basis values] . [16 x 15]  (column 3 e + c = colour c of
@@ -282,7 +306,8 @@ batch_surfel_bwd(const TraceArgs A)
 #pragma unroll
                         for (int c = 0; c < 3; c++) { const float v = rc[c] + 0.5f; cl[c] = v < 0.f; col[c] = cl[c] ? 0.f : v; }
                     } else { const float4 x = sdat[buf][el][4]; col[0] = x.x; col[1] = x.y; col[2] = x.z; }
-                    const float x0 = (!RGBO && A.has_others) ? A.others[2 * sid] : 0.f, x1 = (!RGBO && A.has_others) ? A.others[2 * sid + 1] : 0.f;
+                    float x0 = 0.f, x1 = 0.f;                 // (staged with the record: a global load here sat on every entry's critical path)
+                    if constexpr (OTH) { const float2 xo = sox[buf][el]; x0 = xo.x; x1 = xo.y; }
                     const float alpha = h.alpha, Tb = st0.x;
                     const float w = alpha * Tb;
                     const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
@@ -295,7 +320,9 @@ batch_surfel_bwd(const TraceArgs A)
                     }
                     const float dLa = Tb * gv_ - (Fsum - gS) * inv1m;
                     const float dc[3] = {cl[0] ? 0.f : w * gR0, cl[1] ? 0.f : w * gR1, cl[2] ? 0.f : w * gR2};
-                    if constexpr (!RGBO) { if (A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * gX1); } }
+                    // dL/d(others) = sum over the batch's rays of w g_aux: words 15 / 16 of the (then five-register) transpose-reduce below and ONE two-lane
+                    // atomic per entry (round 6; until then every lane added its own term -- 64 same-address atomics per entry and word: 2.1 of 5.1 ms)
+                    if constexpr (OTH) { gw[15] = w * gX0; gx1 = w * gX1; }
                     const float dLG = s0.w * dLa;
                     const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
                     const float isu = __builtin_amdgcn_rcpf(s1.w), isv = __builtin_amdgcn_rcpf(s2.w);
@@ -322,14 +349,26 @@ batch_surfel_bwd(const TraceArgs A)
 #undef BT
                 if (el + 1 < ne) {                           // next entry's state: in flight during the reduction below
                     k1 = valid ? (int)kmat[buf][el + 1][lane] : 0;
-                    const float4 *sp = k1 > 0 ? state + (size_t)(k1 - 1) : A.state;
-                    st0 = sp[0]; if constexpr (!RGBO) { st1 = sp[plane]; if (A.has_others) { const float2 t2 = reinterpret_cast<const float2 *>(A.state + 2 * plane)[(size_t)(sp - A.state)]; st2.x = t2.x; st2.y = t2.y; } }
+                    fetch_state(k1);
                 }
                 // geometry: lane r*16 + k (k < 4) receives the sum over the 64 rays of word k + 4 r; record words 48 .. 62
                 {
-                    const float gsum = wave_transpose_reduce<4>(gw, lane);
-                    const int word = (lane & 15) + 4 * (lane >> 4);
-                    if ((lane & 15) < 4 && word < 15 && rec < A.num_records) A.records[rec * RECW + 48 + word] = gsum;
+                    if constexpr (OTH && !(ENVGS_BSB_KO & 1)) {
+                        // with dL/d(others): 17 words through the five-register form -- lane r*16 + k (k < 5) receives word k + 5 r; words 15 / 16 (the sums
+                        // of w g_aux, lanes 48 / 49) leave as ONE two-lane atomic per entry
+                        float g20[20];
+#pragma unroll
+                        for (int n = 0; n < 20; n++) g20[n] = n < 15 ? gw[n] : 0.f;
+                        g20[15] = gw[15]; g20[16] = gx1;
+                        const float gsum = wave_transpose_reduce<5>(g20, lane);
+                        const int word = (lane & 15) + 5 * (lane >> 4);
+                        if ((lane & 15) < 5 && word < 15 && rec < A.num_records) A.records[rec * RECW + 48 + word] = gsum;
+                        if ((lane & 15) < 5 && (word == 15 || word == 16) && A.dothers) atomic_add_f32(A.dothers + 2 * sid + (word - 15), gsum);
+                    } else {
+                        const float gsum = wave_transpose_reduce<4>(gw, lane);
+                        const int word = (lane & 15) + 4 * (lane >> 4);
+                        if ((lane & 15) < 4 && word < 15 && rec < A.num_records) A.records[rec * RECW + 48 + word] = gsum;
+                    }
                 }
                 // colour: after the fifth entry of a run (or the last of the group) D[16 x 16] = basis^T[16 x 64 rays] . B[64 rays x 16], K = 64 in
                 // 16 exact-f32 MFMAs (four independent chains: the dependent latency is 40 cycles); column 3 e + c = colour c of the run's
@@ -396,8 +435,9 @@ batch_surfel_bwd(const TraceArgs A)
     }
 }
 
-template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<false>(const TraceArgs A);
-template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<true>(const TraceArgs A);
+template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<false, false>(const TraceArgs A);
+template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<false, true>(const TraceArgs A);
+template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<true, false>(const TraceArgs A);
 
 // Stage 2: sum each surfel's (batch, surfel) records into the (zeroed) gradient buffers -- plain stores, every word has one owner; the
 // K-buffer pass for overflowed rays runs afterwards and adds to the same buffers atomically.  16 lanes per surfel, 16 B per lane = one

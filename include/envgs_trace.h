@@ -93,10 +93,10 @@ typedef struct envgs_trace_lists {
     size_t ray_sort_temp_bytes;
     float *records;          /* backward only: (num_records, 64) one 256 B gradient record per (batch, surfel) entry, grouped by surfel */
     uint64_t num_records;    /* backward only: capacity of `records` in records (>= surf_off[P-1]) */
-    float *hit_state;        /* PLANES of per-hit rows, written by the forward for the backward; rows = compact_rows (or R * cap).  Plane 0 (16 B rows, at
-                                float index 0): (transmittance before the composited hit, the three colour prefix sums after it); plane 1 (16 B rows,
-                                at float index 4 * rows): (depth, normal prefix sums); plane 2 (only with has_others; 8 B rows, at float index
-                                8 * rows): the two aux sums.  8 floats per row and hit, 10 with has_others (12 until round 4).  A backward whose only
+    float *hit_state;        /* two PLANES of per-hit rows, written by the forward for the backward; rows = compact_rows (or R * cap).  Plane 0 (16 B rows, at
+                                float index 0): (transmittance before the composited hit, the three colour prefix sums after it); plane 1 (at float index
+                                4 * rows): (depth, normal prefix sums) in 16 B rows -- with has_others (depth, normal, the two aux sums) in 24 B rows
+                                (until round 6 the aux sums were a third plane).  8 floats per row and hit, 10 with has_others.  A backward whose only
                                 upstream gradient is the colour's reads plane 0 alone */
     uint64_t *entries;       /* (ceil(R/64), 64*cap) distinct surfels of every batch, packed id | hits-1 << 24 | slot << 32 */
     uint32_t *pairs;         /* (ceil(R/64), 64*cap) (lane << 16 | list position) of every composited hit, grouped by entry */
