@@ -162,6 +162,7 @@ def main():
                     "back to back; ms_per_step / value are the MEDIAN region, ms_per_step_spread has min / max (VERDICT r4: 20 steps = 0.17 s was a thin sample)")
     ap.add_argument("--no-reference-caller", action="store_true", help="skip the extra few steps that time the unchanged-EasyVolcap-caller form of the step (config.reference_caller_ms_per_step)")
     ap.add_argument("--step-times", type=int, default=0, help="diagnostics: after the timed region, run this many extra steps one by one (synchronised) and print their wall times and the allocator statistics to stderr")
+    ap.add_argument("--stage-counts", action="store_true", help="diagnostics: after the timed region, one more step with every traced call's counters (rays, hits found / composited, entries) printed to stderr")
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--cpu-rays", type=int, default=2048, help="rays of the same view traced by the brute-force CPU oracle (bounded sample)")
     args = ap.parse_args()
@@ -438,6 +439,28 @@ def main():
         print("step times (ms): %s; allocator during them: %s; reserved %.1f GB, peak allocated %.1f GB" % (
             ts, {k: ms1.get(k, 0) - ms0.get(k, 0) for k in keys}, ms1.get("reserved_bytes.all.current", 0) / 2**30,
             ms1.get("allocated_bytes.all.peak", 0) / 2**30), file=sys.stderr)
+
+    if args.stage_counts and envgs and rank == 0:
+        # diagnostics: one more step with every traced call's counters read back (synchronising) -- rays, hits found / composited, entries per stage
+        orig_tf = tracing.trace_forward
+        seen = []
+
+        def counting_tf(*a, **k):
+            r_ = orig_tf(*a, **k)
+            tc_ = tracing.last_trace_counts()
+            seen.append(dict(rays=tc_["rays"], found=tc_["found"], hits=tc_["hits"], entries=sum(tracing.last_entry_counts()), cap=tc_["cap"], max_list=tc_["max_list"],
+                             rows=tc_["compact_rows"], packet_nodes=tc_["packet_nodes"], packet_leaves=tc_["packet_leaves"], kbuffer_rays=tc_["rays_without_rows"]))
+            return r_
+        tracing.trace_forward = counting_tf
+        try:
+            for v_ in range(8):
+                seen.append("view %d" % v_)
+                step(8 * (args.warmup + args.steps + 100) + v_)
+                torch.cuda.synchronize(dev)
+        finally:
+            tracing.trace_forward = orig_tf
+        for c_ in seen:
+            print(c_ if isinstance(c_, str) else "  traced call: %s" % json.dumps(c_), file=sys.stderr)
 
     # per-kernel HIP-event times (this rank)
     N_avg = n_timed["N"] / max(n_timed["steps"], 1)

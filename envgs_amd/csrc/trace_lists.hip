@@ -2,6 +2,9 @@
 // registration of the composited hits with their surfels (entries, pairs, per-surfel weights).
 #include "trace_common.h"
 
+#ifndef ENVGS_SCF_KO
+#define ENVGS_SCF_KO 0          // measurement builds only (scratch/ab_bsb.sh): 1 = no plane-1 state store, 2 = no `others` gather / scans -- results wrong by construction
+#endif
 namespace envgs {
 
 // Cross-lane fetch of a 32-bit value from lane ^ S (S < 64): DPP quad permutes for 1 and 2, ds_swizzle (crossbar only, no LDS memory)
@@ -267,11 +270,11 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
         const float M1b = M1 + (S1 - mw), M2b = M2 + (S2 - mmw);        // moments before this hit
         dist += (m * m * (1.0f - Tb) + M2b - 2.0f * m * M1b) * w;
         float x0 = 0.f, x1 = 0.f;
-        if (A.has_others && use) { const float2 xo = reinterpret_cast<const float2 *>(A.others)[sid]; x0 = xo.x; x1 = xo.y; }      // one 8 B gather
+        if (A.has_others && use && !(ENVGS_SCF_KO & 2)) { const float2 xo = reinterpret_cast<const float2 *>(A.others)[sid]; x0 = xo.x; x1 = xo.y; }      // one 8 B gather
         float S[10] = {w * col[0], w * col[1], w * col[2], w * t, w, sg * w * s3.x, sg * w * s3.y, sg * w * s3.z, w * x0, w * x1};
 #pragma unroll
         for (int j = 0; j < 8; j++) S[j] = C[j] + wave_scan_add(S[j]);                // inclusive: this hit already added
-        if (A.has_others) { S[8] = C[8] + wave_scan_add(S[8]); S[9] = C[9] + wave_scan_add(S[9]); }      // (the two aux sums: only when there is something to sum)
+        if (A.has_others && !(ENVGS_SCF_KO & 2)) { S[8] = C[8] + wave_scan_add(S[8]); S[9] = C[9] + wave_scan_add(S[9]); }      // (the two aux sums: only when there is something to sum)
         if (use) {
             list[i] = make_uint2(__float_as_uint(w), (unsigned)sid);
             if (state) {
@@ -280,7 +283,7 @@ __device__ __forceinline__ void sort_composite_ray(const TraceArgs &A, const int
                 // streamed once, read once by the backward much later: non-temporal, so it does not evict the surfel records / SH blocks
                 typedef float nt4 __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store((nt4){Tb, S[0], S[1], S[2]}, reinterpret_cast<nt4 *>(o));
-                if (!A.colour_state) {
+                if (!A.colour_state && !(ENVGS_SCF_KO & 1)) {
                     if (A.has_others) {     // plane 1 with `others`: 24 B rows (depth, normal, the two aux sums) as two 12 B halves (4 B alignment is all a dwordx3 needs)
                         typedef float nt3 __attribute__((ext_vector_type(3), aligned(4)));      // (sizeof is 16: the halves are addressed in floats)
                         float *q = reinterpret_cast<float *>(state_row1(A, (size_t)(o - A.state)));

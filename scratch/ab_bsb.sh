@@ -4,6 +4,6 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 cp envgs_amd/libenvgs_hip.so /tmp/_orig.so
 for v in $1; do
   cp scratch/variants/$v.so envgs_amd/libenvgs_hip.so
-  timeout 300 python scratch/bsb_ab.py $v 2>&1 | grep -v Warning | tail -4
+  timeout 300 python scratch/bsb_ab.py $v 2>&1 | grep -v Warning | tail -12
 done
 cp /tmp/_orig.so envgs_amd/libenvgs_hip.so

@@ -57,6 +57,25 @@ def case(label, P_set, ro, rd, sff, others):
         outs, saved = tracing.trace_forward(nodes, ro, rd, P_set["means3D"], P_set["shs"], None, others, P_set["opacities"], P_set["scales"], P_set["rotations"], ts, sff, caps=caps)
         torch.cuda.synchronize()
     tc = tracing.last_trace_counts(); ent = sum(tracing.last_entry_counts())
+    # the forward's own kernels under the three per-hit state forms (per launch; two segments per call)
+    fw = {}
+    for form, co in (("full state", False), ("colour plane only", True)):
+        caps.colour_only = co
+        for _ in range(2):
+            tracing.trace_forward(nodes, ro, rd, P_set["means3D"], P_set["shs"], None, others, P_set["opacities"], P_set["scales"], P_set["rotations"], ts, sff, caps=caps)
+        torch.cuda.synchronize()
+        lib.envgs_prof_enable(1); drain()
+        for _ in range(5):
+            tracing.trace_forward(nodes, ro, rd, P_set["means3D"], P_set["shs"], None, others, P_set["opacities"], P_set["scales"], P_set["rotations"], ts, sff, caps=caps)
+        torch.cuda.synchronize()
+        lib.envgs_prof_enable(0)
+        d = drain()
+        fw[form] = "  ".join("%s %.3f" % (k.replace("trace.", ""), d[k][0]) for k in ("trace.collect_hits", "trace.sort_composite_fwd", "trace.register_hits", "trace_fwd") if k in d)
+    caps.colour_only = False
+    outs, saved = tracing.trace_forward(nodes, ro, rd, P_set["means3D"], P_set["shs"], None, others, P_set["opacities"], P_set["scales"], P_set["rotations"], ts, sff, caps=caps)
+    torch.cuda.synchronize()
+    for k, v in fw.items():
+        print("%s %-34s forward, %s: %s" % (tag, label, k, v), flush=True)
     R = ro.shape[0]
     gen = torch.Generator().manual_seed(5)
     mk = lambda c: (torch.randn(R, c, generator=gen) / R).to(dev)
