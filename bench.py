@@ -97,8 +97,23 @@ def trace_per_ray_model_bytes(kernel, tc, R):
 VALU_PEAK_GINST = 256 * 2 * 2.4
 VALU_MEASURED_GINST = 898.0     # what the chip sustains: independent v_fma_f32 / mixed VALU, 8 waves per SIMD (scratch/valu_peak.hip -> profiles/r02_valu_peak.txt)
 SALU_PEAK_GINST = 256 * 1 * 2.4
-PMC_SUMMARY = os.path.join("profiles", "r05_pmc_envgs.json")
-STEP_INVENTORY = os.path.join("profiles", "r05_step_inventory.txt")     # rocprofv3 kernel trace of this workload's step (scratch/step_inventory.py)
+PMC_TAG = "r06"
+STEP_INVENTORY = os.path.join("profiles", "r06_step_inventory.txt")     # rocprofv3 kernel trace of this workload's step (scratch/step_inventory.py)
+
+
+def workload_key(args, H, W):
+    """Which tracked counter summary (profiles/<tag>_pmc_<key>.json, produced by profiles/collect_profiles.sh <key>) describes THIS run's workload --
+    or None: the line then carries `issue` / `traffic` = null instead of another workload's counters."""
+    base = args.gaussians == 300000 and args.caller == "fused" and args.feature_dtype == "f32"
+    if args.workload == "raster":
+        return "raster" if (args.gaussians == 300000 and H == 800 and W == 800) else None
+    if args.workload == "base_trace":
+        return ("base_trace_d%d" % args.trace_depth) if (args.gaussians == 300000 and H == 800 and W == 800 and args.trace_depth in (0, 2)) else None
+    if H == 1200 and W == 1600 and args.trace_depth == 2 and args.channels == 7 and args.gaussians == 300000 and args.env_gaussians == 163840 and args.caller == "fused":
+        return "config5"
+    if not (base and H == 800 and W == 800 and args.trace_depth == 0 and args.channels == 5 and not args.no_colour_only_state):
+        return None
+    return {163840: "envgs", 700000: "env700k"}.get(args.env_gaussians)
 
 
 def step_inventory():
@@ -122,8 +137,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="envgs", choices=["raster", "envgs"],
-                    help="envgs = BASELINE configs[2] (ch05 raster + env trace, the config the metric is quoted on); raster = configs[1]")
+    ap.add_argument("--workload", default="envgs", choices=["raster", "envgs", "base_trace"],
+                    help="envgs = BASELINE configs[2] (ch05 raster + env trace, the config the metric is quoted on); raster = configs[1]; base_trace = the reference's OTHER "
+                         "tracer call (envgs_sampler.py:508-521 use_base_tracing, gaussian2d_sampler.py:391-449 use_optix_tracing): camera rays over the BASE set, "
+                         "start_from_first=True, SH in-kernel, others_precomp = (specular, roughness), every traced output differentiated; --trace-depth 0 | 2")
+    ap.add_argument("--specular-threshold", type=float, default=None, help="bounce threshold of --trace-depth > 0 (default: 0.5 for the envgs workload's random `others`, "
+                    "0.0 = the reference's default for base_trace)")
     ap.add_argument("--gaussians", type=int, default=300000)
     ap.add_argument("--env-gaussians", type=int, default=163840)
     ap.add_argument("--res", type=int, default=800)
@@ -191,10 +210,11 @@ def main():
     P, H, W = args.gaussians, (args.height or args.res), (args.width or args.res)
     HW = H * W
     envgs = args.workload == "envgs"
+    btrace = args.workload == "base_trace"
     C = args.channels if envgs else 3
     g = synth.base_gaussians(P, seed=0, device=dev)
     cams = [synth.orbit_camera(v, n_views=8, H=H, W=W, fx=1111.1 * W / 800.0, device=dev) for v in range(8)]
-    bg = torch.ones(3, device=dev) if not envgs else torch.zeros(3, device=dev)
+    bg = torch.ones(3, device=dev) if not (envgs or btrace) else torch.zeros(3, device=dev)
     gen = torch.Generator().manual_seed(1)
     dcol = (torch.randn(C, H, W, generator=gen) / HW).to(dev)
     dall = (torch.randn(7, H, W, generator=gen) / HW).to(dev)
@@ -211,7 +231,7 @@ def main():
         env_params = {k: ge[k].clone().requires_grad_(True) for k in names}
         if args.trace_depth > 0:                   # bounces need a per-surfel specular value on the env set (others_precomp[:, 0]); half of the rays bounce
             from envgs_amd import envgs_step as _es
-            _es.TRACE.update(depth=args.trace_depth, specular_threshold=0.5)
+            _es.TRACE.update(depth=args.trace_depth, specular_threshold=(0.5 if args.specular_threshold is None else args.specular_threshold))
             env_others = torch.rand(args.env_gaussians, 2, generator=torch.Generator().manual_seed(3)).to(dev)
 
     if envgs:
@@ -237,6 +257,18 @@ def main():
         rays = [synth.get_rays(c) for c in cams]
         env_bg = torch.zeros(3, device=dev)
         dcol_hw3 = dcol[:3].permute(1, 2, 0).contiguous()
+    elif btrace:
+        import diff_surfel_tracing as tpkg
+        from envgs_amd import fused as _fused
+        params["specular"] = g["specular"].clone().requires_grad_(True)
+        params["roughness"] = g["roughness"].clone().requires_grad_(True)
+        tracer = tpkg.SurfelTracer()
+        tracer.set_structure_policy("adaptive" if args.bvh_rebuild_every > 1 else "rebuild", max_age=max(1, args.bvh_rebuild_every - 1))
+        rays = [synth.get_rays(c) for c in cams]
+        gen_t = torch.Generator().manual_seed(7)
+        d_out = {k: (torch.randn(H, W, c_, generator=gen_t) / HW).to(dev) for k, c_ in (("rgb", 3), ("dpt", 1), ("acc", 1), ("norm", 3), ("aux", 2))}
+        bt_thr = 0.0 if args.specular_threshold is None else args.specular_threshold
+        pkg = None
     else:
         import diff_surfel_rasterization_wet as pkg
     sh_degree = torch.tensor([3], device=dev)
@@ -247,6 +279,21 @@ def main():
     half = args.feature_dtype == "f16"
     import envgs_amd
     envgs_amd.set_feature_storage("f16" if half else "f32")      # half copies inside the autograd nodes: fp32 parameters in, fp32 gradients out
+
+    def base_trace_forward(cam, ray):
+        """HardwareRendering.render_gaussians (optix_utils.py:87-201) as the base samplers call it: quads + rebuild request, SH in-kernel,
+        others_precomp = (specular, roughness), start_from_first=True."""
+        v, f = _fused.surfel_quads(params["means3D"], params["scales"], params["rotations"])
+        tracer.build_acceleration_structure(v, f, rebuild=True)
+        ts = tpkg.SurfelTracingSettings(image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, scale_modifier=1.0,
+                                        viewmatrix=cam.world_view_transform.contiguous(), projmatrix=cam.full_proj_transform.contiguous(), sh_degree=sh_degree,
+                                        campos=cam.camera_center.contiguous(), prefiltered=False, debug=False, max_trace_depth=int(args.trace_depth),
+                                        specular_threshold=float(bt_thr))
+        grads3D = torch.zeros_like(params["means3D"]).requires_grad_(True)
+        others = torch.cat([params["specular"], params["roughness"]], dim=-1)
+        return tracer(ray[0], ray[1], v, means3D=params["means3D"], grads3D=grads3D, shs=params["shs"], colors_precomp=None, others_precomp=others,
+                      opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"], cov3D_precomp=None, tracer_settings=ts,
+                      start_from_first=True)
 
     def settings(cam):
         return pkg.GaussianRasterizationSettings(
@@ -288,13 +335,16 @@ def main():
             loss = (out["rgb"] * dcol_hw3).sum() + (allmap * dall).sum()
             if mode["caller"] == "reference":     # the normal-consistency term consumes render()'s regulariser maps (volumetric_video_supervisor)
                 loss = loss + (out["base"]["surf_normal"] * dnorm_hw).sum()
+        elif btrace:
+            rgb_, dpt_, acc_, norm_, dist_, aux_, mid_, wet_ = base_trace_forward(cam, rays[vi])
+            loss = (rgb_ * d_out["rgb"]).sum() + (dpt_ * d_out["dpt"]).sum() + (acc_ * d_out["acc"]).sum() + (norm_ * d_out["norm"]).sum() + (aux_ * d_out["aux"]).sum()
         else:
             means2D = torch.zeros_like(params["means3D"], requires_grad=True)
             color, radii, allmap, weight = pkg.GaussianRasterizer(raster_settings=settings(cam))(
                 means3D=params["means3D"], means2D=means2D, shs=params["shs"], colors_precomp=None,
                 opacities=params["opacities"], scales=params["scales"], rotations=params["rotations"], cov3D_precomp=None)
             loss = (color * dcol).sum() + (allmap * dall).sum()
-        n_acc["N"] += raster.LAST_STATS["N"]; n_acc["steps"] += 1
+        n_acc["N"] += (raster.LAST_STATS["N"] if not btrace else 0); n_acc["steps"] += 1
         loss.backward()
         nbytes = reducer.finish() if reducer is not None else 0
         if opt is not None:
@@ -440,7 +490,7 @@ def main():
             ts, {k: ms1.get(k, 0) - ms0.get(k, 0) for k in keys}, ms1.get("reserved_bytes.all.current", 0) / 2**30,
             ms1.get("allocated_bytes.all.peak", 0) / 2**30), file=sys.stderr)
 
-    if args.stage_counts and envgs and rank == 0:
+    if args.stage_counts and (envgs or btrace) and rank == 0:
         # diagnostics: one more step with every traced call's counters read back (synchronising) -- rays, hits found / composited, entries per stage
         orig_tf = tracing.trace_forward
         seen = []
@@ -464,8 +514,10 @@ def main():
 
     # per-kernel HIP-event times (this rank)
     N_avg = n_timed["N"] / max(n_timed["steps"], 1)
-    tcounts = tracing.last_trace_counts() if envgs else None
-    entries = sum(tracing.last_entry_counts()) if envgs else 0
+    traced = envgs or btrace
+    P_trace = args.env_gaussians if envgs else P                 # the set the tracer walks
+    tcounts = tracing.last_trace_counts() if traced else None    # (with --trace-depth > 0: the LAST stage's counters)
+    entries = sum(tracing.last_entry_counts()) if traced else 0
 
     # acceleration structure on its own (outside the timed region): a full build (Morton keys, sort, hierarchy, fit) against a REFIT of the same
     # topology (envgs_bvh_refit: OptiX's "update", build_acceleration_structure(rebuild=False)) over the step's own environment set
@@ -495,6 +547,8 @@ def main():
         with torch.no_grad():
             if envgs:
                 envgs_step.envgs_forward(pkg, tpkg, tracer, cams[vi], rays[vi], params, env_in, bg, env_bg, sh_degree)
+            elif btrace:
+                base_trace_forward(cams[vi], rays[vi])
             else:
                 pkg.GaussianRasterizer(raster_settings=settings(cams[vi]))(
                     means3D=params["means3D"], means2D=torch.zeros_like(params["means3D"]), shs=params["shs"], colors_precomp=None,
@@ -516,11 +570,11 @@ def main():
     kernels = {}
     for name, (ms, launches, _tot) in timed_prof.items():      # (the timers of the timed regions were drained right after them: timed_prof)
         if launches > 0:
-            ab = algorithmic_bytes(name, P, N_avg, HW, C, not envgs)
+            ab = algorithmic_bytes(name, P, N_avg, HW, C, not envgs) if not btrace else 0
             pr = 0
-            if not ab and envgs and tcounts:
-                ab = trace_algorithmic_bytes(name, tcounts, args.env_gaussians, HW, entries, others=args.trace_depth > 0,
-                                             colour_state=(args.caller == "fused" and not args.no_colour_only_state and not args.trace_depth))
+            if not ab and traced and tcounts:
+                ab = trace_algorithmic_bytes(name, tcounts, P_trace, HW, entries, others=(args.trace_depth > 0 or btrace), rgb_only=not btrace,
+                                             colour_state=(envgs and args.caller == "fused" and not args.no_colour_only_state and not args.trace_depth))
                 pr = trace_per_ray_model_bytes(name, tcounts, HW)
             if name == "fused_adam_multi":        # 28 B per updated element (p,g,m,v in; p,m,v out), 4 B per skipped one (g only)
                 nz = sum(int((g_ != 0).sum()) for g_ in last_grads if g_ is not None)
@@ -542,10 +596,12 @@ def main():
         dom = max(leaf, key=lambda k: leaf[k]["ms"] * leaf[k]["launches"]) if leaf else None      # most time per step (launches included)
         roof = None
         pm = {}
-        try:                                   # tracked PMC summary of the same workload (profiles/summarize.py; separate --pmc passes)
-            pm = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))["kernels"] if envgs else {}
+        wkey = workload_key(args, H, W)
+        PMC_SUMMARY = os.path.join("profiles", "%s_pmc_%s.json" % (PMC_TAG, wkey)) if wkey else None
+        try:                                   # tracked PMC summary of the SAME workload (profiles/collect_profiles.sh <key> -> profiles/summarize.py; separate --pmc passes)
+            pm = json.load(open(os.path.join(ROOT, PMC_SUMMARY)))["kernels"] if PMC_SUMMARY else {}
         except Exception:
-            pm = {}
+            pm, PMC_SUMMARY = {}, None
 
         def issue_of(name):
             """Instruction-issue roofline of one kernel: wave-instructions per launch (SQ_INSTS_*, from the tracked counter summary) over the
@@ -587,7 +643,7 @@ def main():
                                    "GBps_over_step": round(sum(v["alg_MB"] * max(1, round(v["launches"] / max(n_timed["steps"], 1))) for v in leaf.values()) / 1e3 / (ms_per_step / 1e3), 1)},
                     "note": "dominant kernel = most HIP-event time per step (duration x launches).  achieved = DEDUPLICATED algorithmic HBM bytes per launch (every "
                             "input structure once, every list / state / record element once: bench.py:trace_algorithmic_bytes; raster: SURVEY.md 8d formulas) / launch time; "
-                            "traffic = (2*FETCH_SIZE + WRITE_SIZE) per launch from " + PMC_SUMMARY + " (separate --pmc passes).  The tracer and compositing kernels are "
+                            "traffic = (2*FETCH_SIZE + WRITE_SIZE) per launch from " + (PMC_SUMMARY or "(no tracked counter summary for this workload: traffic / issue are null)") + " (separate --pmc passes).  The tracer and compositing kernels are "
                             "instruction-issue bound, not HBM bound: `issue` carries their VALU / SALU issue rates against the issue peaks (2 VALU + 1 SALU "
                             "wave-instructions per cycle per CU, 256 CUs, 2.4 GHz)"}
             # the next kernels by time per step, the same way (the dominant one can change from round to round -- in round 3 the collection
@@ -603,19 +659,25 @@ def main():
                                                 "traffic": pm.get("composite_bwd", {}).get("hbm_bytes"), "issue": issue_of("composite_bwd")}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(g, cams[0], bg, dcol, dall, H, W, args.cpu_reps, C,
-                               (ge, last_rays, args.cpu_rays) if envgs else None)
+            if not btrace:
+                cpu = cpu_baseline(g, cams[0], bg, dcol, dall, H, W, args.cpu_reps, C,
+                                   (ge, last_rays, args.cpu_rays) if envgs else None)
+            else:
+                cpu = cpu_baseline_trace(g, rays[0], args.cpu_rays, H, W)
         line = {
             "metric": "train iters/s (fwd+bwd of the render hot path + Adam step, one %dx%d view per GPU per iter) + render Mpix/s" % (W, H),
             "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "ms_per_step_spread": spread, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if not half else "f16-storage/f32-acc (feature arrays stored as half, fp32 arithmetic, accumulation and gradients)"), "data": "synthetic (seeded, BASELINE.md section 3; random-init Gaussians)",
             "config": {"workload": (("Ref-Real sedan-like full EnvGS (ch0%d raster + env LBVH trace)" % C) if envgs else
+                                    ("camera rays traced over the base set (use_base_tracing / use_optix_tracing: start_from_first, SH in-kernel, others = specular + roughness, "
+                                     "all five traced outputs differentiated), max_trace_depth %d, specular_threshold %g" % (args.trace_depth, bt_thr)) if btrace else
                                     "Ref-NeRF toaster-like base 2DGS raster only (BASELINE configs[1]), SH deg 3 in-kernel"),
-                       "gaussians": P, "env_gaussians": (args.env_gaussians if envgs else 0), "resolution": [H, W], "trace_depth": (args.trace_depth if envgs else None), "channels": C, "views": 8,
-                       "parallelism": "dp%d (camera batch sharded, %s)" % (world, ("env / base flat grad buffers, %s, %s" % ((args.exchange if exch_tune is None else "auto -> %s (direct %.3f ms, allreduce %.3f ms per exchange of both buckets)" % (exch_tune["chosen"], exch_tune["direct"], exch_tune["allreduce"])), "launched from backward hooks" if not args.no_overlap_allreduce else "after backward")) if reducer is not None else "single GPU"),
+                       "pmc_summary": PMC_SUMMARY,
+                       "gaussians": P, "env_gaussians": (args.env_gaussians if envgs else 0), "resolution": [H, W], "trace_depth": (args.trace_depth if traced else None), "channels": C, "views": 8,
+                       "parallelism": "dp%d (%d ranks seen by torch.distributed over %s, %d GPU(s) visible to this rank; camera batch sharded, %s)" % (world, (dist.get_world_size() if world > 1 else 1), ((dist.get_backend() + (" = RCCL" if dist.get_backend() == "nccl" else "")) if world > 1 else "no process group"), torch.cuda.device_count(), ("env / base flat grad buffers, %s, %s" % ((args.exchange if exch_tune is None else "auto -> %s (direct %.3f ms, allreduce %.3f ms per exchange of both buckets)" % (exch_tune["chosen"], exch_tune["direct"], exch_tune["allreduce"])), "launched from backward hooks" if not args.no_overlap_allreduce else "after backward")) if reducer is not None else "single GPU"),
                        "optimizer": {"fused": "sparse fused Adam, one launch (envgs_amd.optim)", "torch": "torch.optim.Adam", "none": "none"}[args.optim],
-                       "caller_glue": ("n/a (raster only)" if not envgs else {"fused": "fused HIP (envgs_amd.fused)", "twin": "torch expressions (envgs_amd/envgs_step.py)",
+                       "caller_glue": ("n/a (one traced call per step; quads by envgs_amd.fused.surfel_quads)" if btrace else "n/a (raster only)" if not envgs else {"fused": "fused HIP (envgs_amd.fused)", "twin": "torch expressions (envgs_amd/envgs_step.py)",
                                        "reference": "the unchanged EasyVolcap caller's expression forms (batched-matmul get_disks, render()'s regulariser maps + normal term)"}[args.caller]),
                        "reference_caller_ms_per_step": (None if ref_caller_ms is None else round(ref_caller_ms, 3)),
                        "reference_caller_ms_by_torch_blas": ref_caller_by_blas,
@@ -692,6 +754,28 @@ def cpu_baseline(g, cam, bg, dcol, dall, H, W, reps, C, env=None):
             out["sample"] += "; PyTorch-eager config-1 (2 000 surfels, 256x256, CPU): " + out["eager_config1"]["sample"]
         return out
     except Exception as e:                       # the baseline is a reported figure, never a reason to lose the GPU number
+        return {"value": None, "unit": "iters/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+
+
+def cpu_baseline_trace(g, ray, nr, H, W):
+    """base_trace workload: the brute-force tracer oracle (oracle/surfel_trace_oracle.c, OpenMP) forward + backward on a bounded sample of the same
+    camera rays over the same base set, scaled to the full view."""
+    try:
+        import numpy as np
+        from oracle import trace as otr
+        a = {k: v.detach().cpu().numpy() for k, v in g.items()}
+        idx = np.linspace(0, H * W - 1, nr).astype(np.int64)
+        ro = ray[0].reshape(-1, 3).cpu().numpy()[idx]; rd = ray[1].reshape(-1, 3).cpu().numpy()[idx]
+        oth = np.concatenate([a["specular"], a["roughness"]], 1).astype(np.float32)
+        t1 = time.perf_counter()
+        tf = otr.trace_forward(ro, rd, a["means3D"], a["scales"], a["rotations"], a["opacities"], shs=a["shs"], sh_degree=3, others=oth, start_from_first=True)
+        on = lambda c: np.ones((nr, c), np.float32) / (H * W)
+        otr.trace_backward(tf, on(3), on(1)[:, 0], on(1)[:, 0], on(3), on(2))
+        dtt = (time.perf_counter() - t1) * (H * W / nr)
+        return {"value": round(1.0 / dtt, 5), "unit": "iters/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": "brute-force tracer oracle (oracle/surfel_trace_oracle.c: every ray x every surfel, no acceleration structure) fwd+bwd on %d of the %d camera rays x %d base "
+                          "surfels, bounce-free, scaled to the full view (%.1f s/iter); OpenMP over all host cores" % (nr, H * W, a["means3D"].shape[0], dtt)}
+    except Exception as e:
         return {"value": None, "unit": "iters/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
 
 

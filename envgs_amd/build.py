@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "libenvgs_hip.so")
 LIB_DIAG = os.path.join(HERE, "libenvgs_hip_diag.so")
 DIAG_SOURCES = ("trace_collect.hip", "trace_surfel_bwd.hip", "trace_api.hip", "raster_render.hip")
 ARCH = "gfx950"
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fvisibility=hidden",
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++20", "-fPIC", "-munsafe-fp-atomics", "-fvisibility=hidden",
           "-Wall", "-Wno-unused-function"]
 # per-file extra flags; raster_project.hip feeds bit-exact integer keys -> no FMA contraction there; raster_project_bwd.hip (R8, HBM-bound,
 # one lane per surfel) follows the oracle's operation order statement by statement, so without contraction its 3-term dot products against the

@@ -444,7 +444,8 @@ constexpr int COOP_FRONT = 64;            // stop expanding once a level has thi
 constexpr int COOP_ITEMS = 256;           // >= 4 * (largest front - 1)
 constexpr int COOP_QFLUSH = 8;           // deferred exact tests: a wavefront's queue of entered leaf slots is worked off when it holds this many ...
 constexpr int COOP_QCAP = COOP_QFLUSH + 3 + 1;   // ... (a step adds at most four)
-struct CoopLds {
+static_assert(COOP_ODROW % 4 == 0, "the bin rows are read with ds_read_b128");
+struct alignas(16) CoopLds {          // (16 B: refresh_bound reads od[] as float4 -- ADVICE r5; the natural alignment of the members is 8)
     float od[64][COOP_ODROW];                 // ray-major (round 5): a ray's 32 bins are eight ds_read_b128, four in flight at a time, instead of 31 serialised ds_read_b32
     float odtot[64];
     int cnt[64];

@@ -234,6 +234,14 @@ class SurfelSet:
                 self._install(k, g, prm, st, data)
         for s in self.STATS:
             self.stats[s] = next(outs)
+        self._scene_changed()
+
+    @staticmethod
+    def _scene_changed():
+        """Rows were removed / appended or the opacities reset: a tracer's stored topology no longer describes this set even when the count
+        happens to be what it was -- its next request is a full build, not a refit (tracing.invalidate_all_structures)."""
+        from . import tracing
+        tracing.invalidate_all_structures()
 
     def _append(self, new, selected_stats, split, ratio):
         """densification_postfix + densify_stats (:590-621, :650-663): new rows get zero moments; their statistics are the parents' (gradient and
@@ -253,6 +261,7 @@ class SurfelSet:
         s["denom"] = torch.cat([s["denom"], dn.repeat(split, 1)], dim=0)
         s["max_radii2D"] = torch.cat([s["max_radii2D"], mr.repeat(split) * ratio], dim=0)
         s["xyz_weight_accum"] = torch.cat([s["xyz_weight_accum"], wa.repeat(split, 1) * wmax], dim=0)
+        self._scene_changed()
 
     def _selected(self, mask):
         outs = self.rows([self.p[k].data for k in self.names] + [self.stats[s] for s in self.STATS], mask)
@@ -292,6 +301,7 @@ class SurfelSet:
         """:512-515."""
         o = self.p["_opacity"].detach()
         self.replace("_opacity", torch.min(o, torch.logit(torch.ones_like(o) * value)))
+        self._scene_changed()           # (leaf boxes are bounded by the alpha >= 1/255 disc: every box shrinks at once)
 
     def reset_specular(self, value=0.001, reset_all=False):
         """:505-510."""

@@ -170,6 +170,7 @@ class GradExchange:
         if algo not in ("direct", "allreduce", "auto"):
             raise ValueError("algo must be 'direct', 'allreduce' or 'auto', got %r" % (algo,))
         self.auto = algo == "auto"                       # "auto": the direct form until autotune() has measured both on this machine
+        self.tuned = None                                # autotune()'s result
         algo = "direct" if self.auto else algo
         self.average, self.group, self.algo, self.overlap = average, group, algo, overlap
         self.enabled = _active(group)
@@ -275,6 +276,11 @@ class GradExchange:
         self._in_step = False
         if not self.enabled:
             return 0
+        if self.auto and self.tuned is None and not self.__dict__.get("_warned_auto"):
+            import warnings
+            self._warned_auto = True
+            warnings.warn("GradExchange(algo='auto'): autotune() has not been called -- using the direct reduce-scatter + all-gather form; call "
+                          "autotune() between two steps to let the machine choose")
         nbytes = 0
         for B in self.buckets:
             if not B.launched:
@@ -287,14 +293,18 @@ class GradExchange:
         return nbytes
 
     def autotune(self, reps=3):
-        """Measure BOTH exchange forms on buffers of this exchange's own sizes and keep the faster one (collective: every rank calls it at the same
-        point, between steps; the decision is taken on the MAX over ranks, so all ranks switch together).  The direct form assumes that RCCL's
+        """Measure BOTH exchange forms on this exchange's own flat buffers and keep the faster one (collective: every rank calls it at the same
+        point, BETWEEN steps -- after the optimizer consumed the gradients and before the next begin_step(), which zeroes the buffers anyway: their
+        contents are scratch here; the decision is taken on the MAX over ranks, so all ranks switch together).  The direct form assumes that RCCL's
         all-to-all drives the seven xGMI links of a GPU concurrently -- an assumption no run had checked when this was
-        written; `algo="auto"` callers (bench.py's default for N > 1) let the first steps on real hardware decide instead.  Returns
+        written; `algo="auto"` callers (bench.py's default for N > 1) let the first steps on real hardware decide instead: "auto" means the direct
+        form UNTIL this method has run (finish() warns once if it never does).  No second copy of the buckets is made: the direct
+        form's receive / reduce scratch is the persistent one when it exists and becomes the persistent one if the direct form wins.  Returns
         {"direct": ms, "allreduce": ms, "chosen": name} (None with one process)."""
         import time
         if not self.enabled:
             return None
+        reps = max(1, int(reps))
         if not self.buckets:
             self._rebuild(self.get_buckets())
         dev = self.buckets[0].flat.device if self.buckets else torch.device("cpu")
@@ -305,16 +315,17 @@ class GradExchange:
             dist.barrier(group=self.group)
             if dev.type == "cuda":
                 torch.cuda.synchronize(dev)
-        tmp = [torch.zeros_like(B.flat) for B in self.buckets]                       # (the gradients themselves are not touched)
-        scratch = [(torch.empty_like(B.flat), torch.empty(B.flat.numel() // self.world, dtype=torch.float32, device=B.flat.device)) for B in self.buckets]
+        scratch = [((B.recv if B.recv is not None else torch.empty_like(B.flat)),
+                    (B.mine if B.mine is not None else torch.empty(B.flat.numel() // self.world, dtype=torch.float32, device=B.flat.device))) for B in self.buckets]
         ms = {}
         for algo in ("direct", "allreduce"):
+            t0 = None
             for it in range(reps + 1):
                 if it == 1:
                     sync(); t0 = time.perf_counter()
-                for t, (rv, mn) in zip(tmp, scratch):
-                    if t.numel():
-                        exchange_flat(t, average=self.average, group=self.group, algo=algo, recv=rv, mine=mn)
+                for B, (rv, mn) in zip(self.buckets, scratch):
+                    if B.flat.numel():
+                        exchange_flat(B.flat, average=self.average, group=self.group, algo=algo, recv=rv, mine=mn)
             sync()
             ms[algo] = (time.perf_counter() - t0) / reps * 1e3
         tt = torch.tensor([ms["direct"], ms["allreduce"]], dtype=torch.float64, device=dev)
@@ -324,6 +335,7 @@ class GradExchange:
         for B, (rv, mn) in zip(self.buckets, scratch):                                # the direct form's persistent scratch, if it won
             B.recv, B.mine = (rv, mn) if self.algo == "direct" else (None, None)
         ms["chosen"] = self.algo
+        self.tuned = ms
         return ms
 
     def remove(self):

@@ -117,9 +117,13 @@ TRACE = {"depth": 0, "specular_threshold": 0.0}    # EnvGS hard-codes 0 bounces 
 
 
 def _apply_policy(tracer):
-    if hasattr(tracer, "set_structure_policy"):
-        if REFIT["every"] <= 1: tracer.set_structure_policy("rebuild")
-        else: tracer.set_structure_policy("adaptive", max_age=REFIT["every"] - 1)
+    """REFIT["every"] -> the tracer's policy, ONCE per change of the value: a policy the user set on the tracer afterwards stays, and only the
+    fields this module owns (mode, max_age) are touched -- max_growth is the tracer's / the user's."""
+    if not hasattr(tracer, "set_structure_policy") or getattr(tracer, "_envgs_step_refit", None) == REFIT["every"]:
+        return
+    tracer._envgs_step_refit = REFIT["every"]
+    if REFIT["every"] <= 1: tracer.set_structure_policy("rebuild")
+    else: tracer.set_structure_policy("adaptive", max_age=REFIT["every"] - 1)
 
 
 def env_prepare(tracer, env):

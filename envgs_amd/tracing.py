@@ -384,6 +384,15 @@ def frame_from_transmat(cov3D_precomp, settings):
 
 
 _BUILD_STREAMS = {}
+_SCENE_EPOCH = [0]
+
+
+def invalidate_all_structures():
+    """OPTIONAL: every SurfelTracer of the process answers its next `rebuild=True` request with a FULL build -- called by the code that knows the
+    surfel set changed wholesale while keeping its size (envgs_amd.densify.SurfelSet: densify / prune / opacity reset), so that the adaptive
+    build-or-refit policy never serves such a step from a stale topology (the quality guard only sees it one trace later)."""
+    _SCENE_EPOCH[0] += 1
+
 
 
 def _build_stream(dev):
@@ -433,24 +442,31 @@ class SurfelTracer(nn.Module):
         self._age = 0                     # structures derived from the last full build by refits
         self._q = None                    # quality read-backs: dict(host=pinned (2,2) floats, build=(event, row), last=(event, row))
 
-    def set_structure_policy(self, mode="adaptive", max_age=16, max_growth=1.25):
+    def set_structure_policy(self, mode=None, max_age=None, max_growth=None):
         """OPTIONAL, not part of the reference interface.  How a `rebuild=True` request is served when the surfel count is unchanged:
         "adaptive" (default): by a REFIT of the existing topology (envgs_bvh_refit: 6 launches instead of 15; hit sets identical to a fresh build's)
                      unless `max_age` structures have been derived from the last full build, or the tree's surface-area cost measured on the
                      device after the previous refit (envgs_bvh_quality, read back asynchronously -- never a host sync) has grown by more than
                      `max_growth` x since that build (surfels moved far: opacity reset, a prune + densify that kept the count, a scene change);
         "rebuild":   always by a full build -- the literal behaviour of the reference's OptiX GAS.
-        `rebuild=False` requests are always refits (OptiX's update), a changed surfel count always a full build."""
-        if mode not in ("adaptive", "rebuild"):
+        `rebuild=False` requests are always refits (OptiX's update), a changed surfel count always a full build.
+        Only the arguments that are given change (None = keep the current value; defaults: "adaptive", 16, 1.25) -- a caller that tunes one
+        field does not reset the others."""
+        if mode is not None and mode not in ("adaptive", "rebuild"):
             raise ValueError("structure policy must be 'adaptive' or 'rebuild', got %r" % (mode,))
-        self._policy = dict(mode=mode, max_age=int(max_age), max_growth=float(max_growth))
+        if mode is not None: self._policy["mode"] = mode
+        if max_age is not None: self._policy["max_age"] = int(max_age)
+        if max_growth is not None: self._policy["max_growth"] = float(max_growth)
 
     def invalidate_structure(self):
         """OPTIONAL: forget the existing structure (the next request is a full build whatever the policy) -- for a caller that knows the surfel
-        set was re-indexed without changing its size (prune + densify)."""
+        set was re-indexed or moved wholesale without changing its size (prune + densify, opacity reset).  envgs_amd.densify.SurfelSet says so
+        for every tracer of the process through `invalidate_all_structures()`; the unchanged EasyVolcap GaussianModel does not, and pays ONE
+        badly fitted refit before the quality guard rebuilds."""
         self._keep = None
         self.nodes = None
         self._age = 0
+        self._epoch = _SCENE_EPOCH[0]
 
     def _refit_allowed(self):
         pol = self._policy
@@ -500,6 +516,8 @@ class SurfelTracer(nn.Module):
         ev = self.__dict__.pop("_build_event", None)
         if ev is not None and self.nodes is not None:
             torch.cuda.current_stream(self.nodes.device).wait_event(ev)       # (a build started by prepare() that no trace has consumed)
+        if self.__dict__.get("_epoch", 0) != _SCENE_EPOCH[0]:      # invalidate_all_structures() since this tracer's last build: topology is stale
+            self.invalidate_structure()
         have = self.nodes if self.nodes is not None else self._keep
         same = have is not None and vertices.shape[0] // 4 == self.num_surfels
         self._keep = have if (same and (not rebuild or self._refit_allowed())) else None

@@ -112,6 +112,17 @@ def raster_audit(fwd, want_contrib=False, canonical=True):
                 legacy_fragile=legacy, canonical=bool(canonical), tainted=tainted[:P].astype(bool), contrib=contrib, lmax=max(lmax, 1))
 
 
+def raster_dist64(fwd):
+    """Distortion shadow of the forward `fwd` (orc_render_dist64): (dist64 (H,W) float64 = the distortion evaluated in double from the float code's own
+    alphas and depths, bound (H,W) float64 = the a-priori fp32 rounding bound of the moment form, see the C comment)."""
+    L = lib()
+    cfg = fwd["cfg"]; H, W = fwd["H"], fwd["W"]
+    pl = fwd["point_list"] if fwd["N"] > 0 else np.zeros(1, np.uint32)
+    d64 = np.zeros(H * W, np.float64); bd = np.zeros(H * W, np.float64)
+    L.orc_render_dist64(ctypes.byref(cfg), _p(fwd["ranges"]), _p(pl), _p(fwd["transmat"]), _p(fwd["xy"]), _p(fwd["normal_opacity"]), _p(d64), _p(bd))
+    return d64.reshape(H, W), bd.reshape(H, W)
+
+
 def sh_clamp_audit(fwd):
     """(P,) bool: surfels whose SH colour lies within fp32 rounding of the clamp at 0 in some channel (orc_sh_clamp_audit); None without SH."""
     inp = fwd["inputs"]

@@ -176,7 +176,7 @@ static int ent_cmp(const void *a, const void *b)
     return x->id < y->id ? -1 : (x->id > y->id);
 }
 
-typedef struct { float rgb[3], dpt, acc, nrm[3], dist, aux[2], T; int nhit; } stage_t;
+typedef struct { float rgb[3], dpt, acc, nrm[3], dist, aux[2], T; int nhit; double dist64, distb; } stage_t;     /* dist64 / distb: the distortion shadow, see trc_set_dist_shadow */
 
 /* one stage: trace ray (o,d), composite front to back.  ents is scratch of size P. */
 static void trace_stage(const trc_cfg *cfg, const surfel_t *S, const float *shs, const float *colors_precomp,
@@ -195,6 +195,8 @@ static void trace_stage(const trc_cfg *cfg, const surfel_t *S, const float *shs,
     sh_basis(cfg->D, dir, basis);
     memset(out, 0, sizeof(*out));
     float T = 1.0f, M1 = 0.f, M2 = 0.f;
+    double Td = 1.0, M1d = 0.0, M2d = 0.0;
+    const double u = 5.9604644775390625e-8;
     for (int k = 0; k < n; k++) {
         const rhit_t *h = &ents[k].h;
         const int g = ents[k].id;
@@ -207,6 +209,16 @@ static void trace_stage(const trc_cfg *cfg, const surfel_t *S, const float *shs,
         float m = FAR_N / (FAR_N - NEAR_N) * (1.0f - NEAR_N / tt);
         out->dist += (m * m * (1.0f - T) + M2 - 2.0f * m * M1) * w;
         M1 += m * w; M2 += m * m * w;
+        {   /* the distortion in double from the float code's own alpha and t, and the a-priori fp32 bound of the moment form (same definitions as
+               orc_render_dist64 in surfel_raster_oracle.c; the tracer's wavefront scans add log2(64) levels to the running sums: j + 10) */
+            const double wd = (double)h->alpha * Td, A = 1.0 - Td, j = (double)out->nhit;
+            const double md = (double)FAR_N / ((double)FAR_N - (double)NEAR_N) * (1.0 - (double)NEAR_N / (double)tt);
+            const double E = md * md * A + M2d - 2.0 * md * M1d;
+            out->dist64 += E * wd;
+            out->distb += wd * u * ((j + 10.0) * (md * md * A + M2d + 2.0 * fabs(md) * M1d) + (j + 8.0) * md * md + 12.0 * fabs(md) * sqrt(A * (E > 0.0 ? E : 0.0)) + (j + 2.0) * fabs(E));
+            M1d += md * wd; M2d += md * md * wd;
+            Td *= 1.0 - (double)h->alpha;
+        }
         for (int c = 0; c < 3; c++) out->rgb[c] += w * col[c];
         out->dpt += w * h->t;
         out->acc += w;
@@ -228,6 +240,11 @@ static void trace_stage(const trc_cfg *cfg, const surfel_t *S, const float *shs,
  * Forward.  Outputs: rgb (R,3) dpt (R) acc (R) norm (R,3) dist (R) aux (R,2) mid (R,16*(depth+1)) wet (P) double,
  * final_T (R) (stage-0 transmittance; saved for the backward), nhits (R) int32.
  */
+/* Optional outputs of trc_forward (test infrastructure, set before the call, cleared by it): per ray, stage 0's distortion evaluated in double
+ * and the a-priori fp32 rounding bound of its moment form -- what the HIP value is asserted against (tests/test_trace_parity.py). */
+static double *g_dist64 = NULL, *g_distb = NULL;
+void trc_set_dist_shadow(double *dist64, double *bound) { g_dist64 = dist64; g_distb = bound; }
+
 void trc_forward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, const float *means, const float *scales,
                  const float *rots, const float *opac, const float *shs, const float *colors_precomp, const float *others,
                  const float *bg, float *rgb, float *dpt, float *acc, float *norm, float *dist, float *aux, float *mid,
@@ -277,10 +294,13 @@ void trc_forward(const trc_cfg *cfg, const float *ray_o, const float *ray_d, con
             for (int c = 0; c < 3; c++) norm[3 * r + c] = st[0].nrm[c];
             aux[2 * r] = st[0].aux[0]; aux[2 * r + 1] = st[0].aux[1];
             final_T[r] = st[0].T; nhits[r] = st[0].nhit;
+            if (g_dist64) g_dist64[r] = st[0].dist64;
+            if (g_distb) g_distb[r] = st[0].distb;
         }
         free(ents);
     }
     free(S);
+    g_dist64 = NULL; g_distb = NULL;
 }
 
 /*

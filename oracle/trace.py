@@ -29,11 +29,15 @@ def trace_forward(ray_o, ray_d, means3D, scales, rotations, opacities, *, shs=No
     norm = np.zeros((R, 3), np.float32); dist = np.zeros(R, np.float32); aux = np.zeros((R, 2), np.float32)
     mid = np.zeros((R, 16 * ND), np.float32); wet = np.zeros(P, np.float64)
     final_T = np.zeros(R, np.float32); nhits = np.zeros(R, np.int32)
+    # the distortion shadow (trc_set_dist_shadow): stage 0's distortion in double from the float code's own alphas / distances, and the a-priori
+    # fp32 rounding bound of its moment form -- what a HIP value is asserted against
+    dist64 = np.zeros(R, np.float64); dist_bound = np.zeros(R, np.float64)
+    L.trc_set_dist_shadow(_p(dist64), _p(dist_bound))
     L.trc_forward(ctypes.byref(cfg), _p(ray_o), _p(ray_d), _p(means3D), _p(scales), _p(rotations), _p(opacities), _p(shs),
                   _p(colors_precomp), _p(others), _p(bg), _p(rgb), _p(dpt), _p(acc), _p(norm), _p(dist), _p(aux), _p(mid),
                   _p(wet), _p(final_T), _p(nhits))
     return dict(cfg=cfg, rgb=rgb, dpt=dpt, acc=acc, norm=norm, dist=dist, aux=aux, mid=mid, wet=wet, final_T=final_T,
-                nhits=nhits, bg=bg,
+                nhits=nhits, bg=bg, dist64=dist64, dist_bound=dist_bound,
                 inputs=dict(ray_o=ray_o, ray_d=ray_d, means3D=means3D, scales=scales, rotations=rotations,
                             opacities=opacities, shs=shs, colors_precomp=colors_precomp, others=others))
 

@@ -108,9 +108,15 @@ def _compare_forward(test, outs, saved, ref, aud, sh, check_sets):
     check_close(test, "color", color[:, ok], ref["out_color"][:, ok], excluded=nfr)
     for ch, nm in ((0, "depth"), (1, "alpha"), (2, "normal.x"), (3, "normal.y"), (4, "normal.z"), (5, "median")):
         check_close(test, "allmap." + nm, allmap[ch][ok], ref["allmap"][ch][ok], excluded=nfr)
-    # distortion: sum_i w_i (m_i^2 A + M2 - 2 m_i M1) cancels catastrophically in fp32 in BOTH implementations (tests/test_oracle_grad.py);
-    # its floor is the magnitude of what is summed (~ the alpha channel), not of the remainder
-    check_close(test, "allmap.dist", allmap[6][ok], ref["allmap"][6][ok], floor=float(np.abs(ref["allmap"][1][ok]).mean()), excluded=nfr)
+    # distortion: sum_j w_j (m_j^2 A + M2 - 2 m_j M1) cancels catastrophically in fp32 in ANY implementation of the moment form.  Round 6 (VERDICT r5
+    # item 6a): compared with the oracle's evaluation in DOUBLE (of the float code's own alphas and depths) under a DERIVED per-pixel bound --
+    # |hip - dist64| <= 1e-4 |dist64| + bound, bound = the a-priori fp32 rounding of the three moment terms, of a ~3 ulp difference in m and of the
+    # weight (orc_render_dist64) -- instead of a floor of the mean alpha; the plain error against the float oracle stays in the table as a record
+    from oracle import raster as orc_
+    d64, dbound = orc_.raster_dist64(ref)
+    check_close(test, "allmap.dist", allmap[6][ok], d64[ok], excluded=nfr, cond=np.zeros_like(dbound[ok]), unc=dbound[ok], k_unc=1.0)
+    record(test, "allmap.dist.oracle_f32_vs_f64_over_bound", float((np.abs(ref["allmap"][6][ok] - d64[ok]) / (1e-4 * np.abs(d64[ok]) + dbound[ok] + 1e-300)).max()),
+           note="(the float oracle's own distance from the double evaluation, in units of the asserted bound: must be <= 1 too)")
     check_close(test, "final_T", saved["final_T"].cpu().numpy()[:, ok], ref["final_T"][:, ok], excluded=nfr)
     clean = ~aud["tainted"]
     check_close(test, "weight", weight[clean, 0], ref["weight"][clean], excluded=int(aud["tainted"].sum()))
@@ -229,9 +235,10 @@ def test_backward_sparse_distortion_gradient():
     grads = dict(leaves, means2D=means2D)
     for k_hip, k_ref in GRAD_NAMES:
         # the ONLY upstream gradient is the distortion map's: every term is the three-term cancellation M2 + m^2 A - 2 m M1 of the forward's saved
-        # moments, whose `unc` is an a-priori ONE-ulp bound (orc_render_bwd_unc), not a realised error: 16 ulp here, 4 x realised error elsewhere
+        # moments, whose `unc` is an a-priori ONE-ulp bound (orc_render_bwd_unc), not a realised error.  Round 6: asserted at the
+        # suite-wide K_UNC like everything else (rounds 4-5: 16) -- the table's sensitivity columns carry 4 / 0 next to it
         check_close("sparse_distortion_gradient", k_ref, grads[k_hip].grad.cpu().numpy().reshape(rb[k_ref].shape), rb[k_ref],
-                    excluded=int(aud["fragile"].sum()), cond=rb["cond"][k_ref], unc=rb["unc"][k_ref], k_unc=16.0)
+                    excluded=int(aud["fragile"].sum()), cond=rb["cond"][k_ref], unc=rb["unc"][k_ref])
 
 
 def test_precomputed_transmat_path():

@@ -26,13 +26,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _launch(script_args, backend):
+def _launch(script_args, backend, nproc=2):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     if backend == "gloo":
         env["ENVGS_DIST_BACKEND"] = "gloo"
     else:
         env.pop("ENVGS_DIST_BACKEND", None)                  # default on a GPU box: nccl (= RCCL)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + script_args
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=540)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -41,8 +41,8 @@ def _launch(script_args, backend):
     return json.loads(lines[0])
 
 
-def _check_worker(d, backend, exchange):
-    assert d["world"] == 2 and d["backend"] == backend and d["exchange"] == exchange
+def _check_worker(d, backend, exchange, world=2):
+    assert d["world"] == world and d["backend"] == backend and d["exchange"] == exchange
     assert d["identical_on_all_ranks"] is True, d
     assert d["finite"] and d["trained"]
     ev = d["densify"][0]
@@ -56,6 +56,19 @@ def _check_worker(d, backend, exchange):
 def test_dp_training_keeps_ranks_identical_two_ranks_gloo_one_gpu(exchange):
     d = _launch([os.path.join(ROOT, "tests", "dist_train_worker.py"), "--steps", "4", "--densify-at", "2", "--exchange", exchange], "gloo")
     _check_worker(d, "gloo", exchange)
+
+
+@pytest.mark.timeout(900)
+def test_dp_training_keeps_ranks_identical_eight_ranks_gloo_one_gpu():
+    """BASELINE configs[3]'s rank count: EIGHT replicas of the training worker -- sharing the one GPU, over gloo -- through camera
+    sharding, GradExchange with eight chunks per bucket, summed densification statistics and one densify + prune: every parameter and both Adam
+    moments of all eight ranks bit-identical with rank 0's.  (The rendering needs the GPU: there is no CPU path to run this on the host alone;
+    the exchange bookkeeping itself runs with eight CPU ranks in tests/test_dist_gloo.py.)"""
+    d = _launch([os.path.join(ROOT, "tests", "dist_train_worker.py"), "--steps", "3", "--densify-at", "2", "--exchange", "direct", "--gaussians", "8000",
+                 "--env-gaussians", "4096", "--res", "96"], "gloo", nproc=8)
+    assert d["world"] == 8 and d["backend"] == "gloo" and d["identical_on_all_ranks"] is True and d["finite"] and d["trained"], d
+    ev = d["densify"][0]
+    assert ev["base_after"] != ev["base_before"] and ev["env_after"] < 4096
 
 
 @pytest.mark.timeout(600)

@@ -78,7 +78,9 @@ K_UNC = 1.0     # rounds 1-3: 16 (plus, at full size, a tail allowance); round 4
                 # measured for every comparison of the suite.  The one exception is the test whose `unc` is an a-priori ulp bound, not a realised error
                 # (test_raster_parity.py: sparse_distortion_gradient, k_unc=16).
 FRAGILE_PX_MAX = 2e-3       # stated bounds on what the oracle's audit may exclude from a comparison (fail, do not only count): pixels whose
-FRAGILE_RAYS_MAX = 5e-2     # outcome hangs on a threshold inside fp32 noise (measured: <= 7.2e-4 of the pixels, <= 3.3e-2 of the rays of the deep-list cases)
+FRAGILE_RAYS_MAX = 4e-2     # outcome hangs on a threshold inside fp32 noise (measured: <= 7.2e-4 of the pixels, <= 3.3e-2 of the rays of the deep-list cases;
+                            # round 6: 5e-2 -> 4e-2 = the measured maximum + margin, and what the excluded rays do is asserted too:
+                            # tests/test_trace_parity.py::test_fragile_rays_differ_from_the_oracle_by_threshold_hits_only)
 TIMINGS = []                # device times recorded by tests (printed in the summary; never asserted under -m gpu)
 ERROR_TABLE = []
 
