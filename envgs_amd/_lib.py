@@ -44,7 +44,8 @@ class TraceLists(ctypes.Structure):
                 ("records", ctypes.c_void_p),
                 ("num_records", ctypes.c_uint64), ("hit_state", ctypes.c_void_p), ("entries", ctypes.c_void_p), ("pairs", ctypes.c_void_p),
                 ("n_entries", ctypes.c_void_p), ("compact_rows", ctypes.c_uint64), ("row_off", ctypes.c_void_p), ("batch_rows", ctypes.c_void_p),
-                ("row_blk", ctypes.c_void_p), ("sh_perm", ctypes.c_void_p), ("state_planes", ctypes.c_int32)]
+                ("row_blk", ctypes.c_void_p), ("sh_perm", ctypes.c_void_p), ("state_planes", ctypes.c_int32),
+                ("sparse_hits", ctypes.c_void_p), ("sparse_cap", ctypes.c_uint64)]
 
 
 class TraceCfg(ctypes.Structure):

@@ -157,6 +157,13 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         A.state_plane = compact ? (size_t)L->compact_rows : (size_t)cfg->num_rays * (size_t)L->cap;
         A.colour_state = L->state_planes == 1 ? 1 : 0;
         if (compact) { A.row_off = L->row_off; A.batch_rows = (const uint2 *)L->batch_rows; A.batch_cnt = L->row_blk; }
+        if (L->sparse_hits && L->sparse_cap > 0 && L->entries && L->pairs && L->hit_state) {
+            // sparse entries (envgs_trace.h: sparse_hits): entries of at most 4 hits are filed per hit (ENVGS_DBG_SPARSE: value - 1 overrides, 1 = off)
+            const int sw = debug_switch(ENVGS_DBG_SPARSE);
+            A.sparse = (uint4 *)L->sparse_hits;
+            A.sparse_cap = (unsigned)(L->sparse_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : L->sparse_cap);
+            A.sparse_max = sw > 0 ? (sw - 1 > 64 ? 64 : sw - 1) : 4;
+        }
         if (L->sh_perm && shs && cfg->sh_coeffs == 16) {
             const size_t nw = (size_t)cfg->P * 48;
             FP.perm_blocks = (int)((nw + 255) / 256); FP.nb = (cfg->sh_degree + 1) * (cfg->sh_degree + 1); FP.f16 = cfg->feature_f16;
@@ -369,6 +376,11 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
                     if (rgb_only) hipLaunchKernelGGL((batch_surfel_bwd<true, false>), g, dim3(64), 0, stream, A);
                     else if (cfg->has_others) hipLaunchKernelGGL((batch_surfel_bwd<false, true>), g, dim3(64), 0, stream, A);
                     else hipLaunchKernelGGL((batch_surfel_bwd<false, false>), g, dim3(64), 0, stream, A);
+                    if (L->sparse_hits && L->sparse_cap > 0) {      // the hits of sparse entries, one lane each (adds to the ray gradients stored above)
+                        A.sparse = (uint4 *)L->sparse_hits;
+                        A.sparse_cap = (unsigned)(L->sparse_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : L->sparse_cap);
+                        hipLaunchKernelGGL(sparse_hits_bwd, dim3(2048), dim3(256), 0, stream, A, rgb_only ? 1 : 0);
+                    }
                 }
                 { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, stream, A); }
             } else {

@@ -445,7 +445,7 @@ constexpr int COOP_ITEMS = 256;           // >= 4 * (largest front - 1)
 constexpr int COOP_QFLUSH = 8;           // deferred exact tests: a wavefront's queue of entered leaf slots is worked off when it holds this many ...
 constexpr int COOP_QCAP = COOP_QFLUSH + 3 + 1;   // ... (a step adds at most four)
 static_assert(COOP_ODROW % 4 == 0, "the bin rows are read with ds_read_b128");
-struct alignas(16) CoopLds {          // (16 B: refresh_bound reads od[] as float4 -- ADVICE r5; the natural alignment of the members is 8)
+struct CoopLds {                      // (refresh_bound reads od[] as float4: the OBJECT is declared 16 B aligned in the kernel -- see there)
     float od[64][COOP_ODROW];                 // ray-major (round 5): a ray's 32 bins are eight ds_read_b128, four in flight at a time, instead of 31 serialised ds_read_b32
     float odtot[64];
     int cnt[64];
@@ -475,8 +475,14 @@ template <bool DEFER, int WAVES>
 __global__ void __launch_bounds__(64 * COOP_W, WAVES)
 collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const float4 *__restrict__ nodes4, const float4 *__restrict__ srec)
 {
+    // (refresh_bound's ds_read_b128 of L.od needs L 16 B aligned.  It IS -- L is the kernel's first LDS object -- but SAYING so, on the
+    //  type (alignas) or on this declaration, changes the backend's code for the worse: collect 1.59 -> 1.66 ms per launch, both ways, measured
+    //  twice in round 6 (profiles/r06_ab_collect.txt).  So the alignment is CHECKED instead: the diagnostic build traps on a misaligned L.)
     __shared__ CoopLds L;
     __shared__ CoopQueue Q;
+#ifdef ENVGS_DIAG
+    if ((reinterpret_cast<size_t>(&L.od[0][0]) & 15) != 0) __builtin_trap();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slimit = (A.exp & 1024) ? 2 : COOP_STK;     // (test switch: forces the overflow hand-off)
     unsigned found_tot = 0, psteps = 0, pleaves = 0;

@@ -173,6 +173,9 @@ struct TraceArgs {
     int *stack_spill;   // collect_hits: (grid, STACK, 64) ints of stack overflow space
     int only_overflow;  // K-buffer kernels: process only rays whose hit_cnt exceeds cap
     int batch0, batch1; // list-path forward kernels: the range of 64-ray batches this launch owns (segments run on two streams)
+    uint4 *sparse;      // (sparse_cap) hits of SPARSE entries (envgs_trace.h: sparse_hits): {sorted ray slot, list position, surfel id, record slot}; counter[64] = how many
+    unsigned sparse_cap;
+    int sparse_max;     // an entry with at most this many hits is filed per hit instead of becoming an entry of the batch kernel (0 = off)
     int seg;            // segment index: selects the batch-fetch counters and the stack-spill slab
     int spill_stride;   // stack-spill slabs per segment
     unsigned long long *entries;  // (batches, 64*cap) distinct (batch, surfel) entries, see register_hits
@@ -672,6 +675,7 @@ __global__ void __launch_bounds__(256) row_offsets(const TraceArgs A, const unsi
                                                    const unsigned *__restrict__ seg_base, unsigned long long limit);      // blk: exclusive scan of the per-BATCH row counts
 __global__ void __launch_bounds__(256) unpack_surfel_acc(int P, int wfrac, const unsigned long long *__restrict__ acc, unsigned *__restrict__ cnt,
                                                          float *__restrict__ wet, unsigned *ray_counter);
+__global__ void __launch_bounds__(256) sparse_hits_bwd(const TraceArgs A, const int rgbo);
 template <bool RGBO, bool OTH> __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd(const TraceArgs A);
 extern template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<false, false>(const TraceArgs A);
 extern template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<false, true>(const TraceArgs A);

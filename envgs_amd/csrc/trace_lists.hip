@@ -459,8 +459,15 @@ register_hits(const TraceArgs A)
         // Flush in order of FIRST APPEARANCE along the rays (~ front to back): the backward then meets each ray's hits in roughly ascending
         // list position, so the per-hit state it gathers is consumed cache line by cache line instead of at random.
         const unsigned D = ndense;
+        // SPARSE entries (round 6; envgs_trace.h: sparse_hits): a surfel that at most sparse_max of the batch's 64 rays blended does not become an
+        // entry -- batch_surfel_bwd pays one 64-lane pass per entry however few of its lanes are live, and a fifth of the entries of the benchmark
+        // view carry 1.4 % of its hits.  Its hits are filed in a global list instead (one lane of sparse_hits_bwd and one gradient record PER HIT:
+        // the surfel's record count grows by its hit count).  List space is claimed per 64-surfel chunk with one atomic; a chunk that finds no
+        // room gives its claim back and files ordinary entries (successful claims stay compact: a later claim can only succeed once the
+        // counter is back below the capacity, i.e. behind every successful one).
+        const bool sparse_on = A.sparse != nullptr && A.sparse_max > 0 && ent != nullptr && prs != nullptr;
         if (part == 0) {
-            unsigned carry_off = 0u;
+            unsigned carry_off = 0u, carry_d = 0u;
             for (unsigned c = 0; c < D; c += 64) {
                 const unsigned d = c + lane;
                 const bool occ = d < D;
@@ -468,16 +475,44 @@ register_hits(const TraceArgs A)
                 const int sid = occ ? key[h] : 0;
                 const unsigned long long av = occ ? acc[h] : 0ull;
                 const unsigned cn = (unsigned)(av & 0xFFull);
-                const float incl = wave_scan_add((float)cn);                 // exact: at most 64*cap < 2^24 hits per batch
-                const unsigned offh = carry_off + (unsigned)incl - cn;
+                bool sp = sparse_on && occ && cn <= (unsigned)A.sparse_max;
+                unsigned sp_pos = 0u;
+                if (sparse_on) {
+                    const unsigned spn = sp ? cn : 0u;
+                    const float sincl = wave_scan_add((float)spn);
+                    const unsigned stot = (unsigned)wave_bcast(sincl, 63);
+                    if (stot > 0u) {
+                        unsigned sb = 0u;
+                        if (lane == 0) {
+                            sb = atomicAdd(A.counter + 64, stot);
+                            if (sb > A.sparse_cap || stot > A.sparse_cap - sb) { atomicSub(A.counter + 64, stot); sb = 0xFFFFFFFFu; }
+                        }
+                        sb = (unsigned)__builtin_amdgcn_readfirstlane((int)sb);
+                        if (sb == 0xFFFFFFFFu) sp = false;
+                        else sp_pos = sb + (unsigned)sincl - spn;
+                    }
+                }
+                const bool dense = occ && !sp;
+                const unsigned dcn = dense ? cn : 0u;
+                const float incl = wave_scan_add((float)dcn);                // exact: at most 64*cap < 2^24 hits per batch
+                const unsigned offh = carry_off + (unsigned)incl - dcn;
+                const float dincl = wave_scan_add(dense ? 1.0f : 0.0f);
+                const unsigned dd = carry_d + (unsigned)dincl - 1u;         // this entry's place among the batch's (dense) entries: first-appearance order kept
                 if (occ) {
-                    const unsigned long long old = atomicAdd(A.surf_acc + (size_t)sid * NCOPY + copy, ((av >> 8) << 24) | 1ull);
-                    if (ent) ent[d] = (unsigned long long)(unsigned)sid | ((unsigned long long)(cn - 1u) << 24) | ((old & 0xFFFFFFull) << 32);
-                    acc[h] = (unsigned long long)offh;
+                    const unsigned long long old = atomicAdd(A.surf_acc + (size_t)sid * NCOPY + copy, ((av >> 8) << 24) | (unsigned long long)(sp ? cn : 1u));
+                    if (dense) {
+                        if (ent) ent[dd] = (unsigned long long)(unsigned)sid | ((unsigned long long)(cn - 1u) << 24) | ((old & 0xFFFFFFull) << 32);
+                        acc[h] = (unsigned long long)offh;
+                    } else {
+                        // bit 63: sparse; bits 0..31 list position of the surfel's first hit, 32..55 its first record slot, 56..62 the rank handed out next
+                        acc[h] = (1ull << 63) | (unsigned long long)sp_pos | ((old & 0xFFFFFFull) << 32);
+                    }
                 }
                 carry_off += (unsigned)wave_bcast(incl, 63);
+                carry_d += (unsigned)wave_bcast(dincl, 63);
             }
-            if (A.n_entries && lane == 0) { A.n_entries[2 * batch] = (int)D; A.n_entries[2 * batch + 1] = (int)nfail; }
+            if (A.n_entries && lane == 0) { A.n_entries[2 * batch] = (int)carry_d; A.n_entries[2 * batch + 1] = (int)nfail; }
+            if (ent && lane == 0) atomicAdd(A.counter + 65, carry_d + nfail);      // entries of the call (with counters[2..3], the composited hits: how coherent its batches are)
             if (lane == 0) ptotal = carry_off;
         }
         __syncthreads();
@@ -503,15 +538,40 @@ register_hits(const TraceArgs A)
                             h = (h + 1) & (RH_TAB - 1);
                         }
                         if (ok) {
-                            const unsigned long long o = atomicAdd(&acc[h], 1ull << 32);
-                            const unsigned idx = (unsigned)o + (unsigned)(o >> 32), v = ((unsigned)lane << 16) | (unsigned)(kb + j * RH_W);
-                            if (idx < (unsigned)RH_STAGE) pstage[idx] = v; else prs[idx] = v;
+                            if (sparse_on && (acc[h] >> 63)) {               // (the flag never changes once the flush has set it)
+                                const unsigned long long o = atomicAdd(&acc[h], 1ull << 56);
+                                const unsigned rank = (unsigned)(o >> 56) & 0x7Fu;
+                                A.sparse[(unsigned)o + rank] = make_uint4((unsigned)(base + lane), (unsigned)(kb + j * RH_W), sidv[j], ((unsigned)(o >> 32) & 0xFFFFFFu) + rank);
+                            } else {
+                                const unsigned long long o = atomicAdd(&acc[h], 1ull << 32);
+                                const unsigned idx = (unsigned)o + (unsigned)(o >> 32), v = ((unsigned)lane << 16) | (unsigned)(kb + j * RH_W);
+                                if (idx < (unsigned)RH_STAGE) pstage[idx] = v; else prs[idx] = v;
+                            }
                         }
                     }
             }
             __syncthreads();
             const unsigned T = min(ptotal, (unsigned)RH_STAGE);
             for (unsigned i = threadIdx.x; i < T; i += 64 * RH_W) prs[i] = pstage[i];
+            // the hits that found no room in the table (an incoherent batch: more than ~1000 distinct surfels) are one-hit entries filed from the top of
+            // the region: with sparse entries on they move to the sparse list as well -- one claim per batch -- and the batch kernel sees none
+            if (sparse_on && nfail > 0u) {
+                __shared__ unsigned fbase;
+                if (threadIdx.x == 0) {
+                    unsigned sb = atomicAdd(A.counter + 64, nfail);
+                    if (sb > A.sparse_cap || nfail > A.sparse_cap - sb) { atomicSub(A.counter + 64, nfail); sb = 0xFFFFFFFFu; }
+                    fbase = sb;
+                }
+                __syncthreads();                                   // (also: this workgroup's own ent / prs stores of the first phase are visible to it)
+                if (fbase != 0xFFFFFFFFu) {
+                    for (unsigned f = threadIdx.x; f < nfail; f += 64 * RH_W) {
+                        const unsigned long long ev = ent[region - 1 - f];
+                        const unsigned pv = prs[region - 1 - f];
+                        A.sparse[fbase + f] = make_uint4((unsigned)base + (pv >> 16), pv & 0xFFFFu, (unsigned)(ev & 0xFFFFFFull), (unsigned)(ev >> 32));
+                    }
+                    if (threadIdx.x == 0) { if (A.n_entries) A.n_entries[2 * batch + 1] = 0; atomicSub(A.counter + 65, nfail); }
+                }
+            }
         }
     }
 }

@@ -54,7 +54,7 @@ composite_lists_bwd(const TraceArgs A)
 // per-hit gathers of surfel data, no dependent chain along the ray, no atomics.
 constexpr int BS_GROUP = 16;
 #ifndef ENVGS_BSB_KO
-#define ENVGS_BSB_KO 0          // measurement builds only (scratch/ab_bsb.sh): 1 = no dothers, 2 = no aux-plane fetch, 4 = no plane-1 fetch -- results wrong by construction
+#define ENVGS_BSB_KO 0          // measurement builds only (scratch/ab_bsb.sh): 1 = no dothers, 2 = no aux-plane fetch, 4 = no plane-1 fetch, 8 = no plane-0 fetch -- results wrong by construction
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -240,7 +240,7 @@ batch_surfel_bwd(const TraceArgs A)
             // per-hit state of one list position: plane 0 (16 B) -- and, generic form, plane 1: 16 B rows, or 24 B rows = two 12 B halves with `others`
             auto fetch_state = [&](const int k) {
                 const float4 *sp = k > 0 ? state + (size_t)(k - 1) : A.state;      // unconditional (idle lanes share one address): no branch, no wait
-                st0 = sp[0];
+                if (ENVGS_BSB_KO & 8) st0 = make_float4(0.5f, 0.1f, 0.1f, 0.1f); else st0 = sp[0];
                 if constexpr (!RGBO) {
                     if (ENVGS_BSB_KO & 4) return;
                     if constexpr (OTH) {
@@ -438,6 +438,124 @@ batch_surfel_bwd(const TraceArgs A)
 template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<false, false>(const TraceArgs A);
 template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<false, true>(const TraceArgs A);
 template __global__ void __attribute__((amdgpu_waves_per_eu(ENVGS_BSB_WAVES, ENVGS_BSB_WAVES))) __launch_bounds__(64) batch_surfel_bwd<true, false>(const TraceArgs A);
+
+// The hits of SPARSE entries (register_hits; envgs_trace.h: sparse_hits), one LANE per hit: the surfel-major batch kernel above spends a whole
+// 64-lane pass on an entry whatever its hit count, so entries that 1-4 of the batch's rays blended (a fifth of the entries of the benchmark
+// view, three quarters for incoherent bounce rays) are differentiated here instead, each hit on its own -- its ray's constants, its per-hit
+// state row, the surfel's record and SH block gathered per lane -- and write one gradient record PER HIT (no reduction over rays is left to
+// do; reduce_surfel_records sums a surfel's records whoever wrote them).  Same formulas as batch_surfel_bwd (IEEE-rounded where that kernel
+// uses v_rcp_f32: the contract is 1e-4).  Runs AFTER the batch kernel, which stores the rays' gradients: this one adds to them.
+__global__ void __launch_bounds__(256)
+sparse_hits_bwd(const TraceArgs A, const int rgbo)
+{
+    const unsigned filed = __hip_atomic_load(A.counter + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned n = filed < A.sparse_cap ? filed : A.sparse_cap;
+    const int nb = (A.D + 1) * (A.D + 1);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint4 e = A.sparse[i];
+        const int slot = (int)e.x, k = (int)e.y, sid = (int)e.z;
+        const int r = ray_of(A, slot);
+        if (r >= A.R) continue;
+        BwdRay B;
+        bwd_load_ray(A, r, B);
+        float basis[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) basis[q] = 0.f;
+        sh_basis(A.D, B.ux, B.uy, B.uz, basis);
+        const size_t row = state_row0(A, slot, r) + (size_t)k;
+        const float4 st0 = A.state[row];
+        float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float sx0 = 0.f, sx1 = 0.f;
+        if (!rgbo) {
+            if (A.has_others) {
+                const float *q = reinterpret_cast<const float *>(state_row1(A, row));
+                st1 = make_float4(q[0], q[1], q[2], q[3]); sx0 = q[4]; sx1 = q[5];
+            } else st1 = *reinterpret_cast<const float4 *>(state_row1(A, row));
+        }
+        const float4 *sr = A.srec + (size_t)sid * 4;
+        const float4 s0 = sr[0], s1 = sr[1], s2 = sr[2], s3 = sr[3];
+        const SurfHit h = hit_surfel(s0, s1, s2, s3, B.ox, B.oy, B.oz, B.dx, B.dy, B.dz);
+        float shv[48];
+        float col[3]; bool cl[3] = {false, false, false};
+        if (A.M > 0) {
+            load_sh(A, sid, nb, shv);
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { const float b = basis[q]; c0 += b * shv[q * 3]; c1 += b * shv[q * 3 + 1]; c2 += b * shv[q * 3 + 2]; }
+            c0 += 0.5f; c1 += 0.5f; c2 += 0.5f;
+            cl[0] = c0 < 0.f; cl[1] = c1 < 0.f; cl[2] = c2 < 0.f;
+            col[0] = cl[0] ? 0.f : c0; col[1] = cl[1] ? 0.f : c1; col[2] = cl[2] ? 0.f : c2;
+        } else {
+            const Feat c = Feat{A.colors, A.f16 != 0}.at((size_t)sid * 3);
+            col[0] = c[0]; col[1] = c[1]; col[2] = c[2];
+        }
+        const float x0 = (!rgbo && A.has_others) ? A.others[2 * sid] : 0.f, x1 = (!rgbo && A.has_others) ? A.others[2 * sid + 1] : 0.f;
+        const float alpha = h.alpha, Tb = st0.x, w = alpha * Tb;
+        const float sgn = h.denom < 0.0f ? 1.0f : -1.0f;
+        const float nf0 = sgn * s3.x, nf1 = sgn * s3.y, nf2 = sgn * s3.z;
+        const float inv1m = 1.0f / (1.0f - alpha);
+        const float Fsum = B.gR0 * B.fr0 + B.gR1 * B.fr1 + B.gR2 * B.fr2 + B.gD * B.fD + B.gA * B.fA + B.gN0 * B.fN0 + B.gN1 * B.fN1 + B.gN2 * B.fN2 +
+                           B.gX0 * B.fX0 + B.gX1 * B.fX1 + B.fT * B.bgdot;
+        float gv_ = B.gR0 * col[0] + B.gR1 * col[1] + B.gR2 * col[2], gS = B.gR0 * st0.y + B.gR1 * st0.z + B.gR2 * st0.w;
+        if (!rgbo) {
+            gv_ += B.gD * h.t + B.gA + B.gN0 * nf0 + B.gN1 * nf1 + B.gN2 * nf2 + B.gX0 * x0 + B.gX1 * x1;
+            gS += B.gD * st1.x + B.gA * (1.0f - Tb * (1.0f - alpha)) + B.gN0 * st1.y + B.gN1 * st1.z + B.gN2 * st1.w + B.gX0 * sx0 + B.gX1 * sx1;
+        }
+        const float dLa = Tb * gv_ - (Fsum - gS) * inv1m;
+        const float dc[3] = {cl[0] ? 0.f : w * B.gR0, cl[1] ? 0.f : w * B.gR1, cl[2] ? 0.f : w * B.gR2};
+        const float dLG = s0.w * dLa;
+        const float dLu = dLG * (-h.G * h.u), dLv = dLG * (-h.G * h.v);
+        const float qx = B.ox + h.t * B.dx - s0.x, qy = B.oy + h.t * B.dy - s0.y, qz = B.oz + h.t * B.dz - s0.z;
+        const float dq0 = dLu * s1.x + dLv * s2.x, dq1 = dLu * s1.y + dLv * s2.y, dq2 = dLu * s1.z + dLv * s2.z;
+        const float cu = dLu / s1.w, cv = dLv / s2.w;
+        const float dLt_tot = w * B.gD + dq0 * B.dx + dq1 * B.dy + dq2 * B.dz;
+        const float kt = dLt_tot / h.denom;
+        const float e0 = dq0 - kt * s3.x, e1 = dq1 - kt * s3.y, e2 = dq2 - kt * s3.z;
+        float gw[16];
+        gw[0] = -e0; gw[1] = -e1; gw[2] = -e2;
+        gw[3] = cu * qx; gw[4] = cu * qy; gw[5] = cu * qz;
+        gw[6] = cv * qx; gw[7] = cv * qy; gw[8] = cv * qz;
+        const float ws = w * sgn;
+        gw[9] = ws * B.gN0 - kt * qx; gw[10] = ws * B.gN1 - kt * qy; gw[11] = ws * B.gN2 - kt * qz;
+        gw[12] = -cu * h.u * A.mod; gw[13] = -cv * h.v * A.mod; gw[14] = h.G * dLa; gw[15] = 0.f;
+        // the record: (16, 3) SH gradient = basis (x) dL/dcolour (or the 3 colour words), then the 15 geometry words
+        const int copy = (slot >> 6) & (NCOPY - 1);
+        const size_t ci = (size_t)sid * NCOPY + copy;
+        const unsigned long long rec = (unsigned long long)(A.surf_off[ci] - A.surf_cnt[ci]) + (unsigned long long)e.w;
+        if (rec < A.num_records) {
+            float4 *ro = reinterpret_cast<float4 *>(A.records + rec * RECW);
+            if (A.M > 0) {
+#pragma unroll
+                for (int q = 0; q < 12; q++) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const int wd = 4 * q + j; v[j] = basis[wd / 3] * dc[wd % 3]; }
+                    ro[q] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else ro[0] = make_float4(dc[0], dc[1], dc[2], 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; q++) ro[12 + q] = make_float4(gw[4 * q], gw[4 * q + 1], gw[4 * q + 2], gw[4 * q + 3]);
+        }
+        // the ray's share: added to what batch_surfel_bwd stored (bwd_store_ray is linear in its accumulators)
+        float dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
+        if (A.M > 0) {
+            float bgx[16], bgy[16], bgz[16];
+            sh_basis_grad(A.D, B.ux, B.uy, B.uz, bgx, bgy, bgz);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const float sk = q < nb ? shv[q * 3] * dc[0] + shv[q * 3 + 1] * dc[1] + shv[q * 3 + 2] * dc[2] : 0.f;
+                dd0 += bgx[q] * sk; dd1 += bgy[q] * sk; dd2 += bgz[q] * sk;
+            }
+        }
+        const float inv3 = B.il * B.il * B.il;
+        const float f0 = h.t * e0 + ((B.dl2 - B.dx * B.dx) * dd0 - B.dy * B.dx * dd1 - B.dz * B.dx * dd2) * inv3;
+        const float f1 = h.t * e1 + (-B.dx * B.dy * dd0 + (B.dl2 - B.dy * B.dy) * dd1 - B.dz * B.dy * dd2) * inv3;
+        const float f2 = h.t * e2 + (-B.dx * B.dz * dd0 - B.dy * B.dz * dd1 + (B.dl2 - B.dz * B.dz) * dd2) * inv3;
+        atomic_add_f32(A.dray_o + 3 * r, e0); atomic_add_f32(A.dray_o + 3 * r + 1, e1); atomic_add_f32(A.dray_o + 3 * r + 2, e2);
+        atomic_add_f32(A.dray_d + 3 * r, f0); atomic_add_f32(A.dray_d + 3 * r + 1, f1); atomic_add_f32(A.dray_d + 3 * r + 2, f2);
+        if (!rgbo && A.has_others && A.dothers) { atomic_add_f32(A.dothers + 2 * sid, w * B.gX0); atomic_add_f32(A.dothers + 2 * sid + 1, w * B.gX1); }
+    }
+}
 
 // Stage 2: sum each surfel's (batch, surfel) records into the (zeroed) gradient buffers -- plain stores, every word has one owner; the
 // K-buffer pass for overflowed rays runs afterwards and adds to the same buffers atomically.  16 lanes per surfel, 16 B per lane = one

@@ -116,13 +116,14 @@ class CapState:
     def __init__(self, cap=512):
         self.cap = int(cap)
         self.found_per_ray = None   # hits found per ray in the previous call: sizes the COMPACT per-hit buffers (rows) of the next one
+        self.hits_per_entry = None  # composited hits per (batch, surfel) entry of the previous call that prepared a backward: how coherent this tracer's batches are
         self.colour_only = False    # SurfelTracer.set_colour_only_backward: the backward will see the colour's gradient only -> store plane 0 alone
         self._mirrors = {}          # device -> dict(host, event, valid)
 
     def mirror(self, dev):
         m = self._mirrors.get(dev)
         if m is None:
-            m = self._mirrors[dev] = dict(host=torch.zeros(16, dtype=torch.int32).pin_memory(), event=torch.cuda.Event(), valid=False, rays=1)
+            m = self._mirrors[dev] = dict(host=torch.zeros(72, dtype=torch.int32).pin_memory(), event=torch.cuda.Event(), valid=False, rays=1)
         return m
 
     def next_cap(self, dev):
@@ -135,6 +136,10 @@ class CapState:
             self.cap = max(64, min(want, 1024))
             found = (int(m["host"][8]) & 0xFFFFFFFF) | ((int(m["host"][9]) & 0xFFFFFFFF) << 32)
             self.found_per_ray = found / max(1, m["rays"])
+            hits = (int(m["host"][2]) & 0xFFFFFFFF) | ((int(m["host"][3]) & 0xFFFFFFFF) << 32)
+            ent = (int(m["host"][64]) & 0xFFFFFFFF) + (int(m["host"][65]) & 0xFFFFFFFF)       # hits filed per hit + entries of the batch kernel
+            if ent > 0:
+                self.hits_per_entry = hits / ent
         return self.cap
 
     def pinned_word(self):
@@ -163,7 +168,7 @@ class CapState:
     def publish(self, counters, dev, rays=1):
         """Queue the asynchronous read-back of this call's longest list (counters[1]) and of its total of hits found (counters[8:10])."""
         m = self.mirror(dev)
-        m["host"].copy_(counters[0:16], non_blocking=True)                 # (one copy of the head of the counter block: words 1 and 8..9 are read)
+        m["host"].copy_(counters[0:72], non_blocking=True)                 # (one copy of the head of the counter block: words 1, 2..3, 8..9, 64..65 are read)
         m["event"].record(torch.cuda.current_stream(dev)); m["valid"] = True; m["rays"] = int(rays)
 
 
@@ -201,6 +206,9 @@ def _carve_i32(dev, sizes):
     return out
 
 
+# record backward: entries with few hits filed per hit (envgs_trace.h: sparse_hits).  "auto": when this tracer state's previous call averaged fewer than
+# `below` composited hits per entry; "on" / "off": tests
+SPARSE = {"mode": "auto", "below": 6.0}
 QUAD_SH = {"on": True}       # list path: four lanes share the fetch of a surfel's SH block (tests switch it off to cover the per-lane gathers)
 KEEP_LISTS = {"on": False}   # tests: keep the last forward's per-ray hit lists reachable through last_hit_lists()
 
@@ -257,6 +265,13 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
             else:
                 keep.update(hit_state=_scratch((R, cap, sw), torch.float32, dev), entries=_scratch((nbatch, 64 * cap), torch.int64, dev),
                             pairs=_scratch((nbatch, 64 * cap), torch.int32, dev))
+        sparse = SPARSE["mode"] == "on" or (SPARSE["mode"] == "auto" and caps.hits_per_entry is not None and caps.hits_per_entry < SPARSE["below"])
+        if "hit_state" in keep and sparse:
+            # sparse entries (envgs_trace.h: sparse_hits): the previous call of this tracer state was INCOHERENT (few hits per (batch, surfel) entry:
+            # bounce rays off rough geometry) -- entries of at most four hits are filed per hit; room for every row (most hits of such a call are
+            # filed; what finds no room takes the batch kernel -- slower, never wrong)
+            n_rows = rows if rows else R * cap
+            keep["sparse_hits"] = _scratch((max(4096, n_rows), 4), torch.int32, dev)
         lists = _lib.TraceLists(keep["hit_lists"].data_ptr(), keep["hit_cnt"].data_ptr(), keep["n_used"].data_ptr(), cap,
                                 keep["spill"].data_ptr(), keep["surf_acc"].data_ptr(), keep["surf_cnt"].data_ptr(), keep["surf_off"].data_ptr(),
                                 keep["scan_temp"].data_ptr(), sb, keep["ray_keys"].data_ptr() if srt else None,
@@ -264,7 +279,8 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
                                 *[(keep[k].data_ptr() if k in keep else None) for k in ("hit_state", "entries", "pairs")],
                                 keep["n_entries"].data_ptr() if "hit_state" in keep else None, rows,
                                 *[(keep[k].data_ptr() if (k in keep and rows) else None) for k in ("row_off", "batch_rows", "row_blk")],
-                                keep["sh_perm"].data_ptr() if "sh_perm" in keep else None, 0)
+                                keep["sh_perm"].data_ptr() if "sh_perm" in keep else None, 0,
+                                keep["sparse_hits"].data_ptr() if "sparse_hits" in keep else None, keep["sparse_hits"].shape[0] if "sparse_hits" in keep else 0)
         if "hit_state" in keep and getattr(caps, "colour_only", False):
             lists.state_planes = 1
             keep["colour_only"] = True
@@ -707,4 +723,4 @@ def last_trace_counts():
     w = c.cpu()
     v = w[2:20].view(torch.int64)
     return dict(coop_cycles=dict(expand=int(v[6]), walk=int(v[7]), wait=int(v[8])), hits=int(v[0]), node_visits=int(v[1]), rounds=int(v[2]), found=int(v[3]), packet_nodes=int(v[4]), packet_leaves=int(v[5]),
-                max_list=int(w[1]), cap=LAST_STATS["caps"].cap, compact_rows=LAST_STATS.get("rows", 0), rays_without_rows=int(w[21]), rays=LAST_STATS["R"], stack_overflows=int(w[20]))
+                max_list=int(w[1]), sparse_hits=int(w[64]), cap=LAST_STATS["caps"].cap, compact_rows=LAST_STATS.get("rows", 0), rays_without_rows=int(w[21]), rays=LAST_STATS["R"], stack_overflows=int(w[20]))

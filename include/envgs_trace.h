@@ -121,6 +121,16 @@ typedef struct envgs_trace_lists {
                                 colour's upstream gradient only (dL_ddpt = dL_dacc = dL_dnorm = dL_daux = NULL) -- what EnvGS trains with, and the last
                                 stage of a bounce chain: the forward writes plane 0 alone (hit_state: 4 floats per row) -- half of the per-hit bytes it
                                 stores.  envgs_trace_backward returns ENVGS_ERR_BAD_ARG if another gradient arrives after all */
+    uint32_t *sparse_hits;   /* optional (round 6), with sparse_cap: (sparse_cap, 4) uint32 scratch of the record backward -- SPARSE entries.  A (batch, surfel)
+                                entry costs batch_surfel_bwd one 64-lane pass however few of the batch's rays blended the surfel, and a fifth of the entries
+                                of the benchmark view hold 1-4 hits (1.4 % of the hits): the forward files the hits of such entries here as
+                                (sorted ray slot, list position, surfel id, record slot) -- one gradient record PER HIT -- instead of creating the entry,
+                                and envgs_trace_backward differentiates them one lane per hit (sparse_hits_bwd).  NULL / 0 = every entry takes the batch
+                                kernel; hits that find no room here do too.  counters[64] = hits filed, counters[65] = entries left to the batch kernel.
+                                Worth it for INCOHERENT batches only (a filed hit costs ~12x a hit of a full entry: bounce rays off rough geometry,
+                                1-2 hits per entry: 59 -> 48 ms per step; the coherent benchmark views: +-0): envgs_amd.tracing passes the buffer when
+                                the tracer's previous call averaged fewer than 6 composited hits per entry */
+    uint64_t sparse_cap;     /* capacity of sparse_hits in hits */
 } envgs_trace_lists;
 
 /* Scratch bytes for the Morton sort + build of P surfels. */

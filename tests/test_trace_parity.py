@@ -178,6 +178,7 @@ class _Switch:
             elif k == "records": self.old[k] = tracing.USE_RECORDS["on"]; tracing.USE_RECORDS["on"] = v
             elif k == "rows_per_ray": self.old[k] = dict(tracing.ROW_CAP); tracing.ROW_CAP["force_per_ray"] = v
             elif k == "compact": self.old[k] = tracing.COMPACT["on"]; tracing.COMPACT["on"] = v
+            elif k == "sparse": self.old[k] = tracing.SPARSE["mode"]; tracing.SPARSE["mode"] = v
             elif k == "sort_rays": self.old[k] = tracing.SORT_RAYS["on"]; tracing.SORT_RAYS["on"] = v
             elif k == "debug_trace":
                 lib = _lib.load(); self.old[k] = lib.envgs_debug_get(0); lib.envgs_debug_set(0, v)
@@ -189,6 +190,7 @@ class _Switch:
             elif k == "records": tracing.USE_RECORDS["on"] = v
             elif k == "rows_per_ray": tracing.ROW_CAP.clear(); tracing.ROW_CAP.update(v)
             elif k == "compact": tracing.COMPACT["on"] = v
+            elif k == "sparse": tracing.SPARSE["mode"] = v
             elif k == "sort_rays": tracing.SORT_RAYS["on"] = v
             elif k == "debug_trace": _lib.load().envgs_debug_set(0, v)
         if self.lib_kind is not None:
@@ -560,11 +562,74 @@ def test_trace_batch_table_overflow_and_unsorted_rays(sort_rays, request):
              shs=torch.randn(P, 16, 3, generator=gen) * 0.3, others=torch.rand(P, 2, generator=gen), colors_precomp=torch.rand(P, 3, generator=gen))
     ro = (torch.rand(R, 3, generator=gen) * 2 - 1) * 2.0
     rd = torch.randn(R, 3, generator=gen); rd = rd / rd.norm(dim=-1, keepdim=True)
-    res = _parity(request.node.name, g, ro, rd, torch.tensor([0.1, 0.0, 0.2]), 3, True, False, seed=34, hip_ctx=_Switch(sort_rays=sort_rays),
+    res = _parity(request.node.name, g, ro, rd, torch.tensor([0.1, 0.0, 0.2]), 3, True, False, seed=34, hip_ctx=_Switch(sort_rays=sort_rays, sparse="off"),
                   after_hip=tracing.last_entry_counts)
     table, singles = res["extra"]
     assert table > 0 and singles > 0, (table, singles)                 # both kinds of entries were produced
     assert table + singles <= res["cnt"]["hits"]
+
+
+@pytest.mark.parametrize("case", ["camera_sh_others", "free_rays_colours", "incoherent_table_overflow", "many_small_surfels", "colour_only_vs_batch_kernel"])
+def test_trace_sparse_entries_vs_oracle(case, request):
+    """Round 6: SPARSE entries (include/envgs_trace.h: sparse_hits) -- (batch, surfel) entries of at most four hits are filed per hit by the
+    forward and differentiated one lane per hit (sparse_hits_bwd) instead of costing the batch kernel a 64-lane pass each.  Forced on here (the
+    default passes the list only when the tracer's previous call was incoherent): every output and gradient against the oracle, with SH and
+    precomputed colours, with and without `others`, the generic and the colour-only backward, and a batch whose merge table overflows (those
+    one-hit entries are filed too: the batch kernel sees no singles)."""
+    from envgs_amd import tracing
+    kw = dict(hip_ctx=_Switch(sparse="on"), after_hip=tracing.last_entry_counts)
+    if case == "camera_sh_others":
+        g, ro, rd = trace_scene(P=150, R=400, seed=7, camera=True)
+        res = _parity(request.node.name, g, ro, rd, torch.tensor([0.3, 0.1, 0.7]), 3, True, True, **kw)
+    elif case == "free_rays_colours":
+        g, ro, rd = trace_scene(P=150, R=400, seed=7, camera=False)
+        res = _parity(request.node.name, g, ro, rd, torch.tensor([0.3, 0.1, 0.7]), 0, False, False, others=False, which=tuple(k for k in GRADS_ALL if k != "dothers"), **kw)
+    elif case == "incoherent_table_overflow":
+        gen = torch.Generator().manual_seed(33)
+        P, R = 6000, 1000
+        means = (torch.rand(P, 3, generator=gen) * 2 - 1) * 2.0
+        q = torch.randn(P, 4, generator=gen)
+        g = dict(means3D=means, scales=0.12 + 0.1 * torch.rand(P, 2, generator=gen), rotations=q / q.norm(dim=-1, keepdim=True),
+                 opacities=torch.sigmoid(torch.randn(P, 1, generator=gen) - 2.0), shs=torch.randn(P, 16, 3, generator=gen) * 0.3,
+                 others=torch.rand(P, 2, generator=gen), colors_precomp=torch.rand(P, 3, generator=gen))
+        ro = (torch.rand(R, 3, generator=gen) * 2 - 1) * 2.0
+        rd = torch.randn(R, 3, generator=gen); rd = rd / rd.norm(dim=-1, keepdim=True)
+        res = _parity(request.node.name, g, ro, rd, torch.tensor([0.1, 0.0, 0.2]), 3, True, False, seed=34, **kw)
+        assert res["extra"][1] == 0, "the table-overflow singles were meant to be filed as sparse hits"
+    elif case == "colour_only_vs_batch_kernel":
+        # the colour-only form (the EnvGS step: only rgb carries a gradient, dpt / acc / norm / aux arrive as None): sparse entries on against off
+        import diff_surfel_tracing as mod
+        dev = torch.device("cuda:0")
+        g, ro, rd = trace_scene(P=2000, R=1024, seed=9, camera=False)
+        g["scales"] = g["scales"] * 0.35
+        up = torch.randn(1024, 3, generator=torch.Generator().manual_seed(2)).to(dev)
+        got = {}
+        for mode in ("on", "off"):
+            with _Switch(sparse=mode):
+                L = {k: g[k].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+                o = ro.to(dev).requires_grad_(True); d = rd.to(dev).requires_grad_(True)
+                v, f = synth.get_disks(L["means3D"].detach(), L["scales"].detach(), L["rotations"].detach())
+                tracer = mod.SurfelTracer()
+                tracer.build_acceleration_structure(v, f, rebuild=True)
+                outs = tracer(o, d, v, means3D=L["means3D"], grads3D=None, shs=L["shs"], colors_precomp=None, others_precomp=None, opacities=L["opacities"],
+                              scales=L["scales"], rotations=L["rotations"], cov3D_precomp=None, tracer_settings=_settings(mod, torch.zeros(3), 2, dev, 0, 0.0),
+                              start_from_first=False)
+                (outs[0] * up).sum().backward()
+                torch.cuda.synchronize()
+                got[mode] = ({k: t.grad.clone() for k, t in L.items()}, o.grad.clone(), d.grad.clone(), tracing.last_trace_counts()["sparse_hits"])
+        assert got["on"][3] > 0 and got["off"][3] == 0
+        for k in got["on"][0]:
+            a, b = got["on"][0][k].cpu().numpy(), got["off"][0][k].cpu().numpy()
+            check_close(request.node.name, k, a, b, tol=2e-5)
+        check_close(request.node.name, "dray_o", got["on"][1].cpu().numpy(), got["off"][1].cpu().numpy(), tol=2e-5)
+        check_close(request.node.name, "dray_d", got["on"][2].cpu().numpy(), got["off"][2].cpu().numpy(), tol=2e-5)
+        return
+    else:
+        g, ro, rd = trace_scene(P=2000, R=1024, seed=7, camera=False)
+        g["scales"] = g["scales"] * 0.35
+        res = _parity(request.node.name, g, ro, rd, torch.tensor([0.3, 0.1, 0.7]), 2, True, False, zero_geo_grads=True, **kw)
+    assert res["cnt"]["sparse_hits"] > 0, "no hit took the sparse path"
+    assert res["cnt"]["sparse_hits"] + res["extra"][0] <= res["cnt"]["hits"]
 
 
 def test_trace_two_segment_forward_pipeline_vs_oracle():
