@@ -52,6 +52,9 @@ composite_lists_bwd(const TraceArgs A)
 // independently of every other hit, and the 63 gradient words (48 SH + 15 geometry) are transpose-reduced over the wavefront into ONE
 // 256 B record per (batch, surfel) written by the 64 lanes as one coalesced line pair.  ~27x fewer records than one per hit, no
 // per-hit gathers of surfel data, no dependent chain along the ray, no atomics.
+// every LDS read issued so far has returned, and the compiler may not sink a later use's read below this point (s_waitcnt lgkmcnt(0) + a
+// scheduling barrier): used to make a set of MFMAs start with ALL its operands in registers instead of one round trip per operand
+#define ENVGS_LDS_FENCE() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)
 constexpr int BS_GROUP = 16;
 #ifndef ENVGS_BSB_KO
 #define ENVGS_BSB_KO 0          // measurement builds only (scratch/ab_bsb.sh): 1 = no dothers, 2 = no aux-plane fetch, 4 = no plane-1 fetch, 8 = no plane-0 fetch -- results wrong by construction
@@ -279,14 +282,21 @@ batch_surfel_bwd(const TraceArgs A)
                     const int nrun = min(5, ne - el);
                     const int kk = lane >> 4, nn = lane & 15, ee = nn / 3, c2 = nn - 3 * ee;
                     f32x4 cc0 = {0.f, 0.f, 0.f, 0.f}, cc1 = cc0, cc2 = cc0, cc3 = cc0;
+                    // (round 6: every B operand of a set is read from LDS BEFORE the set's first MFMA -- the compiler had put one ds_read + s_waitcnt
+                    //  lgkmcnt(0) in front of every two to four MFMAs: twenty serialised LDS round trips per run of five entries at 2 wavefronts per SIMD)
+                    float bvc[4];
 #pragma unroll
                     for (int ks = 0; ks < 4; ks++) {
-                        float bval = 0.f;
-                        if (nn < 15 && ee < nrun) bval = reinterpret_cast<const float *>(&sdat[buf][el + ee][4])[(4 * ks + kk) * 3 + c2];
-                        cc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Acol[ks], bval, cc0, 0, 0, 0);
-                        cc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Acol[4 + ks], bval, cc1, 0, 0, 0);
-                        cc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Acol[8 + ks], bval, cc2, 0, 0, 0);
-                        cc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(Acol[12 + ks], bval, cc3, 0, 0, 0);
+                        bvc[ks] = 0.f;
+                        if (nn < 15 && ee < nrun) bvc[ks] = reinterpret_cast<const float *>(&sdat[buf][el + ee][4])[(4 * ks + kk) * 3 + c2];
+                    }
+                    ENVGS_LDS_FENCE();
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) {
+                        cc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Acol[ks], bvc[ks], cc0, 0, 0, 0);
+                        cc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Acol[4 + ks], bvc[ks], cc1, 0, 0, 0);
+                        cc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Acol[8 + ks], bvc[ks], cc2, 0, 0, 0);
+                        cc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(Acol[12 + ks], bvc[ks], cc3, 0, 0, 0);
                     }
                     if (nn < 15) {
                         float *trow = &btile[nn][0];
@@ -379,12 +389,16 @@ batch_surfel_bwd(const TraceArgs A)
                         const int n = lane & 15, j = lane >> 4;
                         const float *brow = &btile[n][0];
                         const int rot = 2 * n + j;
+                        float bvr[16];
+#pragma unroll
+                        for (int sI = 0; sI < 16; sI++) bvr[sI] = brow[4 * sI + rot];
+                        ENVGS_LDS_FENCE();
 #pragma unroll
                         for (int sI = 0; sI < 16; sI += 4) {
-                            acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI], brow[4 * sI + rot], acc4, 0, 0, 0);
-                            accB = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 1], brow[4 * sI + 4 + rot], accB, 0, 0, 0);
-                            accC = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 2], brow[4 * sI + 8 + rot], accC, 0, 0, 0);
-                            accD = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 3], brow[4 * sI + 12 + rot], accD, 0, 0, 0);
+                            acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI], bvr[sI], acc4, 0, 0, 0);
+                            accB = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 1], bvr[sI + 1], accB, 0, 0, 0);
+                            accC = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 2], bvr[sI + 2], accC, 0, 0, 0);
+                            accD = __builtin_amdgcn_mfma_f32_16x16x4f32(Areg[sI + 3], bvr[sI + 3], accD, 0, 0, 0);
                         }
                     }
                     acc4 = (acc4 + accB) + (accC + accD);
@@ -402,16 +416,22 @@ batch_surfel_bwd(const TraceArgs A)
                     // from the staged SH blocks: 16 MFMAs per run instead of 48 FMAs and 12 LDS reads per entry and lane
                     if (A.M > 0) {
                         const int kk = lane >> 4, nn = lane & 15;
+                        float bvs[4], avs[16];
 #pragma unroll
                         for (int ks = 0; ks < 4; ks++) {
                             const int col = 4 * ks + kk, ee = col / 3, c2 = col - 3 * ee;
-                            float bval = 0.f;
-                            if (col < 15 && ee <= e5) bval = reinterpret_cast<const float *>(&sdat[buf][el - e5 + ee][4])[nn * 3 + c2];
+                            bvs[ks] = 0.f;
+                            if (col < 15 && ee <= e5) bvs[ks] = reinterpret_cast<const float *>(&sdat[buf][el - e5 + ee][4])[nn * 3 + c2];
                             const float *arow = &btile[col][0];
 #pragma unroll
-                            for (int rb = 0; rb < 4; rb++)
-                                SkM[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[16 * rb + nn + 2 * col], bval, SkM[rb], 0, 0, 0);
+                            for (int rb = 0; rb < 4; rb++) avs[4 * ks + rb] = arow[16 * rb + nn + 2 * col];
                         }
+                        ENVGS_LDS_FENCE();
+#pragma unroll
+                        for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+                            for (int rb = 0; rb < 4; rb++)
+                                SkM[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[4 * ks + rb], bvs[ks], SkM[rb], 0, 0, 0);
                     }
                 }
             }
