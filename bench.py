@@ -512,6 +512,34 @@ def main():
         for c_ in seen:
             print(c_ if isinstance(c_, str) else "  traced call: %s" % json.dumps(c_), file=sys.stderr)
 
+    # R7's LANE OCCUPANCY on this very view: the audit instantiation of the compositing kernel writes, per pixel, which entries of its
+    # tile's list it blended; a (wavefront = 8x8 quadrant, splat) pass of composite_bwd runs when any of the quadrant's 64 pixels blended the splat, with
+    # exactly those lanes live.  Outside the timed region, rank 0.
+    lane_occ = None
+    if rank == 0 and not btrace and H % 16 == 0 and W % 16 == 0:
+        try:
+            with torch.no_grad():
+                st_ = (pkg.GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cams[0].tanfovx, tanfovy=cams[0].tanfovy, bg=(bg if not envgs else torch.zeros(C, device=dev)), scale_modifier=1.0,
+                                                         viewmatrix=cams[0].world_view_transform, projmatrix=cams[0].full_proj_transform, sh_degree=sh_degree,
+                                                         campos=cams[0].camera_center, prefiltered=False, debug=False))
+                cols_ = torch.zeros(P, C, device=dev)                                    # (the contributor sets do not depend on the colours)
+                _, sv_ = raster.rasterize_forward(C, params["means3D"].detach(), None, cols_, params["opacities"].detach(), params["scales"].detach(),
+                                                  params["rotations"].detach(), None, st_)
+                rg_ = sv_["ranges"].view(-1, 2).long()
+                lmax_ = int((rg_[:, 1] - rg_[:, 0]).max())
+                if H * W * lmax_ <= (6 << 30):
+                    contrib_, _, _ = raster.render_audit(sv_, lmax_)
+                    q_ = contrib_.view(H // 8, 8, W // 8, 8, lmax_).permute(0, 2, 4, 1, 3).reshape(H // 8, W // 8, lmax_, 64)
+                    live_ = q_.sum(-1, dtype=torch.int32)
+                    passes_, lanes_ = int((live_ > 0).sum()), int(live_.sum())
+                    lane_occ = {"passes": passes_, "live_lanes": lanes_, "lanes_per_pass": round(lanes_ / max(passes_, 1), 2), "frac": round(lanes_ / max(passes_, 1) / 64.0, 4),
+                                "tile_instances": int(sv_["N"]), "note": "(8x8 quadrant, splat) passes of composite_bwd with a live lane and their live lanes on view 0 of THIS run, counted from "
+                                "the contributor flags the AUDIT instantiation of the compositing kernel writes (envgs_raster_render_audit), outside the timed region"}
+                    del contrib_, q_, live_
+                del sv_
+        except Exception as e_:
+            lane_occ = {"error": repr(e_)[:200]}
+
     # per-kernel HIP-event times (this rank)
     N_avg = n_timed["N"] / max(n_timed["steps"], 1)
     traced = envgs or btrace
@@ -656,7 +684,8 @@ def main():
             rb = kernels.get("composite_bwd")
             if rb and rb["GBps"]:
                 roof["raster_composite_bwd"] = {"achieved": rb["GBps"], "frac": round(rb["GBps"] / HBM_PEAK_GBS, 5), "ms_per_launch": rb["ms"],
-                                                "traffic": pm.get("composite_bwd", {}).get("hbm_bytes"), "issue": issue_of("composite_bwd")}
+                                                "traffic": pm.get("composite_bwd", {}).get("hbm_bytes"), "issue": issue_of("composite_bwd"),
+                                                "lane_occupancy": lane_occ}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             if not btrace:
