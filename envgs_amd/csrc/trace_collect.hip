@@ -445,9 +445,16 @@ constexpr int COOP_ITEMS = 256;           // >= 4 * (largest front - 1)
 constexpr int COOP_QFLUSH = 8;           // deferred exact tests: a wavefront's queue of entered leaf slots is worked off when it holds this many ...
 constexpr int COOP_QCAP = COOP_QFLUSH + 3 + 1;   // ... (a step adds at most four)
 static_assert(COOP_ODROW % 4 == 0, "the bin rows are read with ds_read_b128");
-struct CoopLds {                      // (refresh_bound reads od[] as float4: the OBJECT is declared 16 B aligned in the kernel -- see there)
-    float od[64][COOP_ODROW];                 // ray-major (round 5): a ray's 32 bins are eight ds_read_b128, four in flight at a time, instead of 31 serialised ds_read_b32
-    float odtot[64];
+// Round 6: the optical-depth bins are FIXED POINT (2^-16).  ds_add_f32 is microcoded on gfx950 -- measured (scratch/lds_atomic_rate.hip) 193 cycles of
+// the CU's LDS unit per 64-lane instruction, 43 with 14 live lanes, against 7 / 5 for ds_add_u32 -- and the walk issued two of them per leaf test:
+// a quarter of the kernel's duration during which every other LDS operation of the CU (stack pops, frontier items) queued behind them.  Each hit's
+// -ln(1 - alpha) is rounded DOWN, so the sums stay lower bounds of the true optical depth and the bound stays conservative; integer sums are also
+// independent of the order in which the four wavefronts add.
+constexpr float COOP_OD_SCALE = 65536.0f;
+constexpr unsigned COOP_KILL_Q = (unsigned)(KILL_OD * 65536.0f);
+struct CoopLds {                      // (refresh_bound reads od[] as 16 B vectors: the OBJECT is 16 B aligned -- checked in the kernel, see there)
+    unsigned od[64][COOP_ODROW];              // ray-major (round 5): a ray's 32 bins are eight ds_read_b128, four in flight at a time, instead of 31 serialised ds_read_b32
+    unsigned odtot[64];
     int cnt[64];
     unsigned long long items[2][COOP_ITEMS];      // entry-distance bits << 32 | wide-node index
     int stk[COOP_W][COOP_STK];
@@ -505,8 +512,8 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             if (lane == 0) { L.batch = b; L.nitems[0] = 1; L.nitems[1] = 0; L.items[0][0] = 0ull; L.next = 0; L.ovf = 0; }
         }
 #pragma unroll
-        for (int q = 0; q < (int)(sizeof(L.od) / sizeof(float)) / (64 * COOP_W); q++) (&L.od[0][0])[q * 64 * COOP_W + tid] = 0.f;
-        if (tid < 64) { L.odtot[tid] = 0.f; L.cnt[tid] = 0; }
+        for (int q = 0; q < (int)(sizeof(L.od) / sizeof(unsigned)) / (64 * COOP_W); q++) (&L.od[0][0])[q * 64 * COOP_W + tid] = 0u;
+        if (tid < 64) { L.odtot[tid] = 0u; L.cnt[tid] = 0; }
         __syncthreads();
         const int fb = L.batch;
         if (fb < 0) break;
@@ -530,7 +537,8 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             inv_bin_w = 1.0f / bin_w;
         }
         const float tk_open = valid ? 3.0e38f : -3.0e38f;     // lanes without a ray never pass a slab test
-        float tkill = tk_open, seen = 0.f;               // seen: the ray's optical depth when its bound was last recomputed
+        float tkill = tk_open;
+        unsigned seen = 0u;                              // the ray's (fixed-point) optical depth when its bound was last recomputed
         int pend = 0;
         uint2 *list = A.hits + (size_t)rr * A.cap;
         const f32x2 o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz}, i2x = {ix, ix}, i2y = {iy, iy}, i2z = {iz, iz};
@@ -563,32 +571,32 @@ collect_hits_coop(const TraceArgs A, const float4 *__restrict__ nodes, const flo
             const float x = (h.t - tA) * inv_bin_w;
             int b = x <= 0.0f ? 0 : (int)ceilf(x + 1e-3f);
             b = b > COOP_NBIN - 1 ? COOP_NBIN - 1 : b;
-            const float dep = -__logf(1.0f - h.alpha);
+            const unsigned dep = (unsigned)(-__logf(1.0f - h.alpha) * COOP_OD_SCALE);      // rounded down: alpha <= 0.99 -> at most 4.61 * 2^16
             atomicAdd(&L.od[lane][b], dep);
             atomicAdd(&L.odtot[lane], dep);
         };
         // look at the bound -- and recompute it (eight ds_read_b128 and ~125 VALU, as much as two leaf tests) only when some ray that can be cut at
         // all has gathered noticeably more optical depth than at its last recomputation
         auto refresh_bound = [&]() {
-            const float tot = ENVGS_LDS_READ(L.odtot[lane]);
-            if (__builtin_amdgcn_ballot_w64(tot >= KILL_OD && tot > seen + COOP_REFRESH_OD) != 0ull) {
+            const unsigned tot = ENVGS_LDS_READ(L.odtot[lane]);
+            if (__builtin_amdgcn_ballot_w64(tot >= COOP_KILL_Q && tot > seen + (unsigned)(COOP_REFRESH_OD * COOP_OD_SCALE)) != 0ull) {
                 seen = tot;
-                float cum = 0.f; int kb = COOP_NBIN - 1;
+                unsigned cum = 0u; int kb = COOP_NBIN - 1;
                 // (what other wavefronts add meanwhile may or may not be seen: either way the sums are lower bounds of the true optical depth, the bound stays conservative)
-                const float4 *row = reinterpret_cast<const float4 *>(&L.od[lane][0]);
+                const uint4 *row = reinterpret_cast<const uint4 *>(&L.od[lane][0]);
                 asm volatile("" ::: "memory");                 // (re-read: nothing cached from an earlier refresh)
 #pragma unroll
                 for (int h = 0; h < COOP_NBIN / 16; h++) {    // sixteen bins per round: four ds_read_b128 in flight, 16 VGPRs
-                    float4 v[4];
+                    uint4 v[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) v[q] = row[4 * h + q];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+                        const unsigned e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
                             const int bin = 16 * h + 4 * q + j;
-                            if (bin < COOP_NBIN - 1) { cum += e[j]; kb = (cum >= KILL_OD && kb == COOP_NBIN - 1) ? bin : kb; }
+                            if (bin < COOP_NBIN - 1) { cum += e[j]; kb = (cum >= COOP_KILL_Q && kb == COOP_NBIN - 1) ? bin : kb; }
                         }
                     }
                 }

@@ -25,6 +25,38 @@ __global__ __launch_bounds__(256) void spin(float *out, int iters) {
     __syncthreads();
     out[blockIdx.x * 256 + threadIdx.x] = acc[threadIdx.x];
 }
+// ds_add_u32 vs ds_add_f32 with 64 / 14 live lanes (the collection's per-ray optical-depth bins: ~14 accepted hits per leaf test)
+template <int INT, int LIVE>
+__global__ __launch_bounds__(256) void spin2(float *out, int iters) {
+    __shared__ float accf[64 * 36];
+    __shared__ unsigned acci[64 * 36];
+    for (int i = threadIdx.x; i < 64 * 36; i += 256) { accf[i] = 0.f; acci[i] = 0u; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    unsigned s = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int w = 0; w < 20; w++) {
+            s = s * 1664525u + 1013904223u;
+            const int b = (s >> 10) & 31;
+            if (lane < LIVE) { if (INT) atomicAdd(&acci[lane * 36 + b], 3u); else atomicAdd(&accf[lane * 36 + b], 1.0f); }
+        }
+    }
+    __syncthreads();
+    out[blockIdx.x * 256 + threadIdx.x] = accf[threadIdx.x] + (float)acci[threadIdx.x];
+}
+template <int INT, int LIVE>
+void run2(const char *name, float *out) {
+    int blocks = 256 * 4, iters = 2000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    spin2<INT, LIVE><<<blocks, 256>>>(out, 10);
+    hipEventRecord(e0);
+    spin2<INT, LIVE><<<blocks, 256>>>(out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double insts = (double)blocks * 4 * iters * 20;
+    printf("%-44s %7.1f G wave-inst/s = %.3f per cycle per CU (%.0f cycles each)\n", name, insts / ms / 1e6, insts / ms / 1e6 / 256 / 2.4, 256 * 2.4e9 / (insts / ms * 1e3));
+}
 template <int MODE>
 void run(const char *name, int wgs_per_cu, float *out) {
     int blocks = 256 * wgs_per_cu, iters = 2000;
@@ -45,5 +77,9 @@ int main() {
         run<1>("pixel-major: random splat per lane", w, out);
         run<3>("splat-major: ~28 lanes per accumulator", w, out);
     }
+    run2<0, 64>("ds_add_f32, 64 live lanes, per-lane rows", out);
+    run2<1, 64>("ds_add_u32, 64 live lanes, per-lane rows", out);
+    run2<0, 14>("ds_add_f32, 14 live lanes", out);
+    run2<1, 14>("ds_add_u32, 14 live lanes", out);
     return 0;
 }
