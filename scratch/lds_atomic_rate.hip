@@ -57,6 +57,44 @@ void run2(const char *name, float *out) {
     double insts = (double)blocks * 4 * iters * 20;
     printf("%-44s %7.1f G wave-inst/s = %.3f per cycle per CU (%.0f cycles each)\n", name, insts / ms / 1e6, insts / ms / 1e6 / 256 / 2.4, 256 * 2.4e9 / (insts / ms * 1e3));
 }
+// the other LDS atomics the tracer uses: 64-bit add (register_hits' per-surfel accumulators), returning forms, compare-and-swap (its hash keys)
+template <int KIND, int LIVE>
+__global__ __launch_bounds__(256) void spin3(float *out, int iters) {
+    __shared__ unsigned long long a64[1024];
+    __shared__ int a32[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) { a64[i] = 0ull; a32[i] = -1; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    unsigned s = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    unsigned long long sink = 0;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int w = 0; w < 20; w++) {
+            s = s * 1664525u + 1013904223u;
+            const int h = (s >> 10) & 1023;
+            if (lane < LIVE) {
+                if (KIND == 0) atomicAdd(&a64[h], 257ull);
+                else if (KIND == 1) sink += atomicAdd(&a64[h], 257ull);
+                else if (KIND == 2) sink += (unsigned)atomicAdd(&a32[h], 1);
+                else sink += (unsigned)atomicCAS(&a32[h], -1, (int)s);
+            }
+        }
+    }
+    __syncthreads();
+    out[blockIdx.x * 256 + threadIdx.x] = (float)a64[threadIdx.x] + (float)a32[threadIdx.x] + (float)sink;
+}
+template <int KIND, int LIVE>
+void run3(const char *name, float *out) {
+    int blocks = 256 * 4, iters = 2000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    spin3<KIND, LIVE><<<blocks, 256>>>(out, 10);
+    hipEventRecord(e0);
+    spin3<KIND, LIVE><<<blocks, 256>>>(out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double insts = (double)blocks * 4 * iters * 20;
+    printf("%-44s %7.1f G wave-inst/s (%.0f cycles each)\n", name, insts / ms / 1e6, 256 * 2.4e9 / (insts / ms * 1e3));
+}
 template <int MODE>
 void run(const char *name, int wgs_per_cu, float *out) {
     int blocks = 256 * wgs_per_cu, iters = 2000;
@@ -81,5 +119,9 @@ int main() {
     run2<1, 64>("ds_add_u32, 64 live lanes, per-lane rows", out);
     run2<0, 14>("ds_add_f32, 14 live lanes", out);
     run2<1, 14>("ds_add_u32, 14 live lanes", out);
+    run3<0, 64>("ds_add_u64, 64 lanes, random slots", out);
+    run3<1, 64>("ds_add_rtn_u64, 64 lanes", out);
+    run3<2, 64>("ds_add_rtn_u32, 64 lanes", out);
+    run3<3, 64>("ds_cmpst_rtn_b32 (CAS), 64 lanes", out);
     return 0;
 }
