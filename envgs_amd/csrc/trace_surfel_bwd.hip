@@ -255,7 +255,9 @@ batch_surfel_bwd(const TraceArgs A)
                 }
             };
             fetch_state(k1);
-            for (int el = 0; el < ne; el++) {
+            // (round 6) the entry's place in its run of five is a COMPILE-TIME constant: the loop body is instantiated five times, so the tile rows of
+            // BT(), the `first / last of a run` tests and the run-relative LDS addresses are immediates instead of ~25 scalar / address instructions per entry
+            auto entry = [&]<int e5>(const int el) __attribute__((always_inline)) {
                 const unsigned long long d = sdesc[buf][el];
                 const int sid = (int)(d & 0xFFFFFFull);
                 const unsigned long long rec = d >> 32;
@@ -268,7 +270,6 @@ batch_surfel_bwd(const TraceArgs A)
                 // conflict-free both for the writes (fixed n, 64 rays) and for the MFMA operand reads (16 words x 4 rays).  One wavefront
                 // per workgroup: its LDS operations execute in program order, so no barrier is needed -- and a barrier's vmcnt(0) would
                 // drain the state prefetch that is in flight.
-                const int e5 = el % 5;
                 float gw[16];
 #pragma unroll
                 for (int n = 0; n < 16; n++) gw[n] = 0.f;
@@ -434,6 +435,17 @@ batch_surfel_bwd(const TraceArgs A)
                                 SkM[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[4 * ks + rb], bvs[ks], SkM[rb], 0, 0, 0);
                     }
                 }
+            };
+            for (int el = 0; el < ne; el += 5) {
+                entry.template operator()<0>(el);
+                if (el + 1 >= ne) break;
+                entry.template operator()<1>(el + 1);
+                if (el + 2 >= ne) break;
+                entry.template operator()<2>(el + 2);
+                if (el + 3 >= ne) break;
+                entry.template operator()<3>(el + 3);
+                if (el + 4 >= ne) break;
+                entry.template operator()<4>(el + 4);
             }
         }
         __syncthreads();
