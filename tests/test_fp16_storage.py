@@ -58,10 +58,16 @@ def test_raster_fp16_feature_storage(C, sh):
     assert psnr > 60.0
 
 
+@pytest.mark.parametrize("sparse", ["off", "on"])
 @pytest.mark.parametrize("use_sh", [True, False])
-def test_tracer_fp16_feature_storage(use_sh):
+def test_tracer_fp16_feature_storage(use_sh, sparse, request):
+    """(sparse = "on": the same with the hits of sparse entries differentiated one lane per hit -- sparse_hits_bwd reads the half features too.)"""
     import diff_surfel_tracing as mod
+    from envgs_amd import tracing
     from tests.test_trace_parity import _settings
+    old_mode = tracing.SPARSE["mode"]
+    tracing.SPARSE["mode"] = sparse
+    request.addfinalizer(lambda: tracing.SPARSE.__setitem__("mode", old_mode))
     dev = torch.device("cuda:0")
     g, ro, rd = trace_scene(P=300, R=640, seed=8, camera=False)
     bg = torch.tensor([0.3, 0.1, 0.7])
@@ -79,7 +85,8 @@ def test_tracer_fp16_feature_storage(use_sh):
         (outs[0] * torch.linspace(0.5, 1.5, 3, device=dev)).sum().backward()
         torch.cuda.synchronize()
         out[name] = (outs[0].detach(), {k: x.grad for k, x in L.items()}, fd.grad, o.grad, d.grad)
-    t = "fp16_storage_tracer_%s" % ("sh" if use_sh else "rgb")
+        assert (tracing.last_trace_counts()["sparse_hits"] > 0) == (sparse == "on")
+    t = "fp16_storage_tracer_%s%s" % ("sh" if use_sh else "rgb", "_sparse" if sparse == "on" else "")
     assert out["h"][2].dtype == torch.float16
     out["full"] = None
     assert torch.equal(out["h"][0], out["f"][0])
