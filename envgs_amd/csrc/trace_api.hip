@@ -228,9 +228,10 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             S.batch0 = (int)((long long)nbatch_all * sg / nseg);
             S.batch1 = (int)((long long)nbatch_all * (sg + 1) / nseg);
             const int rays_seg = (S.batch1 - S.batch0) * 64;
-            // (the later segment's collection runs beside the first one's sort pass for most of its life: one more workgroup per CU for it --
-            //  4+4 / 4+5 / 4+6 / 3+5 / 5+4 workgroups: 9.54 / 9.48 / 9.57 / 9.62 / 9.59 ms per step)
-            const int seg_wgs = (nseg > 1 && sg > 0 && debug_switch(ENVGS_DBG_COLLECT_WGS) <= 0) ? coop_wgs + 1 : coop_wgs;
+            // (round 3 gave the later segment's collection one more workgroup per CU -- 4+4 / 4+5 / 4+6 / 3+5 / 5+4 workgroups: 9.54 / 9.48 / 9.57 / 9.62 /
+            //  9.59 ms per step then.  Round 6, with the collection 15 % faster than the sort pass it runs beside: 4+4 wins, three alternating pairs
+            //  7.91 / 7.93 / 7.92 ms against 7.94 / 7.94 / 7.97, configs[4] 50.7 / 50.8 against 50.9 / 51.2 -- the sort pass gets the slots)
+            const int seg_wgs = coop_wgs;
             {
                 ProfScope p1(K_TRACE_COLLECT, st);
 #ifndef ENVGS_DIAG

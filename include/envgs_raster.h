@@ -177,7 +177,7 @@ ENVGS_API const char *envgs_prof_kernel_name(int kernel_id);
  */
 #define ENVGS_DBG_TRACE 0
 #define ENVGS_DBG_SEGMENTS 1
-#define ENVGS_DBG_COLLECT_WGS 2      /* workgroups per CU of the cooperative collection's persistent grid (0 = default: 4 for the first and 5 for the second of two segments in flight, 8 for a single one) */
+#define ENVGS_DBG_COLLECT_WGS 2      /* workgroups per CU of the cooperative collection's persistent grid (0 = default: 4 for each of two segments in flight, 8 for a single one) */
 #define ENVGS_DBG_RASTER_EXACT 3     /* libenvgs_hip_diag.so only: R6 / R7 with IEEE divisions and the library expf instead of v_rcp_f32 (+ Newton) / v_exp_f32 -- the attribution run of the parity tests; no effect in the product library */
 #define ENVGS_DBG_RAYKEY 4           /* ray coherence key (csrc/ray_key.h): value - 1 = direction-only rounds in front of the interleaved (direction, origin) rounds; 0 = default */
 #define ENVGS_DBG_SPARSE 5           /* sparse entries of the tracer's record backward (envgs_trace.h: sparse_hits): value - 1 = the largest hit count an entry may have to be filed per hit; 0 = default (4), 1 = off */
