@@ -55,7 +55,12 @@ composite_lists_bwd(const TraceArgs A)
 // every LDS read issued so far has returned, and the compiler may not sink a later use's read below this point (s_waitcnt lgkmcnt(0) + a
 // scheduling barrier): used to make a set of MFMAs start with ALL its operands in registers instead of one round trip per operand
 #define ENVGS_LDS_FENCE() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)
-constexpr int BS_GROUP = 16;
+#ifndef ENVGS_BS_GROUP
+#define ENVGS_BS_GROUP 15
+#endif
+constexpr int BS_GROUP = ENVGS_BS_GROUP;   // entries staged per group.  15 = three whole runs of five (round 6): with 16 every group ended in a run of ONE entry that paid the three
+                                           // MFMA sets of a run on its own (12 MFMAs per entry instead of 9.6)
+static_assert(BS_GROUP <= 16, "stage() assigns four lanes per entry");
 #ifndef ENVGS_BSB_KO
 #define ENVGS_BSB_KO 0          // measurement builds only (scratch/ab_bsb.sh): 1 = no dothers, 2 = no aux-plane fetch, 4 = no plane-1 fetch, 8 = no plane-0 fetch -- results wrong by construction
 #endif
@@ -149,8 +154,9 @@ batch_surfel_bwd(const TraceArgs A)
         auto stage = [&](int g, int buf) {
             const int el = lane >> 2, part = lane & 3;
             const int e = g * BS_GROUP + el;
+            const bool elv = el < BS_GROUP;
             unsigned long long d = 0ull;
-            if (e < NE) {
+            if (elv && e < NE) {
                 d = e < D ? ent[e] : ent[region - 1 - (size_t)(e - D)];
                 const int sid = (int)(d & 0xFFFFFFull);
                 sdat[buf][el][part] = A.srec[(size_t)sid * 4 + part];
@@ -201,8 +207,8 @@ batch_surfel_bwd(const TraceArgs A)
                     if constexpr (OTH) sox[buf][el] = reinterpret_cast<const float2 *>(A.others)[sid];
                 }
             }
-            if (part == 0) scn[buf][el] = e < NE ? (unsigned)((d >> 24) & 63ull) + 1u : 0u;
-            {   // clear kmat[buf]: 2 KB = 32 B per lane
+            if (part == 0 && elv) scn[buf][el] = e < NE ? (unsigned)((d >> 24) & 63ull) + 1u : 0u;
+            if (lane * 32 < BS_GROUP * 128) {   // clear kmat[buf]: 128 B per entry, 32 B per lane
                 uint4 *km = reinterpret_cast<uint4 *>(&kmat[buf][0][0]);
                 km[lane * 2] = make_uint4(0u, 0u, 0u, 0u); km[lane * 2 + 1] = make_uint4(0u, 0u, 0u, 0u);
             }
