@@ -133,6 +133,11 @@ class CapState:
         if m["valid"] and m["event"].query():
             mx = int(m["host"][1])
             want = ((int(mx * 1.2) + 8 + 63) // 64) * 64          # 20 % headroom, multiple of 64 entries (512 B)
+            if want > 256 and int(mx * 1.1) + 8 <= 256:
+                # 256 is a class boundary: a capacity above it adds the long-list launch to every forward segment (~0.04 ms per step even when it finds
+                # nothing to do: 512 workgroups scheduled onto a busy chip) -- not crossed for less than 10 % of headroom.  A ray that then finds more
+                # than 256 hits takes the K-buffer kernels, as with any capacity
+                want = 256
             self.cap = max(64, min(want, 1024))
             found = (int(m["host"][8]) & 0xFFFFFFFF) | ((int(m["host"][9]) & 0xFFFFFFFF) << 32)
             self.found_per_ray = found / max(1, m["rays"])
