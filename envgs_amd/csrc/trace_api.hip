@@ -268,7 +268,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
                 if (!(S.order && !(S.exp & 512) && !(S.exp & 16) && !(S.exp & 2048)))     // the A/B collection kernels do not write batch counts
                     hipLaunchKernelGGL(row_count, dim3(nblk), dim3(256), 0, st, S, cntb);
 #endif
-                hipLaunchKernelGGL(row_scan_blocks, dim3(1), dim3(1024), 0, st, cntb + S.batch0, nb_seg, counters + 22, counters + 28 + sg);
+                hipLaunchKernelGGL(row_scan_blocks, dim3(1), dim3(256), 0, st, cntb + S.batch0, nb_seg, counters + 22, counters + 28 + sg);
                 hipLaunchKernelGGL(row_offsets, dim3(nblk), dim3(256), 0, st, S, cntb, L->row_off, (uint2 *)L->batch_rows, (const unsigned *)(counters + 28 + sg), limit);
                 ENVGS_CHECK_LAUNCH(dcfg, st);
             }

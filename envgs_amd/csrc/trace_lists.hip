@@ -599,43 +599,56 @@ row_count(const TraceArgs A, unsigned *__restrict__ blk)
     if ((threadIdx.x & 63) == 0) blk[slot >> 6] = (unsigned)s;
 }
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256)
 row_scan_blocks(unsigned *__restrict__ blk, int n, unsigned *rows_used, unsigned *seg_base)
 {
     // (rows_used / seg_base: this segment CLAIMS its rows of the compact per-hit buffers from one counter shared by the call's segments -- round 3
     //  gave every segment the share of the rows that matched its share of the RAYS, which starves a segment whose rays happen to find most of
     //  the hits (the parked rays of a bounce stage sort into batches of their own: one segment may hold nearly all the live ones))
-    // exclusive scan in place, one workgroup, 1024 counts per pass: coalesced loads, integer wave scans (the totals exceed 2^24: no float scan),
-    // the 16 wavefront totals through LDS, a running base carried from pass to pass.  (Round 3: every thread summed a contiguous run of its own and
-    // a ten-round Hillis-Steele pass over LDS joined them: 23 us on the step's critical path, twice.)
-    __shared__ unsigned wtot[16];
+    // exclusive scan in place, ONE workgroup, 1024 counts per pass, four consecutive counts per thread: integer wave scans of the threads' sums (the
+    // totals exceed 2^24: no float scan), the four wavefront totals through LDS, a running base carried from pass to pass.  Round 6: 256 threads
+    // instead of 1024 -- the kernel sits on every forward segment's critical chain (collection -> scan -> row offsets -> sort pass) beside the
+    // OTHER segment's kernels, and a 16-wavefront workgroup has to find sixteen free wavefront slots on ONE CU at once: 10 us of work took 103 us
+    // on average (626 at worst) from first to last wavefront (profiles/r06_envgs_kernel_stats.csv); four wavefronts fit anywhere.
+    __shared__ unsigned wtot[4];
     __shared__ unsigned s_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_base = 0u;
     __syncthreads();
     constexpr int PRE = 8;                     // passes whose loads are issued up front (8192 batches = 524 k rays per segment; beyond that the loop loads as it goes)
-    unsigned pre[PRE];
+    unsigned pre[PRE][4];
 #pragma unroll
-    for (int c = 0; c < PRE; c++) { const int i = c * 1024 + (int)threadIdx.x; pre[c] = i < n ? blk[i] : 0u; }
+    for (int c = 0; c < PRE; c++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int i = c * 1024 + 4 * (int)threadIdx.x + q; pre[c][q] = i < n ? blk[i] : 0u; }
     int c = 0;
     for (int c0 = 0; c0 < n; c0 += 1024, c++) {
-        const int i = c0 + (int)threadIdx.x;
-        unsigned v;
+        const int i0 = c0 + 4 * (int)threadIdx.x;
+        unsigned v[4];
         if (c < PRE) {
-            v = pre[0];
 #pragma unroll
-            for (int q = 1; q < PRE; q++) v = c == q ? pre[q] : v;
-        } else v = i < n ? blk[i] : 0u;
-        unsigned x = v;
+            for (int q = 0; q < 4; q++) {
+                v[q] = pre[0][q];
+#pragma unroll
+                for (int p_ = 1; p_ < PRE; p_++) v[q] = c == p_ ? pre[p_][q] : v[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = i0 + q < n ? blk[i0 + q] : 0u;
+        }
+        const unsigned tsum = v[0] + v[1] + v[2] + v[3];
+        unsigned x = tsum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const unsigned y = (unsigned)__shfl_up((int)x, o); if (lane >= o) x += y; }
         if (lane == 63) wtot[wave] = x;
         __syncthreads();
         unsigned before = s_base;
         for (int w = 0; w < wave; w++) before += wtot[w];
-        if (i < n) blk[i] = before + x - v;
+        unsigned run = before + x - tsum;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { if (i0 + q < n) blk[i0 + q] = run; run += v[q]; }
         __syncthreads();
-        if (threadIdx.x == 1023) s_base = before + x;
+        if (threadIdx.x == 255) s_base = before + x;
         __syncthreads();
     }
     if (threadIdx.x == 0 && rows_used && seg_base) *seg_base = atomicAdd(rows_used, s_base);
