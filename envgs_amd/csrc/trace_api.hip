@@ -109,8 +109,8 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         FP.P = cfg->P; FP.rec_blocks = (cfg->P + 255) / 256; FP.mod = cfg->scale_modifier;
         FP.means = means3D; FP.scales = scales; FP.rots = rotations; FP.opac = opacities; FP.srec = srec;
     }
-    auto launch_prepare = [&]() -> int {
-        hipLaunchKernelGGL(forward_prepare, dim3((unsigned)(FP.zero_blocks + FP.rec_blocks + FP.perm_blocks)), dim3(256), 0, stream, FP);
+    auto launch_prepare = [&](hipStream_t st) -> int {
+        hipLaunchKernelGGL(forward_prepare, dim3((unsigned)(FP.zero_blocks + FP.rec_blocks + FP.perm_blocks)), dim3(256), 0, st, FP);
         return (int)hipGetLastError();
     };
     TraceArgs A;
@@ -135,17 +135,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         if (L->scan_temp_bytes < scan_temp_bytes(cfg->P * NCOPY)) return ENVGS_ERR_TEMP_TOO_SMALL;
         A.hits = (uint2 *)L->hit_lists; A.hit_cnt = L->hit_cnt; A.n_used = L->n_used; A.cap = L->cap; A.stack_spill = L->stack_spill;
         A.surf_cnt = L->surf_cnt; A.surf_off = L->surf_off; A.surf_acc = (unsigned long long *)L->surf_acc;
-        if (L->ray_keys && L->ray_order && L->ray_sort_temp && !(A.exp & 64)) {
-            // coherence sort of the rays: (key, ray id) pairs bucketed and sorted per bucket (raster_bin.hip: launch_ray_sort); the pairs use
-            // ray_keys (2R words = R pairs), the order lands in the second half of ray_order
-            const int R = cfg->num_rays;
-            const int rc = launch_ray_sort(R, ray_o, ray_d, A.nodes, cfg->P, (uint64_t *)L->ray_keys, L->ray_order + R, L->ray_sort_temp,
-                                           L->ray_sort_temp_bytes, stream);
-            if (rc) return rc;
-            ENVGS_CHECK_LAUNCH(dcfg, stream);
-            A.order = L->ray_order + R;
-            A.long_list = L->ray_keys;                        // the pairs are dead now: scratch for the queue of long rays
-        }
+        const bool will_sort = L->ray_keys && L->ray_order && L->ray_sort_temp && !(A.exp & 64);
         {   // 40-bit fixed-point weight: enough integer bits that even a surfel seen with w = 1 by every ray cannot overflow
             int ib = 1;
             while ((1ll << ib) <= (long long)cfg->num_rays) ib++;
@@ -170,8 +160,6 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             FP.shs = (const void *)shs; FP.shp = L->sh_perm;
             A.shp = L->sh_perm;
         }
-        { const int rcp = launch_prepare(); if (rcp) return rcp; }
-        ENVGS_CHECK_LAUNCH(dcfg, stream);
         // The ray batches are split into two segments that run collect -> sort+composite -> register on two streams: the collection
         // kernel is a persistent grid whose wavefronts drain over the time of one whole batch, and the second segment's wavefronts
         // (and the first segment's next kernel) move into the CUs it leaves idle.
@@ -181,7 +169,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         if (nseg > MAX_SEG) nseg = MAX_SEG;                   // (fetch counters: 8 words per segment from counters[32])
         // the per-ray collection kernel (diagnostic: exp & 512, or no coherence sort) spills its stacks into a slab that is sized for two
         // segments (envgs_trace_stack_spill_ints)
-        if (nseg > 2 && !(A.order && !(A.exp & 512))) nseg = 2;
+        if (nseg > 2 && !(will_sort && !(A.exp & 512))) nseg = 2;
         while (nseg > 1 && nbatch_all / nseg < 256) nseg--;
         if (nseg < 1) nseg = 1;
         hipStream_t aux[MAX_SEG] = {};
@@ -206,12 +194,35 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
             }
             if (nseg > 1) {
                 ev_fork = s_fork[dev];
-                if (hipEventRecord(ev_fork, stream) != hipSuccess) return ENVGS_ERR_BAD_ARG;
-                for (int i = 1; i < nseg; i++) {
-                    aux[i] = s_aux[dev][i]; ev_join[i] = s_join[dev][i];
-                    if (hipStreamWaitEvent(aux[i], ev_fork, 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
-                }
+                for (int i = 1; i < nseg; i++) { aux[i] = s_aux[dev][i]; ev_join[i] = s_join[dev][i]; }
             }
+        }
+        // forward_prepare (zero fills, surfel records, permuted SH blocks) reads nothing of the rays: with a second stream at hand it runs
+        // there, beside the coherence sort's seven small launches, instead of after them
+        const bool prepare_aside = nseg > 1 && will_sort && !(A.exp & 16384);
+        if (prepare_aside) {
+            if (hipEventRecord(ev_fork, stream) != hipSuccess || hipStreamWaitEvent(aux[1], ev_fork, 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+            const int rcp = launch_prepare(aux[1]); if (rcp) return rcp;
+            if (hipEventRecord(ev_join[1], aux[1]) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+            ENVGS_CHECK_LAUNCH(dcfg, aux[1]);
+        }
+        if (will_sort) {
+            // coherence sort of the rays: (key, ray id) pairs bucketed and sorted per bucket (raster_bin.hip: launch_ray_sort); the pairs use
+            // ray_keys (2R words = R pairs), the order lands in the second half of ray_order
+            const int R = cfg->num_rays;
+            const int rc = launch_ray_sort(R, ray_o, ray_d, A.nodes, cfg->P, (uint64_t *)L->ray_keys, L->ray_order + R, L->ray_sort_temp,
+                                           L->ray_sort_temp_bytes, stream);
+            if (rc) return rc;
+            ENVGS_CHECK_LAUNCH(dcfg, stream);
+            A.order = L->ray_order + R;
+            A.long_list = L->ray_keys;                        // the pairs are dead now: scratch for the queue of long rays
+        }
+        if (prepare_aside) { if (hipStreamWaitEvent(stream, ev_join[1], 0) != hipSuccess) return ENVGS_ERR_BAD_ARG; }
+        else { const int rcp = launch_prepare(stream); if (rcp) return rcp; ENVGS_CHECK_LAUNCH(dcfg, stream); }
+        if (nseg > 1) {
+            if (hipEventRecord(ev_fork, stream) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+            for (int i = 1; i < nseg; i++)
+                if (hipStreamWaitEvent(aux[i], ev_fork, 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
         }
         // Workgroups per CU of the collection's persistent grid.  8 fill the CU -- and then nothing else gets a wavefront slot until the
         // collection drains: with two segments in flight the other segment's sort / register kernels could only move into the CUs a finishing
@@ -284,7 +295,13 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
                 }
             }
             ENVGS_CHECK_LAUNCH(dcfg, st);
-            { ProfScope p8(K_TRACE_REGISTER, st); hipLaunchKernelGGL(register_hits, dim3(stride_grid(rays_seg, 64)), dim3(64 * RH_W), 0, st, S); }
+            {
+                ProfScope p8(K_TRACE_REGISTER, st);
+                const dim3 gr(stride_grid(rays_seg, 64)), br(64 * RH_W);
+                // (lists of at most 256 hits: each hit's table slot and rank stay in registers between the kernel's phases)
+                if (S.pairs && S.cap <= 256) hipLaunchKernelGGL(register_hits<true>, gr, br, 0, st, S);
+                else hipLaunchKernelGGL(register_hits<false>, gr, br, 0, st, S);
+            }
             ENVGS_CHECK_LAUNCH(dcfg, st);
         }
         for (int i = 1; i < nseg; i++)
@@ -298,7 +315,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         }
         A.only_overflow = 1;
     } else {
-        const int rcp = launch_prepare();
+        const int rcp = launch_prepare(stream);
         if (rcp) return rcp;
         ENVGS_CHECK_LAUNCH(dcfg, stream);
     }

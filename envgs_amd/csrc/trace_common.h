@@ -668,7 +668,7 @@ extern template __global__ void __launch_bounds__(256) sort_composite_fwd<16, tr
 extern template __global__ void __launch_bounds__(256) sort_composite_fwd<4, false, true>(const TraceArgs A);
 extern template __global__ void __launch_bounds__(256) sort_composite_fwd<8, true, true>(const TraceArgs A);
 extern template __global__ void __launch_bounds__(256) sort_composite_fwd<16, true, true>(const TraceArgs A);
-__global__ void __launch_bounds__(64 * RH_W) register_hits(const TraceArgs A);
+template <bool CACHED> __global__ void __launch_bounds__(64 * RH_W) register_hits(const TraceArgs A);
 __global__ void __launch_bounds__(256) row_count(const TraceArgs A, unsigned *__restrict__ blk);
 __global__ void __launch_bounds__(256) row_scan_blocks(unsigned *__restrict__ blk, int n, unsigned *rows_used, unsigned *seg_base);
 __global__ void __launch_bounds__(256) row_offsets(const TraceArgs A, const unsigned *__restrict__ blk, unsigned *__restrict__ row_off, uint2 *__restrict__ batch_rows,

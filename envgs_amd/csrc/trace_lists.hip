@@ -389,7 +389,15 @@ sort_composite_fwd(const TraceArgs A)
 //   pairs[b][...]  (lane << 16 | k) of every hit, grouped by entry in entry order (singles again from the top)
 constexpr int RH_TAB = 1024;
 constexpr int RH_STAGE = 8192;                           // pairs staged in LDS per batch (32 KB); the rest, if any, is stored directly
+template <bool CACHED>                                   // CACHED: lists of at most 256 hits with pairs wanted (see `cached` below); the launch decides
+#ifndef ENVGS_RH_WPE
+#define ENVGS_RH_WPE 6
+#endif
+#if ENVGS_RH_WPE > 0
+__global__ void __launch_bounds__(64 * RH_W) __attribute__((amdgpu_waves_per_eu(ENVGS_RH_WPE, ENVGS_RH_WPE)))
+#else
 __global__ void __launch_bounds__(64 * RH_W)
+#endif
 register_hits(const TraceArgs A)
 {
     __shared__ int key[RH_TAB];
@@ -420,38 +428,88 @@ register_hits(const TraceArgs A)
 #ifndef ENVGS_RH_U
 #define ENVGS_RH_U 4
 #endif
+#ifndef ENVGS_RH_KO
+#define ENVGS_RH_KO 0
+#endif
         constexpr int U = ENVGS_RH_U;
+        // one hit into the table: weight and count of its surfel (RANK: the count before it = the hit's place among its surfel's pairs)
+        auto insert = [&]<bool RANK>(const uint2 e, const int k) __attribute__((always_inline)) -> unsigned {
+            const unsigned long long wq = (unsigned long long)ceilf(__uint_as_float(e.x) * wscale);
+            unsigned h = (e.y * 2654435761u) >> 22;
+            bool ok = false;
+            for (int t = 0; t < 24; t++) {
+                const int old = atomicCAS(&key[h], -1, (int)e.y);
+                if (old == -1) hod[atomicAdd(&ndense, 1u)] = (unsigned short)h;      // first to see this surfel: entries keep this order
+                if (old == -1 || old == (int)e.y) { ok = true; break; }
+                h = (h + 1) & (RH_TAB - 1);
+            }
+            if (ok) {
+                if constexpr (RANK) return h | ((unsigned)(atomicAdd(&acc[h], (wq << 8) | 1ull) & 0xFFull) << 10);
+                atomicAdd(&acc[h], (wq << 8) | 1ull);                     // (no return value needed: the pairs get their ranks in the last phase)
+                return 0u;
+            }
+            // table full around h: an entry of its own
+            const unsigned long long old = atomicAdd(A.surf_acc + (size_t)e.y * NCOPY + copy, (wq << 24) | 1ull);
+            const unsigned f = atomicAdd(&nfail, 1u);
+            if (ent) ent[region - 1 - f] = (unsigned long long)e.y | ((old & 0xFFFFFFull) << 32);
+            if (prs) prs[region - 1 - f] = ((unsigned)lane << 16) | (unsigned)k;
+            return 0xFFFFFFFFu;
+        };
+        // Lists of at most 256 hits (32 per lane) keep each hit's table slot and rank in registers -- 16 bits per hit -- so the last phase
+        // neither reads the list again nor probes nor takes an atomic (round 6: that phase was 0.19 of the kernel's 0.61 ms).
+#ifndef ENVGS_RH_UC
+#define ENVGS_RH_UC 2
+#endif
+        constexpr int UC = ENVGS_RH_UC;                                   // hits per lane and step (2: 78 registers = 6 waves per SIMD and 0.47 ms; 4: 94 = 5 waves, 0.57 ms)
+        constexpr int CIT = 256 / (UC * RH_W);
+        constexpr bool cached = CACHED;
+        unsigned hr[CIT * UC / 2] = {};
+        unsigned fmask = 0u;                                              // hits that found no room in the table
         // (each lane walks its own list row: the loads of one step are 64 different cache lines, so the next step's entries are requested
         //  before this step's chain of LDS atomics starts)
-        uint2 nxt[U];
+        if constexpr (cached) {
+            // (a rolled loop: the newest codes enter at the bottom of hr[] and the older ones move up -- 15 register moves per step; the last
+            //  phase takes them back newest first)
+            uint2 nxt[UC];
 #pragma unroll
-        for (int j = 0; j < U; j++) { const int k = part + j * RH_W; nxt[j] = (k < n) ? list[k] : make_uint2(0u, 0u); }
-        for (int kb = part; kb < n; kb += U * RH_W) {
-            uint2 e[U];
+            for (int j = 0; j < UC; j++) { const int k = part + j * RH_W; nxt[j] = (k < n) ? list[k] : make_uint2(0u, 0u); }
+            for (int kb = part; kb < n; kb += UC * RH_W) {
+                uint2 e[UC];
 #pragma unroll
-            for (int j = 0; j < U; j++) e[j] = nxt[j];
+                for (int j = 0; j < UC; j++) e[j] = nxt[j];
 #pragma unroll
-            for (int j = 0; j < U; j++) { const int k = kb + (U + j) * RH_W; nxt[j] = (k < n) ? list[k] : make_uint2(0u, 0u); }
+                for (int j = 0; j < UC; j++) { const int k = kb + (UC + j) * RH_W; nxt[j] = (k < n) ? list[k] : make_uint2(0u, 0u); }
+                unsigned c[UC / 2] = {}, fm = 0u;
 #pragma unroll
-            for (int j = 0; j < U; j++) {
-                const int k = kb + j * RH_W;
-                if (k >= n) break;
-                const unsigned long long wq = (unsigned long long)ceilf(__uint_as_float(e[j].x) * wscale);
-                unsigned h = (e[j].y * 2654435761u) >> 22;
-                bool ok = false;
-                for (int t = 0; t < 24; t++) {
-                    const int old = atomicCAS(&key[h], -1, (int)e[j].y);
-                    if (old == -1) hod[atomicAdd(&ndense, 1u)] = (unsigned short)h;      // first to see this surfel: entries keep this order
-                    if (old == -1 || old == (int)e[j].y) { ok = true; break; }
-                    h = (h + 1) & (RH_TAB - 1);
+                for (int j = 0; j < UC; j++) {
+                    const int k = kb + j * RH_W;
+                    if (k < n) {
+                        unsigned code = insert.template operator()<true>(e[j], k);
+                        if (code == 0xFFFFFFFFu) { fm |= 1u << j; code = 0u; }
+                        c[j >> 1] |= code << ((j & 1) * 16);
+                    }
                 }
-                if (ok) {
-                    atomicAdd(&acc[h], (wq << 8) | 1ull);                 // (no return value needed: the pairs get their ranks in the last phase)
-                } else {                                                  // table full around h: an entry of its own
-                    const unsigned long long old = atomicAdd(A.surf_acc + (size_t)e[j].y * NCOPY + copy, (wq << 24) | 1ull);
-                    const unsigned f = atomicAdd(&nfail, 1u);
-                    if (ent) ent[region - 1 - f] = (unsigned long long)e[j].y | ((old & 0xFFFFFFull) << 32);
-                    if (prs) prs[region - 1 - f] = ((unsigned)lane << 16) | (unsigned)k;
+#pragma unroll
+                for (int i = CIT * UC / 2 - 1; i >= UC / 2; i--) hr[i] = hr[i - UC / 2];
+#pragma unroll
+                for (int i = 0; i < UC / 2; i++) hr[i] = c[i];
+                fmask = (fmask << UC) | fm;
+            }
+        } else {
+            uint2 nxt[U];
+#pragma unroll
+            for (int j = 0; j < U; j++) { const int k = part + j * RH_W; nxt[j] = (k < n) ? list[k] : make_uint2(0u, 0u); }
+            for (int kb = part; kb < n; kb += U * RH_W) {
+                uint2 e[U];
+#pragma unroll
+                for (int j = 0; j < U; j++) e[j] = nxt[j];
+#pragma unroll
+                for (int j = 0; j < U; j++) { const int k = kb + (U + j) * RH_W; nxt[j] = (k < n) ? list[k] : make_uint2(0u, 0u); }
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const int k = kb + j * RH_W;
+                    if (k >= n) break;
+                    insert.template operator()<false>(e[j], k);
                 }
             }
         }
@@ -516,39 +574,67 @@ register_hits(const TraceArgs A)
             if (lane == 0) ptotal = carry_off;
         }
         __syncthreads();
-        if (prs) {
+        if (prs && !(ENVGS_RH_KO & 1)) {
             // Every hit finds its surfel's table slot again (the same probe sequence; hits that found no room fail again and were filed in
             // the first phase) and takes the next free position of that surfel's run of pairs: acc[h] holds the run's offset in its low word
             // and hands out ranks from its high word.  (Writing slot and rank back into the list in the first phase instead cost a scattered
             // 4 B store -- a whole 32 B sector of write traffic -- and a second gather per hit: 2 GB per step.)
-            constexpr int U2 = ENVGS_RH_U;                      // independent loads first: one memory round trip per 4 hits, not per hit
-            for (int kb = part; kb < n; kb += U2 * RH_W) {
-                unsigned sidv[U2];
+            if constexpr (cached) {
+                for (int it = n > part ? (n - part - 1) / (UC * RH_W) : -1; it >= 0; it--) {
+                    const int kb = part + it * UC * RH_W;
+                    unsigned c[UC / 2];
 #pragma unroll
-                for (int j = 0; j < U2; j++) { const int k = kb + j * RH_W; sidv[j] = (k < n) ? list[k].y : 0xFFFFFFFFu; }
+                    for (int i = 0; i < UC / 2; i++) c[i] = hr[i];
 #pragma unroll
-                for (int j = 0; j < U2; j++)
-                    if (sidv[j] != 0xFFFFFFFFu) {
-                        unsigned h = (sidv[j] * 2654435761u) >> 22;
-                        bool ok = false;
-                        for (int t = 0; t < 24; t++) {
-                            const int kk = key[h];
-                            if (kk == (int)sidv[j]) { ok = true; break; }
-                            if (kk == -1) break;
-                            h = (h + 1) & (RH_TAB - 1);
-                        }
-                        if (ok) {
-                            if (sparse_on && (acc[h] >> 63)) {               // (the flag never changes once the flush has set it)
-                                const unsigned long long o = atomicAdd(&acc[h], 1ull << 56);
-                                const unsigned rank = (unsigned)(o >> 56) & 0x7Fu;
-                                A.sparse[(unsigned)o + rank] = make_uint4((unsigned)(base + lane), (unsigned)(kb + j * RH_W), sidv[j], ((unsigned)(o >> 32) & 0xFFFFFFu) + rank);
-                            } else {
-                                const unsigned long long o = atomicAdd(&acc[h], 1ull << 32);
-                                const unsigned idx = (unsigned)o + (unsigned)(o >> 32), v = ((unsigned)lane << 16) | (unsigned)(kb + j * RH_W);
+                    for (int i = 0; i < CIT * UC / 2 - UC / 2; i++) hr[i] = hr[i + UC / 2];
+                    const unsigned fm = fmask;
+                    fmask >>= UC;
+#pragma unroll
+                    for (int j = 0; j < UC; j++) {
+                        const int k = kb + j * RH_W;
+                        if (k < n && !((fm >> j) & 1u)) {
+                            const unsigned code = (c[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                            const unsigned h = code & (RH_TAB - 1), rank = code >> 10;
+                            const unsigned long long o = acc[h];
+                            if (sparse_on && (o >> 63))
+                                A.sparse[(unsigned)o + rank] = make_uint4((unsigned)(base + lane), (unsigned)k, (unsigned)key[h], ((unsigned)(o >> 32) & 0xFFFFFFu) + rank);
+                            else {
+                                const unsigned idx = (unsigned)o + rank, v = ((unsigned)lane << 16) | (unsigned)k;
                                 if (idx < (unsigned)RH_STAGE) pstage[idx] = v; else prs[idx] = v;
                             }
                         }
                     }
+                }
+            } else {
+                constexpr int U2 = ENVGS_RH_U;                      // independent loads first: one memory round trip per 4 hits, not per hit
+                for (int kb = part; kb < n; kb += U2 * RH_W) {
+                    unsigned sidv[U2];
+    #pragma unroll
+                    for (int j = 0; j < U2; j++) { const int k = kb + j * RH_W; sidv[j] = (k < n) ? list[k].y : 0xFFFFFFFFu; }
+    #pragma unroll
+                    for (int j = 0; j < U2; j++)
+                        if (sidv[j] != 0xFFFFFFFFu) {
+                            unsigned h = (sidv[j] * 2654435761u) >> 22;
+                            bool ok = false;
+                            for (int t = 0; t < 24; t++) {
+                                const int kk = key[h];
+                                if (kk == (int)sidv[j]) { ok = true; break; }
+                                if (kk == -1) break;
+                                h = (h + 1) & (RH_TAB - 1);
+                            }
+                            if (ok) {
+                                if (sparse_on && (acc[h] >> 63)) {               // (the flag never changes once the flush has set it)
+                                    const unsigned long long o = atomicAdd(&acc[h], 1ull << 56);
+                                    const unsigned rank = (unsigned)(o >> 56) & 0x7Fu;
+                                    A.sparse[(unsigned)o + rank] = make_uint4((unsigned)(base + lane), (unsigned)(kb + j * RH_W), sidv[j], ((unsigned)(o >> 32) & 0xFFFFFFu) + rank);
+                                } else {
+                                    const unsigned long long o = atomicAdd(&acc[h], 1ull << 32);
+                                    const unsigned idx = (unsigned)o + (unsigned)(o >> 32), v = ((unsigned)lane << 16) | (unsigned)(kb + j * RH_W);
+                                    if (idx < (unsigned)RH_STAGE) pstage[idx] = v; else prs[idx] = v;
+                                }
+                            }
+                        }
+                }
             }
             __syncthreads();
             const unsigned T = min(ptotal, (unsigned)RH_STAGE);
@@ -575,6 +661,9 @@ register_hits(const TraceArgs A)
         }
     }
 }
+
+template __global__ void register_hits<false>(const TraceArgs A);
+template __global__ void register_hits<true>(const TraceArgs A);
 
 // Row offsets of the compact per-hit buffers (envgs_trace.h: compact_rows).  Runs per forward segment between the collection and the sort:
 // rows of a ray = its hits found (none for a ray whose list overflowed), scanned over the segment's slots in coherence-sorted order.  The

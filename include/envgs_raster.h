@@ -172,7 +172,8 @@ ENVGS_API const char *envgs_prof_kernel_name(int kernel_id);
  *                    64 = no coherence sort of the rays, 512 = per-ray collection kernel even when the rays are sorted,
  *                    1024 = packet stack limited to 2 entries (forces the stack-overflow hand-off to the K-buffer path; tests only),
  *                    2048 = one wavefront per 64-ray batch (collect_hits_packet4) instead of the cooperative workgroup (collect_hits_coop),
- *                    4096 / 8192 = cooperative collection with DEFERRED exact tests at 8 / 6 wavefronts per SIMD (round-5 A/B, diagnostic library)
+ *                    4096 / 8192 = cooperative collection with DEFERRED exact tests at 8 / 6 wavefronts per SIMD (round-5 A/B, diagnostic library),
+ *                    16384 = forward_prepare on the caller's stream after the coherence sort instead of beside it on the second stream (round-6 A/B)
  *   ENVGS_DBG_SEGMENTS  forward batch segments of the tracer (0 = default 2; 1 = single launch)
  */
 #define ENVGS_DBG_TRACE 0
