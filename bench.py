@@ -175,6 +175,8 @@ def main():
                     "(same topology, new boxes; exact) on the others while the tree's measured surface-area cost has not grown; 1 = full build on every request (the literal OptiX behaviour)")
     ap.add_argument("--no-colour-only-state", action="store_true", help="fused caller: let the env trace keep the full per-hit state (as for a caller that may differentiate "
                     "its depth / accumulation / normal outputs) instead of the colour's plane only (SurfelTracer.set_colour_only_backward)")
+    ap.add_argument("--no-deferred-surfel-grads", action="store_true", help="fused caller, N = 1: keep the tracer backward's record sums on the step's stream (the reference's "
+                    "semantics) instead of letting them run beside the base pass's backward (SurfelTracer.set_deferred_surfel_gradients; joined before the optimizer)")
     ap.add_argument("--no-prebuild", action="store_true", help="fused caller: build the environment structure inside the traced call (as the reference caller does) instead of ahead, under the base pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=10, help="the timed region of EXACTLY --steps steps (barrier + synchronize on both sides) is run this many times "
@@ -252,6 +254,8 @@ def main():
         envgs_step.PREBUILD["on"] = not args.no_prebuild
         envgs_step.REFIT["every"] = max(1, args.bvh_rebuild_every)
         envgs_step.COLOUR_ONLY["on"] = not args.no_colour_only_state
+        # N > 1 accumulates into the exchange's flat .grad views inside backward(): the surfel gradients must be complete on the step's stream there
+        envgs_step.DEFER["on"] = world == 1 and not args.no_deferred_surfel_grads
         dnorm_hw = (torch.randn(3, H, W, generator=torch.Generator().manual_seed(2)) / HW).to(dev)
         tracer = tpkg.SurfelTracer()
         rays = [synth.get_rays(c) for c in cams]
@@ -346,6 +350,7 @@ def main():
             loss = (color * dcol).sum() + (allmap * dall).sum()
         n_acc["N"] += (raster.LAST_STATS["N"] if not btrace else 0); n_acc["steps"] += 1
         loss.backward()
+        tracing.join_deferred_gradients()         # (no-op unless the env surfels' gradients were left to finish beside the base pass's backward)
         nbytes = reducer.finish() if reducer is not None else 0
         if opt is not None:
             opt.step()
@@ -718,6 +723,8 @@ def main():
                                          "every call asks for a rebuild (as the reference's caller does); the tracer serves it with a refit while the tree is young: full LBVH build every %d calls or when the measured surface-area cost grew > 1.25x (SurfelTracer.set_structure_policy, all caller forms)" % args.bvh_rebuild_every)),
                        "env_per_hit_state": (None if not envgs else ("colour plane only: the caller promises a colour-only backward (16 B per hit; another gradient raises)"
                                              if (args.caller == "fused" and not args.no_colour_only_state and not args.trace_depth) else "all planes (32 B per hit, 40 with `others`)")),
+                       "env_surfel_gradients": (None if not envgs else ("finished on the library's stream beside the base pass's backward, joined before the optimizer (SurfelTracer.set_deferred_surfel_gradients)"
+                                                if (world == 1 and args.caller == "fused" and not args.no_deferred_surfel_grads and not args.trace_depth) else "on the step's stream")),
                        "torch_blas": str(torch.backends.cuda.preferred_blas_library()).split(".")[-1],
                        "dist_backend": (dist.get_backend() if world > 1 else None),
                        "debug_switches": {"trace": args.debug_trace, "segments": args.debug_segments, "collect_wgs": args.debug_collect_wgs},

@@ -45,7 +45,8 @@ class TraceLists(ctypes.Structure):
                 ("num_records", ctypes.c_uint64), ("hit_state", ctypes.c_void_p), ("entries", ctypes.c_void_p), ("pairs", ctypes.c_void_p),
                 ("n_entries", ctypes.c_void_p), ("compact_rows", ctypes.c_uint64), ("row_off", ctypes.c_void_p), ("batch_rows", ctypes.c_void_p),
                 ("row_blk", ctypes.c_void_p), ("sh_perm", ctypes.c_void_p), ("state_planes", ctypes.c_int32),
-                ("sparse_hits", ctypes.c_void_p), ("sparse_cap", ctypes.c_uint64)]
+                ("sparse_hits", ctypes.c_void_p), ("sparse_cap", ctypes.c_uint64),
+                ("defer_reduce", ctypes.c_uint32), ("reserved0", ctypes.c_uint32)]
 
 
 class TraceCfg(ctypes.Structure):
@@ -76,6 +77,7 @@ SYMBOLS = {
     "envgs_trace_ray_order": (c_int, [ctypes.c_int32, _P, _P, _P, ctypes.c_int32, _P, _P, _P, c_size_t, _P]),
     "envgs_trace_forward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 22 + [ctypes.POINTER(TraceLists), _P]),
     "envgs_trace_backward": (c_int, [ctypes.POINTER(TraceCfg)] + [_P] * 35 + [ctypes.POINTER(TraceLists), _P]),
+    "envgs_trace_backward_join": (c_int, [_P]),
     "envgs_sh_colors_forward": (c_int, [ctypes.c_int32] * 4 + [_P] * 7 + [_P]),
     "envgs_sh_colors_backward": (c_int, [ctypes.c_int32] * 4 + [_P] * 9 + [_P]),
     "envgs_surfel_quads": (c_int, [ctypes.c_int32] + [_P] * 5 + [_P]),

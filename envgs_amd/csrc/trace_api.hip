@@ -62,6 +62,44 @@ static void ray_layout(const envgs_trace_cfg *cfg, int *rh, int *rw)
     *rw = ok ? cfg->ray_w : 0;
 }
 
+static hipStream_t s_aux[16][MAX_SEG] = {};
+static hipEvent_t s_fork[16] = {}, s_join[16][MAX_SEG] = {};
+static std::mutex s_mu;                               // the per-device streams / events are created once, under a lock
+static hipEvent_t s_def_go[16] = {}, s_def_done[16] = {};
+static bool s_def_pending[16] = {};                   // a backward's deferred tail (envgs_trace_lists::defer_reduce) has been queued and nobody has joined it yet
+
+// auxiliary streams + fork / join events of the current device, created on first use (one process drives one GPU in this design, but nothing
+// here assumes it); false = not available (the callers then stay on the caller's stream)
+static bool aux_objects(int *dev_out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    std::lock_guard<std::mutex> lk(s_mu);
+    if (!s_fork[dev]) {
+        bool ok = hipEventCreateWithFlags(&s_fork[dev], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&s_def_go[dev], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&s_def_done[dev], hipEventDisableTiming) == hipSuccess;
+        for (int i = 1; i < MAX_SEG && ok; i++)
+            ok = hipStreamCreateWithFlags(&s_aux[dev][i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&s_join[dev][i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { s_fork[dev] = nullptr; return false; }
+    }
+    *dev_out = dev;
+    return true;
+}
+
+// `stream` waits for the deferred tail of the last backward, if one is still unjoined (every traced call does this first: the tail reads and
+// writes buffers the next call reuses)
+static int join_deferred(hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    std::lock_guard<std::mutex> lk(s_mu);
+    if (!s_def_pending[dev]) return 0;
+    s_def_pending[dev] = false;
+    return hipStreamWaitEvent(stream, s_def_done[dev], 0) == hipSuccess ? 0 : ENVGS_ERR_BAD_ARG;
+}
+
 extern "C" {
 
 size_t envgs_trace_ray_sort_temp_bytes(int32_t num_rays) { return ray_sort_temp_bytes(num_rays); }
@@ -92,6 +130,7 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
     if (cfg->P > 0 && (cfg->sh_coeffs > 0 ? (!shs || cfg->sh_coeffs < (cfg->sh_degree + 1) * (cfg->sh_degree + 1)) : !colors_precomp)) return ENVGS_ERR_BAD_ARG;
     if (cfg->has_others && cfg->P > 0 && !others_precomp) return ENVGS_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
+    if (join_deferred(stream)) return ENVGS_ERR_BAD_ARG;
     envgs_raster_cfg dbg; dbg.debug = cfg->debug;
     const envgs_raster_cfg *dcfg = &dbg;
     hipError_t e;
@@ -175,23 +214,8 @@ int envgs_trace_forward(const envgs_trace_cfg *cfg, const float *nodes, const fl
         hipStream_t aux[MAX_SEG] = {};
         hipEvent_t ev_fork = nullptr, ev_join[MAX_SEG] = {};
         if (nseg > 1) {
-            // auxiliary streams + fork / join events per device, created on first use (one process drives one GPU in this design,
-            // but nothing here assumes it)
-            static hipStream_t s_aux[16][MAX_SEG] = {};
-            static hipEvent_t s_fork[16] = {}, s_join[16][MAX_SEG] = {};
-            static std::mutex s_mu;                               // the per-device streams / events are created once, under a lock
             int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) nseg = 1;
-            else {
-                std::lock_guard<std::mutex> lk(s_mu);
-                if (!s_fork[dev]) {
-                    bool ok = hipEventCreateWithFlags(&s_fork[dev], hipEventDisableTiming) == hipSuccess;
-                    for (int i = 1; i < MAX_SEG && ok; i++)
-                        ok = hipStreamCreateWithFlags(&s_aux[dev][i], hipStreamNonBlocking) == hipSuccess &&
-                             hipEventCreateWithFlags(&s_join[dev][i], hipEventDisableTiming) == hipSuccess;
-                    if (!ok) { s_fork[dev] = nullptr; nseg = 1; }
-                }
-            }
+            if (!aux_objects(&dev)) nseg = 1;
             if (nseg > 1) {
                 ev_fork = s_fork[dev];
                 for (int i = 1; i < nseg; i++) { aux[i] = s_aux[dev][i]; ev_join[i] = s_join[dev][i]; }
@@ -335,6 +359,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
 {
     if (!cfg || cfg->P < 0 || cfg->num_rays < 0) return ENVGS_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
+    if (join_deferred(stream)) return ENVGS_ERR_BAD_ARG;
     envgs_raster_cfg dbg; dbg.debug = cfg->debug;
     const envgs_raster_cfg *dcfg = &dbg;
     const size_t P = (size_t)cfg->P, R = (size_t)cfg->num_rays;
@@ -370,6 +395,8 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     A.f16 = cfg->feature_f16;
     A.dothers = dothers; A.dray_o = dray_o; A.dray_d = dray_d; A.mod = cfg->scale_modifier;
     int rh, rw; ray_layout(cfg, &rh, &rw);
+    bool deferred = false;
+    int def_dev = 0;
     {
         ProfScope prof_(K_TRACE_BWD, stream);
         if (lists_wanted(cfg, L) && !lists_usable_bwd(cfg, L)) return ENVGS_ERR_BAD_ARG;
@@ -400,7 +427,11 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
                         hipLaunchKernelGGL(sparse_hits_bwd, dim3(2048), dim3(256), 0, stream, A, rgb_only ? 1 : 0);
                     }
                 }
-                { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, stream, A); }
+                // defer_reduce (envgs_trace.h): the sum of the records and the conversion of the surfel gradients leave the caller's stream -- the
+                // ray gradients are complete without them -- and run beside whatever the caller queues next; the K-buffer pass then runs BEFORE
+                // the sum, which adds to what it finds
+                if (L->defer_reduce && aux_objects(&def_dev)) deferred = true;
+                else { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, stream, A); }
             } else {
 #ifdef ENVGS_DIAG
                 if (!L->hit_lists) return ENVGS_ERR_BAD_ARG;       // the per-ray atomic-flush backward walks the lists themselves
@@ -418,11 +449,26 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
         { ProfScope p6(K_TRACE_KBUF_BWD, stream); hipLaunchKernelGGL(trace_bwd, dim3(persistent_grid(cfg->num_rays)), dim3(64), 0, stream, A, rh, rw); }
     }
     ENVGS_CHECK_LAUNCH(dcfg, stream);
-    hipLaunchKernelGGL(finish_surfel_grads, dim3((cfg->P + 255) / 256), dim3(256), 0, stream, cfg->P, rotations, geo_rec, dmeans3D, dscales,
+    hipStream_t tail = stream;
+    if (deferred) {
+        tail = s_aux[def_dev][1];       // (a stream of the lowest priority instead: the sum starves -- 0.27 -> 0.74 ms -- and the join comes later: step 7.57 -> 7.85 ms)
+        if (hipEventRecord(s_def_go[def_dev], stream) != hipSuccess || hipStreamWaitEvent(tail, s_def_go[def_dev], 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+        A.reduce_adds = 1;
+        { ProfScope p7(K_TRACE_REDUCE, tail); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, tail, A); }
+        ENVGS_CHECK_LAUNCH(dcfg, tail);
+    }
+    hipLaunchKernelGGL(finish_surfel_grads, dim3((cfg->P + 255) / 256), dim3(256), 0, tail, cfg->P, rotations, geo_rec, dmeans3D, dscales,
                        dopacities, drots, dgrads3D);
-    ENVGS_CHECK_LAUNCH(dcfg, stream);
+    ENVGS_CHECK_LAUNCH(dcfg, tail);
+    if (deferred) {
+        std::lock_guard<std::mutex> lk(s_mu);
+        if (hipEventRecord(s_def_done[def_dev], tail) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+        s_def_pending[def_dev] = true;
+    }
     return 0;
 }
+
+int envgs_trace_backward_join(void *stream) { return join_deferred((hipStream_t)stream); }
 
 }  // extern "C"
 

@@ -176,6 +176,7 @@ struct TraceArgs {
     uint4 *sparse;      // (sparse_cap) hits of SPARSE entries (envgs_trace.h: sparse_hits): {sorted ray slot, list position, surfel id, record slot}; counter[64] = how many
     unsigned sparse_cap;
     int sparse_max;     // an entry with at most this many hits is filed per hit instead of becoming an entry of the batch kernel (0 = off)
+    int reduce_adds;    // reduce_surfel_records adds its sums to what the buffers hold instead of storing them (the backward's deferred tail: the K-buffer pass ran before it)
     int seg;            // segment index: selects the batch-fetch counters and the stack-spill slab
     int spill_stride;   // stack-spill slabs per segment
     unsigned long long *entries;  // (batches, 64*cap) distinct (batch, surfel) entries, see register_hits

@@ -596,7 +596,8 @@ sparse_hits_bwd(const TraceArgs A, const int rgbo)
 }
 
 // Stage 2: sum each surfel's (batch, surfel) records into the (zeroed) gradient buffers -- plain stores, every word has one owner; the
-// K-buffer pass for overflowed rays runs afterwards and adds to the same buffers atomically.  16 lanes per surfel, 16 B per lane = one
+// K-buffer pass for overflowed rays runs afterwards and adds to the same buffers atomically (A.reduce_adds, the deferred form: it ran
+// BEFORE, and the sum is added to what it left -- still one owner per word).  16 lanes per surfel, 16 B per lane = one
 // 256 B record per load instruction; the typical surfel has ~15 records, but a few are seen by thousands of batches: those are deferred
 // and summed by the whole workgroup (16 records per instruction) so that no lane group walks a megabyte on its own.
 constexpr int RED_LONG = 96;
@@ -606,9 +607,14 @@ __device__ __forceinline__ void reduce_store(const TraceArgs &A, const int sid, 
     for (int e = 0; e < 4; e++) {
         const int wd = 4 * q + e;
         if (wd < 48) {
-            if (A.M > 0) { if (wd / 3 < nb) A.dshs[(size_t)sid * A.M * 3 + wd] = v[e]; }
-            else if (wd < 3) A.dcolors[(size_t)sid * 3 + wd] = v[e];
-        } else if (wd < 63) A.geo_rec[(size_t)sid * GEO + (wd - 48)] = v[e];
+            float *o = nullptr;
+            if (A.M > 0) { if (wd / 3 < nb) o = A.dshs + (size_t)sid * A.M * 3 + wd; }
+            else if (wd < 3) o = A.dcolors + (size_t)sid * 3 + wd;
+            if (o) *o = A.reduce_adds ? *o + v[e] : v[e];
+        } else if (wd < 63) {
+            float *o = A.geo_rec + (size_t)sid * GEO + (wd - 48);
+            *o = A.reduce_adds ? *o + v[e] : v[e];
+        }
     }
 }
 __global__ void __launch_bounds__(256)

@@ -19,6 +19,8 @@ class FusedAdam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        from .tracing import join_deferred_gradients
+        join_deferred_gradients()                  # (SurfelTracer.set_deferred_surfel_gradients: the surfel gradients may still be in flight on the library's stream)
         batches = {}
         for group in self.param_groups:
             if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):

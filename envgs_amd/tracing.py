@@ -118,6 +118,7 @@ class CapState:
         self.found_per_ray = None   # hits found per ray in the previous call: sizes the COMPACT per-hit buffers (rows) of the next one
         self.hits_per_entry = None  # composited hits per (batch, surfel) entry of the previous call that prepared a backward: how coherent this tracer's batches are
         self.colour_only = False    # SurfelTracer.set_colour_only_backward: the backward will see the colour's gradient only -> store plane 0 alone
+        self.defer_reduce = False   # SurfelTracer.set_deferred_surfel_gradients: the backward finishes the surfel gradients off the caller's stream
         self._mirrors = {}          # device -> dict(host, event, valid)
 
     def mirror(self, dev):
@@ -218,9 +219,26 @@ QUAD_SH = {"on": True}       # list path: four lanes share the fetch of a surfel
 KEEP_LISTS = {"on": False}   # tests: keep the last forward's per-ray hit lists reachable through last_hit_lists()
 
 
+_DEFERRED = {"pending": False, "keep": None, "dev": None}
+
+
+def join_deferred_gradients():
+    """OPTIONAL, not part of the reference interface (include/envgs_trace.h: defer_reduce / envgs_trace_backward_join).  After a backward of a tracer
+    with set_deferred_surfel_gradients(True), the gradients of the SURFEL parameters are still being finished on a stream of the library's own;
+    this makes the current stream wait for them.  No-op when nothing is pending.  envgs_amd.optim.FusedAdam.step, GradExchange and every later
+    traced call do it themselves; any other consumer of those gradients (a torch optimizer, a hook, .grad arithmetic) must call it first."""
+    if not _DEFERRED["pending"]:
+        return
+    dev = _DEFERRED["dev"]
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().envgs_trace_backward_join(_stream(dev)), "envgs_trace_backward_join")
+    _DEFERRED.update(pending=False, keep=None, dev=None)
+
+
 def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_precomp, opacities, scales, rotations, settings,
                   start_from_first, use_lists=True, need_grad=True, caps=None):
     lib = _lib.load()
+    join_deferred_gradients()                  # (the deferred tail of the previous backward reads scratch this call rewrites)
     caps = _DEFAULT_CAPS if caps is None else caps
     dev = means3D.device
     lead = tuple(ray_o.shape[:-1])
@@ -289,6 +307,8 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
         if "hit_state" in keep and getattr(caps, "colour_only", False):
             lists.state_planes = 1
             keep["colour_only"] = True
+        if "hit_state" in keep and getattr(caps, "defer_reduce", False):
+            keep["defer_reduce"] = True
     p = _lib.ptr
     _lib.check(lib.envgs_trace_forward(cfg, p(nodes), p(ro), p(rd), p(means3D), p(scales), p(rotations), p(opacities), p(shs),
                                        p(colors_precomp), p(others_precomp), p(bg), p(srec), p(counters), p(rgb), p(dpt), p(acc),
@@ -319,6 +339,7 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
 
 def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
     lib = _lib.load()
+    join_deferred_gradients()
     cfg = saved["cfg"]
     P, R = cfg.P, cfg.num_rays
     dev = saved["ro"].device
@@ -353,12 +374,19 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
             records = _scratch((n_rec, 64), torch.float32, dev)
             lists.records = records.data_ptr()
             lists.num_records = n_rec
+    defer = bool(records is not None and s["keep"].get("defer_reduce"))
+    if lists is not None:
+        lists.defer_reduce = 1 if defer else 0
     _lib.check(lib.envgs_trace_backward(cfg, p(s["nodes"]), p(s["ro"]), p(s["rd"]), p(s["means3D"]), p(s["scales"]), p(s["rotations"]),
                                         p(s["opacities"]), p(shs), p(s["colors_precomp"]), p(others), p(s["bg"]), p(s["srec"]),
                                         p(s["counters"]), p(s["rgb"]), p(s["dpt"]), p(s["acc"]), p(s["norm"]), p(s["aux"]), p(s["final_T"]),
                                         p(g_rgb), p(g_dpt), p(g_acc), p(g_norm), p(g_aux), p(geo_rec), p(dmeans), p(dgrads3D), p(dscales),
                                         p(drots), p(dopac), p(dshs), p(dcolors), p(dothers), p(dro), p(drd), lists, _stream(dev)),
                "envgs_trace_backward")
+    if defer:
+        # the tail (record sums -> surfel gradients) runs on the library's stream: its buffers stay referenced until someone joins -- through
+        # their STORAGES, so that autograd still sees the returned tensors as unshared and moves them into .grad instead of copying them
+        _DEFERRED.update(pending=True, dev=dev, keep=[t.untyped_storage() for t in (geo_rec, records, dmeans, dgrads3D, dscales, drots, dopac, dshs, dcolors) if t is not None])
     lead = s["lead"]
     return dict(ray_o=dro.reshape(lead + (3,)), ray_d=drd.reshape(lead + (3,)), means3D=dmeans, grads3D=dgrads3D, shs=dshs,
                 colors_precomp=dcolors, others_precomp=dothers, opacities=dopac, scales=dscales, rotations=drots)
@@ -550,6 +578,15 @@ class SurfelTracer(nn.Module):
         self._age = self._age + 1 if was_refit else 0
         if self._policy["mode"] == "adaptive" and self.num_surfels > 1:
             self._measure(self.nodes, was_refit)
+
+    def set_deferred_surfel_gradients(self, on=True):
+        """OPTIONAL, not part of the reference interface (include/envgs_trace.h: defer_reduce).  The backward of this tracer's bounce-free calls
+        returns as soon as the RAY gradients are complete on the current stream; the gradients of the surfel parameters are finished on a stream
+        of the library's own, beside whatever the caller runs next (the base pass's backward: 0.2 ms of the EnvGS step).  The caller promises
+        (1) that each surfel parameter receives its gradient from ONE traced call per backward pass and has no .grad to accumulate into
+        (otherwise autograd adds on the current stream at once), and (2) to call envgs_amd.tracing.join_deferred_gradients() before anything
+        reads them -- FusedAdam.step and the next traced call do."""
+        self.caps.defer_reduce = bool(on)
 
     def set_colour_only_backward(self, on=True):
         """OPTIONAL, not part of the reference interface (include/envgs_trace.h: state_planes): a promise that the backward of this tracer's

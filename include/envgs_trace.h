@@ -131,6 +131,14 @@ typedef struct envgs_trace_lists {
                                 1-2 hits per entry: 59 -> 48 ms per step; the coherent benchmark views: +-0): envgs_amd.tracing passes the buffer when
                                 the tracer's previous call averaged fewer than 6 composited hits per entry */
     uint64_t sparse_cap;     /* capacity of sparse_hits in hits */
+    uint32_t defer_reduce;   /* optional (round 6), read by envgs_trace_backward on the record path: 1 = the SURFEL gradients (dmeans3D, dgrads3D, dscales,
+                                drots, dopacities, dshs / dcolors, and geo_rec) are finished on a stream of the library's own, off the caller's stream --
+                                the sum of the records and the conversion are a fifth of a millisecond that nothing the caller queues next depends on (the
+                                base pass's backward wants the RAY gradients, which are complete on `stream` when the call returns, as is dothers).  The
+                                caller must not touch the surfel gradients (read, free or reuse their memory) before envgs_trace_backward_join() has made
+                                its stream wait for them; every later envgs_trace_forward / _backward of the device joins first by itself.  0 = everything
+                                on `stream` (the reference's semantics) */
+    uint32_t reserved0;
 } envgs_trace_lists;
 
 /* Scratch bytes for the Morton sort + build of P surfels. */
@@ -221,6 +229,10 @@ ENVGS_API int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *node
                                    float *dmeans3D, float *dgrads3D, float *dscales, float *drots, float *dopacities,
                                    float *dshs, float *dcolors, float *dothers, float *dray_o, float *dray_d,
                                    const envgs_trace_lists *lists, void *stream);
+
+/* Makes `stream` wait for the deferred part of the device's last envgs_trace_backward (envgs_trace_lists::defer_reduce); nothing pending = no-op.
+ * No reference counterpart (the reference's backward is one stream-ordered call: diff_surfel_tracing/__init__.py:144-204). */
+ENVGS_API int envgs_trace_backward_join(void *stream);
 
 #ifdef __cplusplus
 }

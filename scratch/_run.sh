@@ -1,2 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/ -x -q -m gpu > gpurun_out/gpu_suite.log 2>&1; tail -2 gpurun_out/gpu_suite.log
+for rep in 1 2 3; do
+  python bench.py --no-cpu-baseline --no-render --no-reference-caller --steps 20 --warmup 5 2>/dev/null | python scratch/ab_show.py "lowprio.$rep" | grep -v "nodes "
+  python bench.py --no-cpu-baseline --no-render --no-reference-caller --steps 20 --warmup 5 --debug-trace 32768 2>/dev/null | python scratch/ab_show.py "aux1.$rep" | grep -v "nodes "
+done

@@ -208,3 +208,54 @@ def test_full_envgs_step_chain_vs_oracle_chain_diagnostic():
     assert set(g_h) == set(g_o)
     for kk in sorted(g_h):
         check_close(test, kk, n(g_h[kk]), n(g_o[kk]), tol=1e-2)
+
+
+def test_step_with_deferred_env_surfel_gradients():
+    """envgs_step.DEFER (SurfelTracer.set_deferred_surfel_gradients; include/envgs_trace.h: defer_reduce): the fused step whose env-surfel gradients
+    finish on the library's stream beside the base pass's backward, joined by FusedAdam.step -- the parameters after one optimizer step are those
+    of the stream-ordered step, for the base set (which only needs the ray gradients) and the env set alike."""
+    import diff_surfel_rasterization_wet_ch05 as pkg
+    import diff_surfel_tracing as tpkg
+    from envgs_amd import tracing
+    from envgs_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    was = (envgs_step.FUSED["on"], envgs_step.DEFER["on"])
+    res = {}
+    try:
+        envgs_step.FUSED["on"] = True
+        for defer in (False, True):
+            envgs_step.DEFER["on"] = defer
+            base, env, cam = _scene(dev)
+            opt = FusedAdam([{"params": list(base.values()) + list(env.values()), "lr": 1e-3}], eps=1e-15)
+            rays = synth.get_rays(cam)
+            out = envgs_step.envgs_forward(pkg, tpkg, tpkg.SurfelTracer(), cam, rays, base, env, torch.zeros(3, device=dev),
+                                           torch.tensor([0.1, 0.2, 0.3], device=dev), torch.tensor([2], device=dev))
+            dcol, dall = _upstream(cam.image_height, cam.image_width, dev)
+            ((out["rgb"] * dcol).sum() + (out["base"]["allmap"] * dall).sum()).backward()
+            assert tracing._DEFERRED["pending"] == defer
+            if defer:
+                # autograd MOVED the tail's output buffers into .grad (it would copy a tensor somebody else still holds -- on the current stream,
+                # at once, i.e. before the tail has written it): the hazard the promise of set_deferred_surfel_gradients is about, checked here
+                owned = {st.data_ptr() for st in tracing._DEFERRED["keep"]}
+                for k in ("means3D", "scales", "rotations", "opacities", "shs"):
+                    assert env[k].grad.untyped_storage().data_ptr() in owned, k
+            opt.step()                                                   # joins
+            assert not tracing._DEFERRED["pending"]
+            torch.cuda.synchronize()
+            res[defer] = ({("base." + k): v.grad.clone() for k, v in base.items() if v.grad is not None} |
+                          {("env." + k): v.grad.clone() for k, v in env.items() if v.grad is not None},
+                          {("base." + k): v.detach().clone() for k, v in base.items()} | {("env." + k): v.detach().clone() for k, v in env.items()})
+    finally:
+        envgs_step.FUSED["on"], envgs_step.DEFER["on"] = was
+    assert set(res[False][0]) == set(res[True][0]) and any(k.startswith("env.") for k in res[True][0])
+    for k in res[False][0]:
+        a, b = res[False][0][k], res[True][0][k]
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-12, k
+    for k in res[False][1]:
+        # (Adam's first step moves every touched element by ~lr whatever the gradient's size: compare where the gradient is not rounding noise)
+        a, b = res[False][1][k], res[True][1][k]
+        assert float((a - b).abs().max()) <= 2.1e-3, k
+        gk = res[False][0].get(k)
+        if gk is not None:
+            big = gk.abs() > 1e-3 * gk.abs().max()
+            assert float((a - b)[big].abs().max()) <= 1e-5 if big.any() else True, k

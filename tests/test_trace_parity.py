@@ -915,6 +915,59 @@ def test_trace_colour_only_state_promise():
         run(True, True)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_cap", [0, 16])
+def test_trace_deferred_surfel_gradients(force_cap, request):
+    """SurfelTracer.set_deferred_surfel_gradients (include/envgs_trace.h: defer_reduce): the record sums and the conversion of the surfel gradients
+    run on the library's stream; after tracing.join_deferred_gradients() every gradient is the one of the stream-ordered backward to rounding (two
+    runs order a surfel's records differently -- the slots come from atomics -- so neither form repeats itself bit for bit), also when rays took
+    the K-buffer hand-off (force_cap = 16: the sum is then added to the hand-off's contributions instead of the other way round)."""
+    import diff_surfel_tracing as mod
+    from envgs_amd import tracing
+    dev = torch.device("cuda:0")
+    g, _, _ = trace_scene(P=1500, R=4, seed=23, camera=False)
+    g["scales"] = g["scales"] * 0.5
+    cam = synth.orbit_camera(2, H=96, W=96, fx=80.0, radius=1.0)
+    ro, rd = synth.get_rays(cam)
+    ro, rd = ro.reshape(-1, 3).contiguous().to(dev), rd.reshape(-1, 3).contiguous().to(dev)
+    R = ro.shape[0]
+    gen = torch.Generator().manual_seed(4)
+    ups = [(torch.randn(R, c, generator=gen) / R).to(dev) for c in (3, 1, 1, 3, 2)]
+    if force_cap:
+        tracing.HIT_CAP["force"] = force_cap
+        request.addfinalizer(lambda: tracing.HIT_CAP.pop("force", None))
+
+    def run(defer):
+        L = {k: g[k].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs", "others")}
+        o = ro.clone().requires_grad_(True); d = rd.clone().requires_grad_(True)
+        v, f = synth.get_disks(L["means3D"].detach(), L["scales"].detach(), L["rotations"].detach())
+        tracer = mod.SurfelTracer()
+        tracer.set_deferred_surfel_gradients(defer)
+        tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
+        outs = tracer(o, d, v, means3D=L["means3D"], grads3D=None, shs=L["shs"], colors_precomp=None, others_precomp=L["others"],
+                      opacities=L["opacities"], scales=L["scales"], rotations=L["rotations"], cov3D_precomp=None,
+                      tracer_settings=_settings(mod, torch.tensor([0.2, 0.3, 0.1]), 3, dev), start_from_first=False)
+        loss = sum((x.reshape(R, -1) * y).sum() for x, y in zip((outs[0], outs[1], outs[2], outs[3], outs[5]), ups))
+        loss.backward()
+        pending = tracing._DEFERRED["pending"]
+        tracing.join_deferred_gradients()                       # the current stream now waits for the tail; the clones below are queued behind it
+        assert not tracing._DEFERRED["pending"]
+        gr = {k: t.grad.clone() for k, t in L.items()}
+        gr["ray_o"], gr["ray_d"] = o.grad.clone(), d.grad.clone()
+        torch.cuda.synchronize()
+        return gr, pending, tracing.last_trace_counts()
+
+    ref, p0, _ = run(False)
+    got, p1, tc = run(True)
+    assert not p0 and p1                                        # the promise reached the library (records exist: the list path composited hits)
+    if force_cap:
+        assert tc["max_list"] > force_cap                       # some rays did take the hand-off
+    for k in ref:
+        err = float((ref[k] - got[k]).abs().max())
+        assert err <= 2e-5 * float(ref[k].abs().max()) + 1e-12, (k, err)
+        assert float(got[k].abs().max()) > 0
+
+
 def test_trace_c_abi_refuses_a_lists_struct_with_a_missing_buffer():
     """the forward fell back to the K-buffer kernels when a scratch pointer of the lists struct was NULL, and a backward that found ITS
     pointers complete then took the list path and read counts nobody had written (silently wrong gradients).  Which path a call takes now depends
