@@ -724,7 +724,7 @@ def main():
                        "env_per_hit_state": (None if not envgs else ("colour plane only: the caller promises a colour-only backward (16 B per hit; another gradient raises)"
                                              if (args.caller == "fused" and not args.no_colour_only_state and not args.trace_depth) else "all planes (32 B per hit, 40 with `others`)")),
                        "env_surfel_gradients": (None if not envgs else ("finished on the library's stream beside the base pass's backward, joined before the optimizer (SurfelTracer.set_deferred_surfel_gradients)"
-                                                if (world == 1 and args.caller == "fused" and not args.no_deferred_surfel_grads and not args.trace_depth) else "on the step's stream")),
+                                                if (world == 1 and args.caller == "fused" and not args.no_deferred_surfel_grads) else "on the step's stream")),
                        "torch_blas": str(torch.backends.cuda.preferred_blas_library()).split(".")[-1],
                        "dist_backend": (dist.get_backend() if world > 1 else None),
                        "debug_switches": {"trace": args.debug_trace, "segments": args.debug_segments, "collect_wgs": args.debug_collect_wgs},

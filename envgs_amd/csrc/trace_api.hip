@@ -359,7 +359,11 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
 {
     if (!cfg || cfg->P < 0 || cfg->num_rays < 0) return ENVGS_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
-    if (join_deferred(stream)) return ENVGS_ERR_BAD_ARG;
+    // envgs_trace.h: defer_reduce bits (1 = tail off the caller's stream, 2 = the surfel accumulators hold earlier calls' sums, 4 = leave them unconverted)
+    const unsigned dflags = L ? L->defer_reduce : 0u;
+    const bool accumulate = (dflags & ENVGS_TRACE_ACCUMULATE) != 0, no_finish = (dflags & ENVGS_TRACE_NO_FINISH) != 0;
+    // (a call that continues a chain leaves the previous tail running under its own record kernels and waits for it before its K-buffer pass)
+    if (!accumulate && join_deferred(stream)) return ENVGS_ERR_BAD_ARG;
     envgs_raster_cfg dbg; dbg.debug = cfg->debug;
     const envgs_raster_cfg *dcfg = &dbg;
     const size_t P = (size_t)cfg->P, R = (size_t)cfg->num_rays;
@@ -367,17 +371,18 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     {
         ZeroBatch zb; zb.count = 0;
 #define ZERO(buf_, nn) do { if ((buf_) && (nn) > 0) { zb.ptr[zb.count] = (buf_); zb.n[zb.count] = (unsigned long long)(nn); zb.count++; } } while (0)
-        ZERO(geo_rec, P * ENVGS_GEOREC_STRIDE); ZERO(dmeans3D, P * 3); ZERO(dgrads3D, P * 3); ZERO(dscales, P * 2); ZERO(drots, P * 4);
-        ZERO(dopacities, P); ZERO(dothers, P * 2); ZERO(dray_o, R * 3); ZERO(dray_d, R * 3);
-        if (cfg->sh_coeffs > 0) ZERO(dshs, P * cfg->sh_coeffs * 3); else ZERO(dcolors, P * 3);
+        if (!accumulate) { ZERO(geo_rec, P * ENVGS_GEOREC_STRIDE); if (cfg->sh_coeffs > 0) ZERO(dshs, P * cfg->sh_coeffs * 3); else ZERO(dcolors, P * 3); }
+        if (!no_finish) { ZERO(dmeans3D, P * 3); ZERO(dgrads3D, P * 3); ZERO(dscales, P * 2); ZERO(drots, P * 4); ZERO(dopacities, P); }
+        ZERO(dothers, P * 2); ZERO(dray_o, R * 3); ZERO(dray_d, R * 3);
         if (counters && cfg->num_rays > 0 && cfg->P > 0) ZERO(reinterpret_cast<float *>(counters), 1);      // only the ray-fetch counter: [1] (largest list) and the stats stay readable
 #undef ZERO
         const int rcz = launch_zero_many(zb, stream);              // one launch instead of eleven fills
         if (rcz) return rcz;
     }
     if (cfg->num_rays == 0 || cfg->P == 0) return 0;
-    if (!nodes || !ray_o || !ray_d || !srec || !counters || !rgb || !dpt || !acc || !norm || !aux || !final_T || !geo_rec || !dmeans3D || !dscales || !drots || !dopacities || !dray_o || !dray_d || !rotations || !bg)
+    if (!nodes || !ray_o || !ray_d || !srec || !counters || !rgb || !dpt || !acc || !norm || !aux || !final_T || !geo_rec || !dray_o || !dray_d || !rotations || !bg)
         return ENVGS_ERR_BAD_ARG;
+    if (!no_finish && (!dmeans3D || !dscales || !drots || !dopacities)) return ENVGS_ERR_BAD_ARG;
     if (cfg->sh_coeffs > 0 ? (!shs || !dshs) : (!colors_precomp || !dcolors)) return ENVGS_ERR_BAD_ARG;
     TraceArgs A;
     A = TraceArgs{};
@@ -395,7 +400,7 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     A.f16 = cfg->feature_f16;
     A.dothers = dothers; A.dray_o = dray_o; A.dray_d = dray_d; A.mod = cfg->scale_modifier;
     int rh, rw; ray_layout(cfg, &rh, &rw);
-    bool deferred = false;
+    bool deferred = false, have_records = false;
     int def_dev = 0;
     {
         ProfScope prof_(K_TRACE_BWD, stream);
@@ -430,8 +435,9 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
                 // defer_reduce (envgs_trace.h): the sum of the records and the conversion of the surfel gradients leave the caller's stream -- the
                 // ray gradients are complete without them -- and run beside whatever the caller queues next; the K-buffer pass then runs BEFORE
                 // the sum, which adds to what it finds
-                if (L->defer_reduce && aux_objects(&def_dev)) deferred = true;
-                else { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, stream, A); }
+                have_records = true;
+                if ((dflags & ENVGS_TRACE_DEFER) && aux_objects(&def_dev)) deferred = true;
+                else if (!accumulate) { ProfScope p7(K_TRACE_REDUCE, stream); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, stream, A); }
             } else {
 #ifdef ENVGS_DIAG
                 if (!L->hit_lists) return ENVGS_ERR_BAD_ARG;       // the per-ray atomic-flush backward walks the lists themselves
@@ -446,20 +452,27 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
             }
             A.only_overflow = 1;
         }
+        // (the K-buffer pass adds to the accumulators atomically: the previous call's tail, which adds to them with plain read-modify-writes, must be through)
+        if (accumulate && join_deferred(stream)) return ENVGS_ERR_BAD_ARG;
         { ProfScope p6(K_TRACE_KBUF_BWD, stream); hipLaunchKernelGGL(trace_bwd, dim3(persistent_grid(cfg->num_rays)), dim3(64), 0, stream, A, rh, rw); }
     }
     ENVGS_CHECK_LAUNCH(dcfg, stream);
+    if ((dflags & ENVGS_TRACE_DEFER) && !deferred && aux_objects(&def_dev)) deferred = true;       // (no records: the tail is the conversion alone)
     hipStream_t tail = stream;
     if (deferred) {
         tail = s_aux[def_dev][1];       // (a stream of the lowest priority instead: the sum starves -- 0.27 -> 0.74 ms -- and the join comes later: step 7.57 -> 7.85 ms)
         if (hipEventRecord(s_def_go[def_dev], stream) != hipSuccess || hipStreamWaitEvent(tail, s_def_go[def_dev], 0) != hipSuccess) return ENVGS_ERR_BAD_ARG;
+    }
+    if (have_records && (deferred || accumulate)) {          // after the K-buffer pass: the sums are added to what it left (and to earlier calls' sums)
         A.reduce_adds = 1;
         { ProfScope p7(K_TRACE_REDUCE, tail); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, tail, A); }
         ENVGS_CHECK_LAUNCH(dcfg, tail);
     }
-    hipLaunchKernelGGL(finish_surfel_grads, dim3((cfg->P + 255) / 256), dim3(256), 0, tail, cfg->P, rotations, geo_rec, dmeans3D, dscales,
-                       dopacities, drots, dgrads3D);
-    ENVGS_CHECK_LAUNCH(dcfg, tail);
+    if (!no_finish) {
+        hipLaunchKernelGGL(finish_surfel_grads, dim3((cfg->P + 255) / 256), dim3(256), 0, tail, cfg->P, rotations, geo_rec, dmeans3D, dscales,
+                           dopacities, drots, dgrads3D);
+        ENVGS_CHECK_LAUNCH(dcfg, tail);
+    }
     if (deferred) {
         std::lock_guard<std::mutex> lk(s_mu);
         if (hipEventRecord(s_def_done[def_dev], tail) != hipSuccess) return ENVGS_ERR_BAD_ARG;

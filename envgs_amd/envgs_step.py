@@ -113,7 +113,7 @@ REFIT = {"every": 16}
 # fused caller, bounce-free env pass: only its colour is supervised (envgs_sampler.py: the loss sees the blended rgb; dpt / acc / norm are
 # visualisation outputs) -> SurfelTracer.set_colour_only_backward: the forward stores the colour's per-hit state only
 COLOUR_ONLY = {"on": True}
-# fused caller, bounce-free env pass, ONE process, gradients not accumulated over several backward passes: the tracer's backward finishes the env
+# fused caller, ONE process, gradients not accumulated over several backward passes: the tracer's backward finishes the env
 # surfels' gradients beside the base pass's backward (SurfelTracer.set_deferred_surfel_gradients; the caller joins before reading them --
 # envgs_amd.tracing.join_deferred_gradients, done by FusedAdam.step).  Off unless the training loop says so: it is the loop that knows.
 DEFER = {"on": False}
@@ -163,7 +163,7 @@ def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree, prepared_v
     if hasattr(tracer, "set_colour_only_backward"):
         tracer.set_colour_only_backward(bool(FUSED["on"] and not REFERENCE_FORMS["on"] and COLOUR_ONLY["on"] and int(TRACE["depth"]) == 0))
     if hasattr(tracer, "set_deferred_surfel_gradients"):
-        tracer.set_deferred_surfel_gradients(bool(FUSED["on"] and not REFERENCE_FORMS["on"] and DEFER["on"] and int(TRACE["depth"]) == 0))
+        tracer.set_deferred_surfel_gradients(bool(FUSED["on"] and not REFERENCE_FORMS["on"] and DEFER["on"]))       # (bounce stages chain their accumulators)
     if FUSED["on"] and not REFERENCE_FORMS["on"]:
         grads3D = torch.zeros_like(env["means3D"]).requires_grad_(True)          # (gradient sink, never read: one fill, no `+ 0`)
     else:

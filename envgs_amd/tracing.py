@@ -337,9 +337,20 @@ def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_prec
     return outs, saved
 
 
-def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
+class _BounceChain:
+    """The traced calls of ONE multi-bounce forward (SurfelTracer._forward_bounces) differentiate the same surfels.  With deferred surfel
+    gradients their backwards share the accumulators (include/envgs_trace.h: ENVGS_TRACE_ACCUMULATE / _NO_FINISH): the first backward to run
+    allocates and zeroes them, stage 0 -- the last: every later stage's rays hang off its outputs -- converts them and returns the gradients;
+    the stages in between return none for the surfel parameters."""
+
+    def __init__(self):
+        self.acc = None
+        self.plain = False                               # a stage of the chain ran the stream-ordered backward (no record path): all of them must
+
+
+def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux, chain=None):
+    """chain = (a _BounceChain, this call's stage index) for the stages of a multi-bounce forward whose tracer defers its surfel gradients."""
     lib = _lib.load()
-    join_deferred_gradients()
     cfg = saved["cfg"]
     P, R = cfg.P, cfg.num_rays
     dev = saved["ro"].device
@@ -347,16 +358,35 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
     z = lambda g, c: None if g is None else _f32c(g).reshape(R, c)          # an output the loss does not use: NULL = zero upstream gradient
     g_rgb, g_dpt, g_acc, g_norm, g_aux = z(g_rgb, 3), z(g_dpt, 1), z(g_acc, 1), z(g_norm, 3), z(g_aux, 2)
     shs, others = saved["shs"], saved["others"]
-    geo_rec = torch.empty(max(P, 1), 16, **f32)
-    dmeans = torch.empty(P, 3, **f32); dgrads3D = torch.empty(P, 3, **f32); dscales = torch.empty(P, 2, **f32)
-    drots = torch.empty(P, 4, **f32); dopac = torch.empty(P, 1, **f32)
-    dshs = torch.empty(shs.shape, **f32) if shs is not None else None            # gradients are fp32 whatever the feature storage
-    dcolors = torch.empty(P, 3, **f32) if shs is None else None
-    dothers = torch.empty(P, 2, **f32) if others is not None else None
-    dro = torch.empty(R, 3, **f32); drd = torch.empty(R, 3, **f32)
     p = _lib.ptr
     s = saved
     lists = s["lists"]
+    defer = bool(lists is not None and USE_RECORDS["on"] and "hit_state" in s["keep"] and s["keep"].get("defer_reduce"))
+    chained = defer and chain is not None
+    if chain is not None:
+        if (not defer and chain[0].acc is not None) or (defer and chain[0].plain):
+            raise RuntimeError("SurfelTracer: the stages of one multi-bounce call disagree about the record backward (deferred surfel gradients need it in every stage)")
+        chain[0].plain = not defer
+    first = not chained or chain[0].acc is None          # (of the chain: zeroes the accumulators)
+    last = not chained or chain[1] == 0                  # converts them
+    if first:
+        join_deferred_gradients()
+    if chained and not first:
+        geo_rec, dshs, dcolors = chain[0].acc
+    else:
+        geo_rec = torch.empty(max(P, 1), 16, **f32)
+        dshs = torch.empty(shs.shape, **f32) if shs is not None else None            # gradients are fp32 whatever the feature storage
+        dcolors = torch.empty(P, 3, **f32) if shs is None else None
+        if chained:
+            chain[0].acc = (geo_rec, dshs, dcolors)
+    if chained and last:
+        chain[0].acc = None                              # (a second backward pass through a retained graph starts over)
+    dmeans = dgrads3D = dscales = drots = dopac = None
+    if last:
+        dmeans = torch.empty(P, 3, **f32); dgrads3D = torch.empty(P, 3, **f32); dscales = torch.empty(P, 2, **f32)
+        drots = torch.empty(P, 4, **f32); dopac = torch.empty(P, 1, **f32)
+    dothers = torch.empty(P, 2, **f32) if others is not None else None
+    dro = torch.empty(R, 3, **f32); drd = torch.empty(R, 3, **f32)
     records = None
     if lists is not None and s["keep"].get("colour_only") and any(g_ is not None for g_ in (g_dpt, g_acc, g_norm, g_aux)):
         raise RuntimeError("SurfelTracer: set_colour_only_backward(True) promised that only the colour output would be differentiated, but a gradient "
@@ -374,9 +404,8 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
             records = _scratch((n_rec, 64), torch.float32, dev)
             lists.records = records.data_ptr()
             lists.num_records = n_rec
-    defer = bool(records is not None and s["keep"].get("defer_reduce"))
     if lists is not None:
-        lists.defer_reduce = 1 if defer else 0
+        lists.defer_reduce = (1 if defer else 0) | (0 if first else 2) | (0 if last else 4)
     _lib.check(lib.envgs_trace_backward(cfg, p(s["nodes"]), p(s["ro"]), p(s["rd"]), p(s["means3D"]), p(s["scales"]), p(s["rotations"]),
                                         p(s["opacities"]), p(shs), p(s["colors_precomp"]), p(others), p(s["bg"]), p(s["srec"]),
                                         p(s["counters"]), p(s["rgb"]), p(s["dpt"]), p(s["acc"]), p(s["norm"]), p(s["aux"]), p(s["final_T"]),
@@ -384,10 +413,14 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux):
                                         p(drots), p(dopac), p(dshs), p(dcolors), p(dothers), p(dro), p(drd), lists, _stream(dev)),
                "envgs_trace_backward")
     if defer:
-        # the tail (record sums -> surfel gradients) runs on the library's stream: its buffers stay referenced until someone joins -- through
-        # their STORAGES, so that autograd still sees the returned tensors as unshared and moves them into .grad instead of copying them
-        _DEFERRED.update(pending=True, dev=dev, keep=[t.untyped_storage() for t in (geo_rec, records, dmeans, dgrads3D, dscales, drots, dopac, dshs, dcolors) if t is not None])
+        # the tail (record sums -> surfel gradients) runs on the library's stream: what it reads and writes stays referenced until someone joins
+        # (the forward's scratch through `saved`: autograd drops its own reference as soon as this node returns) -- the gradients through their
+        # STORAGES, so that autograd still sees the returned tensors as unshared and moves them into .grad instead of copying them
+        held = [saved] + [t.untyped_storage() for t in (geo_rec, records, dmeans, dgrads3D, dscales, drots, dopac, dshs, dcolors) if t is not None]
+        _DEFERRED.update(pending=True, dev=dev, keep=(_DEFERRED["keep"] or []) + held)
     lead = s["lead"]
+    if not last:
+        dshs = dcolors = None                            # (the accumulators: stage 0 returns them)
     return dict(ray_o=dro.reshape(lead + (3,)), ray_d=drd.reshape(lead + (3,)), means3D=dmeans, grads3D=dgrads3D, shs=dshs,
                 colors_precomp=dcolors, others_precomp=dothers, opacities=dopac, scales=dscales, rotations=drots)
 
@@ -454,13 +487,14 @@ def _build_stream(dev):
 class _TraceSurfels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ray_o, ray_d, v, means3D, grads3D, shs, colors_precomp, others_precomp, opacities, scales, rotations,
-                cov3D_precomp, tracer_settings, start_from_first, nodes, caps=None):
+                cov3D_precomp, tracer_settings, start_from_first, nodes, caps=None, chain=None):
         ctx.set_materialize_grads(False)          # outputs the loss does not use arrive as None (= NULL upstream pointer), not as buffers of zeros
         none = lambda t: None if (t is None or t.numel() == 0) else t
         from .raster import _store                       # fp16 feature storage selected (envgs_amd.set_feature_storage): half copies made HERE, fp32 gradients
         outs, saved = trace_forward(nodes, ray_o, ray_d, means3D, _store(none(shs)), _store(none(colors_precomp)), none(others_precomp), opacities,
                                     scales, rotations, tracer_settings, start_from_first, need_grad=any(ctx.needs_input_grad), caps=caps)
         ctx.saved = saved
+        ctx.chain = chain
         ctx.in_dtypes = tuple(None if t is None else t.dtype for t in (ray_o, ray_d, means3D, grads3D, shs, colors_precomp,
                                                                         others_precomp, opacities, scales, rotations))
         rgb, dpt, acc, norm, dist, aux, mid, wet = outs
@@ -469,11 +503,11 @@ class _TraceSurfels(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_dpt, g_acc, g_norm, g_dist, g_aux, g_mid, g_wet):
-        g = trace_backward(ctx.saved, g_rgb, g_dpt, g_acc, g_norm, g_aux)
+        g = trace_backward(ctx.saved, g_rgb, g_dpt, g_acc, g_norm, g_aux, chain=ctx.chain)
         order = ("ray_o", "ray_d", "means3D", "grads3D", "shs", "colors_precomp", "others_precomp", "opacities", "scales", "rotations")
         vals = [None if (g[k] is None or dt is None) else g[k].to(dt) for k, dt in zip(order, ctx.in_dtypes)]
         ro, rd, m3, g3, sh, col, oth, op, sc, rot = vals
-        return ro, rd, None, m3, g3, sh, col, oth, op, sc, rot, None, None, None, None, None
+        return ro, rd, None, m3, g3, sh, col, oth, op, sc, rot, None, None, None, None, None, None
 
 
 class SurfelTracer(nn.Module):
@@ -689,8 +723,9 @@ class SurfelTracer(nn.Module):
         dev = o.device
         was = self.caps.colour_only
         self.caps.colour_only = False                  # (its depth / accumulation / normal / specular outputs build the next stage's rays)
+        chain = _BounceChain() if self.caps.defer_reduce else None        # set_deferred_surfel_gradients: the stages' backwards share their accumulators
         try:
-            out0 = _TraceSurfels.apply(o, d, *args, s0, start_from_first, self.nodes, self.caps)
+            out0 = _TraceSurfels.apply(o, d, *args, s0, start_from_first, self.nodes, self.caps, (chain, 0) if chain else None)
         finally:
             self.caps.colour_only = was
         stages = [dict(o=o, d=d, out=out0, idx=torch.arange(R, device=dev), sel=None)]
@@ -708,12 +743,13 @@ class SurfelTracer(nn.Module):
             # backward, through advanced indexing, was a SORTED index_put: 4 ms of radix sorts per 1200x1600 step
             o2, d2 = fused.bounce_rays(p["o"], p["d"], dpt, acc, norm, sel)
             bc = self.bounce_caps(k)
-            was_k = bc.colour_only
+            was_k = bc.colour_only, bc.defer_reduce
             bc.colour_only = k == depth                 # the last stage's other outputs go into `mid` (no gradient) and nowhere else
+            bc.defer_reduce = chain is not None
             try:
-                out = _TraceSurfels.apply(o2, d2, *args, s0, 2, self.nodes, bc)
+                out = _TraceSurfels.apply(o2, d2, *args, s0, 2, self.nodes, bc, (chain, k) if chain else None)
             finally:
-                bc.colour_only = was_k                  # (the promise is this call's, not the stage state's: ADVICE r4)
+                bc.colour_only, bc.defer_reduce = was_k  # (the promises are this call's, not the stage state's: ADVICE r4)
             stages.append(dict(o=o2, d=d2, out=out, idx=p["idx"].index_select(0, sel), sel=sel))
         col = stages[-1]["out"][0]
         for k in range(len(stages) - 2, -1, -1):

@@ -131,15 +131,25 @@ typedef struct envgs_trace_lists {
                                 1-2 hits per entry: 59 -> 48 ms per step; the coherent benchmark views: +-0): envgs_amd.tracing passes the buffer when
                                 the tracer's previous call averaged fewer than 6 composited hits per entry */
     uint64_t sparse_cap;     /* capacity of sparse_hits in hits */
-    uint32_t defer_reduce;   /* optional (round 6), read by envgs_trace_backward on the record path: 1 = the SURFEL gradients (dmeans3D, dgrads3D, dscales,
-                                drots, dopacities, dshs / dcolors, and geo_rec) are finished on a stream of the library's own, off the caller's stream --
-                                the sum of the records and the conversion are a fifth of a millisecond that nothing the caller queues next depends on (the
-                                base pass's backward wants the RAY gradients, which are complete on `stream` when the call returns, as is dothers).  The
-                                caller must not touch the surfel gradients (read, free or reuse their memory) before envgs_trace_backward_join() has made
-                                its stream wait for them; every later envgs_trace_forward / _backward of the device joins first by itself.  0 = everything
-                                on `stream` (the reference's semantics) */
+    uint32_t defer_reduce;   /* optional (round 6), read by envgs_trace_backward: bit mask of ENVGS_TRACE_DEFER / _ACCUMULATE / _NO_FINISH (below).  0 = everything
+                                on `stream`, outputs zeroed and complete on return (the reference's semantics).
+                                DEFER: the SURFEL gradients (dmeans3D, dgrads3D, dscales, drots, dopacities, dshs / dcolors, and geo_rec) are finished on a
+                                stream of the library's own -- the sum of the records and the conversion are a fifth of a millisecond that nothing the caller
+                                queues next depends on (the base pass's backward wants the RAY gradients, which are complete on `stream` when the call
+                                returns, as is dothers).  The caller must not touch the surfel gradients (read, free or reuse their memory, or the records /
+                                surf_cnt / surf_off scratch) before envgs_trace_backward_join() has made its stream wait; every later envgs_trace_forward /
+                                _backward of the device joins first by itself.
+                                ACCUMULATE + NO_FINISH: the stages of a bounce chain differentiate the SAME surfels; instead of one set of gradient tensors
+                                per stage and sums in the caller, the stages share the accumulators geo_rec and dshs / dcolors: every call but the first
+                                passes ACCUMULATE (they are not zeroed, the record sums are added; the call does not join a pending tail on entry but
+                                before its K-buffer pass, so the previous stage's sums run under this stage's record kernels), every call but the last
+                                passes NO_FINISH (geo_rec stays unconverted; dmeans3D .. dopacities may be NULL).  The conversion is linear in geo_rec, so
+                                converting the sum once equals the sum of the conversions */
     uint32_t reserved0;
 } envgs_trace_lists;
+#define ENVGS_TRACE_DEFER 1u
+#define ENVGS_TRACE_ACCUMULATE 2u
+#define ENVGS_TRACE_NO_FINISH 4u
 
 /* Scratch bytes for the Morton sort + build of P surfels. */
 ENVGS_API size_t envgs_bvh_temp_bytes(int32_t P);

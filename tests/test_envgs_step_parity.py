@@ -236,7 +236,7 @@ def test_step_with_deferred_env_surfel_gradients():
             if defer:
                 # autograd MOVED the tail's output buffers into .grad (it would copy a tensor somebody else still holds -- on the current stream,
                 # at once, i.e. before the tail has written it): the hazard the promise of set_deferred_surfel_gradients is about, checked here
-                owned = {st.data_ptr() for st in tracing._DEFERRED["keep"]}
+                owned = {st.data_ptr() for st in tracing._DEFERRED["keep"] if isinstance(st, torch.UntypedStorage)}
                 for k in ("means3D", "scales", "rotations", "opacities", "shs"):
                     assert env[k].grad.untyped_storage().data_ptr() in owned, k
             opt.step()                                                   # joins

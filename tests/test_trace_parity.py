@@ -968,6 +968,65 @@ def test_trace_deferred_surfel_gradients(force_cap, request):
         assert float(got[k].abs().max()) > 0
 
 
+@pytest.mark.parametrize("force_cap", [0, 12])
+def test_trace_deferred_surfel_gradients_over_a_bounce_chain(force_cap, request):
+    """max_trace_depth = 2 with set_deferred_surfel_gradients: the three stages' backwards share their accumulators (include/envgs_trace.h:
+    ENVGS_TRACE_ACCUMULATE / _NO_FINISH), each stage's record sums run under the next stage's record kernels, stage 0 converts once -- every
+    gradient equals the stream-ordered chain's (one gradient set per stage, summed by autograd) to rounding; force_cap = 12: some rays of every
+    stage take the K-buffer hand-off, whose atomics land in the shared accumulators between two stages' sums."""
+    import diff_surfel_tracing as mod
+    from envgs_amd import tracing
+    dev = torch.device("cuda:0")
+    g, ro, rd = trace_scene(P=150, R=400, seed=4, camera=True)
+    thr, depth, deg = 0.1, 2, 1
+    R = ro.shape[0]
+    gen = torch.Generator().manual_seed(12)
+    ups = [(torch.randn(R, c, generator=gen)).to(dev) for c in (3, 1, 1, 3, 2)]
+    if force_cap:
+        tracing.HIT_CAP["force"] = force_cap
+        request.addfinalizer(lambda: tracing.HIT_CAP.pop("force", None))
+
+    def run(defer):
+        L = {k: g[k].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs", "others")}
+        o = ro.to(dev).requires_grad_(True); d = rd.to(dev).requires_grad_(True)
+        v, f = synth.get_disks(L["means3D"].detach(), L["scales"].detach(), L["rotations"].detach())
+        tracer = mod.SurfelTracer()
+        tracer.set_deferred_surfel_gradients(defer)
+        tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
+        g3 = torch.zeros_like(L["means3D"]).requires_grad_(True)
+        calls = []
+        orig = tracing.trace_backward
+        def counting(saved, *a, chain=None):
+            r = orig(saved, *a, chain=chain)
+            calls.append((None if chain is None else chain[1], saved["lists"].defer_reduce, sorted(k for k in ("means3D", "shs", "others_precomp", "ray_o") if r[k] is not None)))
+            return r
+        tracing.trace_backward = counting
+        try:
+            outs = tracer(o, d, v, means3D=L["means3D"], grads3D=g3, shs=L["shs"], colors_precomp=None, others_precomp=L["others"],
+                          opacities=L["opacities"], scales=L["scales"], rotations=L["rotations"], cov3D_precomp=None,
+                          tracer_settings=_settings(mod, torch.zeros(3), deg, dev, depth, thr), start_from_first=True)
+            loss = sum((x.reshape(R, -1) * y).sum() for x, y in zip((outs[0], outs[1], outs[2], outs[3], outs[5]), ups))
+            loss.backward()
+        finally:
+            tracing.trace_backward = orig
+        tracing.join_deferred_gradients()
+        gr = {k: t.grad.clone() for k, t in L.items()}
+        gr["ray_o"], gr["ray_d"], gr["grads3D"] = o.grad.clone(), d.grad.clone(), g3.grad.clone()
+        torch.cuda.synchronize()
+        return gr, calls
+
+    ref, c0 = run(False)
+    got, c1 = run(True)
+    assert [c[:2] for c in c0] == [(None, 0)] * 3
+    # deepest stage first: it zeroes the accumulators and leaves them unconverted, the middle one adds, stage 0 adds and converts -- and only stage 0
+    # hands surfel gradients to autograd (`others` and the rays come from every stage: they are complete on the caller's stream)
+    assert [c[:2] for c in c1] == [(2, 1 | 4), (1, 1 | 2 | 4), (0, 1 | 2)], c1
+    assert [c[2] for c in c1] == [["others_precomp", "ray_o"], ["others_precomp", "ray_o"], ["means3D", "others_precomp", "ray_o", "shs"]]
+    for k in ref:
+        err = float((ref[k] - got[k]).abs().max())
+        assert float(ref[k].abs().max()) > 0 and err <= 3e-5 * float(ref[k].abs().max()) + 1e-12, (k, err)
+
+
 def test_trace_c_abi_refuses_a_lists_struct_with_a_missing_buffer():
     """the forward fell back to the K-buffer kernels when a scratch pointer of the lists struct was NULL, and a backward that found ITS
     pointers complete then took the list path and read counts nobody had written (silently wrong gradients).  Which path a call takes now depends
