@@ -268,6 +268,8 @@ def main():
         params["roughness"] = g["roughness"].clone().requires_grad_(True)
         tracer = tpkg.SurfelTracer()
         tracer.set_structure_policy("adaptive" if args.bvh_rebuild_every > 1 else "rebuild", max_age=max(1, args.bvh_rebuild_every - 1))
+        # (each parameter's gradient comes from this call alone; joined after backward().  Bounce-free there is nothing for the tail to run beside: 6.62 against 6.55 ms)
+        tracer.set_deferred_surfel_gradients(world == 1 and args.trace_depth > 0 and not args.no_deferred_surfel_grads)
         rays = [synth.get_rays(c) for c in cams]
         gen_t = torch.Generator().manual_seed(7)
         d_out = {k: (torch.randn(H, W, c_, generator=gen_t) / HW).to(dev) for k, c_ in (("rgb", 3), ("dpt", 1), ("acc", 1), ("norm", 3), ("aux", 2))}
@@ -723,8 +725,8 @@ def main():
                                          "every call asks for a rebuild (as the reference's caller does); the tracer serves it with a refit while the tree is young: full LBVH build every %d calls or when the measured surface-area cost grew > 1.25x (SurfelTracer.set_structure_policy, all caller forms)" % args.bvh_rebuild_every)),
                        "env_per_hit_state": (None if not envgs else ("colour plane only: the caller promises a colour-only backward (16 B per hit; another gradient raises)"
                                              if (args.caller == "fused" and not args.no_colour_only_state and not args.trace_depth) else "all planes (32 B per hit, 40 with `others`)")),
-                       "env_surfel_gradients": (None if not envgs else ("finished on the library's stream beside the base pass's backward, joined before the optimizer (SurfelTracer.set_deferred_surfel_gradients)"
-                                                if (world == 1 and args.caller == "fused" and not args.no_deferred_surfel_grads) else "on the step's stream")),
+                       "surfel_gradients": (None if not (envgs or btrace) else ("finished on the library's stream beside the base pass's backward, joined before the optimizer (SurfelTracer.set_deferred_surfel_gradients)"
+                                                if (world == 1 and ((btrace and args.trace_depth > 0) or (envgs and args.caller == "fused")) and not args.no_deferred_surfel_grads) else "on the step's stream")),
                        "torch_blas": str(torch.backends.cuda.preferred_blas_library()).split(".")[-1],
                        "dist_backend": (dist.get_backend() if world > 1 else None),
                        "debug_switches": {"trace": args.debug_trace, "segments": args.debug_segments, "collect_wgs": args.debug_collect_wgs},
