@@ -465,7 +465,11 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
     }
     if (have_records && (deferred || accumulate)) {          // after the K-buffer pass: the sums are added to what it left (and to earlier calls' sums)
         A.reduce_adds = 1;
-        { ProfScope p7(K_TRACE_REDUCE, tail); hipLaunchKernelGGL(reduce_surfel_records, dim3(stride_grid(cfg->P, 16)), dim3(256), 0, tail, A); }
+        // off the caller's stream the sum shares the chip with what the caller queued next (the base pass's compositing backward): a grid of two
+        // workgroups per CU instead of one per 16 surfels stretches it (0.26 -> 0.41 ms) and leaves the neighbour its slots -- R7 0.84 -> 0.79 ms,
+        // step 7.51 -> 7.45 ms (256 / 512 / 1024 workgroups: 7.44 / 7.45 / 7.48; configs[4] 49.06 / 49.08 against 49.64)
+        const int rg = deferred ? min(stride_grid(cfg->P, 16), 512) : stride_grid(cfg->P, 16);
+        { ProfScope p7(K_TRACE_REDUCE, tail); hipLaunchKernelGGL(reduce_surfel_records, dim3(rg), dim3(256), 0, tail, A); }
         ENVGS_CHECK_LAUNCH(dcfg, tail);
     }
     if (!no_finish) {
