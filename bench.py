@@ -693,6 +693,9 @@ def main():
                 roof["raster_composite_bwd"] = {"achieved": rb["GBps"], "frac": round(rb["GBps"] / HBM_PEAK_GBS, 5), "ms_per_launch": rb["ms"],
                                                 "traffic": pm.get("composite_bwd", {}).get("hbm_bytes"), "issue": issue_of("composite_bwd"),
                                                 "lane_occupancy": lane_occ}
+                if envgs and world == 1 and args.caller == "fused" and not args.no_deferred_surfel_grads:
+                    roof["raster_composite_bwd"]["shares_the_chip"] = ("with the tracer backward's deferred record sums (reduce_surfel_records on the library's stream, 512 workgroups): "
+                                                                       "its launch time here includes that; alone (--no-deferred-surfel-grads) it takes ~0.06 ms less")
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             if not btrace:
