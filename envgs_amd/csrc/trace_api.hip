@@ -468,7 +468,11 @@ int envgs_trace_backward(const envgs_trace_cfg *cfg, const float *nodes, const f
         // off the caller's stream the sum shares the chip with what the caller queued next (the base pass's compositing backward): a grid of two
         // workgroups per CU instead of one per 16 surfels stretches it (0.26 -> 0.41 ms) and leaves the neighbour its slots -- R7 0.84 -> 0.79 ms,
         // step 7.51 -> 7.45 ms (256 / 512 / 1024 workgroups: 7.44 / 7.45 / 7.48; configs[4] 49.06 / 49.08 against 49.64)
-        const int rg = deferred ? min(stride_grid(cfg->P, 16), 512) : stride_grid(cfg->P, 16);
+        // (... for the ~2 M records of such a view; the grid grows with the records -- 20 M of them, an incoherent bounce stage over the base set,
+        //  took 2.8 ms on 512 workgroups and were still running when the caller joined)
+        const unsigned long long rwant = (A.num_records / 4096ull + 7ull) & ~7ull;
+        const int rfull = stride_grid(cfg->P, 16);
+        const int rg = deferred ? min(rfull, max(512, (int)(rwant < (unsigned long long)rfull ? rwant : (unsigned long long)rfull))) : rfull;
         { ProfScope p7(K_TRACE_REDUCE, tail); hipLaunchKernelGGL(reduce_surfel_records, dim3(rg), dim3(256), 0, tail, A); }
         ENVGS_CHECK_LAUNCH(dcfg, tail);
     }
