@@ -1027,6 +1027,47 @@ def test_trace_deferred_surfel_gradients_over_a_bounce_chain(force_cap, request)
         assert float(ref[k].abs().max()) > 0 and err <= 3e-5 * float(ref[k].abs().max()) + 1e-12, (k, err)
 
 
+def test_trace_two_tracers_with_deferred_surfel_gradients():
+    """Two tracers in one backward pass (the reference's samplers hold one over the base set and one over the environment set:
+    envgs_sampler.py:508-521 next to :548), both deferring: the second backward to run joins the first one's tail on entry (scratch reuse is safe
+    whatever the caller does) and leaves its own tail pending; one join afterwards covers both.  Gradients = the stream-ordered ones to rounding."""
+    import diff_surfel_tracing as mod
+    from envgs_amd import tracing
+    dev = torch.device("cuda:0")
+    sets = [trace_scene(P=900, R=4, seed=31, camera=False)[0], trace_scene(P=700, R=4, seed=32, camera=False)[0]]
+    cam = synth.orbit_camera(1, H=64, W=64, fx=60.0, radius=1.0)
+    ro, rd = synth.get_rays(cam)
+    ro, rd = ro.reshape(-1, 3).contiguous().to(dev), rd.reshape(-1, 3).contiguous().to(dev)
+    R = ro.shape[0]
+    up = [(torch.randn(R, 3, generator=torch.Generator().manual_seed(5 + i)) / R).to(dev) for i in range(2)]
+
+    def run(defer):
+        Ls, loss = [], 0.0
+        for i, g in enumerate(sets):
+            L = {k: g[k].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+            v, f = synth.get_disks(L["means3D"].detach(), L["scales"].detach(), L["rotations"].detach())
+            tracer = mod.SurfelTracer()
+            tracer.set_deferred_surfel_gradients(defer)
+            tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
+            outs = tracer(ro, rd, v, means3D=L["means3D"], grads3D=None, shs=L["shs"], colors_precomp=None, others_precomp=None,
+                          opacities=L["opacities"], scales=L["scales"], rotations=L["rotations"], cov3D_precomp=None,
+                          tracer_settings=_settings(mod, torch.tensor([0.2, 0.3, 0.1]), 3, dev), start_from_first=False)
+            loss = loss + (outs[0] * up[i]).sum()
+            Ls.append(L)
+        loss.backward()
+        assert tracing._DEFERRED["pending"] == defer
+        tracing.join_deferred_gradients()
+        gr = [{k: t.grad.clone() for k, t in L.items()} for L in Ls]
+        torch.cuda.synchronize()
+        return gr
+
+    ref, got = run(False), run(True)
+    for a, b in zip(ref, got):
+        for k in a:
+            err = float((a[k] - b[k]).abs().max())
+            assert float(a[k].abs().max()) > 0 and err <= 2e-5 * float(a[k].abs().max()) + 1e-12, (k, err)
+
+
 def test_trace_c_abi_refuses_a_lists_struct_with_a_missing_buffer():
     """the forward fell back to the K-buffer kernels when a scratch pointer of the lists struct was NULL, and a backward that found ITS
     pointers complete then took the list path and read counts nobody had written (silently wrong gradients).  Which path a call takes now depends
