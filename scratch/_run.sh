@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_trace_parity.py -x -q -m gpu -k "deferred" 2>&1 | tail -2
+bash scratch/ab_rh.sh "scf_k0 scf_early"
+bash scratch/ab.sh "scf_k0 scf_early scf_k0 scf_early" | grep -v "nodes "
