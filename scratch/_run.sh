@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-bash scratch/ab_rh.sh "scf_k0 scf_early"
-bash scratch/ab.sh "scf_k0 scf_early scf_k0 scf_early" | grep -v "nodes "
+bash scratch/ab_rh.sh "scf_base scf_xcd"
+bash scratch/ab.sh "scf_base scf_xcd scf_base scf_xcd" | grep -v "nodes "
