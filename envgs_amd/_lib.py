@@ -103,6 +103,7 @@ SYMBOLS = {
     "envgs_debug_set": (None, [ctypes.c_int32, ctypes.c_int32]),
     "envgs_debug_get": (ctypes.c_int32, [ctypes.c_int32]),
     "envgs_prof_enable": (None, [c_int]),
+    "envgs_prof_select": (None, [ctypes.c_uint64]),
     "envgs_prof_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     "envgs_prof_kernel_name": (ctypes.c_char_p, [c_int]),
 }

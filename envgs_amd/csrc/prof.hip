@@ -11,6 +11,7 @@ namespace envgs {
 namespace {
 struct Pair { hipEvent_t a, b; };
 bool g_on = false;
+unsigned long long g_mask = ~0ull;    // envgs_prof_select: the scopes that record while the timers are on
 std::mutex g_mu;
 std::vector<Pair> g_open[K_COUNT];       // recorded, not yet read
 std::vector<Pair> g_pool;                // recycled events
@@ -32,7 +33,7 @@ int debug_switch(int which) { return (which >= 0 && which < ENVGS_DBG_COUNT) ? g
 
 void prof_begin(int id, hipStream_t stream)
 {
-    if (!g_on) return;
+    if (!g_on || !((g_mask >> id) & 1ull)) return;
     std::lock_guard<std::mutex> lk(g_mu);
     Pair p = get_pair();
     (void)hipEventRecord(p.a, stream);
@@ -72,6 +73,12 @@ void envgs_prof_enable(int on)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     g_on = on != 0;
+}
+
+void envgs_prof_select(uint64_t kernel_mask)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_mask = kernel_mask;
 }
 
 int envgs_prof_read(int kernel_id, double *total_ms, int *launches)
