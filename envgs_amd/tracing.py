@@ -348,8 +348,9 @@ class _BounceChain:
         self.plain = False                               # a stage of the chain ran the stream-ordered backward (no record path): all of them must
 
 
-def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux, chain=None):
-    """chain = (a _BounceChain, this call's stage index) for the stages of a multi-bounce forward whose tracer defers its surfel gradients."""
+def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux, chain=None, allow_defer=True):
+    """chain = (a _BounceChain, this call's stage index) for the stages of a multi-bounce forward whose tracer defers its surfel gradients;
+    allow_defer = False: the autograd node found a surfel input that is not a plain leaf without a gradient and without hooks -- stream-ordered then."""
     lib = _lib.load()
     cfg = saved["cfg"]
     P, R = cfg.P, cfg.num_rays
@@ -361,7 +362,7 @@ def trace_backward(saved, g_rgb, g_dpt, g_acc, g_norm, g_aux, chain=None):
     p = _lib.ptr
     s = saved
     lists = s["lists"]
-    defer = bool(lists is not None and USE_RECORDS["on"] and "hit_state" in s["keep"] and s["keep"].get("defer_reduce"))
+    defer = bool(allow_defer and lists is not None and USE_RECORDS["on"] and "hit_state" in s["keep"] and s["keep"].get("defer_reduce"))
     chained = defer and chain is not None
     if chain is not None:
         if (not defer and chain[0].acc is not None) or (defer and chain[0].plain):
@@ -495,6 +496,11 @@ class _TraceSurfels(torch.autograd.Function):
                                     scales, rotations, tracer_settings, start_from_first, need_grad=any(ctx.needs_input_grad), caps=caps)
         ctx.saved = saved
         ctx.chain = chain
+        # deferred surfel gradients (set_deferred_surfel_gradients) are only safe when autograd does nothing with them but MOVE them into .grad: every
+        # differentiated surfel input must be a leaf (a non-leaf's gradient is fed to the next backward node on the current stream at once); whether
+        # it has a .grad to add into, or hooks that would read it, is looked at when the backward runs
+        ctx.surfel_inputs = [t for t in (means3D, grads3D, shs, colors_precomp, opacities, scales, rotations) if t is not None and t.requires_grad]
+        ctx.surfel_leaves = all(t.is_leaf for t in ctx.surfel_inputs)
         ctx.in_dtypes = tuple(None if t is None else t.dtype for t in (ray_o, ray_d, means3D, grads3D, shs, colors_precomp,
                                                                         others_precomp, opacities, scales, rotations))
         rgb, dpt, acc, norm, dist, aux, mid, wet = outs
@@ -503,7 +509,9 @@ class _TraceSurfels(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_dpt, g_acc, g_norm, g_dist, g_aux, g_mid, g_wet):
-        g = trace_backward(ctx.saved, g_rgb, g_dpt, g_acc, g_norm, g_aux, chain=ctx.chain)
+        quiet = lambda t: t.grad is None and not getattr(t, "_backward_hooks", None) and not getattr(t, "_post_accumulate_grad_hooks", None)
+        g = trace_backward(ctx.saved, g_rgb, g_dpt, g_acc, g_norm, g_aux, chain=ctx.chain,
+                           allow_defer=bool(ctx.surfel_leaves and all(quiet(t) for t in ctx.surfel_inputs)))
         order = ("ray_o", "ray_d", "means3D", "grads3D", "shs", "colors_precomp", "others_precomp", "opacities", "scales", "rotations")
         vals = [None if (g[k] is None or dt is None) else g[k].to(dt) for k, dt in zip(order, ctx.in_dtypes)]
         ro, rd, m3, g3, sh, col, oth, op, sc, rot = vals
@@ -616,10 +624,13 @@ class SurfelTracer(nn.Module):
     def set_deferred_surfel_gradients(self, on=True):
         """OPTIONAL, not part of the reference interface (include/envgs_trace.h: defer_reduce).  The backward of this tracer's bounce-free calls
         returns as soon as the RAY gradients are complete on the current stream; the gradients of the surfel parameters are finished on a stream
-        of the library's own, beside whatever the caller runs next (the base pass's backward: 0.2 ms of the EnvGS step).  The caller promises
-        (1) that each surfel parameter receives its gradient from ONE traced call per backward pass and has no .grad to accumulate into
-        (otherwise autograd adds on the current stream at once), and (2) to call envgs_amd.tracing.join_deferred_gradients() before anything
-        reads them -- FusedAdam.step and the next traced call do."""
+        of the library's own, beside whatever the caller runs next (the base pass's backward: 0.2 ms of the EnvGS step).  That is only sound when
+        autograd does nothing with those gradients but move them into `.grad`, which the autograd node CHECKS per call -- every differentiated
+        surfel input a leaf, without a `.grad` to add into and without tensor / post-accumulate hooks; anything else (activated parameters as in
+        the unchanged EasyVolcap caller, gradient accumulation over several backward passes, GradExchange's flat `.grad` views) takes the
+        stream-ordered backward -- and when each parameter receives its gradient from ONE traced call (or bounce chain) per backward pass.  What
+        the caller still promises: to call envgs_amd.tracing.join_deferred_gradients() before anything reads the gradients -- FusedAdam.step and
+        the next traced call do."""
         self.caps.defer_reduce = bool(on)
 
     def set_colour_only_backward(self, on=True):

@@ -996,8 +996,8 @@ def test_trace_deferred_surfel_gradients_over_a_bounce_chain(force_cap, request)
         g3 = torch.zeros_like(L["means3D"]).requires_grad_(True)
         calls = []
         orig = tracing.trace_backward
-        def counting(saved, *a, chain=None):
-            r = orig(saved, *a, chain=chain)
+        def counting(saved, *a, chain=None, **kw):
+            r = orig(saved, *a, chain=chain, **kw)
             calls.append((None if chain is None else chain[1], saved["lists"].defer_reduce, sorted(k for k in ("means3D", "shs", "others_precomp", "ray_o") if r[k] is not None)))
             return r
         tracing.trace_backward = counting
@@ -1025,6 +1025,59 @@ def test_trace_deferred_surfel_gradients_over_a_bounce_chain(force_cap, request)
     for k in ref:
         err = float((ref[k] - got[k]).abs().max())
         assert float(ref[k].abs().max()) > 0 and err <= 3e-5 * float(ref[k].abs().max()) + 1e-12, (k, err)
+
+
+@pytest.mark.parametrize("case", ["activated_parameters", "existing_grad", "tensor_hook", "post_accumulate_hook"])
+def test_trace_deferral_steps_aside_when_autograd_would_touch_the_gradients(case):
+    """set_deferred_surfel_gradients is only sound when autograd MOVES the surfel gradients into .grad.  The autograd node checks that per call and
+    takes the stream-ordered backward otherwise: non-leaf inputs (the unchanged EasyVolcap caller feeds sigmoid / exp / normalize of its raw
+    parameters: the activation's backward would read the gradient at once), a .grad to add into (gradient accumulation, GradExchange's flat views),
+    a tensor hook or a post-accumulate hook on a parameter.  Nothing is left pending, and the gradients are the stream-ordered ones."""
+    import diff_surfel_tracing as mod
+    from envgs_amd import tracing
+    dev = torch.device("cuda:0")
+    g, _, _ = trace_scene(P=800, R=4, seed=41, camera=False)
+    cam = synth.orbit_camera(2, H=48, W=48, fx=50.0, radius=1.0)
+    ro, rd = synth.get_rays(cam)
+    ro, rd = ro.reshape(-1, 3).contiguous().to(dev), rd.reshape(-1, 3).contiguous().to(dev)
+    R = ro.shape[0]
+    up = (torch.randn(R, 3, generator=torch.Generator().manual_seed(3)) / R).to(dev)
+    seen = []
+
+    def run(defer, twist):
+        raw = {k: g[k].to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+        L = dict(raw)
+        if twist == "activated_parameters":
+            raw["opacities"] = torch.logit(g["opacities"].clamp(1e-4, 1 - 1e-4)).to(dev).requires_grad_(True)
+            L["opacities"] = torch.sigmoid(raw["opacities"])
+        if twist == "existing_grad":
+            raw["scales"].grad = torch.zeros_like(raw["scales"])
+        if twist == "tensor_hook":
+            raw["means3D"].register_hook(lambda gr: seen.append(float(gr.abs().sum())) or None)
+        if twist == "post_accumulate_hook":
+            raw["shs"].register_post_accumulate_grad_hook(lambda p_: seen.append(float(p_.grad.abs().sum())))
+        v, f = synth.get_disks(L["means3D"].detach(), L["scales"].detach(), L["rotations"].detach())
+        tracer = mod.SurfelTracer()
+        tracer.set_deferred_surfel_gradients(defer)
+        tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
+        outs = tracer(ro, rd, v, means3D=L["means3D"], grads3D=None, shs=L["shs"], colors_precomp=None, others_precomp=None,
+                      opacities=L["opacities"], scales=L["scales"], rotations=L["rotations"], cov3D_precomp=None,
+                      tracer_settings=_settings(mod, torch.tensor([0.2, 0.3, 0.1]), 3, dev), start_from_first=False)
+        (outs[0] * up).sum().backward()
+        pending = tracing._DEFERRED["pending"]
+        tracing.join_deferred_gradients()
+        gr = {k: t.grad.clone() for k, t in raw.items()}
+        torch.cuda.synchronize()
+        return gr, pending
+
+    ref, _ = run(False, case)
+    got, pending = run(True, case)
+    assert not pending                                       # the node saw the twist and did not defer
+    plain, pend_plain = run(True, None)
+    assert pend_plain                                        # ... and does defer the same call without it
+    for k in ref:
+        err = float((ref[k] - got[k]).abs().max())
+        assert float(ref[k].abs().max()) > 0 and err <= 2e-5 * float(ref[k].abs().max()) + 1e-12, (k, err)
 
 
 def test_trace_two_tracers_with_deferred_surfel_gradients():
