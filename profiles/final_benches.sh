@@ -5,6 +5,7 @@ Q="--no-cpu-baseline --no-reference-caller"
 timeout 500 python bench.py > $O/bench_envgs_final.json 2> $O/bench_envgs_final.err
 timeout 150 python bench.py --caller reference --no-cpu-baseline > $O/bench_envgs_reference_caller_final.json 2> $O/bench_envgs_reference_caller_final.err
 timeout 150 python bench.py --caller twin $Q > $O/bench_envgs_twin_caller_final.json 2> $O/bench_envgs_twin_caller_final.err
+timeout 150 python bench.py --no-deferred-surfel-grads $Q > $O/bench_envgs_stream_ordered_final.json 2> $O/bench_envgs_stream_ordered_final.err
 timeout 250 python bench.py --workload raster > $O/bench_raster_final.json 2> $O/bench_raster_final.err
 timeout 150 python bench.py --env-gaussians 700000 $Q --steps 15 --warmup 4 > $O/bench_env700k_final.json 2> $O/bench_env700k_final.err
 timeout 200 python bench.py --gaussians 1800000 --env-gaussians 630000 $Q --steps 10 --warmup 3 > $O/bench_caps_final.json 2> $O/bench_caps_final.err

@@ -100,7 +100,7 @@ for P_ in (163840, 700000):
             f.write("name,calls,avg_us\n")
             for r in rows[:20]:
                 f.write("%s,%s,%.1f\n" % (short(r['Name']), r['Calls'], float(r['AverageNs']) / 1e3))
-for n in ('envgs', 'envgs_reference_caller', 'envgs_twin_caller', 'envgs_f16', 'raster', 'env700k', 'caps', 'config5', 'base_trace_d0', 'base_trace_d2'):
+for n in ('envgs', 'envgs_reference_caller', 'envgs_twin_caller', 'envgs_stream_ordered', 'envgs_f16', 'raster', 'env700k', 'caps', 'config5', 'base_trace_d0', 'base_trace_d2'):
     src = os.path.join(ROOT, 'gpurun_out', 'bench_%s_final.json' % n)
     if os.path.exists(src) and os.path.getsize(src) > 10:
         open(os.path.join(ROOT, 'profiles', '%s_bench_%s.json' % (TAG, n)), 'w').write(open(src).read())
