@@ -177,6 +177,15 @@ def env_pass(tracer, tpkg, cam, env, ref_o, ref_d, env_bg, sh_degree, prepared_v
 def envgs_forward(pkg, tpkg, tracer, cam, rays, base, env, bg, env_bg, sh_degree):
     """One EnvGS forward: base raster -> reflect -> env trace -> blend.  Returns dict of (H,W,*) maps."""
     H, W = cam.image_height, cam.image_width
+    if FUSED["on"] and not REFERENCE_FORMS["on"] and DEFER["on"]:
+        # env surfel tensors that are not leaves (activated parameters): through the barrier node NOW, before the base pass, so that its backward --
+        # the join -- comes up after the base pass's backward has been queued (envgs_amd.tracing.defer_barrier); the tracer is their only consumer here
+        from . import tracing
+        keys = [k for k in ("means3D", "shs", "opacities", "scales", "rotations") if k in env and env[k].requires_grad and not env[k].is_leaf]
+        if keys:
+            outs = tracing.defer_barrier(*[env[k].contiguous() for k in keys])
+            env = dict(env)
+            env.update(zip(keys, outs if isinstance(outs, tuple) else (outs,)))
     prepared_v = env_prepare(tracer, env) if (FUSED["on"] and not REFERENCE_FORMS["on"] and PREBUILD["on"] and hasattr(tracer, "prepare")) else None
     b = base_pass(pkg, cam, base, bg, sh_degree)
     ray_o, ray_d = rays

@@ -235,6 +235,40 @@ def join_deferred_gradients():
     _DEFERRED.update(pending=False, keep=None, dev=None)
 
 
+class _DeferBarrier(torch.autograd.Function):
+    """Identity in the forward; its backward joins the deferred surfel gradients before handing them on."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        return tuple(t.view_as(t) for t in ts)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        join_deferred_gradients()
+        return gs
+
+
+def defer_barrier(*tensors):
+    """OPTIONAL, for a training loop whose tracer inputs are NOT leaves (EasyVolcap feeds the tracer sigmoid / exp / normalize of its raw parameters)
+    and that wants set_deferred_surfel_gradients all the same:
+
+        act = [torch.sigmoid(raw_opacity), torch.exp(raw_scale), ...]          # at the START of the step, before the base pass
+        opacities, scales, ... = envgs_amd.tracing.defer_barrier(*act)         # identity; pass THESE (and only to) the tracer
+
+    The tracer's backward returns its (still unfinished) surfel gradients into this node, whose backward makes the current stream wait for them and
+    only then hands them to the activations' backward.  Autograd runs ready nodes latest-created first, so a barrier created BEFORE the base pass
+    comes up after the base pass's backward has been queued -- which is the overlap the deferral is for; created later it is merely correct.
+    The returned tensors must feed the tracer and nothing else (a second consumer makes autograd ADD the two gradients on arrival, before the
+    join), and each parameter must still receive its tracer gradient from one traced call or bounce chain per backward pass."""
+    outs = _DeferBarrier.apply(*tensors)
+    return outs if len(tensors) != 1 else outs[0]
+
+
+def _behind_barrier(t):
+    fn = t.grad_fn
+    return fn is not None and type(fn).__name__ == "_DeferBarrierBackward" and not getattr(t, "_backward_hooks", None)
+
+
 def trace_forward(nodes, ray_o, ray_d, means3D, shs, colors_precomp, others_precomp, opacities, scales, rotations, settings,
                   start_from_first, use_lists=True, need_grad=True, caps=None):
     lib = _lib.load()
@@ -499,8 +533,9 @@ class _TraceSurfels(torch.autograd.Function):
         # deferred surfel gradients (set_deferred_surfel_gradients) are only safe when autograd does nothing with them but MOVE them into .grad: every
         # differentiated surfel input must be a leaf (a non-leaf's gradient is fed to the next backward node on the current stream at once); whether
         # it has a .grad to add into, or hooks that would read it, is looked at when the backward runs
-        ctx.surfel_inputs = [t for t in (means3D, grads3D, shs, colors_precomp, opacities, scales, rotations) if t is not None and t.requires_grad]
-        ctx.surfel_leaves = all(t.is_leaf for t in ctx.surfel_inputs)
+        ctx.surfel_inputs = [t for t in (means3D, grads3D, shs, colors_precomp, opacities, scales, rotations) if t is not None and t.requires_grad and t.is_leaf]
+        ctx.surfel_leaves = all(t.is_leaf or _behind_barrier(t) for t in (means3D, grads3D, shs, colors_precomp, opacities, scales, rotations)
+                                if t is not None and t.requires_grad)           # (or the output of defer_barrier: that node joins before anyone else sees the gradient)
         ctx.in_dtypes = tuple(None if t is None else t.dtype for t in (ray_o, ray_d, means3D, grads3D, shs, colors_precomp,
                                                                         others_precomp, opacities, scales, rotations))
         rgb, dpt, acc, norm, dist, aux, mid, wet = outs

@@ -210,6 +210,52 @@ def test_full_envgs_step_chain_vs_oracle_chain_diagnostic():
         check_close(test, kk, n(g_h[kk]), n(g_o[kk]), tol=1e-2)
 
 
+def test_step_with_deferred_env_surfel_gradients_and_activated_parameters():
+    """The same with RAW env parameters behind activations (sigmoid / exp / normalize, as EasyVolcap's GaussianModel holds them): envgs_forward puts the
+    activated tensors through tracing.defer_barrier before the base pass; the tracer defers, the barrier joins inside backward() -- nothing is pending
+    afterwards -- and the raw parameters' gradients are those of the stream-ordered step."""
+    import diff_surfel_rasterization_wet_ch05 as pkg
+    import diff_surfel_tracing as tpkg
+    from envgs_amd import tracing
+    dev = torch.device("cuda:0")
+    was = (envgs_step.FUSED["on"], envgs_step.DEFER["on"])
+    res, deferred_calls = {}, {}
+    try:
+        envgs_step.FUSED["on"] = True
+        for defer in (False, True):
+            envgs_step.DEFER["on"] = defer
+            base, env, cam = _scene(dev)
+            raw = dict(means3D=env["means3D"].detach().clone().requires_grad_(True), shs=env["shs"].detach().clone().requires_grad_(True),
+                       opacities=torch.logit(env["opacities"].detach().clamp(1e-4, 1 - 1e-4)).requires_grad_(True),
+                       scales=torch.log(env["scales"].detach()).requires_grad_(True), rotations=(env["rotations"].detach() * 1.3).requires_grad_(True))
+            act = dict(means3D=raw["means3D"] * 1.0, shs=raw["shs"] * 1.0, opacities=torch.sigmoid(raw["opacities"]), scales=torch.exp(raw["scales"]),
+                       rotations=torch.nn.functional.normalize(raw["rotations"], dim=-1))
+            n = [0]
+            orig = tracing.trace_backward
+            def counting(saved, *a, **kw):
+                r = orig(saved, *a, **kw)
+                n[0] += int(saved["lists"].defer_reduce & 1)
+                return r
+            tracing.trace_backward = counting
+            try:
+                out = envgs_step.envgs_forward(pkg, tpkg, tpkg.SurfelTracer(), cam, synth.get_rays(cam), base, act, torch.zeros(3, device=dev),
+                                               torch.tensor([0.1, 0.2, 0.3], device=dev), torch.tensor([2], device=dev))
+                dcol, dall = _upstream(cam.image_height, cam.image_width, dev)
+                ((out["rgb"] * dcol).sum() + (out["base"]["allmap"] * dall).sum()).backward()
+            finally:
+                tracing.trace_backward = orig
+            assert not tracing._DEFERRED["pending"]
+            deferred_calls[defer] = n[0]
+            torch.cuda.synchronize()
+            res[defer] = {("raw." + k): v.grad.clone() for k, v in raw.items()} | {("base." + k): v.grad.clone() for k, v in base.items() if v.grad is not None}
+    finally:
+        envgs_step.FUSED["on"], envgs_step.DEFER["on"] = was
+    assert deferred_calls == {False: 0, True: 1}
+    for k in res[False]:
+        a, b = res[False][k], res[True][k]
+        assert (float(a.abs().max()) > 0 or not k.startswith("raw.")) and float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-12, k
+
+
 def test_step_with_deferred_env_surfel_gradients():
     """envgs_step.DEFER (SurfelTracer.set_deferred_surfel_gradients; include/envgs_trace.h: defer_reduce): the fused step whose env-surfel gradients
     finish on the library's stream beside the base pass's backward, joined by FusedAdam.step -- the parameters after one optimizer step are those

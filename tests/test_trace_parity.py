@@ -1080,6 +1080,59 @@ def test_trace_deferral_steps_aside_when_autograd_would_touch_the_gradients(case
         assert float(ref[k].abs().max()) > 0 and err <= 2e-5 * float(ref[k].abs().max()) + 1e-12, (k, err)
 
 
+def test_trace_deferral_behind_a_barrier_serves_activated_parameters():
+    """tracing.defer_barrier: raw parameters -> activations -> barrier (identity) -> tracer.  The tracer defers (its inputs are barrier outputs), the
+    barrier's backward joins before the activations' backward sees the gradients -- no explicit join anywhere --, and because the barrier was created
+    BEFORE the other branch of the step (a stand-in for the base pass) autograd reaches it AFTER that branch's backward has been queued: the overlap
+    the deferral is for.  Raw-parameter gradients = those of the stream-ordered backward."""
+    import diff_surfel_tracing as mod
+    from envgs_amd import tracing
+    dev = torch.device("cuda:0")
+    g, _, _ = trace_scene(P=800, R=4, seed=43, camera=False)
+    cam = synth.orbit_camera(1, H=48, W=48, fx=50.0, radius=1.0)
+    ro, rd = synth.get_rays(cam)
+    ro, rd = ro.reshape(-1, 3).contiguous().to(dev), rd.reshape(-1, 3).contiguous().to(dev)
+    R = ro.shape[0]
+    up = (torch.randn(R, 3, generator=torch.Generator().manual_seed(3)) / R).to(dev)
+
+    def run(defer):
+        raw = dict(means3D=g["means3D"].to(dev).requires_grad_(True), shs=g["shs"].to(dev).requires_grad_(True),
+                   opacities=torch.logit(g["opacities"].clamp(1e-4, 1 - 1e-4)).to(dev).requires_grad_(True),
+                   scales=torch.log(g["scales"]).to(dev).requires_grad_(True), rotations=(g["rotations"] * 1.7).to(dev).requires_grad_(True))
+        other = torch.ones(16, device=dev, requires_grad=True)
+        order = []
+        act = (raw["means3D"] * 1.0, raw["shs"] * 1.0, torch.sigmoid(raw["opacities"]), torch.exp(raw["scales"]), torch.nn.functional.normalize(raw["rotations"], dim=-1))
+        m3, sh, op, sc, rot = tracing.defer_barrier(*act) if defer else act        # first thing of the step
+        base_like = (other * 3.0)                                                 # the rest of the step's forward comes after it
+        base_like.register_hook(lambda gr: order.append("other branch") or None)
+        v, f = synth.get_disks(m3.detach(), sc.detach(), rot.detach())
+        tracer = mod.SurfelTracer()
+        tracer.set_deferred_surfel_gradients(defer)
+        tracer.build_acceleration_structure(v.detach().clone(), f.detach().clone(), rebuild=True)
+        outs = tracer(ro, rd, v, means3D=m3, grads3D=None, shs=sh, colors_precomp=None, others_precomp=None, opacities=op, scales=sc, rotations=rot,
+                      cov3D_precomp=None, tracer_settings=_settings(mod, torch.tensor([0.2, 0.3, 0.1]), 3, dev), start_from_first=False)
+        orig = tracing.join_deferred_gradients
+        def joining():
+            if tracing._DEFERRED["pending"]: order.append("join")
+            orig()
+        tracing.join_deferred_gradients = joining
+        try:
+            ((outs[0] * up).sum() + base_like.sum()).backward()
+        finally:
+            tracing.join_deferred_gradients = orig
+        assert not tracing._DEFERRED["pending"]                    # the barrier joined: nothing for the caller to do
+        gr = {k: t.grad.clone() for k, t in raw.items()}
+        torch.cuda.synchronize()
+        return gr, order
+
+    ref, o0 = run(False)
+    got, o1 = run(True)
+    assert o0 == ["other branch"] and o1 == ["other branch", "join"], (o0, o1)
+    for k in ref:
+        err = float((ref[k] - got[k]).abs().max())
+        assert float(ref[k].abs().max()) > 0 and err <= 2e-5 * float(ref[k].abs().max()) + 1e-12, (k, err)
+
+
 def test_trace_two_tracers_with_deferred_surfel_gradients():
     """Two tracers in one backward pass (the reference's samplers hold one over the base set and one over the environment set:
     envgs_sampler.py:508-521 next to :548), both deferring: the second backward to run joins the first one's tail on entry (scratch reuse is safe
